@@ -1,0 +1,454 @@
+"""CPU oracle (numpy) for the MPPI rollout hot path of SensorsINI/CartPoleSimulation.
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module; the product package ``cartpolesimulation_amd`` never does (it fails loudly if
+its HIP library is missing instead of falling back to anything in here).
+
+This is a *restatement* of the reference algorithm (nothing is copied): every function cites the reference
+``file:line`` it follows (paths relative to the reference checkout).  It is PINNED by the golden vectors under
+``tests/golden/`` which ``oracle/gen_golden.py`` produced by executing the reference's own in-tree code objects
+(see ``tests/test_oracle_golden.py``).  What is pinned: the ODE_v0 substep / control-step / rollout arithmetic,
+the three in-tree cost formulations, the soft-min weighted average, the "interpolated" sampler and the complete
+legacy ``controller_mppi_cartpole.step``.  What is NOT pinned in-tree ("parity unpinned"): the absent
+``Control_Toolkit.optimizer_mppi`` glue (clip / shift / horizon mean-vs-sum / which ``u`` enters the correction
+term) — exposed here as explicit flags of :func:`mppi_step`.
+
+Arithmetic modes
+  * ``"f32"``    — mode A, strict float32 per operation: what the in-tree code does when imported under numpy >= 2.
+  * ``"f64sub"`` — mode B, substeps carried in float64 and rounded to float32 once per control step: closest
+    emulation of numba's typing of the same source (``array(float32) * float64 -> float64``).
+"""
+from dataclasses import dataclass, field
+import numpy as np
+
+# --------------------------------------------------------------------------------------------------------------------
+# a1 — state layout.  CartPole/state_utilities.py:5-23 (alphabetical order of the six names)
+ANGLE_IDX, ANGLED_IDX, ANGLE_COS_IDX, ANGLE_SIN_IDX, POSITION_IDX, POSITIOND_IDX = 0, 1, 2, 3, 4, 5
+STATE_VARIABLES = ("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")
+
+f32 = np.float32
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# a2 — physical parameters.  CartPole/cartpole_parameters.py:8-31 reading cartpole_physical_parameters.yml:6-17,34,42
+@dataclass
+class CartPoleParams:
+    k: np.float32 = f32(1.0 / 3.0)            # "1.0/3.0" -> float(1.0)/float(3.0) -> float32   (:23-24,:29)
+    m_cart: np.float32 = f32(0.230)
+    m_pole: np.float32 = f32(0.087)
+    g: np.float32 = f32(9.81)
+    J_fric: np.float32 = f32(5.0e-5)
+    M_fric: np.float32 = f32(3.22)
+    L: np.float32 = f32(0.395)
+    u_max: np.float32 = f32(1.77)
+    TrackHalfLength: np.float32 = f32((44.0e-2 - 4.4e-2) / 2.0)   # (:31) (track_length - cart_length)/2 -> float32
+
+
+DEFAULT_PARAMS = CartPoleParams()
+
+
+def create_cartpole_state(angle=0.0, angleD=0.0, position=0.0, positionD=0.0):
+    """CartPole/state_utilities.py:26-53 — float32[6] with cos/sin filled from ``angle`` (float64 cos, stored f32)."""
+    s = np.zeros(6, dtype=f32)
+    s[ANGLE_IDX], s[ANGLED_IDX], s[POSITION_IDX], s[POSITIOND_IDX] = angle, angleD, position, positionD
+    s[ANGLE_COS_IDX], s[ANGLE_SIN_IDX] = np.cos(angle), np.sin(angle)
+    return s
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# a3 — CartPole/cartpole_equations.py:119-127 (Q2u), called through CartPoleEquations.Q2u :159-163
+def Q2u(Q, p=DEFAULT_PARAMS):
+    return p.u_max * np.asarray(Q, dtype=f32)
+
+
+# a4 — CartPole/cartpole_equations.py:44-105 (_cartpole_ode); op grouping kept exactly
+def cartpole_ode(ca, sa, angleD, positionD, u, L, p=DEFAULT_PARAMS):
+    k, m_cart, m_pole, g, J_fric, M_fric = p.k, p.m_cart, p.m_pole, p.g, p.J_fric, p.M_fric
+    A = (k + 1) * (m_cart + m_pole) - m_pole * (ca * ca)                                  # :71
+    F_fric = -M_fric * positionD                                                         # :72
+    T_fric = -J_fric * angleD                                                            # :73
+    L_half = L / 2.0                                                                     # :74
+    positionDD = (
+        m_pole * g * sa * ca
+        + ((T_fric * ca) / L_half)
+        + (k + 1) * (-(m_pole * L_half * (angleD * angleD) * sa) + F_fric + u)
+    ) / A                                                                                # :76-87
+    angleDD = (g * sa + positionDD * ca + T_fric / (m_pole * L_half)) / ((k + 1) * L_half)   # :95-99
+    return angleDD, positionDD
+
+
+# a7 — CartPole/_CartPole_mathematical_helpers.py:24-29 (wrap_angle_rad_inplace); 2*pi and pi take the array dtype
+def wrap_angle_rad(angle):
+    dt = angle.dtype.type
+    two_pi, pi = dt(2 * np.pi), dt(np.pi)
+    m = np.fmod(angle, two_pi)
+    return np.where(m < -pi, m + two_pi, np.where(m > pi, m - two_pi, m))
+
+
+# a5 + a6 + a7 + a8 — CartPole/cartpole_numba.py:55-78 (cartpole_fine_integration_numba), with
+#   cartpole_equations.py:356-364 (simultaneous forward Euler), :341-347 (edge_bounce, per element,
+#   cartpole_numba.py:47-52) and the wrap above.
+def fine_integration(angle, angleD, ca, sa, position, positionD, u, t_step, S, L, p=DEFAULT_PARAMS):
+    THL = p.TrackHalfLength
+    for _ in range(S):
+        angleDD, positionDD = cartpole_ode(ca, sa, angleD, positionD, u, L, p)
+        # simultaneous Euler: every right-hand side uses the OLD values                     (cartpole_equations.py:359-362)
+        angle, angleD, position, positionD = (angle + angleD * t_step, angleD + angleDD * t_step,
+                                              position + positionD * t_step, positionD + positionDD * t_step)
+        cb = np.cos(angle)                                                                # cartpole_numba.py:69 (unwrapped)
+        hit = (position >= THL) | (-position >= THL)                                      # cartpole_equations.py:342
+        if np.any(hit):
+            # sequential: uses the UPDATED angleD and positionD                            (:343-346)
+            angleD_b = angleD - 2 * (positionD * cb) / (0.5 * L)
+            angle_b = angle + angleD_b * t_step
+            positionD_b = -positionD
+            position_b = position + positionD_b * t_step
+            angle, angleD = np.where(hit, angle_b, angle), np.where(hit, angleD_b, angleD)
+            position, positionD = np.where(hit, position_b, position), np.where(hit, positionD_b, positionD)
+        angle = wrap_angle_rad(angle)                                                     # cartpole_numba.py:73
+        ca, sa = np.cos(angle), np.sin(angle)                                             # :75-76
+    return angle, angleD, ca, sa, position, positionD
+
+
+# a9 + a10 — cartpole_numba.py:10-41 (interface: unpack, scatter into float32 zeros_like(s)) and
+#   SI_Toolkit_ASF/ToolkitCustomization/predictors_customization_v0.py:41-55 (step: L override, squeeze Q, Q2u)
+def ode_v0_step(s, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32"):
+    """One control step of predictor_ODE_v0.  s[N,6] f32, Q[N] f32 -> s_next[N,6] f32."""
+    s = np.asarray(s, dtype=f32)
+    Q = np.asarray(Q, dtype=f32).reshape(s.shape[0])
+    L = p.L if L is None else f32(L)
+    t_step = float(dt / float(S))                                 # predictors_customization_v0.py:39 (python float)
+    u = Q2u(Q, p)
+    cols = [s[:, ANGLE_IDX], s[:, ANGLED_IDX], s[:, ANGLE_COS_IDX], s[:, ANGLE_SIN_IDX], s[:, POSITION_IDX],
+            s[:, POSITIOND_IDX]]
+    if mode == "f64sub":
+        cols = [c.astype(np.float64) for c in cols]
+        u = u.astype(np.float64)
+    elif mode != "f32":
+        raise ValueError(mode)
+    a, ad, ca, sa, x, xd = fine_integration(*cols, u, t_step, S, L, p)
+    out = np.zeros_like(s)
+    out[:, ANGLE_IDX], out[:, ANGLED_IDX], out[:, ANGLE_COS_IDX] = a, ad, ca
+    out[:, ANGLE_SIN_IDX], out[:, POSITION_IDX], out[:, POSITIOND_IDX] = sa, x, xd
+    return out
+
+
+# a11 — the absent predictor_ODE_v0.predict_core, witnessed by controller_mppi_cartpole.py:191 and
+#   SI_Toolkit_ASF/ToolkitCustomization/Modules/ODE_module.py:46-50: out[:,0]=s0; out[:,k+1]=step(out[:,k], Q[:,k])
+def predict_core(s0, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32"):
+    """s0[N,6] (or [6]), Q[N,H] (or [N,H,1]) -> trajectories [N,H+1,6] float32."""
+    Q = np.asarray(Q, dtype=f32)
+    if Q.ndim == 3:
+        Q = Q[:, :, 0]
+    s0 = np.asarray(s0, dtype=f32)
+    if s0.ndim == 1:
+        s0 = np.tile(s0, (Q.shape[0], 1))
+    N, H = Q.shape
+    out = np.zeros((N, H + 1, 6), dtype=f32)
+    out[:, 0] = s0
+    for k in range(H):
+        out[:, k + 1] = ode_v0_step(out[:, k], Q[:, k], dt, S, L, p, mode)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Cost functions
+@dataclass
+class CostConfig:
+    """Weights of Control_Toolkit_ASF/config_cost_function.yml and config_controllers.yml:16-21."""
+    # quadratic_boundary_grad_minimal  (config_cost_function.yml:37-45)
+    qbgm_dd_quadratic_weight: float = 10.0
+    qbgm_ep_weight: float = 40.0
+    qbgm_ekp_weight: float = 1.0
+    qbgm_db_weight: float = 10000.0
+    qbgm_cc_weight: float = 5.0
+    qbgm_R: float = 1.0
+    qbgm_permissible_track_fraction: float = 0.85
+    # default  (config_cost_function.yml:6-11)
+    def_dd_weight: float = 600.0
+    def_ep_weight: float = 20000.0
+    def_cc_weight: float = 1.0
+    def_R: float = 1.0
+    # legacy mppi-cartpole  (config_controllers.yml:16-21)
+    leg_dd_weight: float = 120.0
+    leg_ep_weight: float = 50000.0
+    leg_ekp_weight: float = 0.01
+    leg_ekc_weight: float = 5.0
+    leg_cc_weight: float = 1.0
+    leg_ccrc_weight: float = 1.0
+
+
+DEFAULT_COST = CostConfig()
+COST_QBGM, COST_DEFAULT, COST_LEGACY = 0, 1, 2
+
+
+# a12 — Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad_minimal.py:64-126
+def qbgm_stage_cost(states, inputs, target_position, target_equilibrium, p=DEFAULT_PARAMS, c=DEFAULT_COST):
+    """states[N,H,6], inputs[N,H] -> stage cost [N,H] float32 (terminal cost is zero, :95-97)."""
+    THL = p.TrackHalfLength
+    x = states[:, :, POSITION_IDX]
+    ptf = f32(c.qbgm_permissible_track_fraction)
+    dd = f32(c.qbgm_dd_quadratic_weight) * ((x - target_position) / (2 * THL)) ** 2                        # :65-71,:110-113
+    near = (np.abs(x) > ptf * THL).astype(f32)                                                            # :77
+    db = f32(c.qbgm_db_weight) * (near * ((np.abs(x) - ptf * THL) / ((1 - ptf) * THL)) ** 2)              # :78-81,:115
+    ep = f32(c.qbgm_ep_weight) * (1.0 - target_equilibrium * np.cos(states[:, :, ANGLE_IDX])) ** 2        # :84-86,:116
+    ekp = f32(c.qbgm_ekp_weight) * states[:, :, ANGLED_IDX] ** 2                                          # :88-90,:117
+    cc = f32(c.qbgm_cc_weight) * (f32(c.qbgm_R) * inputs ** 2)                                            # :92-93,:119
+    return dd + db + ep + ekp + cc                                                                        # :125
+
+
+# a13 — Control_Toolkit_ASF/Cost_Functions/CartPole/default.py:23-88
+def default_stage_cost(states, inputs, target_position, target_equilibrium, p=DEFAULT_PARAMS, c=DEFAULT_COST):
+    THL = p.TrackHalfLength
+    x = states[:, :, POSITION_IDX]
+    dd = c.def_dd_weight * (((x - target_position) / (2.0 * THL)) ** 2
+                            + (np.abs(x) > 0.90 * THL).astype(f32) * 1.0e7)                                # :24-31,:81
+    ep = c.def_ep_weight * (target_equilibrium * 0.25 * (1.0 - np.cos(states[:, :, ANGLE_IDX])) ** 2)     # :34-36,:82
+    cc = c.def_cc_weight * (c.def_R * inputs ** 2)                                                        # :39-40,:83
+    return (dd + ep + cc).astype(f32)                                                                     # :87 (ccrc = 0)
+
+
+def default_terminal_cost(terminal_states, target_position, p=DEFAULT_PARAMS):
+    """default.py:55-63 — 10000 * indicator(|angle| > 0.2 or |x - x*| > 0.1*THL)."""
+    THL = p.TrackHalfLength
+    bad = (np.abs(terminal_states[:, ANGLE_IDX]) > 0.2) | (
+        np.abs(terminal_states[:, POSITION_IDX] - target_position) > 0.1 * THL)
+    return 10000 * bad.astype(f32)
+
+
+# a14 — Control_Toolkit_ASF/Controllers/controller_mppi_cartpole.py:119-161 (helpers), :227-275 (q), :278-303 (phi)
+def legacy_stage_cost(states, u, delta_u, u_prev, target_position, R=1.0, NU=1000.0, p=DEFAULT_PARAMS,
+                      c=DEFAULT_COST):
+    """states[N,H,6], u[H] nominal, delta_u[N,H], u_prev[H] -> q[N,H] float32."""
+    THL = p.TrackHalfLength
+    x = states[:, :, POSITION_IDX]
+    dd = c.leg_dd_weight * (((x - target_position) / (2.0 * THL)) ** 2
+                            + (np.abs(x) > 0.95 * THL) * 1.0e6).astype(f32)                                # :141-146,:255-257
+    ep = c.leg_ep_weight * (0.25 * (1.0 - np.cos(states[:, :, ANGLE_IDX])) ** 2).astype(f32)              # :134-137,:258
+    ekp = c.leg_ekp_weight * (states[:, :, ANGLED_IDX] ** 2).astype(f32)                                  # :128-131,:259
+    ekc = c.leg_ekc_weight * (states[:, :, POSITIOND_IDX] ** 2).astype(f32)                               # :122-125,:260
+    cc = c.leg_cc_weight * (0.5 * (1 - 1.0 / NU) * R * (delta_u ** 2) + R * u * delta_u + 0.5 * R * (u ** 2))   # :261-263
+    ccrc = c.leg_ccrc_weight * ((u + delta_u - u_prev) ** 2).astype(f32)                                  # :149-152,:264-266
+    cc = np.where(np.abs(u + delta_u) > 1.0, f32(1.0e5), cc)                                              # :270-271
+    return dd + ep + ekp + ekc + cc + ccrc                                                                # :273
+
+
+def legacy_terminal_cost(terminal_states, target_position, p=DEFAULT_PARAMS):
+    """controller_mppi_cartpole.py:278-303 (phi)."""
+    THL = p.TrackHalfLength
+    bad = (np.abs(terminal_states[:, ANGLE_IDX]) > 0.2) | (
+        np.abs(terminal_states[:, POSITION_IDX] - target_position) > 0.1 * THL)
+    return 10000 * bad
+
+
+def trajectory_cost(cost_id, traj, inputs, target_position, target_equilibrium, horizon_reduce="sum",
+                    p=DEFAULT_PARAMS, c=DEFAULT_COST):
+    """cost_function_base.get_trajectory_cost for the plugin costs: stage on traj[:, :-1], terminal on traj[:, -1].
+
+    In-tree witnesses use SUM over the horizon: Cost_Functions/GymlikeCartPole/cost_function_gym.py:18-21,
+    controller_mppi_cartpole.py:194-199.  ``horizon_reduce="mean"`` is the [recalled, unpinned] upstream variant:
+    mean over the H stage costs concatenated with the terminal cost (H+1 terms).
+    """
+    if cost_id == COST_QBGM:
+        stage = qbgm_stage_cost(traj[:, :-1], inputs, target_position, target_equilibrium, p, c)
+        term = np.zeros(traj.shape[0], dtype=f32)
+    elif cost_id == COST_DEFAULT:
+        stage = default_stage_cost(traj[:, :-1], inputs, target_position, target_equilibrium, p, c)
+        term = default_terminal_cost(traj[:, -1], target_position, p)
+    else:
+        raise ValueError(cost_id)
+    if horizon_reduce == "sum":
+        return (np.sum(stage, axis=1) + term).astype(f32)
+    return np.mean(np.concatenate([stage, term[:, None]], axis=1), axis=1).astype(f32)
+
+
+# a15 — MPPI correction term; algebra of controller_mppi_cartpole.py:261-263
+def mppi_correction_cost(u, delta_u, cc_weight=1.0, R=1.0, NU=1000.0):
+    """u broadcastable to delta_u[N,H] -> [N] float32."""
+    u = np.asarray(u, dtype=f32)
+    delta_u = np.asarray(delta_u, dtype=f32)
+    return np.sum(cc_weight * (0.5 * (1 - 1.0 / NU) * R * (delta_u ** 2) + R * u * delta_u + 0.5 * R * (u ** 2)),
+                  axis=1).astype(f32)
+
+
+# a16 — controller_mppi_cartpole.py:306-321 (reward_weighted_average)
+def reward_weighted_average(S, delta_u, LBD=100.0):
+    rho = np.min(S)
+    exp_s = np.exp(-1.0 / LBD * (S - rho))
+    a = np.sum(exp_s)
+    return np.sum(np.multiply(np.expand_dims(exp_s, 1), delta_u) / a, axis=0)
+
+
+# a17 — controller_mppi_cartpole.py:434-446 ("interpolated" sampler).  Linear interpolation between knots placed
+#   every ``period`` steps; knots ~ stdev * standard_normal(float32); the interpolation itself runs in float64
+#   (scipy interp1d: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x - x_lo) + y_lo) and is stored as float32.
+def knot_count(H, period=10):
+    return int(np.ceil(H / period)) + 1
+
+
+def sample_knots(rng, N, H, stdev, period=10):
+    """``stdev`` is a numpy float64 scalar in the reference (``SQRTRHOINV * (1 / np.sqrt(dt))``,
+    controller_mppi_cartpole.py:91), so the product ``stdev * z`` is formed in float64 and rounded to float32 on the
+    store into ``delta_u`` (:441-443)."""
+    z = rng.standard_normal(size=(N, knot_count(H, period)), dtype=f32)
+    return (np.float64(stdev) * z.astype(np.float64)).astype(f32)
+
+
+def interpolate_knots(knots, H, period=10):
+    """knots[N,P] float32 -> delta_u[N,H] float32 (scipy interp1d 'linear' as called at :444-445)."""
+    knots = np.asarray(knots, dtype=f32)
+    N, P = knots.shape
+    t = np.arange((P - 1) * period + 1)
+    lo = np.minimum(t // period, P - 2)
+    y_lo, y_hi = knots[:, lo], knots[:, lo + 1]
+    slope = (y_hi - y_lo) / np.float64(period)            # float32 difference, then float64 (int64 x-grid)
+    full = (slope * (t - lo * period).astype(np.float64) + y_lo).astype(f32)
+    on_knot = (t % period) == 0
+    full[:, on_knot] = knots[:, t[on_knot] // period]
+    return full[:, :H]
+
+
+def sample_delta_u(rng, N, H, stdev, period=10):
+    return interpolate_knots(sample_knots(rng, N, H, stdev, period), H, period)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# One full MPPI optimizer step.
+@dataclass
+class MPPIConfig:
+    """config_optimizers.yml:87-97 (mppi) / config_controllers.yml:9-30 (mppi-cartpole)."""
+    N: int = 3500
+    H: int = 35
+    dt: float = 0.02
+    S: int = 10
+    cc_weight: float = 1.0
+    R: float = 1.0
+    LBD: float = 100.0
+    NU: float = 1000.0
+    SQRTRHOINV: float = 0.03
+    period: int = 10
+    cost_id: int = COST_QBGM
+    horizon_reduce: str = "sum"       # "sum" (in-tree witnesses) | "mean" (recalled upstream)
+    control_mode: str = "clip"        # "clip" (recalled optimizer_mppi) | "penalise" (legacy, in-tree)
+    shift_mode: str = "repeat_last"   # "repeat_last" (recalled) | "append_zero" (legacy, in-tree) | "none"
+    correction_u: str = "u_run"       # which u enters a15: "u_run" (recalled) | "u_nom" (legacy, in-tree)
+    cost: CostConfig = field(default_factory=CostConfig)
+
+    @property
+    def stdev(self):
+        return self.SQRTRHOINV * (1.0 / np.sqrt(self.dt))
+
+
+def legacy_rollout_costs(s, u, delta_u, u_prev, target_position, cfg, L=None, p=DEFAULT_PARAMS, mode="f32"):
+    """controller_mppi_cartpole.py:164-199 (trajectory_rollouts): predict(tile(s), u+delta_u), sum_k q + phi."""
+    N = delta_u.shape[0]
+    traj = predict_core(np.tile(s, (N, 1)), (u + delta_u), cfg.dt, cfg.S, L, p, mode)
+    q = legacy_stage_cost(traj[:, :-1], u, delta_u, u_prev, target_position, cfg.R, cfg.NU, p, cfg.cost)
+    return np.sum(q, axis=1) + legacy_terminal_cost(traj[:, -1], target_position, p), traj
+
+
+def legacy_mppi_update(s, u, delta_u, u_prev, target_position, cfg, L=None, p=DEFAULT_PARAMS, mode="f32"):
+    """The deterministic core of controller_mppi_cartpole.step (:476-497): costs then u += weighted average.
+
+    Returns (S[N], u_new[H], traj).  The caller owns RNG, output noise (:553), clip (:555) and the shift (:561-562).
+    """
+    S_cost, traj = legacy_rollout_costs(s, u, delta_u, u_prev, target_position, cfg, L, p, mode)
+    u_new = (u + reward_weighted_average(S_cost, delta_u, cfg.LBD)).astype(f32)
+    return S_cost, u_new, traj
+
+
+def mppi_step(s, u_nom, delta_u, target_position, target_equilibrium, cfg, u_prev=None, L=None, p=DEFAULT_PARAMS,
+              mode="f32", low=-1.0, high=1.0):
+    """One optimizer step on GIVEN perturbations (the deterministic part of optimizer_mppi.predict_and_cost).
+
+    s[6], u_nom[H] (as left by the previous step, i.e. BEFORE the shift), delta_u[N,H].
+    Returns dict(S[N], u_new[H], Q, traj[N,H+1,6], u_run[N,H]).  Flags: see MPPIConfig.
+    """
+    s = np.asarray(s, dtype=f32)
+    u_nom = np.asarray(u_nom, dtype=f32)
+    delta_u = np.asarray(delta_u, dtype=f32)
+    if cfg.shift_mode == "repeat_last":
+        u_nom = np.concatenate([u_nom[1:], u_nom[-1:]])
+    elif cfg.shift_mode == "append_zero":
+        u_nom = np.concatenate([u_nom[1:], np.zeros(1, dtype=f32)])
+    if cfg.cost_id == COST_LEGACY:
+        if u_prev is None:
+            u_prev = np.zeros_like(u_nom)
+        S_cost, u_new, traj = legacy_mppi_update(s, u_nom, delta_u, u_prev, target_position, cfg, L, p, mode)
+        return dict(S=S_cost.astype(f32), u_new=u_new, Q=u_new[0], traj=traj, u_run=(u_nom + delta_u))
+    u_run = u_nom[None, :] + delta_u
+    if cfg.control_mode == "clip":
+        u_run = np.clip(u_run, f32(low), f32(high))
+    traj = predict_core(np.tile(s, (delta_u.shape[0], 1)), u_run, cfg.dt, cfg.S, L, p, mode)
+    S_cost = trajectory_cost(cfg.cost_id, traj, u_run, target_position, target_equilibrium, cfg.horizon_reduce, p,
+                             cfg.cost)
+    u_corr = u_run if cfg.correction_u == "u_run" else u_nom[None, :]
+    S_cost = (S_cost + mppi_correction_cost(u_corr, delta_u, cfg.cc_weight, cfg.R, cfg.NU)).astype(f32)
+    u_new = (u_nom + reward_weighted_average(S_cost, delta_u, cfg.LBD)).astype(f32)
+    if cfg.control_mode == "clip":
+        u_new = np.clip(u_new, f32(low), f32(high))
+    return dict(S=S_cost, u_new=u_new, Q=u_new[0], traj=traj, u_run=u_run)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The plant (caller side of the boundary; needed only for the C1 closed-loop "plumbing" fixture)
+def plant_substep(s, angleDD, positionDD, dt_sim, L, p=DEFAULT_PARAMS):
+    """CartPole/__init__.py:296-308 for one scalar env: Euler-Cromer (cartpole_equations.py:367-378), edge bounce
+    (:341-347 with cos of the integrated angle, __init__.py:462-470), cos/sin (:329-331), wrap (:333-334)."""
+    s = s.copy()
+    angleD = s[ANGLED_IDX] + angleDD * dt_sim
+    positionD = s[POSITIOND_IDX] + positionDD * dt_sim
+    angle = s[ANGLE_IDX] + angleD * dt_sim
+    position = s[POSITION_IDX] + positionD * dt_sim
+    THL = p.TrackHalfLength
+    if position >= THL or -position >= THL:
+        angleD = angleD - 2 * (positionD * np.cos(angle)) / (0.5 * L)
+        angle = angle + angleD * dt_sim
+        positionD = -positionD
+        position = position + positionD * dt_sim
+    s[ANGLE_IDX], s[ANGLED_IDX], s[POSITION_IDX], s[POSITIOND_IDX] = angle, angleD, position, positionD
+    s[ANGLE_COS_IDX], s[ANGLE_SIN_IDX] = np.cos(s[ANGLE_IDX]), np.sin(s[ANGLE_IDX])
+    s[ANGLE_IDX] = wrap_angle_rad(s[ANGLE_IDX:ANGLE_IDX + 1])[0]
+    return s
+
+
+def plant_ode(s, Q, L, p=DEFAULT_PARAMS):
+    """CartPole/__init__.py:342-346: u = Q2u(Q); (angleDD, positionDD) = cartpole_ode_interface(s, u, L=float(L))."""
+    u = Q2u(f32(Q), p)
+    return cartpole_ode(s[ANGLE_COS_IDX], s[ANGLE_SIN_IDX], s[ANGLED_IDX], s[POSITIOND_IDX], u, L, p)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The complete legacy controller (pins sampler + rollouts + cost + update + output noise + shift as ONE unit)
+class LegacyMPPIController:
+    """Restatement of controller_mppi_cartpole (controller_mppi_cartpole.py:338-580) for ODE_v0 prediction.
+
+    RNG discipline (SFC64): ``configure`` draws 5 uniforms for the cost-weight noise (:355-359; the noise amplitude
+    is 0.0 in the shipped YAML so the weights are unchanged, but the draws advance the stream); each ``step`` draws
+    the knots (:441-443) and then ONE uniform for the multiplicative output noise (:553).
+    """
+
+    def __init__(self, seed, N, H, SQRTRHOINV=0.02, dt=0.02, p_Q=0.1, LBD=100.0, NU=1000.0, R=1.0,
+                 p=DEFAULT_PARAMS, cost=DEFAULT_COST, mode="f32"):
+        self.cfg = MPPIConfig(N=N, H=H, dt=dt, SQRTRHOINV=SQRTRHOINV, LBD=LBD, NU=NU, R=R, cost_id=COST_LEGACY,
+                              control_mode="penalise", shift_mode="append_zero", correction_u="u_nom", cost=cost)
+        self.p, self.mode, self.p_Q = p, mode, p_Q
+        self.rng = np.random.Generator(np.random.SFC64(seed))                          # :351-352
+        for _ in range(5):                                                             # :355-359
+            self.rng.uniform(-1.0, 1.0)
+        self.stdev = np.float64(SQRTRHOINV) * (1 / np.sqrt(dt))                        # :91
+        self.u = np.zeros(H, dtype=f32)                                                # :369
+        self.u_prev = np.zeros(H, dtype=f32)                                           # :370
+        self.S = np.zeros(N, dtype=f32)
+        self.delta_u = None
+
+    def step(self, s, target_position, L=None):
+        cfg = self.cfg
+        self.delta_u = sample_delta_u(self.rng, cfg.N, cfg.H, self.stdev, cfg.period)  # :479-483
+        self.S, self.u, _ = legacy_mppi_update(np.asarray(s, dtype=f32), self.u, self.delta_u, self.u_prev,
+                                               target_position, cfg, L, self.p, self.mode)   # :487-497
+        Q = f32(self.u[0] * (1 + self.p_Q * self.rng.uniform(-1.0, 1.0)))              # :536,:553
+        Q = np.clip(Q, f32(-1.0), f32(1.0))                                            # :555
+        self.u_prev = self.u.copy()                                                    # :558
+        self.u = np.concatenate([self.u[1:], np.zeros(1, dtype=f32)])                  # :561-562
+        return Q

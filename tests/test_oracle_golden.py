@@ -1,0 +1,169 @@
+"""Pin the numpy oracle (oracle/oracle_np.py) to the golden vectors produced by the reference's own code.
+
+CPU-only.  The goldens were generated with numpy float32 kernels on x86-64; numpy's float32 sin/cos are not
+guaranteed bit-identical across CPU families, so physics comparisons allow a few float32 ulps per control step
+(they are bit-exact on the machine that generated them) and chaotic 50-step rollouts get the H1 tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+from numpy.random import SFC64, Generator
+
+from oracle import oracle_np as O
+
+f32 = np.float32
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def per_L(s, Q, L, fn):
+    out = np.zeros_like(s)
+    for Lv in np.unique(L):
+        m = L == Lv
+        out[m] = fn(s[m], Q[m], Lv)
+    return out
+
+
+def test_state_layout_and_params(golden_dir):
+    g = load(golden_dir, "kat_step.npz")
+    assert tuple(g["state_variables"]) == O.STATE_VARIABLES
+    P = O.DEFAULT_PARAMS
+    mine = np.array([P.k, P.m_cart, P.m_pole, P.g, P.J_fric, P.M_fric, P.L, P.u_max, P.TrackHalfLength], dtype=f32)
+    assert np.array_equal(mine, g["params"])
+
+
+@pytest.mark.parametrize("key,kw,mode", [
+    ("sub1_A", dict(dt=0.002, S=1), "f32"),
+    ("step1_A", dict(), "f32"),
+    ("step1_B", dict(), "f64sub"),
+])
+def test_single_step_kats(golden_dir, key, kw, mode):
+    g = load(golden_dir, "kat_step.npz")
+    out = per_L(g["s_in"], g["Q_in"], g["L_in"], lambda s, Q, Lv: O.ode_v0_step(s, Q, L=Lv, mode=mode, **kw))
+    np.testing.assert_allclose(out, g[key], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("key,mode", [("step2_A", "f32"), ("step2_B", "f64sub")])
+def test_two_step_kats(golden_dir, key, mode):
+    g = load(golden_dir, "kat_step.npz")
+    fn = lambda s, Q, Lv: O.ode_v0_step(O.ode_v0_step(s, Q, L=Lv, mode=mode), Q, L=Lv, mode=mode)
+    out = per_L(g["s_in"], g["Q_in"], g["L_in"], fn)
+    np.testing.assert_allclose(out, g[key], rtol=5e-6, atol=5e-6)
+
+
+def test_kats_cover_bounce_and_wrap(golden_dir):
+    """The KAT set must exercise the two discontinuities (edge bounce, angle wrap)."""
+    g = load(golden_dir, "kat_step.npz")
+    s, out = g["s_in"], g["sub1_A"]
+    bounced = np.sign(out[:, O.POSITIOND_IDX]) != np.sign(s[:, O.POSITIOND_IDX])
+    wrapped = np.abs(out[:, O.ANGLE_IDX] - s[:, O.ANGLE_IDX]) > np.pi
+    assert bounced.sum() >= 16 and wrapped.sum() >= 4
+
+
+def regen_delta_u(seed, N, H, stdev):
+    rng = Generator(SFC64(int(seed)))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    return O.sample_delta_u(rng, N, H, np.float64(stdev))
+
+
+def test_sampler_and_rwa(golden_dir):
+    h = load(golden_dir, "sampler_rwa.npz")
+    du = regen_delta_u(h["seed"], int(h["N"]), int(h["H"]), h["stdev"])
+    assert np.array_equal(du[0], h["du_row0"]) and np.array_equal(du[-1], h["du_row3499"])
+    assert abs(du.astype(np.float64).sum() - h["du_sum64"]) < 1e-9
+    np.testing.assert_allclose(O.reward_weighted_average(h["S_kat"], h["du_kat"], 100.0), h["rwa_lbd100"], rtol=1e-6)
+    np.testing.assert_allclose(O.reward_weighted_average(h["S_kat"], h["du_kat"], 1.0), h["rwa_lbd1"], rtol=1e-6)
+
+
+def state_tol(ref):
+    """|d| <= 1e-4 + 1e-4*|x| on states."""
+    return 1e-4 + 1e-4 * np.abs(ref)
+
+
+@pytest.fixture(scope="module")
+def c2(golden_dir):
+    return load(golden_dir, "rollouts_c2.npz")
+
+
+@pytest.mark.parametrize("name", ["upright", "hanging", "near_edge", "fast", "random0", "random1", "random2", "random3"])
+def test_c2_rollouts_costs_update(c2, name):
+    g = c2
+    N, H = int(g["N"]), int(g["H"])
+    du = regen_delta_u(g[f"{name}/seed"], N, H, g["stdev"])
+    assert np.array_equal(du[:4], g[f"{name}/delta_u_head"])
+    # float64 checksum (the reference summed a strided view -> different pairwise order, so not bit-equal)
+    assert abs(du.astype(np.float64).sum() - g[f"{name}/delta_u_sum64"]) < 1e-9
+    s0, u_nom, u_prev, target = g[f"{name}/s0"], g[f"{name}/u_nom"], g[f"{name}/u_prev"], g[f"{name}/target"]
+    for tag in ("raw", "clip"):
+        u_run = (u_nom + du).astype(f32)
+        if tag == "clip":
+            u_run = np.clip(u_run, f32(-1), f32(1))
+        traj = O.predict_core(s0, u_run)
+        head = g[f"{name}/{tag}/traj_head"]
+        # bit-exact on the generating machine; elsewhere allow trig ulps amplified over the horizon
+        assert np.all(np.abs(traj[:head.shape[0]] - head) <= 0.2 * state_tol(head))
+        assert np.all(np.abs(traj[:, -1] - g[f"{name}/{tag}/final"]) <= 0.2 * state_tol(g[f"{name}/{tag}/final"]))
+        S_q = O.trajectory_cost(O.COST_QBGM, traj, u_run, target, f32(1.0))
+        np.testing.assert_allclose(S_q, g[f"{name}/{tag}/S_qbgm"], rtol=2e-5)
+        S_d = O.trajectory_cost(O.COST_DEFAULT, traj, u_run, target, f32(1.0))
+        np.testing.assert_allclose(S_d, g[f"{name}/{tag}/S_default"], rtol=2e-5)
+        stage = O.qbgm_stage_cost(traj[:head.shape[0], :-1], u_run[:head.shape[0]], target, f32(1.0))
+        np.testing.assert_allclose(stage, g[f"{name}/{tag}/stage_qbgm_head"], rtol=2e-5, atol=1e-6)
+    # mode B endpoint
+    trajB = O.predict_core(s0, (u_nom + du).astype(f32), mode="f64sub")
+    assert np.all(np.abs(trajB[:, -1] - g[f"{name}/raw/final_B"]) <= 0.2 * state_tol(g[f"{name}/raw/final_B"]))
+    # legacy cost + update
+    cfg = O.MPPIConfig(N=N, H=H, cost_id=O.COST_LEGACY)
+    S_leg, u_new, _ = O.legacy_mppi_update(s0, u_nom, du, u_prev, target, cfg)
+    np.testing.assert_allclose(S_leg, g[f"{name}/S_legacy"], rtol=2e-5)
+    np.testing.assert_allclose(u_new, g[f"{name}/u_new_legacy"], atol=2e-6)
+    # (the reference sums a strided view, which numpy reduces pairwise: last-ulp summation-order differences)
+    np.testing.assert_allclose(O.reward_weighted_average(g[f"{name}/raw/S_qbgm"], du), g[f"{name}/rwa_qbgm_raw"],
+                               atol=5e-7)
+
+
+def test_mode_A_vs_B_gap_documented(c2):
+    """H1: the reference's own two plausible arithmetic modes differ by more than 1e-4 on some rollouts."""
+    worst = max(np.abs(c2[f"{n}/raw/final"] - c2[f"{n}/raw/final_B"]).max() for n in c2["names"])
+    assert 1e-5 < worst < 5e-3
+
+
+@pytest.mark.parametrize("shape", ["256x20", "1024x50"])
+def test_legacy_controller_full_step(golden_dir, shape):
+    g = load(golden_dir, f"legacy_step_{shape}.npz")
+    ctrl = O.LegacyMPPIController(int(g["seed"]), int(g["N"]), int(g["H"]), SQRTRHOINV=0.02, p_Q=float(g["p_Q"]))
+    assert np.isclose(ctrl.stdev, g["stdev"], rtol=0, atol=0)
+    for it in range(g["s_seq"].shape[0]):
+        Q = ctrl.step(g["s_seq"][it], g["target"])
+        assert abs(ctrl.delta_u.astype(np.float64).sum() - g["delta_u_sum64"][it]) < 1e-9
+        np.testing.assert_allclose(ctrl.S, g["S"][it], rtol=5e-5)
+        np.testing.assert_allclose(ctrl.u_prev, g["u_updated"][it], atol=5e-6)
+        np.testing.assert_allclose(Q, g["Q"][it], atol=5e-6)
+
+
+def test_closed_loop_c1_plumbing(golden_dir):
+    """BASELINE config C1: 256 x 20 legacy MPPI in closed loop with the plant (SURVEY.md §8b harness row)."""
+    g = load(golden_dir, "closed_loop_c1.npz")
+    N, H = int(g["N"]), int(g["H"])
+    ctrl = O.LegacyMPPIController(int(g["seed"]), N, H, SQRTRHOINV=0.02, p_Q=float(g["p_Q"]))
+    s = g["s"][0].copy()
+    P = O.DEFAULT_PARAMS
+    n_match = 0
+    for c in range(g["s"].shape[0]):
+        if c < 10:   # before chaotic divergence could matter: states and controls must track the reference trace
+            np.testing.assert_allclose(s, g["s"][c], atol=2e-4, rtol=1e-4)
+        Q = ctrl.step(s, g["target"], L=P.L)
+        if c < 10:
+            np.testing.assert_allclose(Q, g["Q"][c], atol=1e-4)
+            n_match += 1
+        add, pdd = O.plant_ode(s, Q, P.L)
+        for _ in range(10):
+            s = O.plant_substep(s, add, pdd, 0.002, P.L)
+            add, pdd = O.plant_ode(s, Q, P.L)
+    assert n_match == 10
+    # qualitatively stabilising afterwards
+    assert abs(s[O.ANGLE_IDX]) < 0.2 and abs(s[O.POSITION_IDX]) < 0.198
