@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — MPPI rollouts/s of the fused HIP hot path on MI355X (BASELINE.json metric).
+
+A "step" = one full MPPI optimizer step for a batch of E independent problem instances (envs) of the C2 shape
+(1024 samples x 50-step horizon x 10 Euler substeps, BASELINE.json configs[1]): perturbation sampling (a17) +
+rollout (a3-a11) + cost (a12, a15) + importance-weighted update (a16) + shift/clip (a18).  One rollout = one sampled
+control sequence integrated over the horizon + its cost + its share of the update.  Inputs are synthetic and resident
+in HBM before the timed region.  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank owns
+E envs (weak scaling, no data-path collective) and the chosen control sequences are gathered with ONE RCCL all-gather
+per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def algorithmic_bytes_per_rollout(N, H):
+    """delta_u read once (4H), S written once (4), per-env vectors amortised over N."""
+    return 4.0 * H + 4.0 + (24.0 + 8.0 * H + 12.0) / N
+
+
+def algorithmic_flops_per_rollout(H, S=10):
+    """38 algebraic flops per substep + ~30 per control step for cost/correction/update."""
+    return H * (S * 38.0 + 30.0) + 2.0 * H
+
+
+def synthetic_inputs(E, H, seed, device):
+    """s0 as data_generator.py:221-256 / config_data_gen.yml:14-18; targets and L per env."""
+    import torch
+    rng = np.random.Generator(np.random.SFC64(seed))
+    THL = 0.198
+    angle = np.where(rng.uniform(size=E) > 0.5, 1.0, -1.0) * rng.uniform(0.0, 180.0, E) * np.pi / 180.0
+    s0 = np.zeros((E, 6), dtype=np.float32)
+    s0[:, 0] = angle
+    s0[:, 1] = rng.uniform(-1, 1, E) * 1200.0 * np.pi / 180.0
+    s0[:, 2], s0[:, 3] = np.cos(angle), np.sin(angle)
+    s0[:, 4] = rng.uniform(-1, 1, E) * THL * 0.8
+    s0[:, 5] = rng.uniform(-1, 1, E) * THL * 0.5
+    tp = (rng.uniform(-0.8, 0.8, E) * THL).astype(np.float32)
+    te = np.ones(E, dtype=np.float32)
+    L = rng.uniform(0.2, 0.5, E).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device=device)
+    return t(s0), t(tp), t(te), t(L)
+
+
+def cpu_baseline(N, H, budget_s=12.0):
+    """The plain-C oracle (validated against the golden vectors) timed on this host's cores: same step, same shape."""
+    from oracle import oracle_np as O
+    from oracle import oracle_c as OC
+    cfg = O.MPPIConfig(N=N, H=H)
+    c = OC.make_config(cfg)
+    threads = OC.max_threads()
+    rng = np.random.Generator(np.random.SFC64(4))
+
+    def run(E):
+        s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-5, 5), rng.uniform(-0.15, 0.15),
+                                               rng.uniform(-0.3, 0.3)) for _ in range(E)])
+        du = (cfg.stdev * rng.standard_normal((E, N, H))).astype(np.float32)
+        t0 = time.perf_counter()
+        OC.step(c, s0, np.zeros((E, H), np.float32), du, 0.0, 1.0, n_threads=threads, want_S=False)
+        return time.perf_counter() - t0
+
+    t1 = run(threads)                      # one env per core: calibrates the sample size
+    reps = int(max(1, min(64, budget_s / max(t1, 1e-3))))
+    E = threads * reps
+    t = run(E)
+    return {"value": E * N / t, "unit": "rollouts/s", "cores": threads, "kind": "port",
+            "sample": f"{E} envs x {N} rollouts x {H} steps x 10 substeps in {t:.2f} s; oracle/cpmppi_oracle.c "
+                      f"(gcc -O2, no fast-math, OpenMP over envs x rollouts)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=2048, help="independent MPPI problem instances per GPU")
+    ap.add_argument("--rollouts", type=int, default=1024)
+    ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--noise", choices=["buffer", "philox"], default="buffer",
+                    help="buffer: device sampler writes delta_u[E,N,H] to HBM, rollout kernel reads it; "
+                         "philox: perturbations regenerated in-kernel (no buffer)")
+    ap.add_argument("--math", choices=["fast", "precise"], default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-env", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+
+    E, N, H = args.envs, args.rollouts, args.horizon
+    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=args.math)
+    eng = MPPIEngine(E, cfg, device=local_rank)
+    s0, tp, te, L = synthetic_inputs(E, H, seed=2 + rank, device=device)
+    u_nom = eng.zeros(E, H)
+    Q_out = eng.empty(E)
+    du = eng.empty(E, N, H) if args.noise == "buffer" else None
+    gathered = torch.empty(world * E * H, dtype=torch.float32, device=device) if world > 1 else None
+    seed = 1234
+
+    def step(i):
+        if args.noise == "buffer":
+            eng._check(eng.lib.cpmppi_sample(eng._h, E, seed, i, rank * E, None, du.data_ptr(), eng._stream()))
+            eng.step(s0, u_nom, tp, te, L=L, delta_u=du, Q_out=Q_out)
+        else:
+            eng.step(s0, u_nom, tp, te, L=L, seed=seed, offset=i, env_offset=rank * E, Q_out=Q_out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, u_nom.view(-1))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rollout_ms, finalize_ms = eng.get_profile()
+    eng.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(u_nom).all(), "non-finite nominal controls"
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * E * N * args.steps / elapsed
+        k_ms = float(np.mean(rollout_ms))
+        bytes_launch = algorithmic_bytes_per_rollout(N, H) * E * N
+        flops_launch = algorithmic_flops_per_rollout(H) * E * N
+        achieved_gbs = bytes_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("E") == E and rec.get("N") == N and rec.get("H") == H and rec.get("noise") == args.noise:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPPI rollouts/sec (1024 samples x 50-step horizon)", "value": value, "unit": "rollouts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2-shape MPPI problems: {N} samples x {H}-step horizon x 10 Euler substeps, "
+                                   f"{E} independent envs per GPU batched in one launch (BASELINE configs[1] shape)",
+                       "envs_per_gpu": E, "rollouts": N, "horizon": H, "substeps": 10,
+                       "cost": cfg.cost_function_specification, "noise": args.noise, "math": args.math,
+                       "parallelism": f"env-sharded x{world}, one RCCL all-gather of u_nom per step" if world > 1
+                       else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": achieved_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": k_ms, "finalize_kernel_ms": float(np.mean(finalize_ms)),
+                         "algorithmic_bytes_per_rollout": algorithmic_bytes_per_rollout(N, H),
+                         "note": "the path is fp32-VALU bound, not HBM bound (SURVEY.md F8): see roofline_valu"},
+            "roofline_valu": {"bound": "fp32-valu", "achieved": flops_launch / (k_ms * 1e-3) / 1e12,
+                              "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": flops_launch / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                              "algorithmic_flops_per_rollout": algorithmic_flops_per_rollout(H)},
+        }
+        if not args.no_single_env:
+            # latency of ONE problem instance (BASELINE configs[1] literally: single env), same kernels
+            e1 = MPPIEngine(1, cfg, device=local_rank)
+            u1 = e1.zeros(1, H)
+            for i in range(5):
+                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 50
+            for i in range(reps):
+                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=100 + i)
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / reps
+            out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox"}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, H)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""ctypes binding of libcpmppi.so (include/cpmppi.h).  There is NO fallback: a missing library is an ImportError."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpmppi.so")
+
+ABI_VERSION = 1
+COST_QBGM, COST_DEFAULT, COST_LEGACY = 0, 1, 2
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+CONTROL_CLIP, CONTROL_PENALISE = 0, 1
+SHIFT_REPEAT_LAST, SHIFT_APPEND_ZERO, SHIFT_NONE = 0, 1, 2
+CORRECTION_U_RUN, CORRECTION_U_NOM = 0, 1
+MATH_PRECISE, MATH_FAST = 0, 1
+NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX = 0, 1, 2
+
+EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
+           "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
+           "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_set_profiling", "cpmppi_get_profile",
+           "cpmppi_version")
+
+
+class cpmppi_config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("E", C.c_uint32), ("N", C.c_uint32), ("H", C.c_uint32),
+                ("S", C.c_uint32), ("dt", C.c_float),
+                ("k", C.c_float), ("m_cart", C.c_float), ("m_pole", C.c_float), ("g", C.c_float),
+                ("J_fric", C.c_float), ("M_fric", C.c_float), ("u_max", C.c_float), ("track_half_length", C.c_float),
+                ("L_default", C.c_float),
+                ("cost_id", C.c_uint32), ("cost_w", C.c_float * 16),
+                ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("cc_weight", C.c_float),
+                ("sigma", C.c_float), ("period", C.c_uint32), ("action_low", C.c_float), ("action_high", C.c_float),
+                ("horizon_reduce", C.c_uint32), ("control_mode", C.c_uint32), ("shift_mode", C.c_uint32),
+                ("correction_u", C.c_uint32), ("math_mode", C.c_uint32)]
+
+
+class cpmppi_step_args(C.Structure):
+    _fields_ = [("E", C.c_uint32), ("s0", C.c_void_p), ("u_nom", C.c_void_p), ("u_prev", C.c_void_p),
+                ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p), ("L", C.c_void_p),
+                ("noise_kind", C.c_uint32), ("noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("env_offset", C.c_uint32), ("Q_out", C.c_void_p), ("S_out", C.c_void_p)]
+
+
+class CpmppiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libcpmppi error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libcpmppi.so (built by __graft_entry__.build()).  Raises ImportError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  cartpolesimulation_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
+    lib.cpmppi_create.argtypes = [C.POINTER(cpmppi_config), C.c_int, C.POINTER(vp)]
+    lib.cpmppi_destroy.argtypes = [vp]
+    lib.cpmppi_destroy.restype = None
+    lib.cpmppi_last_error.argtypes = [vp]
+    lib.cpmppi_last_error.restype = C.c_char_p
+    lib.cpmppi_get_config.argtypes = [vp, C.POINTER(cpmppi_config)]
+    lib.cpmppi_set_cost_weights.argtypes = [vp, u32, C.POINTER(f), u32]
+    lib.cpmppi_sample.argtypes = [vp, u32, u64, u64, u32, vp, vp, vp]
+    lib.cpmppi_interpolate.argtypes = [vp, u32, vp, vp, vp]
+    lib.cpmppi_predict.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
+    lib.cpmppi_trajectory_cost.argtypes = [vp, u32, u32, vp, vp, f, f, vp, vp, vp, vp, vp, vp]
+    lib.cpmppi_step.argtypes = [vp, C.POINTER(cpmppi_step_args), vp]
+    lib.cpmppi_reward_weighted_average.argtypes = [vp, u32, vp, vp, vp, vp]
+    lib.cpmppi_plant_advance.argtypes = [vp, u32, vp, vp, vp, u32, f, vp]
+    lib.cpmppi_set_profiling.argtypes = [vp, C.c_int]
+    lib.cpmppi_get_profile.argtypes = [vp, C.POINTER(f), C.POINTER(f), u32, C.POINTER(u32)]
+    lib.cpmppi_version.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares
+    _lib = lib
+    return lib

@@ -1,0 +1,697 @@
+// cpmppi.hip — HIP kernels (gfx950) and the C ABI of libcpmppi.so.   See include/cpmppi.h for the contract.
+//
+// Kernel inventory
+//   rollout_cost_kernel<COST,FAST,NOISE>  the hot path: one lane = one rollout, 6-float state + held control + running
+//                                         cost in VGPRs; per-env data wave-uniform (SGPR); perturbation tile staged
+//                                         through LDS with coalesced HBM reads; block-level soft-min partials
+//                                         {min S, sum e, sum e*du[.]} via wave shuffles + LDS.
+//   finalize_kernel<KNOT_SPACE>           merges the per-block partials of one env (rescaled to the env-wide minimum),
+//                                         applies shift / update / clip, writes u_nom and Q.
+//   sample_kernel / interpolate_kernel    a17 (Philox knots, scipy-interp1d-compatible interpolation).
+//   predict_kernel<FAST>                  predictor seam: trajectories [B,H+1,6].
+//   trajectory_cost_kernel                cost seam on materialised trajectories.
+//   rwa_kernel                            a16 on given (S, delta_u).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "cpmppi.h"
+#include "cpmppi_device.hpp"
+
+using namespace cpmppi;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int TK = 16;                       // time-steps per LDS perturbation tile
+constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
+
+struct StepPtrs {
+  const float* s0;
+  const float* u_nom;
+  const float* u_prev;
+  const float* x_t;
+  const float* te;
+  const float* L;
+  const float* noise;
+  uint64_t seed, offset;
+  uint32_t env_offset;
+  uint32_t nb;          // blocks per env
+  uint32_t W;           // width of the weighted-sum vector (H in delta_u space, P in knot space)
+  float* S_out;
+  float* partial;       // [E][nb][2 + W]
+};
+
+// Nominal control for stage k after the configured shift (a18).
+__device__ __forceinline__ float shifted_nominal(const Params& p, const float* __restrict__ un, uint32_t k) {
+  if (p.shift_mode == CPMPPI_SHIFT_NONE) return un[k];
+  if (k + 1 < p.H) return un[k + 1];
+  return (p.shift_mode == CPMPPI_SHIFT_REPEAT_LAST) ? un[p.H - 1] : 0.0f;
+}
+
+template <int COST, bool FAST, int NOISE>
+__global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const Params p, const StepPtrs a) {
+  __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * TILE_STRIDE : 1];
+  __shared__ float red[2 * WAVES];
+  extern __shared__ float bsum[];            // [WAVES][W]
+
+  const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n = blk * BLOCK + tid;
+  const bool valid = n < p.N;
+  const uint32_t H = p.H;
+
+  // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
+  const float L = a.L ? a.L[env] : p.L_default;
+  const EnvConst ec = make_env_const(p, L);
+  const float x_t = a.x_t[env], te = a.te[env];
+  const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
+  const float* __restrict__ un = a.u_nom + (size_t)env * H;
+  const float* __restrict__ up = (a.u_prev ? a.u_prev : a.u_nom) + (size_t)env * H;
+  State st{s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
+
+  float cost = 0.0f, corr = 0.0f;
+  float cosang = cosf(st.th);               // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+
+  auto control_step = [&](uint32_t k, float du) {
+    const float uk = shifted_nominal(p, un, k);
+    float ur = uk + du;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = fminf(fmaxf(ur, p.lo), p.hi);
+    if constexpr (COST == COST_QBGM) {
+      cost += stage_qbgm(p, st.x, cosang, st.w, ur, x_t, te);
+      corr += mppi_correction(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
+    } else if constexpr (COST == COST_DEFAULT) {
+      cost += stage_default(p, st.x, cosang, ur, x_t, te);
+      corr += mppi_correction(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
+    } else {
+      cost += stage_legacy(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
+    }
+    const float u = p.u_max * ur;           // Q2u, cartpole_equations.py:119-127
+    const float uK = ec.kp1 * u;
+    for (uint32_t sub = 0; sub < p.S; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+    cosang = st.c;
+  };
+
+  // ---- rollout over the horizon ----------------------------------------------------------------------------------
+  if constexpr (NOISE == NOISE_DELTA_U) {
+    // The 64 rollouts of a wave are one contiguous span of 64*H floats in delta_u[E,N,H]; a tile of TK time-steps is
+    // fetched with 64-byte row segments (4 rows per wave-instruction), parked in registers while the previous tile is
+    // integrated, then written to LDS and read back one row per lane.
+    const uint32_t row0 = blk * BLOCK + wave * 64;
+    const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * H;
+    float* __restrict__ my_tile = tile + wave * 64 * TILE_STRIDE;
+    float pre[TK];
+    auto gload = [&](uint32_t k0) {
+#pragma unroll
+      for (int i = 0; i < TK; ++i) {
+        const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
+        const uint32_t k = k0 + col;
+        pre[i] = (row0 + row < p.N && k < H) ? src[(size_t)row * H + k] : 0.0f;
+      }
+    };
+    gload(0);
+    for (uint32_t k0 = 0; k0 < H; k0 += TK) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TK; ++i) {
+        const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
+        my_tile[row * TILE_STRIDE + col] = pre[i];
+      }
+      __syncthreads();
+      if (k0 + TK < H) gload(k0 + TK);
+      const uint32_t kend = (H - k0 < (uint32_t)TK) ? (H - k0) : (uint32_t)TK;
+      for (uint32_t kk = 0; kk < kend; ++kk) control_step(k0 + kk, my_tile[lane * TILE_STRIDE + kk]);
+    }
+  } else {
+    const uint32_t nn = valid ? n : 0;
+    const float* __restrict__ kn = (NOISE == NOISE_KNOTS) ? a.noise + ((size_t)env * p.N + nn) * p.P : nullptr;
+    auto knot = [&](uint32_t j) -> float {
+      if constexpr (NOISE == NOISE_KNOTS) return kn[j];
+      else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
+    };
+    float z_lo = knot(0), z_hi = knot(1);
+    uint32_t i = 0, j = 0;
+    for (uint32_t k = 0; k < H; ++k) {
+      control_step(k, interp_knots(z_lo, z_hi, i, p.period));
+      if (++i == p.period) {
+        i = 0; ++j;
+        z_lo = z_hi;
+        if (j + 1 < p.P) z_hi = knot(j + 1);
+      }
+    }
+  }
+
+  // ---- per-rollout total cost ------------------------------------------------------------------------------------
+  float S_total;
+  if constexpr (COST == COST_LEGACY) {
+    S_total = cost + terminal_indicator(p, st.th, st.x, x_t);       // sum_k q + phi  (:197-199)
+  } else {
+    const float term = (COST == COST_DEFAULT) ? terminal_indicator(p, st.th, st.x, x_t) : 0.0f;
+    S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / (float)(H + 1);
+    S_total += corr;
+  }
+  if (a.S_out && valid) a.S_out[(size_t)env * p.N + n] = S_total;
+
+  // ---- block-level soft-min partials (a16) -----------------------------------------------------------------------
+  const float m_w = wave_min(valid ? S_total : INFINITY);
+  if (lane == 0) red[wave] = m_w;
+  __syncthreads();
+  float m_b = red[0];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) m_b = fminf(m_b, red[w]);
+  const float e = valid ? expf((-1.0f / p.LBD) * (S_total - m_b)) : 0.0f;
+  const float a_w = wave_sum(e);
+  if (lane == 0) red[WAVES + wave] = a_w;
+
+  const uint32_t W = a.W;
+  float* __restrict__ my_bsum = bsum + wave * W;
+  if constexpr (NOISE == NOISE_PHILOX) {
+    const uint32_t nn = valid ? n : 0;
+    for (uint32_t j = 0; j < W; ++j) {
+      const float v = wave_sum(e * philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma));
+      if (lane == 0) my_bsum[j] = v;
+    }
+  } else {
+    // transposed pass: lane = column (time-step or knot), loop over the wave's 64 rows, rows read coalesced (L2-hot)
+    const uint32_t row0 = blk * BLOCK + wave * 64;
+    const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * W;
+    const uint32_t rows = (row0 < p.N) ? ((p.N - row0 < 64u) ? p.N - row0 : 64u) : 0u;
+    for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+      const uint32_t col = c0 + lane;
+      float acc = 0.0f;
+      for (uint32_t r = 0; r < rows; ++r) {
+        const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
+        if (col < W) acc = __builtin_fmaf(er, src[(size_t)r * W + col], acc);
+      }
+      if (col < W) my_bsum[col] = acc;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ out = a.partial + ((size_t)env * a.nb + blk) * (2 + W);
+  if (tid == 0) {
+    float a_b = red[WAVES];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) a_b += red[WAVES + w];
+    out[0] = m_b;
+    out[1] = a_b;
+  }
+  for (uint32_t c = tid; c < W; c += BLOCK) {
+    float v = bsum[c];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v += bsum[w * W + c];
+    out[2 + c] = v;
+  }
+}
+
+// One block per env: merge partials, update the nominal sequence.
+template <bool KNOT_SPACE>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const Params p, const float* __restrict__ partial,
+                                                         uint32_t nb, uint32_t W, float* __restrict__ u_nom,
+                                                         float* __restrict__ Q_out) {
+  __shared__ float u_new[CPMPPI_MAX_HORIZON];
+  __shared__ float bz[KNOT_SPACE ? (CPMPPI_MAX_HORIZON + 2) : 1];
+  const uint32_t env = blockIdx.x, tid = threadIdx.x, H = p.H;
+  const float* __restrict__ pe = partial + (size_t)env * nb * (2 + W);
+  float M = INFINITY;
+  for (uint32_t b = 0; b < nb; ++b) M = fminf(M, pe[(size_t)b * (2 + W)]);
+  float a = 0.0f;
+  for (uint32_t b = 0; b < nb; ++b) {
+    const float* pb = pe + (size_t)b * (2 + W);
+    a += pb[1] * expf((-1.0f / p.LBD) * (pb[0] - M));
+  }
+  auto merged = [&](uint32_t c) {
+    float v = 0.0f;
+    for (uint32_t b = 0; b < nb; ++b) {
+      const float* pb = pe + (size_t)b * (2 + W);
+      v = __builtin_fmaf(pb[2 + c], expf((-1.0f / p.LBD) * (pb[0] - M)), v);
+    }
+    return v;
+  };
+  if constexpr (KNOT_SPACE) {
+    for (uint32_t c = tid; c < W; c += BLOCK) bz[c] = merged(c);
+    __syncthreads();
+  }
+  float* __restrict__ un = u_nom + (size_t)env * H;
+  for (uint32_t k = tid; k < H; k += BLOCK) {
+    float bk;
+    if constexpr (KNOT_SPACE) {
+      const uint32_t j = k / p.period, i = k % p.period;
+      bk = bz[j] + (bz[j + 1] - bz[j]) * ((float)i / (float)p.period);
+    } else {
+      bk = merged(k);
+    }
+    float v = shifted_nominal(p, un, k) + bk / a;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) v = fminf(fmaxf(v, p.lo), p.hi);
+    u_new[k] = v;
+  }
+  __syncthreads();                          // every read of the old nominal sequence is done
+  for (uint32_t k = tid; k < H; k += BLOCK) un[k] = u_new[k];
+  if (tid == 0 && Q_out) Q_out[env] = u_new[0];
+}
+
+// a17: knots[E,N,P] and/or delta_u[E,N,H]
+__global__ __launch_bounds__(BLOCK) void sample_kernel(const Params p, uint32_t E, uint64_t seed, uint64_t offset,
+                                                       uint32_t env_offset, const float* __restrict__ knots_in,
+                                                       float* __restrict__ knots_out, float* __restrict__ du_out) {
+  const size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x;     // flat (env, rollout)
+  if (r >= (size_t)E * p.N) return;
+  const uint32_t env = (uint32_t)(r / p.N), n = (uint32_t)(r % p.N);
+  auto knot = [&](uint32_t j) -> float {
+    return knots_in ? knots_in[r * p.P + j] : philox_knot(seed, offset, env_offset + env, n, j, p.sigma);
+  };
+  float z_lo = knot(0);
+  if (knots_out) knots_out[r * p.P] = z_lo;
+  uint32_t k = 0;
+  for (uint32_t j = 0; j + 1 < p.P; ++j) {
+    const float z_hi = knot(j + 1);
+    if (knots_out) knots_out[r * p.P + j + 1] = z_hi;
+    if (du_out)
+      for (uint32_t i = 0; i < p.period && k < p.H; ++i, ++k) du_out[r * p.H + k] = interp_knots(z_lo, z_hi, i, p.period);
+    z_lo = z_hi;
+  }
+}
+
+// predictor seam
+template <bool FAST>
+__global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t B, uint32_t H,
+                                                        const float* __restrict__ s0, const float* __restrict__ Q,
+                                                        const float* __restrict__ Lp, float* __restrict__ traj) {
+  const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (b >= B) return;
+  const EnvConst ec = make_env_const(p, Lp ? Lp[b] : p.L_default);
+  const float* s = s0 + b * 6;
+  State st{s[0], s[1], s[2], s[3], s[4], s[5]};
+  float* o = traj + b * (size_t)(H + 1) * 6;
+  o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
+  for (uint32_t k = 0; k < H; ++k) {
+    const float u = p.u_max * Q[b * H + k];
+    const float uK = ec.kp1 * u;
+    for (uint32_t sub = 0; sub < p.S; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+    o += 6;
+    o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
+  }
+}
+
+// cost seam on materialised trajectories
+__global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, uint32_t B, uint32_t H,
+                                                                const float* __restrict__ traj,
+                                                                const float* __restrict__ inputs, float x_t, float te,
+                                                                const float* __restrict__ u_nom,
+                                                                const float* __restrict__ u_prev,
+                                                                float* __restrict__ stage_out,
+                                                                float* __restrict__ terminal_out,
+                                                                float* __restrict__ total_out) {
+  const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (b >= B) return;
+  const float* t = traj + b * (size_t)(H + 1) * 6;
+  float sum = 0.0f;
+  for (uint32_t k = 0; k < H; ++k, t += 6) {
+    const float in = inputs[b * H + k];
+    const float cosang = cosf(t[0]);
+    float c;
+    if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm(p, t[4], cosang, t[1], in, x_t, te);
+    else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default(p, t[4], cosang, in, x_t, te);
+    else c = stage_legacy(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
+    if (stage_out) stage_out[b * H + k] = c;
+    sum += c;
+  }
+  const float term = (p.cost_id == CPMPPI_COST_QBGM) ? 0.0f : terminal_indicator(p, t[0], t[4], x_t);
+  if (terminal_out) terminal_out[b] = term;
+  if (total_out)
+    total_out[b] = (p.cost_id == CPMPPI_COST_LEGACY || p.horizon_reduce == CPMPPI_REDUCE_SUM)
+                       ? (sum + term) : (sum + term) / (float)(H + 1);
+}
+
+// a16 on given (S, delta_u): one block per env
+__global__ __launch_bounds__(BLOCK) void rwa_kernel(const Params p, const float* __restrict__ S,
+                                                    const float* __restrict__ du, float* __restrict__ out) {
+  __shared__ float red[WAVES];
+  __shared__ float sh_m, sh_a;
+  const uint32_t env = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const float* Se = S + (size_t)env * p.N;
+  const float* de = du + (size_t)env * p.N * p.H;
+  float m = INFINITY;
+  for (uint32_t n = tid; n < p.N; n += BLOCK) m = fminf(m, Se[n]);
+  m = wave_min(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) { float v = red[0]; for (int w = 1; w < WAVES; ++w) v = fminf(v, red[w]); sh_m = v; }
+  __syncthreads();
+  m = sh_m;
+  float a = 0.0f;
+  for (uint32_t n = tid; n < p.N; n += BLOCK) a += expf((-1.0f / p.LBD) * (Se[n] - m));
+  a = wave_sum(a);
+  __syncthreads();
+  if (lane == 0) red[wave] = a;
+  __syncthreads();
+  if (tid == 0) { float v = red[0]; for (int w = 1; w < WAVES; ++w) v += red[w]; sh_a = v; }
+  __syncthreads();
+  a = sh_a;
+  for (uint32_t k = tid; k < p.H; k += BLOCK) {
+    float acc = 0.0f;
+    for (uint32_t n = 0; n < p.N; ++n)
+      acc += expf((-1.0f / p.LBD) * (Se[n] - m)) * de[(size_t)n * p.H + k] / a;
+    out[(size_t)env * p.H + k] = acc;
+  }
+}
+
+// Plant (caller side): advance E simulated cartpoles n_sub simulation steps under held controls.
+__global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E, float* __restrict__ s,
+                                                      const float* __restrict__ Q, const float* __restrict__ Lp,
+                                                      uint32_t n_sub, float dt_sim) {
+  const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
+  if (env >= E) return;
+  const EnvConst ec = make_env_const(p, Lp ? Lp[env] : p.L_default);
+  float* se = s + (size_t)env * 6;
+  State st{se[0], se[1], se[2], se[3], se[4], se[5]};
+  const float u = p.u_max * Q[env];
+  float aDD, xDD;
+  ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);       // CartPole/__init__.py:342-346
+  for (uint32_t i = 0; i < n_sub; ++i) {
+    plant_substep(st, aDD, xDD, dt_sim, p, ec);
+    ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);
+  }
+  se[0] = st.th; se[1] = st.w; se[2] = st.c; se[3] = st.s; se[4] = st.x; se[5] = st.v;
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct cpmppi_handle {
+  cpmppi_config cfg;
+  Params prm;
+  int device;
+  float* workspace;
+  size_t workspace_floats;
+  uint32_t nb;
+  std::string err;
+  // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;          // triples per step: before rollout, between, after finalize
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(cpmppi_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define CPMPPI_HIP(h, call)                                                                        \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail((h), CPMPPI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+uint32_t knot_count(uint32_t H, uint32_t period) { return (H + period - 1) / period + 1; }
+
+void fill_params(const cpmppi_config& c, Params& p) {
+  memset(&p, 0, sizeof(p));
+  p.E = c.E; p.N = c.N; p.H = c.H; p.S = c.S; p.period = c.period;
+  p.P = knot_count(c.H, c.period);
+  p.t_step = (float)((double)c.dt / (double)c.S);      // predictors_customization_v0.py:39
+  p.k = c.k; p.m_cart = c.m_cart; p.m_pole = c.m_pole; p.g = c.g; p.J_fric = c.J_fric; p.M_fric = c.M_fric;
+  p.u_max = c.u_max; p.THL = c.track_half_length; p.L_default = c.L_default;
+  p.cost_id = c.cost_id;
+  memcpy(p.w, c.cost_w, sizeof(p.w));
+  p.R = c.R; p.LBD = c.LBD; p.NU = c.NU; p.cc_weight = c.cc_weight; p.sigma = c.sigma;
+  p.lo = c.action_low; p.hi = c.action_high;
+  p.horizon_reduce = c.horizon_reduce; p.control_mode = c.control_mode; p.shift_mode = c.shift_mode;
+  p.correction_u = c.correction_u;
+}
+
+int ensure_device(cpmppi_handle* h) {
+  int cur = -1;
+  CPMPPI_HIP(h, hipGetDevice(&cur));
+  if (cur != h->device) CPMPPI_HIP(h, hipSetDevice(h->device));
+  return 0;
+}
+
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
+
+template <int COST, bool FAST>
+hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
+                                const StepPtrs& a) {
+  switch (noise) {
+    case CPMPPI_NOISE_DELTA_U:
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U>), grid, dim3(BLOCK), lds, s, p, a); break;
+    case CPMPPI_NOISE_KNOTS:
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS>), grid, dim3(BLOCK), lds, s, p, a); break;
+    default:
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX>), grid, dim3(BLOCK), lds, s, p, a); break;
+  }
+  return hipGetLastError();
+}
+
+template <int COST>
+hipError_t launch_rollout_math(uint32_t math, uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
+                               const StepPtrs& a) {
+  return math == CPMPPI_MATH_FAST ? launch_rollout_noise<COST, true>(noise, grid, lds, s, p, a)
+                                  : launch_rollout_noise<COST, false>(noise, grid, lds, s, p, a);
+}
+
+hipError_t launch_rollout(const cpmppi_handle* h, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
+                          const StepPtrs& a) {
+  switch (h->prm.cost_id) {
+    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, noise, grid, lds, s, h->prm, a);
+    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, noise, grid, lds, s, h->prm, a);
+    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, noise, grid, lds, s, h->prm, a);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cpmppi_version(void) { return "cpmppi 1 gfx950 hip"; }
+
+const char* cpmppi_last_error(const cpmppi_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
+  if (!cfg || !out) return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != CPMPPI_ABI_VERSION)
+    return fail(nullptr, CPMPPI_ERR_ABI, "cpmppi_create: abi_version mismatch");
+  if (cfg->E == 0 || cfg->N == 0 || cfg->H == 0 || cfg->S == 0 || cfg->period == 0 || cfg->H > CPMPPI_MAX_HORIZON)
+    return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: E, N, H, S, period must be > 0 and H <= 1024");
+  if (!(cfg->dt > 0.0f) || !(cfg->LBD > 0.0f) || !(cfg->NU > 0.0f) || !(cfg->L_default > 0.0f))
+    return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: dt, LBD, NU, L_default must be > 0");
+  if (cfg->cost_id > CPMPPI_COST_LEGACY || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
+      cfg->correction_u > 1 || cfg->math_mode > 1)
+    return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: unknown enum value");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return fail(nullptr, CPMPPI_ERR_NO_DEVICE, "cpmppi_create: no HIP device (this library has no CPU fallback)");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return fail(nullptr, CPMPPI_ERR_NO_DEVICE, "cpmppi_create: hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, CPMPPI_ERR_NO_DEVICE,
+                std::string("cpmppi_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  cpmppi_handle* h = new cpmppi_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  fill_params(*cfg, h->prm);
+  h->nb = (cfg->N + BLOCK - 1) / BLOCK;
+  const uint32_t Wmax = cfg->H > h->prm.P ? cfg->H : h->prm.P;
+  h->workspace_floats = (size_t)cfg->E * h->nb * (2 + Wmax);
+  h->workspace = nullptr;
+  int cur = 0;
+  hipError_t e = hipGetDevice(&cur);
+  if (e == hipSuccess) e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&h->workspace, h->workspace_floats * sizeof(float));
+  if (e == hipSuccess) e = hipSetDevice(cur);
+  if (e != hipSuccess) {
+    std::string msg = std::string("cpmppi_create: hipMalloc workspace: ") + hipGetErrorString(e);
+    delete h;
+    return fail(nullptr, CPMPPI_ERR_HIP, msg);
+  }
+  *out = h;
+  return CPMPPI_OK;
+}
+
+void cpmppi_destroy(cpmppi_handle* h) {
+  if (!h) return;
+  if (h->workspace) (void)hipFree(h->workspace);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out) {
+  if (!h || !out) return CPMPPI_ERR_BAD_ARG;
+  *out = h->cfg;
+  return CPMPPI_OK;
+}
+
+int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cost_w, uint32_t n) {
+  if (!h || !cost_w || n > 16 || cost_id > CPMPPI_COST_LEGACY)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_cost_weights: bad argument");
+  h->cfg.cost_id = cost_id;
+  h->prm.cost_id = cost_id;
+  for (uint32_t i = 0; i < n; ++i) h->cfg.cost_w[i] = h->prm.w[i] = cost_w[i];
+  return CPMPPI_OK;
+}
+
+int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, uint32_t env_offset, float* knots_out,
+                  float* delta_u_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || (!knots_out && !delta_u_out))
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: E out of range or no output buffer");
+  if (misaligned(knots_out) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_sample: misaligned");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t rows = (size_t)E * h->cfg.N;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     h->prm, E, seed, offset, env_offset, (const float*)nullptr, knots_out, delta_u_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* delta_u_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !knots || !delta_u_out)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: bad argument");
+  if (misaligned(knots) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_interpolate: misaligned");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t rows = (size_t)E * h->cfg.N;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     h->prm, E, (uint64_t)0, (uint64_t)0, 0u, knots, (float*)nullptr, delta_u_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* L,
+                   float* traj_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (horizon == 0) horizon = h->cfg.H;
+  if (B == 0 || !s0 || !Q || !traj_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_predict: bad argument");
+  if (misaligned(s0) || misaligned(Q) || misaligned(L) || misaligned(traj_out))
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_predict: misaligned pointer");
+  if (int rc = ensure_device(h)) return rc;
+  const dim3 grid((B + BLOCK - 1) / BLOCK);
+  if (h->cfg.math_mode == CPMPPI_MATH_FAST)
+    hipLaunchKernelGGL(predict_kernel<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, h->prm, B, horizon, s0, Q, L,
+                       traj_out);
+  else
+    hipLaunchKernelGGL(predict_kernel<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, h->prm, B, horizon, s0, Q, L,
+                       traj_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* traj, const float* inputs,
+                           float target_position, float target_equilibrium, const float* u_nom, const float* u_prev,
+                           float* stage_out, float* terminal_out, float* total_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (horizon == 0) horizon = h->cfg.H;
+  if (B == 0 || !traj || !inputs || (!stage_out && !terminal_out && !total_out))
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_trajectory_cost: bad argument");
+  if (h->prm.cost_id == CPMPPI_COST_LEGACY && !u_nom)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_trajectory_cost: legacy cost needs u_nom");
+  if (int rc = ensure_device(h)) return rc;
+  hipLaunchKernelGGL(trajectory_cost_kernel, dim3((B + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm,
+                     B, horizon, traj, inputs, target_position, target_equilibrium, u_nom, u_prev, stage_out,
+                     terminal_out, total_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (!a) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: null args");
+  if (a->E == 0 || a->E > h->cfg.E) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: E out of range");
+  if (!a->s0 || !a->u_nom || !a->target_position || !a->target_equilibrium)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: s0, u_nom, target_position, target_equilibrium are required");
+  if (a->noise_kind > CPMPPI_NOISE_PHILOX) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: unknown noise_kind");
+  if (a->noise_kind != CPMPPI_NOISE_PHILOX && !a->noise)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: noise buffer required for this noise_kind");
+  if (misaligned(a->s0) || misaligned(a->u_nom) || misaligned(a->noise) || misaligned(a->S_out) ||
+      misaligned(a->Q_out))
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_step: misaligned pointer");
+  if (int rc = ensure_device(h)) return rc;
+  StepPtrs p;
+  p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
+  p.L = a->L; p.noise = a->noise; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
+  p.nb = h->nb;
+  p.W = (a->noise_kind == CPMPPI_NOISE_DELTA_U) ? h->cfg.H : h->prm.P;
+  p.S_out = a->S_out; p.partial = h->workspace;
+  const hipStream_t s = (hipStream_t)stream;
+  hipEvent_t* ev = nullptr;
+  if (h->profiling) {
+    if (h->ev_used + 3 > h->ev.size()) {
+      for (int i = 0; i < 3; ++i) {
+        hipEvent_t e;
+        CPMPPI_HIP(h, hipEventCreate(&e));
+        h->ev.push_back(e);
+      }
+    }
+    ev = &h->ev[h->ev_used];
+    h->ev_used += 3;
+    CPMPPI_HIP(h, hipEventRecord(ev[0], s));
+  }
+  CPMPPI_HIP(h, launch_rollout(h, a->noise_kind, dim3(a->E * h->nb), (size_t)WAVES * p.W * sizeof(float), s, p));
+  if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
+  if (a->noise_kind == CPMPPI_NOISE_DELTA_U)
+    hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, h->nb,
+                       p.W, a->u_nom, a->Q_out);
+  else
+    hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, h->nb,
+                       p.W, a->u_nom, a->Q_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  if (ev) CPMPPI_HIP(h, hipEventRecord(ev[2], s));
+  return CPMPPI_OK;
+}
+
+int cpmppi_set_profiling(cpmppi_handle* h, int enable) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  h->profiling = enable != 0;
+  h->ev_used = 0;
+  return CPMPPI_OK;
+}
+
+int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, uint32_t max_steps, uint32_t* n_steps) {
+  if (!h || !n_steps) return CPMPPI_ERR_BAD_ARG;
+  const uint32_t n = (uint32_t)(h->ev_used / 3);
+  *n_steps = n;
+  for (uint32_t i = 0; i < n && i < max_steps; ++i) {
+    hipEvent_t* ev = &h->ev[(size_t)i * 3];
+    CPMPPI_HIP(h, hipEventSynchronize(ev[2]));
+    float a = 0.f, b = 0.f;
+    CPMPPI_HIP(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+    CPMPPI_HIP(h, hipEventElapsedTime(&b, ev[1], ev[2]));
+    if (rollout_ms) rollout_ms[i] = a;
+    if (finalize_ms) finalize_ms[i] = b;
+  }
+  h->ev_used = 0;
+  return CPMPPI_OK;
+}
+
+int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S, const float* delta_u, float* out,
+                                   void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || !S || !delta_u || !out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_reward_weighted_average: bad argument");
+  if (int rc = ensure_device(h)) return rc;
+  hipLaunchKernelGGL(rwa_kernel, dim3(E), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, S, delta_u, out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
+                         float dt_sim, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance: bad argument");
+  if (misaligned(s) || misaligned(Q) || misaligned(L)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance: misaligned");
+  if (int rc = ensure_device(h)) return rc;
+  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
+                     L, n_substeps, dt_sim);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+/*
+ * cpmppi.h — C ABI of libcpmppi.so: the MI355X-native (gfx950) MPPI rollout hot path for CartPoleSimulation.
+ *
+ * One fused HIP path replaces three nested Python plugin seams of the reference (paths relative to the
+ * reference checkout):
+ *
+ *   predictor seam   PredictorWrapper.predict_core(s[N,6], Q[N,H,1]) -> [N,H+1,6]
+ *                    call sites: Control_Toolkit_ASF/Controllers/controller_mppi_cartpole.py:191,
+ *                    SI_Toolkit_ASF/ToolkitCustomization/Modules/ODE_module.py:46-50; per-step hook
+ *                    SI_Toolkit_ASF/ToolkitCustomization/predictors_customization_v0.py:41-55
+ *                    -> cpmppi_predict()
+ *   cost seam        cost_function.get_stage_cost / get_terminal_cost / get_trajectory_cost
+ *                    Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad_minimal.py:95-126,
+ *                    .../default.py:41-88, Cost_Functions/GymlikeCartPole/cost_function_gym.py:12-21
+ *                    -> cpmppi_trajectory_cost()
+ *   optimizer seam   optimizer_mppi.step(s, time) (Control_Toolkit submodule, absent from the reference mount;
+ *                    in-tree statement of the same algorithm: controller_mppi_cartpole.py:454-569 with
+ *                    trajectory_rollouts :164-224, q :227-275, phi :278-303, reward_weighted_average :306-321,
+ *                    initialize_perturbations :392-452)
+ *                    -> cpmppi_sample() + cpmppi_step()
+ *
+ * Conventions
+ *   - every array argument is a caller-owned DEVICE pointer to contiguous float32 (e.g. torch.Tensor.data_ptr() of a
+ *     ROCm tensor); the library owns only the handle and its small reduction workspace;
+ *   - all work is enqueued on the hipStream_t passed as `stream` (NULL = default stream); no hidden synchronisation,
+ *     no allocation inside the launch functions (they are hipGraph-capturable);
+ *   - return value 0 = success, negative = cpmppi_status; the message of the last failure of a handle is
+ *     available from cpmppi_last_error();
+ *   - a handle is not thread-safe: one handle per (device, stream);
+ *   - there is NO CPU fallback: without a gfx950 device cpmppi_create() fails with CPMPPI_ERR_NO_DEVICE.
+ *
+ * State layout (CartPole/state_utilities.py:5-23): [angle, angleD, angle_cos, angle_sin, position, positionD].
+ */
+#ifndef CPMPPI_H
+#define CPMPPI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPMPPI_ABI_VERSION 1u
+#define CPMPPI_STATE_DIM 6u
+#define CPMPPI_MAX_HORIZON 1024u
+
+typedef enum {
+  CPMPPI_OK = 0,
+  CPMPPI_ERR_BAD_ARG = -1,      /* null pointer, bad shape, unknown enum value */
+  CPMPPI_ERR_ABI = -2,          /* abi_version mismatch */
+  CPMPPI_ERR_NO_DEVICE = -3,    /* no HIP device / not a gfx950 part */
+  CPMPPI_ERR_HIP = -4,          /* a HIP runtime call failed (text in cpmppi_last_error) */
+  CPMPPI_ERR_ALIGN = -5         /* pointer not 4-byte aligned */
+} cpmppi_status;
+
+/* cost_id: which in-tree cost formulation the rollout kernel evaluates. */
+enum {
+  CPMPPI_COST_QBGM = 0,    /* quadratic_boundary_grad_minimal.py:64-126 ; cost_w = {dd_quadratic_weight, db_weight,
+                              ep_weight, ekp_weight, cc_weight, R, permissible_track_fraction} */
+  CPMPPI_COST_DEFAULT = 1, /* default.py:23-88 ; cost_w = {dd_weight, ep_weight, cc_weight, R} */
+  CPMPPI_COST_LEGACY = 2   /* controller_mppi_cartpole.py:119-161,227-303 (q + phi); cost_w = {dd_weight, ep_weight,
+                              ekp_weight, ekc_weight, cc_weight, ccrc_weight}; the MPPI correction term is part of q */
+};
+
+enum { CPMPPI_REDUCE_SUM = 0, CPMPPI_REDUCE_MEAN = 1 };            /* horizon aggregation of the plugin costs */
+enum { CPMPPI_CONTROL_CLIP = 0, CPMPPI_CONTROL_PENALISE = 1 };     /* clip u_run & u_nom | legacy 1e5 penalty */
+enum { CPMPPI_SHIFT_REPEAT_LAST = 0, CPMPPI_SHIFT_APPEND_ZERO = 1, CPMPPI_SHIFT_NONE = 2 };
+enum { CPMPPI_CORRECTION_U_RUN = 0, CPMPPI_CORRECTION_U_NOM = 1 }; /* which u enters the MPPI correction term */
+enum { CPMPPI_MATH_PRECISE = 0,  /* IEEE divide, libm-grade sincos, no FMA contraction: closest to numpy float32 */
+       CPMPPI_MATH_FAST = 1 };   /* same float32 formulas with FMA contraction, reciprocal+Newton divide (<=1 ulp),
+                                    range-reduced polynomial sincos (<=1.5 ulp on [-pi,pi]) */
+enum { CPMPPI_NOISE_DELTA_U = 0, /* noise = delta_u[E,N,H]  (reference layout, rollout-major)              */
+       CPMPPI_NOISE_KNOTS = 1,   /* noise = knots[E,N,P], P = ceil(H/period)+1; interpolated in-kernel       */
+       CPMPPI_NOISE_PHILOX = 2 };/* knots generated in-kernel from (seed, offset): no perturbation buffer   */
+
+typedef struct {
+  uint32_t abi_version;          /* CPMPPI_ABI_VERSION */
+  uint32_t E;                    /* capacity: independent MPPI problem instances (envs) per call */
+  uint32_t N;                    /* rollouts (samples) per env          config_optimizers.yml:91 num_rollouts */
+  uint32_t H;                    /* horizon in control steps            config_optimizers.yml:89 mpc_horizon  */
+  uint32_t S;                    /* Euler substeps per control step     config_predictors.yml:21 intermediate_steps */
+  float dt;                      /* control period; t_step = dt / S     config_optimizers.yml:90 mpc_timestep */
+  /* physics — cartpole_physical_parameters.yml:6-17,34,42 rounded to float32 (cartpole_parameters.py:27-31) */
+  float k, m_cart, m_pole, g, J_fric, M_fric, u_max, track_half_length;
+  float L_default;               /* used where the per-env L pointer is NULL */
+  /* cost */
+  uint32_t cost_id;
+  float cost_w[16];
+  /* MPPI — config_optimizers.yml:92-97 */
+  float R, LBD, NU, cc_weight;
+  float sigma;                   /* knot std-dev = SQRTRHOINV / sqrt(dt) */
+  uint32_t period;               /* period_interpolation_inducing_points */
+  float action_low, action_high; /* control_limits */
+  uint32_t horizon_reduce;       /* CPMPPI_REDUCE_*      (unpinned upstream choice) */
+  uint32_t control_mode;         /* CPMPPI_CONTROL_*     (u3) */
+  uint32_t shift_mode;           /* CPMPPI_SHIFT_*       (u2) */
+  uint32_t correction_u;         /* CPMPPI_CORRECTION_*  */
+  uint32_t math_mode;            /* CPMPPI_MATH_* */
+} cpmppi_config;
+
+typedef struct cpmppi_handle cpmppi_handle;
+
+/* One optimizer step for `E` envs (E <= config.E).  All pointers are device pointers. */
+typedef struct {
+  uint32_t E;                       /* active envs in this call */
+  const float* s0;                  /* [E,6]  current state of each env */
+  float* u_nom;                     /* [E,H]  in: nominal sequence as left by the previous step (the kernel applies
+                                              config.shift_mode itself); out: updated nominal sequence */
+  const float* u_prev;              /* [E,H]  legacy control-change-rate term only; NULL = use u_nom as found on entry
+                                              (controller_mppi_cartpole.py:558) */
+  const float* target_position;     /* [E] */
+  const float* target_equilibrium;  /* [E] */
+  const float* L;                   /* [E] pole length per env, or NULL = config.L_default */
+  uint32_t noise_kind;              /* CPMPPI_NOISE_* */
+  const float* noise;               /* delta_u[E,N,H] or knots[E,N,P]; ignored for CPMPPI_NOISE_PHILOX */
+  uint64_t seed;                    /* CPMPPI_NOISE_PHILOX: key */
+  uint64_t offset;                  /* CPMPPI_NOISE_PHILOX: step counter (fresh noise per step) */
+  uint32_t env_offset;              /* CPMPPI_NOISE_PHILOX: global index of env 0 (rank * E_local when sharded) */
+  float* Q_out;                     /* [E]    first element of the updated nominal sequence */
+  float* S_out;                     /* [E,N]  per-rollout total cost, or NULL */
+} cpmppi_step_args;
+
+int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out);
+void cpmppi_destroy(cpmppi_handle* h);
+const char* cpmppi_last_error(const cpmppi_handle* h);  /* h may be NULL: error of the last failed cpmppi_create */
+int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out);
+
+/* Mutable per-call knobs (GUI sliders / attribute updates in the reference mutate these between steps). */
+int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cost_w, uint32_t n);
+
+/* a17 — device sampler: knots ~ sigma * N(0,1) from Philox4x32-10 keyed by (seed), counter (rollout, env, knot pair,
+ * offset); writes knots[E,N,P] and/or the interpolated delta_u[E,N,H] (either pointer may be NULL).
+ * Interpolation follows controller_mppi_cartpole.py:434-446. */
+int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, uint32_t env_offset,
+                  float* knots_out, float* delta_u_out, void* stream);
+
+/* Interpolate caller-provided knots[E,N,P] (e.g. drawn with numpy SFC64 for bit-identical parity runs) to
+ * delta_u[E,N,H]. */
+int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* delta_u_out, void* stream);
+
+/* Predictor seam (a9-a11): B independent rollouts.  s0[B,6], Q[B,H] (dimensionless control in [-1,1]),
+ * L[B] or NULL -> traj[B,H+1,6] with traj[:,0]=s0.  horizon may be < config.H (0 = config.H). */
+int cpmppi_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* L,
+                   float* traj_out, void* stream);
+
+/* Cost seam (a12-a14): trajectories traj[B,H+1,6], inputs[B,H] -> stage_out[B,H] (may be NULL), terminal_out[B]
+ * (may be NULL), total_out[B] (may be NULL; sum or mean per config.horizon_reduce, plugin costs only).
+ * target_position / target_equilibrium are host scalars here (the plugin reads them from variable_parameters).
+ * Legacy cost additionally needs u_nom[H], u_prev[H] (device) and interprets `inputs` as delta_u. */
+int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* traj, const float* inputs,
+                           float target_position, float target_equilibrium, const float* u_nom, const float* u_prev,
+                           float* stage_out, float* terminal_out, float* total_out, void* stream);
+
+/* Fused hot path: rollout (a3-a11) + cost (a12-a15) + importance-weighted update (a16) + shift/clip (a18). */
+int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* args, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (off by default).  While enabled, every
+ * cpmppi_step records three events (before the rollout kernel, between the kernels, after the finalize kernel).
+ * cpmppi_get_profile synchronises on them, returns the elapsed milliseconds of the steps recorded since the last
+ * call (at most max_steps entries are written; *n_steps receives the number recorded) and resets the recorder. */
+int cpmppi_set_profiling(cpmppi_handle* h, int enable);
+int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, uint32_t max_steps, uint32_t* n_steps);
+
+/* a16 alone: S[E,N], delta_u[E,N,H] -> weighted average [E,H] (controller_mppi_cartpole.py:306-321). */
+int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S, const float* delta_u, float* out,
+                                   void* stream);
+
+/* Plant (the CALLER of the hot path; SURVEY.md §8b harness row / §8f N1): advance E simulated cartpoles by
+ * n_substeps simulation steps of dt_sim under the held controls Q[E] — Euler-Cromer + edge bounce + cos/sin + wrap as
+ * CartPole/__init__.py:283-324 (cartpole_equations.py:367-378, :341-347).  s[E,6] is updated in place. */
+int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
+                         float dt_sim, void* stream);
+
+/* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */
+const char* cpmppi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPMPPI_H */

@@ -1,0 +1,273 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors and the numpy oracle.
+
+Tolerances (BASELINE.json north_star "within 1e-4"):
+  * states            |d| <= 1e-4 + 1e-4*|x|, evaluated on rollouts that stay clear of the two discontinuities
+                      (edge bounce, +-pi wrap); at least 97 % of all rollouts must be inside the band, bounced or not
+  * controls (u_new, Q, soft-min weights)   1e-4 absolute
+  * costs             1e-4 relative (+ the same state-induced slack scaled by the 1e4-magnitude penalty weights)
+"""
+import os
+
+import numpy as np
+import pytest
+from numpy.random import SFC64, Generator
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402  (the checker)
+
+f32 = np.float32
+MATH_MODES = ["precise", "fast"]
+
+
+def engine(E, N, H, **kw):
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    return MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, **kw))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def state_ok(out, ref, scale=1.0):
+    return np.abs(out - ref) <= scale * (1e-4 + 1e-4 * np.abs(ref))
+
+
+def regen_delta_u(seed, N, H, stdev):
+    rng = Generator(SFC64(int(seed)))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    kn = O.sample_knots(rng, N, H, np.float64(stdev))
+    return kn, O.interpolate_knots(kn, H)
+
+
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+def test_predict_single_step_kats(golden_dir, math_mode):
+    g = load(golden_dir, "kat_step.npz")
+    eng = engine(1, 256, 1, math_mode=math_mode)
+    s, Q, L = g["s_in"], g["Q_in"], g["L_in"]
+    out1 = eng.predict(s, Q[:, None], L=L)[:, 1].cpu().numpy()
+    for ref in (g["step1_A"], g["step1_B"]):
+        ok = state_ok(out1, ref, 0.1).all(axis=1)          # one control step: a tenth of the band
+        assert ok.mean() >= 0.97, f"{(~ok).sum()} of {len(ok)} rows off"
+    eng2 = engine(1, 256, 2, math_mode=math_mode)
+    out2 = eng2.predict(s, np.stack([Q, Q], 1), L=L)[:, 2].cpu().numpy()
+    ok = state_ok(out2, g["step2_A"], 0.2).all(axis=1)
+    assert ok.mean() >= 0.97
+    # one substep: run with dt = 0.002, S = 1 through a dedicated engine
+    eng3 = engine(1, 256, 1, math_mode=math_mode, mpc_timestep=0.002, intermediate_steps=1)
+    sub = eng3.predict(s, Q[:, None], L=L)[:, 1].cpu().numpy()
+    assert np.abs(sub - g["sub1_A"]).max() < 2e-5          # includes the bounce and wrap rows
+
+
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+@pytest.mark.parametrize("name", ["upright", "hanging", "near_edge", "fast", "random0", "random1", "random2", "random3"])
+def test_c2_rollouts_costs_update(golden_dir, name, math_mode):
+    g = load(golden_dir, "rollouts_c2.npz")
+    N, H = int(g["N"]), int(g["H"])
+    kn, du = regen_delta_u(g[f"{name}/seed"], N, H, g["stdev"])
+    s0, u_nom, u_prev, target = g[f"{name}/s0"], g[f"{name}/u_nom"], g[f"{name}/u_prev"], float(g[f"{name}/target"])
+    THL = float(O.DEFAULT_PARAMS.TrackHalfLength)
+
+    # ---- predictor seam: trajectories
+    eng = engine(1, N, H, math_mode=math_mode, shift_mode="none", control_mode="penalise", correction_u="u_nom")
+    u_run = (u_nom + du).astype(f32)
+    traj = eng.predict(s0, u_run).cpu().numpy()
+    head, final = g[f"{name}/raw/traj_head"], g[f"{name}/raw/final"]
+    ref_traj = O.predict_core(s0, u_run)                                  # oracle, full tensor
+    # rollouts that never come near the edge and whose angle never sits near +-pi are "smooth"
+    near_edge = (np.abs(ref_traj[:, :, O.POSITION_IDX]) > THL - 2e-3).any(axis=1)
+    near_wrap = (np.abs(np.abs(ref_traj[:, :, O.ANGLE_IDX]) - np.pi) < 2e-3).any(axis=1)
+    smooth = ~(near_edge | near_wrap)
+    okA = state_ok(traj[:, -1], final).all(axis=1)
+    okB = state_ok(traj[:, -1], g[f"{name}/raw/final_B"]).all(axis=1)
+    ok = okA | okB                                                        # within the band of either reference mode
+    assert ok.mean() >= 0.97, f"{name}: only {ok.mean():.3f} of rollouts within 1e-4 band"
+    if smooth.sum() > 16:
+        assert ok[smooth].mean() >= 0.99
+    assert state_ok(traj[:head.shape[0], :H // 2], head[:, :H // 2]).all(axis=(1, 2)).mean() >= 0.9
+
+    # ---- cost seam on the ORACLE's trajectories (isolates the cost arithmetic from integration differences)
+    for cost_name, key in (("quadratic_boundary_grad_minimal", "S_qbgm"), ("default", "S_default")):
+        eng.set_cost(cost_name)
+        _, _, total = eng.trajectory_cost(ref_traj, u_run, target, 1.0)
+        np.testing.assert_allclose(total.cpu().numpy(), g[f"{name}/raw/{key}"], rtol=1e-4)
+    eng.set_cost("quadratic_boundary_grad_minimal")
+    stage, _, _ = eng.trajectory_cost(ref_traj[:32], u_run[:32], target, 1.0, want=("stage",))
+    np.testing.assert_allclose(stage.cpu().numpy(), g[f"{name}/raw/stage_qbgm_head"], rtol=1e-4, atol=1e-5)
+
+    # ---- fused step, plugin cost, both input conventions; compare S and the soft-min update
+    for tag, control_mode in (("raw", "penalise"), ("clip", "clip")):
+        e2 = engine(1, N, H, math_mode=math_mode, shift_mode="none", control_mode=control_mode, correction_u="u_nom",
+                    cc_weight=0.0)       # cc_weight 0: S is the plugin trajectory cost alone (what the golden holds)
+        un = e2.tensor(u_nom[None].copy())
+        S = e2.empty(1, N)
+        e2.step(s0[None], un, target, 1.0, delta_u=du[None], S_out=S)
+        S = S.cpu().numpy()[0]
+        S_ref = g[f"{name}/{tag}/S_qbgm"]
+        rel = np.abs(S - S_ref) / np.abs(S_ref)
+        assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.97, f"{name}/{tag}: median rel {np.median(rel):.2e}"
+        u_new_ref = u_nom + O.reward_weighted_average(S_ref, du)
+        if control_mode == "clip":
+            u_new_ref = np.clip(u_new_ref, -1, 1)
+        np.testing.assert_allclose(un.cpu().numpy()[0], u_new_ref, atol=1e-4)
+
+    # ---- fused step, legacy cost (q + phi + 1e5 penalty + ccrc) against the reference's own S and u
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    e3 = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H, shift_mode="none", math_mode=math_mode))
+    un = e3.tensor(u_nom[None].copy())
+    S = e3.empty(1, N)
+    e3.step(s0[None], un, target, 1.0, delta_u=du[None], u_prev=u_prev[None], S_out=S)
+    S, S_ref = S.cpu().numpy()[0], g[f"{name}/S_legacy"]
+    rel = np.abs(S - S_ref) / np.abs(S_ref)
+    assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.95
+    np.testing.assert_allclose(un.cpu().numpy()[0], g[f"{name}/u_new_legacy"], atol=1e-4)
+
+
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+def test_noise_sources_agree(math_mode):
+    """delta_u buffer == in-kernel interpolation of the same knots == in-kernel Philox of the same (seed, offset)."""
+    E, N, H = 3, 700, 35
+    eng = engine(E, N, H, math_mode=math_mode)
+    rng = Generator(SFC64(7))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-5, 5), rng.uniform(-0.15, 0.15),
+                                           rng.uniform(-0.3, 0.3)) for _ in range(E)])
+    tp = rng.uniform(-0.1, 0.1, E).astype(f32)
+    te = np.ones(E, dtype=f32)
+    Lv = rng.uniform(0.2, 0.5, E).astype(f32)
+    u0 = (0.2 * rng.standard_normal((E, H))).astype(f32)
+    kn, du = eng.sample(seed=1234, offset=5, env_offset=11, knots=True, delta_u=True)
+    # device interpolation == oracle interpolation (bit-exact: float64 slope, float32 store)
+    assert np.array_equal(du.cpu().numpy().reshape(E * N, H), O.interpolate_knots(kn.cpu().numpy().reshape(E * N, -1), H))
+    assert np.array_equal(eng.interpolate(kn).cpu().numpy(), du.cpu().numpy())
+    outs = []
+    for kw in (dict(delta_u=du), dict(knots=kn), dict(seed=1234, offset=5, env_offset=11)):
+        un = eng.tensor(u0.copy())
+        S = eng.empty(E, N)
+        Q, _ = eng.step(s0, un, tp, te, L=Lv, S_out=S, **kw)
+        outs.append((un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy()))
+    for o in outs[1:]:
+        assert np.array_equal(o[1], outs[0][1])                    # identical perturbations -> identical costs
+        np.testing.assert_allclose(o[0], outs[0][0], atol=2e-6)    # knot-space vs delta_u-space reduction order
+        np.testing.assert_allclose(o[2], outs[0][2], atol=2e-6)
+    # Philox knots are ~ sigma * N(0,1)
+    z = kn.cpu().numpy().ravel() / eng.mppi.sigma
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 3).mean()) < 0.05
+    assert abs((z ** 4).mean() - 3) < 0.15
+    # different offsets / envs give different streams
+    kn2, _ = eng.sample(seed=1234, offset=6, env_offset=11)
+    assert not np.array_equal(kn2.cpu().numpy(), kn.cpu().numpy())
+
+
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+@pytest.mark.parametrize("flags", [
+    dict(),                                                          # Control_Toolkit-flavoured defaults
+    dict(horizon_reduce="mean"),
+    dict(shift_mode="append_zero", correction_u="u_nom"),
+    dict(cost_function_specification="default", control_mode="penalise"),
+])
+def test_fused_step_vs_oracle_multi_env(math_mode, flags):
+    """Full optimizer step (shift, clip, cost, correction, soft-min update) for several envs with per-env L / targets."""
+    E, N, H = 4, 1000, 30            # N not a multiple of the 256-thread block: ragged last block
+    eng = engine(E, N, H, math_mode=math_mode, **flags)
+    rng = Generator(SFC64(21))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-0.6, 0.6), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1),
+                                           rng.uniform(-0.2, 0.2)) for _ in range(E)])
+    tp = rng.uniform(-0.08, 0.08, E).astype(f32)
+    te = np.ones(E, dtype=f32)
+    Lv = rng.uniform(0.25, 0.45, E).astype(f32)
+    u0 = (0.3 * rng.standard_normal((E, H))).astype(f32)
+    du = np.stack([O.sample_delta_u(rng, N, H, np.float64(eng.mppi.sigma)) for _ in range(E)])
+    un = eng.tensor(u0.copy())
+    S = eng.empty(E, N)
+    Q, _ = eng.step(s0, un, tp, te, L=Lv, delta_u=du, S_out=S)
+    un, S, Q = un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy()
+    m = eng.mppi
+    cid = {"quadratic_boundary_grad_minimal": O.COST_QBGM, "default": O.COST_DEFAULT}[m.cost_function_specification]
+    cfg = O.MPPIConfig(N=N, H=H, cc_weight=m.cc_weight, R=m.R, LBD=m.LBD, NU=m.NU, cost_id=cid,
+                       horizon_reduce=m.horizon_reduce, control_mode=m.control_mode, shift_mode=m.shift_mode,
+                       correction_u=m.correction_u)
+    for e in range(E):
+        ref = O.mppi_step(s0[e], u0[e], du[e], tp[e], te[e], cfg, L=Lv[e])
+        rel = np.abs(S[e] - ref["S"]) / np.abs(ref["S"])
+        assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.97, f"env {e}: median rel {np.median(rel):.2e}"
+        np.testing.assert_allclose(un[e], ref["u_new"], atol=1e-4)
+        np.testing.assert_allclose(Q[e], ref["Q"], atol=1e-4)
+
+
+def test_reward_weighted_average_seam(golden_dir):
+    h = load(golden_dir, "sampler_rwa.npz")
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    for lbd, key in ((100.0, "rwa_lbd100"), (1.0, "rwa_lbd1")):
+        eng = MPPIEngine(1, MPPIConfig(num_rollouts=4, mpc_horizon=3, LBD=lbd))
+        out = eng.reward_weighted_average(h["S_kat"], h["du_kat"]).cpu().numpy()[0]
+        np.testing.assert_allclose(out, h[key], atol=1e-6)
+
+
+def test_edge_cases():
+    """N=1, H=1, H not a multiple of the period or the LDS tile, N below one wave."""
+    for (N, H) in ((1, 1), (5, 7), (63, 17), (257, 33)):
+        eng = engine(2, N, H)
+        rng = Generator(SFC64(N * 100 + H))
+        du = (0.2 * rng.standard_normal((2, N, H))).astype(f32)
+        s0 = np.stack([O.create_cartpole_state(0.1, 0.2, 0.01, 0.0), O.create_cartpole_state(-2.5, 1.0, -0.1, 0.1)])
+        un = eng.zeros(2, H)
+        S = eng.empty(2, N)
+        Q, _ = eng.step(s0, un, 0.0, 1.0, delta_u=du, S_out=S)
+        cfg = O.MPPIConfig(N=N, H=H)
+        for e in range(2):
+            ref = O.mppi_step(s0[e], np.zeros(H, f32), du[e], f32(0), f32(1), cfg)
+            np.testing.assert_allclose(S.cpu().numpy()[e], ref["S"], rtol=2e-4)
+            np.testing.assert_allclose(un.cpu().numpy()[e], ref["u_new"], atol=1e-4)
+
+
+def test_error_behaviour():
+    from cartpolesimulation_amd import _lib as L
+    eng = engine(2, 64, 10)
+    un = eng.zeros(3, 10)                                   # E larger than the handle's capacity
+    with pytest.raises(ValueError):
+        eng.step(np.zeros((3, 6), f32), un, 0.0, 1.0, seed=1)
+    with pytest.raises(ValueError):
+        eng.step(np.zeros((2, 6), f32), eng.zeros(2, 10), 0.0, 1.0)          # no noise source
+    import ctypes as C
+    a = L.cpmppi_step_args()
+    a.E = 5
+    rc = eng.lib.cpmppi_step(eng._h, C.byref(a), None)
+    assert rc == -1 and b"E out of range" in eng.lib.cpmppi_last_error(eng._h)
+    with pytest.raises(ValueError):
+        engine(1, 8, 8, horizon_reduce="median")
+
+
+def test_closed_loop_c1_plumbing(golden_dir):
+    """BASELINE config C1 (256 x 20, legacy MPPI, closed loop with the plant) on the HIP path: SFC64 knots from the
+    host (identical noise seeds), rollouts/cost/update and the plant on the GPU."""
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    g = load(golden_dir, "closed_loop_c1.npz")
+    N, H = int(g["N"]), int(g["H"])
+    cfg = legacy_mppi_config(num_rollouts=N, mpc_horizon=H, math_mode="precise")
+    eng = MPPIEngine(1, cfg)
+    rng = Generator(SFC64(int(g["seed"])))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    s = eng.tensor(g["s"][0][None].copy())
+    un = eng.zeros(1, H)
+    for c in range(g["s"].shape[0]):
+        s_host = s.cpu().numpy()[0]
+        if c < 10:
+            np.testing.assert_allclose(s_host, g["s"][c], atol=2e-4, rtol=1e-4)
+        kn = O.sample_knots(rng, N, H, np.float64(g["stdev"]))
+        Qd, _ = eng.step(s, un, float(g["target"]), 1.0, knots=kn[None])
+        Q = f32(Qd.cpu().numpy()[0] * (1 + float(g["p_Q"]) * rng.uniform(-1.0, 1.0)))     # :553
+        Q = np.clip(Q, f32(-1), f32(1))
+        if c < 10:
+            np.testing.assert_allclose(Q, g["Q"][c], atol=1e-4)
+            np.testing.assert_allclose(un.cpu().numpy()[0], g["u_updated"][c], atol=1e-4)
+        eng.plant_advance(s, np.array([Q], dtype=f32), n_substeps=10, dt_sim=0.002)
+    s_host = s.cpu().numpy()[0]
+    assert abs(s_host[O.ANGLE_IDX]) < 0.2 and abs(s_host[O.POSITION_IDX]) < 0.198
