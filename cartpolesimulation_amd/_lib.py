@@ -57,6 +57,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  cartpolesimulation_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7) but its libraries ask for it by file name, so
+    # if the system runtime were loaded first the process would end up with two HIP runtimes.  Importing torch first
+    # makes libcpmppi.so (NEEDED libamdhip64.so.7) bind to the runtime torch already loaded: one runtime, shared
+    # streams and device pointers.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
     lib.cpmppi_create.argtypes = [C.POINTER(cpmppi_config), C.c_int, C.POINTER(vp)]

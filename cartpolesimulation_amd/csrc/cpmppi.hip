@@ -27,7 +27,13 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
-constexpr int TK = 16;                       // time-steps per LDS perturbation tile
+#ifndef CPMPPI_TK
+#define CPMPPI_TK 16
+#endif
+#ifndef CPMPPI_MIN_WAVES
+#define CPMPPI_MIN_WAVES 1
+#endif
+constexpr int TK = CPMPPI_TK;                // time-steps per LDS perturbation tile
 constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
 
 struct StepPtrs {
@@ -53,8 +59,9 @@ __device__ __forceinline__ float shifted_nominal(const Params& p, const float* _
   return (p.shift_mode == CPMPPI_SHIFT_REPEAT_LAST) ? un[p.H - 1] : 0.0f;
 }
 
-template <int COST, bool FAST, int NOISE>
-__global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const Params p, const StepPtrs a) {
+// S_CT: compile-time number of Euler substeps (10 = the reference's intermediate_steps; 0 = read p.S at run time).
+template <int COST, bool FAST, int NOISE, int S_CT>
+__global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
   __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * TILE_STRIDE : 1];
   __shared__ float red[2 * WAVES];
   extern __shared__ float bsum[];            // [WAVES][W]
@@ -92,7 +99,15 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const Params p, con
     }
     const float u = p.u_max * ur;           // Q2u, cartpole_equations.py:119-127
     const float uK = ec.kp1 * u;
-    for (uint32_t sub = 0; sub < p.S; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+#ifndef CPMPPI_UNROLL_S
+#define CPMPPI_UNROLL_S 1
+#endif
+    if constexpr (S_CT > 0) {
+#pragma unroll CPMPPI_UNROLL_S
+      for (int sub = 0; sub < S_CT; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+    } else {
+      for (uint32_t sub = 0; sub < p.S; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+    }
     cosang = st.c;
   };
 
@@ -436,16 +451,16 @@ int ensure_device(cpmppi_handle* h) {
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
-template <int COST, bool FAST>
+template <int COST, bool FAST, int S_CT>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                 const StepPtrs& a) {
   switch (noise) {
     case CPMPPI_NOISE_DELTA_U:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, S_CT>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_KNOTS:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, S_CT>), grid, dim3(BLOCK), lds, s, p, a); break;
     default:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, S_CT>), grid, dim3(BLOCK), lds, s, p, a); break;
   }
   return hipGetLastError();
 }
@@ -453,8 +468,10 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                const StepPtrs& a) {
-  return math == CPMPPI_MATH_FAST ? launch_rollout_noise<COST, true>(noise, grid, lds, s, p, a)
-                                  : launch_rollout_noise<COST, false>(noise, grid, lds, s, p, a);
+  if (math == CPMPPI_MATH_FAST)
+    return p.S == 10 ? launch_rollout_noise<COST, true, 10>(noise, grid, lds, s, p, a)
+                     : launch_rollout_noise<COST, true, 0>(noise, grid, lds, s, p, a);
+  return launch_rollout_noise<COST, false, 0>(noise, grid, lds, s, p, a);
 }
 
 hipError_t launch_rollout(const cpmppi_handle* h, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,

@@ -88,15 +88,6 @@ __device__ __forceinline__ void sincos_pi(float x, float& sn, float& cs) {
   cs = __uint_as_float(__float_as_uint(c0) ^ cflip);
 }
 
-// Wrap to [-pi, pi] exactly as fmod(theta, 2pi) followed by the two comparisons of the reference.
-// For |theta| < 2pi the fmod is the identity and for 2pi <= |theta| < 4pi it is one exact subtraction, so the hot
-// path is two compares and one add; anything larger (|angleD| > 1500 rad/s) takes the rare fmodf branch.
-__device__ __forceinline__ float wrap_angle(float th) {
-  if (__builtin_expect(__builtin_fabsf(th) >= TWO_PI_F, 0)) th = fmodf(th, TWO_PI_F);
-  const float off = (th > PI_F) ? -TWO_PI_F : ((th < -PI_F) ? TWO_PI_F : 0.0f);
-  return th + off;
-}
-
 struct State {
   float th, w, c, s, x, v;   // angle, angleD, angle_cos, angle_sin, position, positionD
 };
@@ -167,6 +158,10 @@ __device__ __forceinline__ void plant_substep(State& st, float aDD, float xDD, f
   st.w = w1; st.x = x1; st.v = v1;
 }
 
+#ifndef CPMPPI_RARE_MODE
+#define CPMPPI_RARE_MODE 1     // 0: per-lane divergent branches (compiler exec masking)  1: wave-uniform test, inline cold path
+#endif
+
 template <>
 __device__ __forceinline__ void substep<true>(State& st, float /*u*/, float uK, float t, const Params& p,
                                               const EnvConst& e) {
@@ -184,6 +179,7 @@ __device__ __forceinline__ void substep<true>(State& st, float /*u*/, float uK, 
   float w1 = __builtin_fmaf(aDD, t, w);
   float x1 = __builtin_fmaf(v, t, st.x);
   float v1 = __builtin_fmaf(xDD, t, v);
+#if CPMPPI_RARE_MODE == 0
   if (__builtin_expect(__builtin_fabsf(x1) >= p.THL, 0)) {
     const float cb = cosf(th1);
     w1 = __builtin_fmaf(-(2.0f * (v1 * cb)), e.inv_halfL, w1);
@@ -191,7 +187,25 @@ __device__ __forceinline__ void substep<true>(State& st, float /*u*/, float uK, 
     v1 = -v1;
     x1 = __builtin_fmaf(v1, t, x1);
   }
-  th1 = wrap_angle(th1);
+  if (__builtin_expect(__builtin_fabsf(th1) >= TWO_PI_F, 0)) th1 = fmodf(th1, TWO_PI_F);
+#else
+  // One wave-uniform test for both rare events (edge bounce, cartpole_equations.py:341-347; an angle beyond one
+  // 2*pi wrap, |angleD| > 1500 rad/s): the hot instruction stream carries no exec-mask bookkeeping.
+  const bool rare = (__builtin_fabsf(x1) >= p.THL) | (__builtin_fabsf(th1) >= TWO_PI_F);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+    if (__builtin_fabsf(x1) >= p.THL) {
+      const float cb = cosf(th1);
+      w1 = __builtin_fmaf(-(2.0f * (v1 * cb)), e.inv_halfL, w1);
+      th1 = __builtin_fmaf(w1, t, th1);
+      v1 = -v1;
+      x1 = __builtin_fmaf(v1, t, x1);
+    }
+    if (__builtin_fabsf(th1) >= TWO_PI_F) th1 = fmodf(th1, TWO_PI_F);
+  }
+#endif
+  // fmod(theta, 2pi) is the identity for |theta| < 2pi; then the reference's two comparisons
+  const float off = (th1 > PI_F) ? -TWO_PI_F : ((th1 < -PI_F) ? TWO_PI_F : 0.0f);
+  th1 += off;
   st.th = th1; st.w = w1; st.x = x1; st.v = v1;
   sincos_pi(th1, st.s, st.c);
 }
@@ -298,9 +312,12 @@ __device__ __forceinline__ float philox_knot(uint64_t seed, uint64_t offset, uin
 // Linear interpolation between knots as scipy interp1d does it at controller_mppi_cartpole.py:444-445:
 // slope = float64(float32(hi - lo)) / period ; y = slope * i + float64(lo) ; stored as float32.
 __device__ __forceinline__ float interp_knots(float z_lo, float z_hi, uint32_t i, uint32_t period) {
+#pragma clang fp contract(off)
   if (i == 0) return z_lo;
-  const double slope = __ddiv_rn((double)(z_hi - z_lo), (double)period);
-  return (float)__dadd_rn(__dmul_rn(slope, (double)i), (double)z_lo);
+  const float diff = z_hi - z_lo;                         // float32 difference, as numpy forms it
+  const double slope = (double)diff / (double)period;
+  const double prod = slope * (double)i;                  // two roundings (no FMA), as numpy
+  return (float)(prod + (double)z_lo);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib as L
+from . import _lib as _L
 from .configs import MPPIConfig, PhysicalParameters, build_c_config, cost_vector
 
 
@@ -18,7 +18,7 @@ def _ptr(t):
 
 class MPPIEngine:
     def __init__(self, E, mppi: MPPIConfig = None, phys: PhysicalParameters = None, device=0):
-        self.lib = L.load()
+        self.lib = _L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("cartpolesimulation_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; "
                                "there is no CPU fallback.")
@@ -31,7 +31,7 @@ class MPPIEngine:
         self._h = C.c_void_p()
         rc = self.lib.cpmppi_create(C.byref(self._cfg), self.device.index, C.byref(self._h))
         if rc != 0:
-            raise L.CpmppiError(rc, self.lib.cpmppi_last_error(None).decode())
+            raise _L.CpmppiError(rc, self.lib.cpmppi_last_error(None).decode())
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -47,7 +47,7 @@ class MPPIEngine:
 
     def _check(self, rc):
         if rc != 0:
-            raise L.CpmppiError(rc, self.lib.cpmppi_last_error(self._h).decode())
+            raise _L.CpmppiError(rc, self.lib.cpmppi_last_error(self._h).decode())
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -182,7 +182,7 @@ class MPPIEngine:
         given = [x is not None for x in (delta_u, knots, seed)]
         if sum(given) != 1:
             raise ValueError("give exactly one of delta_u, knots, seed")
-        a = L_step_args = L.cpmppi_step_args()
+        a = _L.cpmppi_step_args()
         s0 = self.tensor(s0, (E, 6))
         tp = self.tensor(target_position).reshape(-1)
         te = self.tensor(target_equilibrium).reshape(-1)
@@ -214,8 +214,7 @@ class MPPIEngine:
         a.S_out = S_out.data_ptr() if S_out is not None else None
         self._check(self.lib.cpmppi_step(self._h, C.byref(a), self._stream()))
         # keep the temporaries alive until the launch is enqueued (stream-ordered frees are safe in torch's allocator)
-        del L_step_args
         return Q_out, S_out
 
 
-L_NOISE = (L.NOISE_DELTA_U, L.NOISE_KNOTS, L.NOISE_PHILOX)
+L_NOISE = (_L.NOISE_DELTA_U, _L.NOISE_KNOTS, _L.NOISE_PHILOX)
