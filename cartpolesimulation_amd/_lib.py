@@ -30,7 +30,7 @@ class cpmppi_config(C.Structure):
                 ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("cc_weight", C.c_float),
                 ("sigma", C.c_float), ("period", C.c_uint32), ("action_low", C.c_float), ("action_high", C.c_float),
                 ("horizon_reduce", C.c_uint32), ("control_mode", C.c_uint32), ("shift_mode", C.c_uint32),
-                ("correction_u", C.c_uint32), ("math_mode", C.c_uint32)]
+                ("correction_u", C.c_uint32), ("math_mode", C.c_uint32), ("rollouts_per_lane", C.c_uint32)]
 
 
 class cpmppi_step_args(C.Structure):

@@ -73,6 +73,7 @@ class MPPIConfig:
     shift_mode: str = "repeat_last"      # "repeat_last" | "append_zero" | "none"
     correction_u: str = "u_run"          # "u_run" | "u_nom"
     math_mode: str = "fast"              # "fast" | "precise"
+    rollouts_per_lane: int = 0           # 0 auto | 1 (latency mapping) | 2 (packed float2 throughput mapping)
     action_low: float = -1.0
     action_high: float = 1.0
 
@@ -133,6 +134,7 @@ def build_c_config(E, mppi: MPPIConfig, phys: PhysicalParameters = None):
         if val not in table:
             raise ValueError(f"{key}={val!r}; expected one of {sorted(table)}")
         setattr(c, key, table[val])
+    c.rollouts_per_lane = int(mppi.rollouts_per_lane)
     return c
 
 

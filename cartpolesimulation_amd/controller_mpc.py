@@ -1,0 +1,97 @@
+"""controller_mpc — the controller seam of the reference, driving optimizer_mppi on the HIP path.
+
+Call-site contract (CartPole/__init__.py:755-779,509-520,805,419; others/Tests/test_controller_mppi_tf.py:
+10-16,34): ``Controller(environment_name, initial_environment_attributes, control_limits)``; ``configure(optimizer_name)``;
+``step(s, time, updated_attributes) -> value castable by float()``; ``controller_reset()``; attributes
+``has_optimizer``, ``optimizer.optimizer_name``, ``controller_data_for_csv``.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+from .configs import MPPIConfig, PhysicalParameters
+from .cost_functions import CostFunctionWrapper
+from .optimizer_mppi import optimizer_mppi
+from .predictors import PredictorWrapper
+
+
+class template_controller:
+    def __init__(self, environment_name="CartPole", initial_environment_attributes=None, control_limits=None, **kwargs):
+        self.environment_name = environment_name
+        self.variable_parameters = SimpleNamespace(**(initial_environment_attributes or {}))
+        if control_limits is None:
+            control_limits = (np.array([-1.0], dtype=np.float32), np.array([1.0], dtype=np.float32))
+        self.control_limits = control_limits
+        self.action_low, self.action_high = control_limits
+        self.controller_data_for_csv = {}
+        self.has_optimizer = False
+
+    def update_attributes(self, updated_attributes):
+        for k, v in (updated_attributes or {}).items():
+            setattr(self.variable_parameters, k, v)
+
+    def controller_reset(self):
+        raise NotImplementedError
+
+    def controller_report(self):
+        return None
+
+
+class controller_mpc(template_controller):
+    """``configure(optimizer_name="mppi")`` builds CostFunctionWrapper + PredictorWrapper-equivalent + optimizer;
+    ``step`` = update_attributes -> optimizer.step -> logging.  Only the MPPI optimizer is built on this tier."""
+
+    def __init__(self, environment_name="CartPole", initial_environment_attributes=None, control_limits=None,
+                 action_space=None, observation_space=None, config=None, phys=None, device=0, num_envs=1, **kwargs):
+        if control_limits is None and action_space is not None:          # the gym-style ctor of others/Tests/*.py
+            control_limits = (np.asarray(action_space.low, dtype=np.float32), np.asarray(action_space.high, dtype=np.float32))
+        super().__init__(environment_name, initial_environment_attributes, control_limits)
+        if environment_name != "CartPole":
+            raise ValueError("only the CartPole environment is built")
+        self.config_optimizer = dict(config or {})     # overrides of config_optimizers.yml:87-97 + glue flags
+        self.phys = phys or PhysicalParameters()
+        self.device, self.num_envs = device, num_envs
+        self.has_optimizer = True
+        self.optimizer = None
+        self.cost_function_wrapper = None
+        self.predictor = None
+        self.controller_logging = False
+
+    def configure(self, optimizer_name=None, predictor_specification=None, cost_function_specification=None,
+                  controller_logging=False, **kwargs):
+        optimizer_name = optimizer_name or "mppi"
+        if optimizer_name != "mppi":
+            raise NotImplementedError(f"optimizer {optimizer_name!r}: only 'mppi' is on the built hot path "
+                                      "(cem / rpgd are SURVEY.md §8f N4)")
+        cfg = dict(self.config_optimizer)
+        cfg.update(kwargs)
+        cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
+            "quadratic_boundary_grad_minimal"
+        self.controller_logging = controller_logging
+        opt_probe = MPPIConfig(**{k: v for k, v in cfg.items() if k in MPPIConfig.__dataclass_fields__})
+        self.cost_function_wrapper = CostFunctionWrapper()
+        self.cost_function_wrapper.configure(batch_size=opt_probe.num_rollouts, horizon=opt_probe.mpc_horizon,
+                                             variable_parameters=self.variable_parameters,
+                                             environment_name=self.environment_name,
+                                             cost_function_specification=cost_name,
+                                             weights=cfg.get("cost_weights"), phys=self.phys, device=self.device)
+        self.predictor = PredictorWrapper(self.phys, device=self.device)
+        self.predictor.configure(batch_size=opt_probe.num_rollouts, horizon=opt_probe.mpc_horizon,
+                                 dt=opt_probe.mpc_timestep, predictor_specification=predictor_specification or "ODE_v0",
+                                 variable_parameters=self.variable_parameters)
+        self.optimizer = optimizer_mppi(predictor=self.predictor, cost_function=self.cost_function_wrapper.cost_function,
+                                        control_limits=self.control_limits, optimizer_logging=controller_logging,
+                                        phys=self.phys, device=self.device, num_envs=self.num_envs,
+                                        variable_parameters=self.variable_parameters, **cfg)
+        self.optimizer.configure(dt=opt_probe.mpc_timestep, predictor_specification="ODE_v0")
+
+    def step(self, s, time=None, updated_attributes=None):
+        self.update_attributes(updated_attributes)
+        u = self.optimizer.step(np.asarray(s, dtype=np.float32) if not hasattr(s, "is_cuda") else s, time)
+        if self.controller_logging:
+            self.controller_data_for_csv = dict(self.optimizer.logging_values)
+        return u
+
+    def controller_reset(self):
+        if self.optimizer is not None:
+            self.optimizer.optimizer_reset()

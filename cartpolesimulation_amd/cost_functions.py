@@ -1,0 +1,128 @@
+"""Cost-function seam — the reference's plugin interface backed by cpmppi_trajectory_cost (HIP).
+
+Mirrors Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad_minimal.py:17-139, .../default.py:19-88 and
+the absent ``cost_function_base`` / ``CostFunctionWrapper`` as their in-tree callers use them
+(Cost_Functions/GymlikeCartPole/cost_function_gym.py:12-21, GymlikeCartPole/mpc_cost_function.py:18-43):
+``cls(variable_parameters, lib)``, ``get_stage_cost(states[N,H,6], inputs[N,H,1], previous_input) -> [N,H]``,
+``get_terminal_cost(terminal_states[N,6]) -> [N,1]``, ``get_trajectory_cost(state_horizon[N,H+1,6], inputs,
+previous_input=None) -> [N]``; target_position / target_equilibrium are read from ``variable_parameters`` at call time.
+"""
+import numpy as np
+
+from .configs import COST_WEIGHTS, MPPIConfig, PhysicalParameters
+
+
+def _scalar(x, default):
+    if x is None:
+        return float(default)
+    return float(np.asarray(x.cpu() if hasattr(x, "cpu") else x).reshape(-1)[0])
+
+
+class cost_function_base:
+    cost_name = None
+
+    def __init__(self, variable_parameters=None, lib=None, weights=None, phys=None, horizon_reduce="sum", device=0):
+        self.variable_parameters = variable_parameters
+        self.lib = lib
+        self.weights = dict(COST_WEIGHTS[self.cost_name][2])
+        self.weights.update(weights or {})
+        self.config = self.weights
+        self.phys = phys or PhysicalParameters()
+        self.horizon_reduce = horizon_reduce
+        self.logged_attributes = {}
+        self._device = device
+        self._engines = {}
+
+    def set_logged_attributes(self, d):
+        self.logged_attributes = d
+
+    def reload_cost_parameters_from_config(self, weights=None):
+        self.weights.update(weights or {})
+        for eng in self._engines.values():
+            eng.set_cost(self.cost_name, self.weights)
+
+    def _engine(self, H):
+        from .engine import MPPIEngine
+        if H not in self._engines:
+            cfg = MPPIConfig(num_rollouts=1, mpc_horizon=H, cost_function_specification=self.cost_name,
+                             cost_weights=self.weights, horizon_reduce=self.horizon_reduce)
+            self._engines[H] = MPPIEngine(1, cfg, self.phys, device=self._device)
+        return self._engines[H]
+
+    def _targets(self):
+        vp = self.variable_parameters
+        return (_scalar(getattr(vp, "target_position", None), 0.0), _scalar(getattr(vp, "target_equilibrium", None), 1.0))
+
+    @staticmethod
+    def _out(t, as_tensor):
+        return t if as_tensor else t.cpu().numpy()
+
+    def get_stage_cost(self, states, inputs, previous_input=None, as_tensor=False):
+        H = states.shape[1]
+        eng = self._engine(H)
+        st = eng.tensor(states)
+        traj = eng.empty(st.shape[0], H + 1, 6)
+        traj[:, :H] = st
+        traj[:, H] = st[:, H - 1]
+        tp, te = self._targets()
+        stage, _, _ = eng.trajectory_cost(traj, inputs, tp, te, want=("stage",))
+        return self._out(stage, as_tensor)
+
+    def get_terminal_cost(self, terminal_states, as_tensor=False):
+        eng = self._engine(1)
+        ts = eng.tensor(terminal_states)
+        traj = ts.unsqueeze(1).expand(ts.shape[0], 2, 6).contiguous()
+        tp, te = self._targets()
+        _, term, _ = eng.trajectory_cost(traj, eng.zeros(ts.shape[0], 1), tp, te, want=("terminal",))
+        return self._out(term.reshape(-1, 1), as_tensor)
+
+    def get_trajectory_cost(self, state_horizon, inputs, previous_input=None, as_tensor=False):
+        H = state_horizon.shape[1] - 1
+        tp, te = self._targets()
+        _, _, total = self._engine(H).trajectory_cost(state_horizon, inputs, tp, te, want=("total",))
+        return self._out(total, as_tensor)
+
+    def get_summed_stage_cost(self, states, inputs, previous_input=None, as_tensor=False):
+        stage = self.get_stage_cost(states, inputs, previous_input, as_tensor=True)
+        return self._out(stage.sum(dim=1), as_tensor)
+
+
+class quadratic_boundary_grad_minimal(cost_function_base):
+    cost_name = "quadratic_boundary_grad_minimal"
+
+
+class default(cost_function_base):
+    cost_name = "default"
+    MAX_COST = 600.0 * 1.0e7 + 20000.0 + 1.0 * 1.0 * (1.77 ** 2)      # default.py:20
+
+
+COST_FUNCTIONS = {"quadratic_boundary_grad_minimal": quadratic_boundary_grad_minimal, "default": default}
+
+
+class CostFunctionWrapper:
+    """configure(...) then forwards the plugin interface to the selected cost function."""
+
+    def __init__(self):
+        self.cost_function = None
+        self.cost_function_name = None
+        self.variable_parameters = None
+
+    def configure(self, batch_size=None, horizon=None, variable_parameters=None, environment_name="CartPole",
+                  computation_library=None, cost_function_specification=None, weights=None, **kwargs):
+        name = cost_function_specification or "quadratic_boundary_grad_minimal"
+        if name not in COST_FUNCTIONS:
+            raise ValueError(f"cost_function_specification {name!r} not available; have {sorted(COST_FUNCTIONS)}")
+        if environment_name != "CartPole":
+            raise ValueError("only the CartPole environment is built")
+        self.cost_function_name = name
+        self.variable_parameters = variable_parameters
+        self.cost_function = COST_FUNCTIONS[name](variable_parameters, computation_library, weights=weights, **kwargs)
+
+    def update_cost_function_name_from_specification(self, environment_name="CartPole", cost_function_specification=None):
+        self.cost_function_name = cost_function_specification or "quadratic_boundary_grad_minimal"
+
+    def __getattr__(self, item):
+        cf = self.__dict__.get("cost_function")
+        if cf is None:
+            raise AttributeError(item)
+        return getattr(cf, item)

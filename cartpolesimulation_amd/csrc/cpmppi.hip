@@ -28,7 +28,7 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_TK
-#define CPMPPI_TK 16
+#define CPMPPI_TK 8
 #endif
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
@@ -59,17 +59,24 @@ __device__ __forceinline__ float shifted_nominal(const Params& p, const float* _
   return (p.shift_mode == CPMPPI_SHIFT_REPEAT_LAST) ? un[p.H - 1] : 0.0f;
 }
 
-// S_CT: compile-time number of Euler substeps (10 = the reference's intermediate_steps; 0 = read p.S at run time).
-template <int COST, bool FAST, int NOISE, int S_CT>
+// The hot path.  R = rollouts per lane (1: latency mapping, 2: packed float2 throughput mapping, FAST only).
+// A block of 256 threads owns 256*R consecutive rollouts of one env; wave w owns rows [w*64*R, (w+1)*64*R) and lane l
+// integrates rows l (component 0) and l+64 (component 1).
+template <int COST, bool FAST, int NOISE, int R>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
-  __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * TILE_STRIDE : 1];
+  using F = typename Lanes<R>::F;
+  static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");
+  __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * R * TILE_STRIDE : 1];
   __shared__ float red[2 * WAVES];
   extern __shared__ float bsum[];            // [WAVES][W]
 
   const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t n = blk * BLOCK + tid;
-  const bool valid = n < p.N;
+  const uint32_t row0 = blk * (BLOCK * R) + wave * (64 * R);     // first rollout of this wave
+  uint32_t n[R];
+  bool valid[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) { n[i] = row0 + i * 64 + lane; valid[i] = n[i] < p.N; }
   const uint32_t H = p.H;
 
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
@@ -79,50 +86,46 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
   const float* __restrict__ up = (a.u_prev ? a.u_prev : a.u_nom) + (size_t)env * H;
-  State st{s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
+  State<F> st{splat<F>(s0[0]), splat<F>(s0[1]), splat<F>(s0[2]), splat<F>(s0[3]), splat<F>(s0[4]), splat<F>(s0[5])};
 
-  float cost = 0.0f, corr = 0.0f;
-  float cosang = cosf(st.th);               // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+  F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
+  F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
 
-  auto control_step = [&](uint32_t k, float du) {
+  auto control_step = [&](uint32_t k, F du) {
     const float uk = shifted_nominal(p, un, k);
-    float ur = uk + du;
-    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = fminf(fmaxf(ur, p.lo), p.hi);
+    F ur = splat<F>(uk) + du;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
     if constexpr (COST == COST_QBGM) {
-      cost += stage_qbgm(p, st.x, cosang, st.w, ur, x_t, te);
-      corr += mppi_correction(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
+      cost += stage_qbgm<F>(p, st.x, cosang, st.w, ur, x_t, te);
+      corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
-      cost += stage_default(p, st.x, cosang, ur, x_t, te);
-      corr += mppi_correction(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
+      cost += stage_default<F>(p, st.x, cosang, ur, x_t, te);
+      corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else {
-      cost += stage_legacy(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
+      cost += stage_legacy<F>(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
     }
-    const float u = p.u_max * ur;           // Q2u, cartpole_equations.py:119-127
-    const float uK = ec.kp1 * u;
-#ifndef CPMPPI_UNROLL_S
-#define CPMPPI_UNROLL_S 1
-#endif
-    if constexpr (S_CT > 0) {
-#pragma unroll CPMPPI_UNROLL_S
-      for (int sub = 0; sub < S_CT; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+    const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
+    if constexpr (FAST) {
+      const F uK = u * splat<F>(ec.kp1);
+      for (uint32_t sub = 0; sub < p.S; ++sub) substep_fast<F>(st, uK, p.t_step, p, ec);
     } else {
-      for (uint32_t sub = 0; sub < p.S; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+      for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
     cosang = st.c;
   };
 
   // ---- rollout over the horizon ----------------------------------------------------------------------------------
   if constexpr (NOISE == NOISE_DELTA_U) {
-    // The 64 rollouts of a wave are one contiguous span of 64*H floats in delta_u[E,N,H]; a tile of TK time-steps is
-    // fetched with 64-byte row segments (4 rows per wave-instruction), parked in registers while the previous tile is
-    // integrated, then written to LDS and read back one row per lane.
-    const uint32_t row0 = blk * BLOCK + wave * 64;
+    // The 64*R rollouts of a wave are one contiguous span of 64*R*H floats in delta_u[E,N,H]; a tile of TK time-steps
+    // is fetched in whole row segments (TK*4 bytes per row), parked in registers while the previous tile is
+    // integrated, then written to LDS and read back one row per lane (odd row stride: conflict-free).
+    constexpr int NLOAD = R * TK;            // elements per lane per tile
     const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * H;
-    float* __restrict__ my_tile = tile + wave * 64 * TILE_STRIDE;
-    float pre[TK];
+    float* __restrict__ my_tile = tile + wave * (64 * R * TILE_STRIDE);
+    float pre[NLOAD];
     auto gload = [&](uint32_t k0) {
 #pragma unroll
-      for (int i = 0; i < TK; ++i) {
+      for (int i = 0; i < NLOAD; ++i) {
         const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
         const uint32_t k = k0 + col;
         pre[i] = (row0 + row < p.N && k < H) ? src[(size_t)row * H + k] : 0.0f;
@@ -132,75 +135,103 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     for (uint32_t k0 = 0; k0 < H; k0 += TK) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < TK; ++i) {
+      for (int i = 0; i < NLOAD; ++i) {
         const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
         my_tile[row * TILE_STRIDE + col] = pre[i];
       }
       __syncthreads();
       if (k0 + TK < H) gload(k0 + TK);
       const uint32_t kend = (H - k0 < (uint32_t)TK) ? (H - k0) : (uint32_t)TK;
-      for (uint32_t kk = 0; kk < kend; ++kk) control_step(k0 + kk, my_tile[lane * TILE_STRIDE + kk]);
+      for (uint32_t kk = 0; kk < kend; ++kk) {
+        F du;
+#pragma unroll
+        for (int i = 0; i < R; ++i) put(du, i, my_tile[(i * 64 + lane) * TILE_STRIDE + kk]);
+        control_step(k0 + kk, du);
+      }
     }
   } else {
-    const uint32_t nn = valid ? n : 0;
-    const float* __restrict__ kn = (NOISE == NOISE_KNOTS) ? a.noise + ((size_t)env * p.N + nn) * p.P : nullptr;
-    auto knot = [&](uint32_t j) -> float {
-      if constexpr (NOISE == NOISE_KNOTS) return kn[j];
+    auto knot = [&](int i, uint32_t j) -> float {
+      const uint32_t nn = valid[i] ? n[i] : 0;
+      if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
       else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
     };
-    float z_lo = knot(0), z_hi = knot(1);
-    uint32_t i = 0, j = 0;
+    float z_lo[R], z_hi[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { z_lo[i] = knot(i, 0); z_hi[i] = knot(i, 1); }
+    uint32_t ii = 0, j = 0;
     for (uint32_t k = 0; k < H; ++k) {
-      control_step(k, interp_knots(z_lo, z_hi, i, p.period));
-      if (++i == p.period) {
-        i = 0; ++j;
-        z_lo = z_hi;
-        if (j + 1 < p.P) z_hi = knot(j + 1);
+      F du;
+#pragma unroll
+      for (int i = 0; i < R; ++i) put(du, i, interp_knots(z_lo[i], z_hi[i], ii, p.period));
+      control_step(k, du);
+      if (++ii == p.period) {
+        ii = 0; ++j;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          z_lo[i] = z_hi[i];
+          if (j + 1 < p.P) z_hi[i] = knot(i, j + 1);
+        }
       }
     }
   }
 
   // ---- per-rollout total cost ------------------------------------------------------------------------------------
-  float S_total;
+  F S_total;
   if constexpr (COST == COST_LEGACY) {
-    S_total = cost + terminal_indicator(p, st.th, st.x, x_t);       // sum_k q + phi  (:197-199)
+    S_total = cost + terminal_indicator<F>(p, st.th, st.x, x_t);     // sum_k q + phi  (:197-199)
   } else {
-    const float term = (COST == COST_DEFAULT) ? terminal_indicator(p, st.th, st.x, x_t) : 0.0f;
-    S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / (float)(H + 1);
+    const F term = (COST == COST_DEFAULT) ? terminal_indicator<F>(p, st.th, st.x, x_t) : splat<F>(0.0f);
+    S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / splat<F>((float)(H + 1));
     S_total += corr;
   }
-  if (a.S_out && valid) a.S_out[(size_t)env * p.N + n] = S_total;
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (a.S_out && valid[i]) a.S_out[(size_t)env * p.N + n[i]] = get(S_total, i);
 
   // ---- block-level soft-min partials (a16) -----------------------------------------------------------------------
-  const float m_w = wave_min(valid ? S_total : INFINITY);
+  float m_l = INFINITY;
+#pragma unroll
+  for (int i = 0; i < R; ++i) m_l = fminf(m_l, valid[i] ? get(S_total, i) : INFINITY);
+  const float m_w = wave_min(m_l);
   if (lane == 0) red[wave] = m_w;
   __syncthreads();
   float m_b = red[0];
 #pragma unroll
   for (int w = 1; w < WAVES; ++w) m_b = fminf(m_b, red[w]);
-  const float e = valid ? expf((-1.0f / p.LBD) * (S_total - m_b)) : 0.0f;
-  const float a_w = wave_sum(e);
+  float e[R], e_l = 0.0f;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    e[i] = valid[i] ? expf((-1.0f / p.LBD) * (get(S_total, i) - m_b)) : 0.0f;
+    e_l += e[i];
+  }
+  const float a_w = wave_sum(e_l);
   if (lane == 0) red[WAVES + wave] = a_w;
 
   const uint32_t W = a.W;
   float* __restrict__ my_bsum = bsum + wave * W;
   if constexpr (NOISE == NOISE_PHILOX) {
-    const uint32_t nn = valid ? n : 0;
     for (uint32_t j = 0; j < W; ++j) {
-      const float v = wave_sum(e * philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma));
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        v += e[i] * philox_knot(a.seed, a.offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma);
+      v = wave_sum(v);
       if (lane == 0) my_bsum[j] = v;
     }
   } else {
-    // transposed pass: lane = column (time-step or knot), loop over the wave's 64 rows, rows read coalesced (L2-hot)
-    const uint32_t row0 = blk * BLOCK + wave * 64;
+    // transposed pass: lane = column (time-step or knot), loop over the wave's rows, rows read coalesced (cache-hot)
     const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * W;
-    const uint32_t rows = (row0 < p.N) ? ((p.N - row0 < 64u) ? p.N - row0 : 64u) : 0u;
     for (uint32_t c0 = 0; c0 < W; c0 += 64) {
       const uint32_t col = c0 + lane;
       float acc = 0.0f;
-      for (uint32_t r = 0; r < rows; ++r) {
-        const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
-        if (col < W) acc = __builtin_fmaf(er, src[(size_t)r * W + col], acc);
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const uint32_t base = row0 + i * 64;
+        const uint32_t rows = (base < p.N) ? ((p.N - base < 64u) ? p.N - base : 64u) : 0u;
+        for (uint32_t r = 0; r < rows; ++r) {
+          const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), r));
+          if (col < W) acc = __builtin_fmaf(er, src[(size_t)(i * 64 + r) * W + col], acc);
+        }
       }
       if (col < W) my_bsum[col] = acc;
     }
@@ -268,25 +299,34 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const Params p, const f
   if (tid == 0 && Q_out) Q_out[env] = u_new[0];
 }
 
-// a17: knots[E,N,P] and/or delta_u[E,N,H]
+// a17: knots[E,N,P] and/or delta_u[E,N,H].  One lane draws (or loads) the knots of one rollout into LDS; the wave then
+// writes its 64 delta_u rows with lane = time-step, i.e. whole 256-byte row segments per store instruction.
 __global__ __launch_bounds__(BLOCK) void sample_kernel(const Params p, uint32_t E, uint64_t seed, uint64_t offset,
                                                        uint32_t env_offset, const float* __restrict__ knots_in,
                                                        float* __restrict__ knots_out, float* __restrict__ du_out) {
-  const size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x;     // flat (env, rollout)
-  if (r >= (size_t)E * p.N) return;
-  const uint32_t env = (uint32_t)(r / p.N), n = (uint32_t)(r % p.N);
-  auto knot = [&](uint32_t j) -> float {
-    return knots_in ? knots_in[r * p.P + j] : philox_knot(seed, offset, env_offset + env, n, j, p.sigma);
-  };
-  float z_lo = knot(0);
-  if (knots_out) knots_out[r * p.P] = z_lo;
-  uint32_t k = 0;
-  for (uint32_t j = 0; j + 1 < p.P; ++j) {
-    const float z_hi = knot(j + 1);
-    if (knots_out) knots_out[r * p.P + j + 1] = z_hi;
-    if (du_out)
-      for (uint32_t i = 0; i < p.period && k < p.H; ++i, ++k) du_out[r * p.H + k] = interp_knots(z_lo, z_hi, i, p.period);
-    z_lo = z_hi;
+  extern __shared__ float kn_lds[];                               // [WAVES][64][P+1]
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const size_t total = (size_t)E * p.N;
+  const size_t wave_row0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t r = wave_row0 + lane;                              // flat (env, rollout)
+  const uint32_t stride = p.P + 1;
+  float* __restrict__ mine = kn_lds + (wave * 64 + lane) * stride;
+  if (r < total) {
+    const uint32_t env = (uint32_t)(r / p.N), n = (uint32_t)(r % p.N);
+    for (uint32_t j = 0; j < p.P; ++j) {
+      const float z = knots_in ? knots_in[r * p.P + j] : philox_knot(seed, offset, env_offset + env, n, j, p.sigma);
+      mine[j] = z;
+      if (knots_out) knots_out[r * p.P + j] = z;
+    }
+  }
+  if (!du_out) return;
+  __syncthreads();
+  const float* __restrict__ wk = kn_lds + wave * 64 * stride;
+  for (uint32_t row = 0; row < 64 && wave_row0 + row < total; ++row) {
+    for (uint32_t k = lane; k < p.H; k += 64) {
+      const uint32_t j = k / p.period, i = k % p.period;
+      du_out[(wave_row0 + row) * p.H + k] = interp_knots(wk[row * stride + j], wk[row * stride + j + 1], i, p.period);
+    }
   }
 }
 
@@ -299,13 +339,15 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
   if (b >= B) return;
   const EnvConst ec = make_env_const(p, Lp ? Lp[b] : p.L_default);
   const float* s = s0 + b * 6;
-  State st{s[0], s[1], s[2], s[3], s[4], s[5]};
+  State<float> st{s[0], s[1], s[2], s[3], s[4], s[5]};
   float* o = traj + b * (size_t)(H + 1) * 6;
   o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
   for (uint32_t k = 0; k < H; ++k) {
     const float u = p.u_max * Q[b * H + k];
-    const float uK = ec.kp1 * u;
-    for (uint32_t sub = 0; sub < p.S; ++sub) substep<FAST>(st, u, uK, p.t_step, p, ec);
+    for (uint32_t sub = 0; sub < p.S; ++sub) {
+      if constexpr (FAST) substep_fast<float>(st, ec.kp1 * u, p.t_step, p, ec);
+      else substep_precise(st, u, p.t_step, p, ec);
+    }
     o += 6;
     o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
   }
@@ -328,13 +370,13 @@ __global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, 
     const float in = inputs[b * H + k];
     const float cosang = cosf(t[0]);
     float c;
-    if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm(p, t[4], cosang, t[1], in, x_t, te);
-    else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default(p, t[4], cosang, in, x_t, te);
-    else c = stage_legacy(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
+    if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm<float>(p, t[4], cosang, t[1], in, x_t, te);
+    else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default<float>(p, t[4], cosang, in, x_t, te);
+    else c = stage_legacy<float>(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
     if (stage_out) stage_out[b * H + k] = c;
     sum += c;
   }
-  const float term = (p.cost_id == CPMPPI_COST_QBGM) ? 0.0f : terminal_indicator(p, t[0], t[4], x_t);
+  const float term = (p.cost_id == CPMPPI_COST_QBGM) ? 0.0f : terminal_indicator<float>(p, t[0], t[4], x_t);
   if (terminal_out) terminal_out[b] = term;
   if (total_out)
     total_out[b] = (p.cost_id == CPMPPI_COST_LEGACY || p.horizon_reduce == CPMPPI_REDUCE_SUM)
@@ -382,7 +424,7 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E
   if (env >= E) return;
   const EnvConst ec = make_env_const(p, Lp ? Lp[env] : p.L_default);
   float* se = s + (size_t)env * 6;
-  State st{se[0], se[1], se[2], se[3], se[4], se[5]};
+  State<float> st{se[0], se[1], se[2], se[3], se[4], se[5]};
   const float u = p.u_max * Q[env];
   float aDD, xDD;
   ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);       // CartPole/__init__.py:342-346
@@ -451,35 +493,35 @@ int ensure_device(cpmppi_handle* h) {
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
-template <int COST, bool FAST, int S_CT>
+template <int COST, bool FAST, int R>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                 const StepPtrs& a) {
   switch (noise) {
     case CPMPPI_NOISE_DELTA_U:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, S_CT>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, R>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_KNOTS:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, S_CT>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R>), grid, dim3(BLOCK), lds, s, p, a); break;
     default:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, S_CT>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R>), grid, dim3(BLOCK), lds, s, p, a); break;
   }
   return hipGetLastError();
 }
 
 template <int COST>
-hipError_t launch_rollout_math(uint32_t math, uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
-                               const StepPtrs& a) {
+hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
+                               const Params& p, const StepPtrs& a) {
   if (math == CPMPPI_MATH_FAST)
-    return p.S == 10 ? launch_rollout_noise<COST, true, 10>(noise, grid, lds, s, p, a)
-                     : launch_rollout_noise<COST, true, 0>(noise, grid, lds, s, p, a);
-  return launch_rollout_noise<COST, false, 0>(noise, grid, lds, s, p, a);
+    return rpl == 2 ? launch_rollout_noise<COST, true, 2>(noise, grid, lds, s, p, a)
+                    : launch_rollout_noise<COST, true, 1>(noise, grid, lds, s, p, a);
+  return launch_rollout_noise<COST, false, 1>(noise, grid, lds, s, p, a);
 }
 
-hipError_t launch_rollout(const cpmppi_handle* h, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
+hipError_t launch_rollout(const cpmppi_handle* h, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                           const StepPtrs& a) {
   switch (h->prm.cost_id) {
-    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, noise, grid, lds, s, h->prm, a);
-    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, noise, grid, lds, s, h->prm, a);
-    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, noise, grid, lds, s, h->prm, a);
+    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
+    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
+    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
   }
 }
 
@@ -501,7 +543,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   if (!(cfg->dt > 0.0f) || !(cfg->LBD > 0.0f) || !(cfg->NU > 0.0f) || !(cfg->L_default > 0.0f))
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: dt, LBD, NU, L_default must be > 0");
   if (cfg->cost_id > CPMPPI_COST_LEGACY || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
-      cfg->correction_u > 1 || cfg->math_mode > 1)
+      cfg->correction_u > 1 || cfg->math_mode > 1 || cfg->rollouts_per_lane > 2)
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: unknown enum value");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
@@ -562,10 +604,13 @@ int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, 
   if (E == 0 || E > h->cfg.E || (!knots_out && !delta_u_out))
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: E out of range or no output buffer");
   if (misaligned(knots_out) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_sample: misaligned");
+  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > 65536)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: more than 63 knots per rollout are not supported");
   if (int rc = ensure_device(h)) return rc;
   const size_t rows = (size_t)E * h->cfg.N;
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
-                     h->prm, E, seed, offset, env_offset, (const float*)nullptr, knots_out, delta_u_out);
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK),
+                     (size_t)BLOCK * (h->prm.P + 1) * sizeof(float), (hipStream_t)stream, h->prm, E, seed, offset,
+                     env_offset, (const float*)nullptr, knots_out, delta_u_out);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
@@ -575,10 +620,13 @@ int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* 
   if (E == 0 || E > h->cfg.E || !knots || !delta_u_out)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: bad argument");
   if (misaligned(knots) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_interpolate: misaligned");
+  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > 65536)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: more than 63 knots per rollout are not supported");
   if (int rc = ensure_device(h)) return rc;
   const size_t rows = (size_t)E * h->cfg.N;
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
-                     h->prm, E, (uint64_t)0, (uint64_t)0, 0u, knots, (float*)nullptr, delta_u_out);
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK),
+                     (size_t)BLOCK * (h->prm.P + 1) * sizeof(float), (hipStream_t)stream, h->prm, E, (uint64_t)0,
+                     (uint64_t)0, 0u, knots, (float*)nullptr, delta_u_out);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
@@ -635,7 +683,12 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   StepPtrs p;
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
   p.L = a->L; p.noise = a->noise; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
-  p.nb = h->nb;
+  // lane mapping: two rollouts per lane (packed float2) once the launch is big enough to keep >= 2 such waves on
+  // every SIMD; one rollout per lane (shortest critical path) for small launches
+  uint32_t rpl = h->cfg.rollouts_per_lane;
+  if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
+  else if (rpl == 0) rpl = ((uint64_t)a->E * h->cfg.N >= 262144ull) ? 2 : 1;
+  p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = (a->noise_kind == CPMPPI_NOISE_DELTA_U) ? h->cfg.H : h->prm.P;
   p.S_out = a->S_out; p.partial = h->workspace;
   const hipStream_t s = (hipStream_t)stream;
@@ -652,13 +705,13 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     h->ev_used += 3;
     CPMPPI_HIP(h, hipEventRecord(ev[0], s));
   }
-  CPMPPI_HIP(h, launch_rollout(h, a->noise_kind, dim3(a->E * h->nb), (size_t)WAVES * p.W * sizeof(float), s, p));
+  CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), (size_t)WAVES * p.W * sizeof(float), s, p));
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
   if (a->noise_kind == CPMPPI_NOISE_DELTA_U)
-    hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, h->nb,
+    hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, p.nb,
                        p.W, a->u_nom, a->Q_out);
   else
-    hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, h->nb,
+    hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, p.nb,
                        p.W, a->u_nom, a->Q_out);
   CPMPPI_HIP(h, hipGetLastError());
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[2], s));

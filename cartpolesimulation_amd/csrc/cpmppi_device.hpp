@@ -6,8 +6,15 @@
 //   CartPole/cartpole_equations.py:341-347  edge_bounce
 //   CartPole/_CartPole_mathematical_helpers.py:24-29  wrap_angle_rad_inplace
 //   CartPole/cartpole_numba.py:55-78        cartpole_fine_integration_numba (the substep loop)
-// Everything is float32.  One lane integrates one rollout; all per-env quantities are wave-uniform and end up in
-// SGPRs (they are derived from kernel arguments and blockIdx only).
+// Everything is float32.  All per-env quantities are wave-uniform and end up in SGPRs (they are derived from kernel
+// arguments and blockIdx only).
+//
+// Lane mapping.  A rollout is one serial dependency chain of ~30 000 VALU instructions.  Measured on MI355X
+// (tools/valu_peak.hip): a dependent chain inside ONE wave issues at ~1.85 ns per wave64 instruction however many
+// waves share the SIMD, two independent chains inside one wave at ~1.0 ns, and v_pk_fma_f32 performs two FMAs for the
+// price of one instruction.  The FAST path is therefore written generically over F = float (one rollout per lane: the
+// latency-optimal mapping when there are few rollouts) and F = float2 (two rollouts per lane: every arithmetic
+// instruction is a packed v_pk_* op or one of two independent scalar ops; the throughput mapping).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -61,42 +68,74 @@ __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// float / float2 helpers
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int R> struct Lanes;
+template <> struct Lanes<1> { using F = float; };
+template <> struct Lanes<2> { using F = f2; };
+
+template <class F> struct Width;
+template <> struct Width<float> { static constexpr int value = 1; };
+template <> struct Width<f2> { static constexpr int value = 2; };
+
+__device__ __forceinline__ float get(float v, int) { return v; }
+__device__ __forceinline__ float get(f2 v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ void put(float& v, int, float x) { v = x; }
+__device__ __forceinline__ void put(f2& v, int i, float x) { if (i == 0) v.x = x; else v.y = x; }
+template <class F> __device__ __forceinline__ F splat(float x);
+template <> __device__ __forceinline__ float splat<float>(float x) { return x; }
+template <> __device__ __forceinline__ f2 splat<f2>(float x) { return f2{x, x}; }
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ f2 rcp_(f2 a) { return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ float rint_(float a) { return __builtin_rintf(a); }
+__device__ __forceinline__ f2 rint_(f2 a) { return f2{__builtin_rintf(a.x), __builtin_rintf(a.y)}; }
+__device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ f2 abs_(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
+__device__ __forceinline__ float clamp_(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
+__device__ __forceinline__ f2 clamp_(f2 a, float lo, float hi) { return f2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
+__device__ __forceinline__ float cos_(float a) { return cosf(a); }
+__device__ __forceinline__ f2 cos_(f2 a) { return f2{cosf(a.x), cosf(a.y)}; }
+
+// ------------------------------------------------------------------------------------------------------------------
 // sincos on [-pi_f32, pi_f32] (the angle is wrapped every substep, so the argument never leaves this range).
 // Cody-Waite reduction to |r| <= pi/4 with q in {-2..2} (q*PIO2_HI is exact), then the classic single-precision
 // minimax polynomials; <= 1.5 ulp for both outputs over the range.
-__device__ __forceinline__ void sincos_pi(float x, float& sn, float& cs) {
+template <class F>
+__device__ __forceinline__ void sincos_pi(F x, F& sn, F& cs) {
   constexpr float TWO_OVER_PI = 0.636619746685028076f;
   constexpr float PIO2_HI = 1.57079637050628662f;
   constexpr float PIO2_LO = -4.37113900018624283e-8f;
-  const float q = __builtin_rintf(x * TWO_OVER_PI);
-  float r = __builtin_fmaf(-q, PIO2_HI, x);
-  r = __builtin_fmaf(-q, PIO2_LO, r);
-  const float r2 = r * r;
-  float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-  ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
-  const float S = __builtin_fmaf(ps * r2, r, r);
-  float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-  pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
-  const float C = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
-  const int n = (int)q;
-  const bool swap = (n & 1) != 0;
-  const float s0 = swap ? C : S;
-  const float c0 = swap ? S : C;
-  const uint32_t sflip = ((uint32_t)n & 2u) << 30;
-  const uint32_t cflip = ((uint32_t)(n + 1) & 2u) << 30;
-  sn = __uint_as_float(__float_as_uint(s0) ^ sflip);
-  cs = __uint_as_float(__float_as_uint(c0) ^ cflip);
+  const F q = rint_(x * splat<F>(TWO_OVER_PI));
+  F r = fma_(-q, splat<F>(PIO2_HI), x);
+  r = fma_(-q, splat<F>(PIO2_LO), r);
+  const F r2 = r * r;
+  F ps = fma_(r2, splat<F>(-1.9515295891e-4f), splat<F>(8.3321608736e-3f));
+  ps = fma_(ps, r2, splat<F>(-1.6666654611e-1f));
+  const F S = fma_(ps * r2, r, r);
+  F pc = fma_(r2, splat<F>(2.443315711809948e-5f), splat<F>(-1.388731625493765e-3f));
+  pc = fma_(pc, r2, splat<F>(4.166664568298827e-2f));
+  const F C = fma_(pc * r2, r2, fma_(splat<F>(-0.5f), r2, splat<F>(1.0f)));
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) {
+    const int n = (int)get(q, i);
+    const bool swap = (n & 1) != 0;
+    const float s0 = swap ? get(C, i) : get(S, i);
+    const float c0 = swap ? get(S, i) : get(C, i);
+    const uint32_t sflip = ((uint32_t)n & 2u) << 30;
+    const uint32_t cflip = ((uint32_t)(n + 1) & 2u) << 30;
+    put(sn, i, __uint_as_float(__float_as_uint(s0) ^ sflip));
+    put(cs, i, __uint_as_float(__float_as_uint(c0) ^ cflip));
+  }
 }
 
+template <class F>
 struct State {
-  float th, w, c, s, x, v;   // angle, angleD, angle_cos, angle_sin, position, positionD
+  F th, w, c, s, x, v;   // angle, angleD, angle_cos, angle_sin, position, positionD
 };
-
-// One Euler substep.  FAST=false follows the reference's operand grouping with IEEE divides, libm sincos and no FMA
-// contraction; FAST=true evaluates the same float32 formulas with folded per-env constants, FMA, a
-// reciprocal+Newton divide and sincos_pi.
-template <bool FAST>
-__device__ __forceinline__ void substep(State& st, float u, float uK, float t, const Params& p, const EnvConst& e);
 
 // _cartpole_ode with the reference's operand grouping (cartpole_equations.py:71-99), IEEE divides, no contraction.
 __device__ __forceinline__ void ode_precise(float c, float s, float w, float v, float u, const Params& p,
@@ -110,9 +149,9 @@ __device__ __forceinline__ void ode_precise(float c, float s, float w, float v, 
   aDD = (p.g * s + xDD * c + T / (p.m_pole * Lh)) / (e.kp1 * Lh);
 }
 
-template <>
-__device__ __forceinline__ void substep<false>(State& st, float u, float /*uK*/, float t, const Params& p,
-                                               const EnvConst& e) {
+// One Euler substep, PRECISE: the reference's operand grouping with IEEE divides, libm sincos and no FMA contraction.
+__device__ __forceinline__ void substep_precise(State<float>& st, float u, float t, const Params& p,
+                                                const EnvConst& e) {
 #pragma clang fp contract(off)
   const float w = st.w, v = st.v;
   float aDD, xDD;
@@ -137,7 +176,7 @@ __device__ __forceinline__ void substep<false>(State& st, float u, float /*uK*/,
 
 // One simulation step of the PLANT (the caller side of the boundary): Euler-Cromer (cartpole_equations.py:367-378),
 // edge bounce with cos of the integrated angle (CartPole/__init__.py:462-470), cos/sin (:329-331), wrap (:333-334).
-__device__ __forceinline__ void plant_substep(State& st, float aDD, float xDD, float t, const Params& p,
+__device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float xDD, float t, const Params& p,
                                               const EnvConst& e) {
 #pragma clang fp contract(off)
   float w1 = st.w + aDD * t;
@@ -158,117 +197,139 @@ __device__ __forceinline__ void plant_substep(State& st, float aDD, float xDD, f
   st.w = w1; st.x = x1; st.v = v1;
 }
 
-#ifndef CPMPPI_RARE_MODE
-#define CPMPPI_RARE_MODE 1     // 0: per-lane divergent branches (compiler exec masking)  1: wave-uniform test, inline cold path
-#endif
-
-template <>
-__device__ __forceinline__ void substep<true>(State& st, float /*u*/, float uK, float t, const Params& p,
-                                              const EnvConst& e) {
-  const float c = st.c, s = st.s, w = st.w, v = st.v;
-  const float A = __builtin_fmaf(-(p.m_pole * c), c, e.kp1_mt);
-  const float t1 = __builtin_fmaf(e.mg, s, -(e.JinvLh * w));
-  float num = __builtin_fmaf(c, t1, uK);
-  num = __builtin_fmaf(-(e.kmLh * (w * w)), s, num);
-  num = __builtin_fmaf(-e.kM, v, num);
-  const float r = __builtin_amdgcn_rcpf(A);          // A in [0.33, 0.43]: no scaling needed
-  const float q0 = num * r;
-  const float xDD = __builtin_fmaf(__builtin_fmaf(-A, q0, num), r, q0);
-  const float aDD = __builtin_fmaf(e.g_i, s, __builtin_fmaf(xDD * c, e.inv_kLh, -(e.cT_i * w)));
-  float th1 = __builtin_fmaf(w, t, st.th);
-  float w1 = __builtin_fmaf(aDD, t, w);
-  float x1 = __builtin_fmaf(v, t, st.x);
-  float v1 = __builtin_fmaf(xDD, t, v);
-#if CPMPPI_RARE_MODE == 0
-  if (__builtin_expect(__builtin_fabsf(x1) >= p.THL, 0)) {
-    const float cb = cosf(th1);
-    w1 = __builtin_fmaf(-(2.0f * (v1 * cb)), e.inv_halfL, w1);
-    th1 = __builtin_fmaf(w1, t, th1);
-    v1 = -v1;
-    x1 = __builtin_fmaf(v1, t, x1);
-  }
-  if (__builtin_expect(__builtin_fabsf(th1) >= TWO_PI_F, 0)) th1 = fmodf(th1, TWO_PI_F);
-#else
+// One Euler substep, FAST: the same float32 formulas with folded per-env constants, FMA, a reciprocal + one Newton
+// correction for the divide (<= 1 ulp; A is in [0.33, 0.43] so no scaling is needed) and sincos_pi.
+template <class F>
+__device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
+  constexpr int W = Width<F>::value;
+  const F c = st.c, s = st.s, w = st.w, v = st.v;
+  const F A = fma_(-(c * splat<F>(p.m_pole)), c, splat<F>(e.kp1_mt));
+  const F t1 = fma_(splat<F>(e.mg), s, -(w * splat<F>(e.JinvLh)));
+  F num = fma_(c, t1, uK);
+  num = fma_(-((w * w) * splat<F>(e.kmLh)), s, num);
+  num = fma_(splat<F>(-e.kM), v, num);
+  const F r = rcp_(A);
+  const F q0 = num * r;
+  const F xDD = fma_(fma_(-A, q0, num), r, q0);
+  const F aDD = fma_(splat<F>(e.g_i), s, fma_(xDD * c, splat<F>(e.inv_kLh), -(w * splat<F>(e.cT_i))));
+  const F tt = splat<F>(t);
+  F th1 = fma_(w, tt, st.th);
+  F w1 = fma_(aDD, tt, w);
+  F x1 = fma_(v, tt, st.x);
+  F v1 = fma_(xDD, tt, v);
   // One wave-uniform test for both rare events (edge bounce, cartpole_equations.py:341-347; an angle beyond one
   // 2*pi wrap, |angleD| > 1500 rad/s): the hot instruction stream carries no exec-mask bookkeeping.
-  const bool rare = (__builtin_fabsf(x1) >= p.THL) | (__builtin_fabsf(th1) >= TWO_PI_F);
+  bool rare = false;
+#pragma unroll
+  for (int i = 0; i < W; ++i)
+    rare |= (__builtin_fabsf(get(x1, i)) >= p.THL) | (__builtin_fabsf(get(th1, i)) >= TWO_PI_F);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
-    if (__builtin_fabsf(x1) >= p.THL) {
-      const float cb = cosf(th1);
-      w1 = __builtin_fmaf(-(2.0f * (v1 * cb)), e.inv_halfL, w1);
-      th1 = __builtin_fmaf(w1, t, th1);
-      v1 = -v1;
-      x1 = __builtin_fmaf(v1, t, x1);
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
+      if (__builtin_fabsf(xi) >= p.THL) {
+        const float cb = cosf(thi);
+        wi = __builtin_fmaf(-(2.0f * (vi * cb)), e.inv_halfL, wi);
+        thi = __builtin_fmaf(wi, t, thi);
+        vi = -vi;
+        xi = __builtin_fmaf(vi, t, xi);
+      }
+      if (__builtin_fabsf(thi) >= TWO_PI_F) thi = fmodf(thi, TWO_PI_F);
+      put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
     }
-    if (__builtin_fabsf(th1) >= TWO_PI_F) th1 = fmodf(th1, TWO_PI_F);
   }
-#endif
   // fmod(theta, 2pi) is the identity for |theta| < 2pi; then the reference's two comparisons
-  const float off = (th1 > PI_F) ? -TWO_PI_F : ((th1 < -PI_F) ? TWO_PI_F : 0.0f);
+  F off;
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const float thi = get(th1, i);
+    put(off, i, (thi > PI_F) ? -TWO_PI_F : ((thi < -PI_F) ? TWO_PI_F : 0.0f));
+  }
   th1 += off;
   st.th = th1; st.w = w1; st.x = x1; st.v = v1;
-  sincos_pi(th1, st.s, st.c);
+  sincos_pi<F>(th1, st.s, st.c);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Stage / terminal costs.  `x_t` target position, `te` target equilibrium, `u` the control applied at this stage.
+// Stage / terminal costs (generic over float / float2).  `x_t` target position, `te` target equilibrium, `u` the
+// control applied at this stage.
 // quadratic_boundary_grad_minimal.py:64-126; w = {dd, db, ep, ekp, cc, R, permissible_track_fraction}
-__device__ __forceinline__ float stage_qbgm(const Params& p, float x, float cosang, float w_ang, float u, float x_t,
-                                            float te) {
+template <class F>
+__device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang, F u, float x_t, float te) {
   const float THL = p.THL;
-  const float d = (x - x_t) / (2.0f * THL);
-  const float dd = p.w[0] * (d * d);
+  const F d = (x - splat<F>(x_t)) / splat<F>(2.0f * THL);
+  const F dd = (d * d) * splat<F>(p.w[0]);
   const float ptf = p.w[6];
-  const float ax = __builtin_fabsf(x);
-  const float near = (ax > ptf * THL) ? 1.0f : 0.0f;
-  const float b = (ax - ptf * THL) / ((1.0f - ptf) * THL);
-  const float db = p.w[1] * (near * (b * b));
-  const float e1 = 1.0f - te * cosang;
-  const float ep = p.w[2] * (e1 * e1);
-  const float ekp = p.w[3] * (w_ang * w_ang);
-  const float cc = p.w[4] * (p.w[5] * (u * u));
+  const F ax = abs_(x);
+  F near;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) put(near, i, (get(ax, i) > ptf * THL) ? 1.0f : 0.0f);
+  const F b = (ax - splat<F>(ptf * THL)) / splat<F>((1.0f - ptf) * THL);
+  const F db = (near * (b * b)) * splat<F>(p.w[1]);
+  const F e1 = splat<F>(1.0f) - cosang * splat<F>(te);
+  const F ep = (e1 * e1) * splat<F>(p.w[2]);
+  const F ekp = (w_ang * w_ang) * splat<F>(p.w[3]);
+  const F cc = ((u * u) * splat<F>(p.w[5])) * splat<F>(p.w[4]);
   return dd + db + ep + ekp + cc;
 }
 
 // default.py:23-88; w = {dd, ep, cc, R}
-__device__ __forceinline__ float stage_default(const Params& p, float x, float cosang, float u, float x_t, float te) {
+template <class F>
+__device__ __forceinline__ F stage_default(const Params& p, F x, F cosang, F u, float x_t, float te) {
   const float THL = p.THL;
-  const float d = (x - x_t) / (2.0f * THL);
-  const float ind = (__builtin_fabsf(x) > 0.90f * THL) ? 1.0e7f : 0.0f;
-  const float dd = p.w[0] * (d * d + ind);
-  const float e1 = 1.0f - cosang;
-  const float ep = p.w[1] * (te * 0.25f * (e1 * e1));
-  const float cc = p.w[2] * (p.w[3] * (u * u));
+  const F d = (x - splat<F>(x_t)) / splat<F>(2.0f * THL);
+  F ind;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) put(ind, i, (__builtin_fabsf(get(x, i)) > 0.90f * THL) ? 1.0e7f : 0.0f);
+  const F dd = (d * d + ind) * splat<F>(p.w[0]);
+  const F e1 = splat<F>(1.0f) - cosang;
+  const F ep = ((e1 * e1) * splat<F>(0.25f) * splat<F>(te)) * splat<F>(p.w[1]);
+  const F cc = ((u * u) * splat<F>(p.w[3])) * splat<F>(p.w[2]);
   return dd + ep + cc;
 }
 
 // default.py:55-63 and controller_mppi_cartpole.py:278-303 (phi): 10000 * 1[|angle| > 0.2 or |x - x*| > 0.1*THL]
-__device__ __forceinline__ float terminal_indicator(const Params& p, float angle, float x, float x_t) {
-  const bool bad = (__builtin_fabsf(angle) > 0.2f) || (__builtin_fabsf(x - x_t) > 0.1f * p.THL);
-  return bad ? 10000.0f : 0.0f;
+template <class F>
+__device__ __forceinline__ F terminal_indicator(const Params& p, F angle, F x, float x_t) {
+  F out;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) {
+    const bool bad = (__builtin_fabsf(get(angle, i)) > 0.2f) || (__builtin_fabsf(get(x, i) - x_t) > 0.1f * p.THL);
+    put(out, i, bad ? 10000.0f : 0.0f);
+  }
+  return out;
 }
 
 // MPPI correction term, algebra of controller_mppi_cartpole.py:261-263
-__device__ __forceinline__ float mppi_correction(const Params& p, float u, float du) {
-  return p.cc_weight * (0.5f * (1.0f - 1.0f / p.NU) * p.R * (du * du) + p.R * u * du + 0.5f * p.R * (u * u));
+template <class F>
+__device__ __forceinline__ F mppi_correction(const Params& p, F u, F du) {
+  const float half_nu = 0.5f * (1.0f - 1.0f / p.NU) * p.R;
+  return ((du * du) * splat<F>(half_nu) + (u * du) * splat<F>(p.R) + (u * u) * splat<F>(0.5f * p.R)) *
+         splat<F>(p.cc_weight);
 }
 
-// controller_mppi_cartpole.py:227-275 (q); w = {dd, ep, ekp, ekc, cc, ccrc}
-__device__ __forceinline__ float stage_legacy(const Params& p, float x, float cosang, float w_ang, float v, float u,
-                                              float du, float u_prev, float x_t) {
+// controller_mppi_cartpole.py:227-275 (q); w = {dd, ep, ekp, ekc, cc, ccrc}; u = nominal control of the stage
+template <class F>
+__device__ __forceinline__ F stage_legacy(const Params& p, F x, F cosang, F w_ang, F v, float u, F du, float u_prev,
+                                          float x_t) {
   const float THL = p.THL;
-  const float d = (x - x_t) / (2.0f * THL);
-  const float ind = (__builtin_fabsf(x) > 0.95f * THL) ? 1.0e6f : 0.0f;
-  const float dd = p.w[0] * (d * d + ind);
-  const float e1 = 1.0f - cosang;
-  const float ep = p.w[1] * (0.25f * (e1 * e1));
-  const float ekp = p.w[2] * (w_ang * w_ang);
-  const float ekc = p.w[3] * (v * v);
-  float cc = p.w[4] * (0.5f * (1.0f - 1.0f / p.NU) * p.R * (du * du) + p.R * u * du + 0.5f * p.R * (u * u));
-  const float ur = u + du;
-  if (__builtin_fabsf(ur) > 1.0f) cc = 1.0e5f;
-  const float dcr = ur - u_prev;
-  const float ccrc = p.w[5] * (dcr * dcr);
+  const F d = (x - splat<F>(x_t)) / splat<F>(2.0f * THL);
+  F ind;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) put(ind, i, (__builtin_fabsf(get(x, i)) > 0.95f * THL) ? 1.0e6f : 0.0f);
+  const F dd = (d * d + ind) * splat<F>(p.w[0]);
+  const F e1 = splat<F>(1.0f) - cosang;
+  const F ep = ((e1 * e1) * splat<F>(0.25f)) * splat<F>(p.w[1]);
+  const F ekp = (w_ang * w_ang) * splat<F>(p.w[2]);
+  const F ekc = (v * v) * splat<F>(p.w[3]);
+  const float half_nu = 0.5f * (1.0f - 1.0f / p.NU) * p.R;
+  F cc = ((du * du) * splat<F>(half_nu) + du * splat<F>(p.R * u) + splat<F>(0.5f * p.R * (u * u))) * splat<F>(p.w[4]);
+  const F ur = splat<F>(u) + du;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i)
+    if (__builtin_fabsf(get(ur, i)) > 1.0f) put(cc, i, 1.0e5f);
+  const F dcr = ur - splat<F>(u_prev);
+  const F ccrc = (dcr * dcr) * splat<F>(p.w[5]);
   return dd + ep + ekp + ekc + cc + ccrc;
 }
 
@@ -300,8 +361,7 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint64_t offse
   z1 = r * sn;
 }
 
-// Knot j of (env, rollout) scaled by sigma: the float32 product of the float64 values, as the reference forms
-// stdev * z in float64 before the float32 store (controller_mppi_cartpole.py:441-443).
+// Knot j of (env, rollout) scaled by sigma.
 __device__ __forceinline__ float philox_knot(uint64_t seed, uint64_t offset, uint32_t env, uint32_t rollout,
                                              uint32_t j, float sigma) {
   float z0, z1;

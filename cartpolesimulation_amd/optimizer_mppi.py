@@ -1,0 +1,137 @@
+"""optimizer_mppi — the optimizer seam on the fused HIP path (cpmppi_step).
+
+Constructor keyword arguments are the keys of ``config_optimizers.yml:87-97`` (section ``mppi``) plus the objects
+``controller_mpc.configure`` passes to every optimizer (``predictor, cost_function, control_limits,
+computation_library, optimizer_logging, calculate_optimal_trajectory``) — SURVEY.md §8(b).  The absent upstream
+``Control_Toolkit.Optimizers.optimizer_mppi`` fixes neither horizon aggregation, shift, clipping nor which ``u`` enters
+the correction term (§8c u1-u5); they are explicit options here (defaults = the recalled upstream behaviour; the
+in-tree legacy behaviour is ``configs.legacy_mppi_config``).
+
+Differences from a drop-in that only replaced the arithmetic: ``num_envs`` independent problem instances are stepped
+in ONE launch (``step`` accepts ``s[6]`` or ``s[E,6]``), and perturbations come from a counter-based device RNG unless
+``noise="sfc64"`` asks for numpy's SFC64 stream (bit-identical knots to the reference's sampler for a given seed).
+"""
+import time as _time
+
+import numpy as np
+
+from .configs import MPPIConfig, PhysicalParameters
+
+
+def _vec(x, E, default):
+    if x is None:
+        return np.full(E, default, dtype=np.float32)
+    x = np.asarray(x.cpu() if hasattr(x, "cpu") else x, dtype=np.float32).reshape(-1)
+    return np.full(E, x[0], dtype=np.float32) if x.size == 1 else x.astype(np.float32)
+
+
+class optimizer_mppi:
+    optimizer_name = "mppi"
+
+    def __init__(self, predictor=None, cost_function=None, control_limits=None, computation_library=None, seed=None,
+                 cc_weight=1.0, R=1.0, LBD=100.0, mpc_horizon=35, num_rollouts=3500, NU=1000.0, SQRTRHOINV=0.03,
+                 period_interpolation_inducing_points=10, optimizer_logging=False, calculate_optimal_trajectory=False,
+                 mpc_timestep=0.02, num_envs=1, noise="philox", cost_function_specification=None, cost_weights=None,
+                 horizon_reduce="sum", control_mode="clip", shift_mode="repeat_last", correction_u="u_run",
+                 math_mode="fast", intermediate_steps=10, phys=None, device=0, variable_parameters=None, **kwargs):
+        self.predictor, self.cost_function = predictor, cost_function
+        low, high = (-1.0, 1.0) if control_limits is None else (float(np.asarray(control_limits[0]).reshape(-1)[0]),
+                                                                  float(np.asarray(control_limits[1]).reshape(-1)[0]))
+        self.action_low, self.action_high = low, high
+        self.lib = computation_library
+        if seed is None:                                   # others/globals_and_utils.py:198-214 (time xor pid)
+            import os
+            seed = (_time.time_ns() ^ os.getpid()) & 0x7FFFFFFFFFFFFFFF
+        self.seed = int(seed)
+        self.num_envs = int(num_envs)
+        if noise not in ("philox", "sfc64"):
+            raise ValueError("noise must be 'philox' (device RNG) or 'sfc64' (numpy stream, reference-identical knots)")
+        self.noise = noise
+        if cost_function is not None and cost_function_specification is None:
+            cost_function_specification = getattr(cost_function, "cost_name", None) or \
+                getattr(cost_function, "cost_function_name", None)
+            cost_weights = cost_weights or getattr(cost_function, "weights", None)
+        self.variable_parameters = variable_parameters if variable_parameters is not None else \
+            getattr(cost_function, "variable_parameters", None)
+        self.cfg = MPPIConfig(seed=self.seed, mpc_horizon=int(mpc_horizon), mpc_timestep=float(mpc_timestep),
+                              num_rollouts=int(num_rollouts), cc_weight=cc_weight, R=R, LBD=LBD, NU=NU,
+                              SQRTRHOINV=SQRTRHOINV,
+                              period_interpolation_inducing_points=int(period_interpolation_inducing_points),
+                              intermediate_steps=int(intermediate_steps),
+                              cost_function_specification=cost_function_specification or
+                              "quadratic_boundary_grad_minimal",
+                              cost_weights=dict(cost_weights or {}), horizon_reduce=horizon_reduce,
+                              control_mode=control_mode, shift_mode=shift_mode, correction_u=correction_u,
+                              math_mode=math_mode, action_low=low, action_high=high)
+        self.phys = phys or PhysicalParameters()
+        self.device = device
+        self.num_rollouts, self.mpc_horizon = self.cfg.num_rollouts, self.cfg.mpc_horizon
+        self.optimizer_logging = optimizer_logging
+        self.calculate_optimal_trajectory = calculate_optimal_trajectory
+        self.logging_values = {}
+        self.optimal_trajectory = None
+        self.engine = None
+        self.u_nom = None
+        self.step_counter = 0
+
+    # ------------------------------------------------------------------
+    def configure(self, dt=None, predictor_specification=None, num_envs=None, **kwargs):
+        from .engine import MPPIEngine
+        if dt is not None:
+            self.cfg.mpc_timestep = float(dt)
+        if num_envs is not None:
+            self.num_envs = int(num_envs)
+        if predictor_specification not in (None, "ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
+            raise NotImplementedError("only the ODE_v0 predictor is built into the fused kernel on this tier")
+        self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
+        E, N, H = self.num_envs, self.num_rollouts, self.mpc_horizon
+        self.u_nom = self.engine.zeros(E, H)
+        self.Q = self.engine.empty(E)
+        self.S = self.engine.empty(E, N) if self.optimizer_logging else None
+        self._rng = np.random.Generator(np.random.SFC64(self.seed))
+        self.optimizer_reset()
+
+    def optimizer_reset(self):
+        """u_nom = midpoint of the control limits; restart the noise stream."""
+        if self.u_nom is not None:
+            self.u_nom.fill_(0.5 * (self.action_low + self.action_high))
+        self.step_counter = 0
+        self._rng = np.random.Generator(np.random.SFC64(self.seed))
+
+    # ------------------------------------------------------------------
+    def _attributes(self, E):
+        vp = self.variable_parameters
+        tp = _vec(getattr(vp, "target_position", None), E, 0.0)
+        te = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
+        L = _vec(getattr(vp, "L", None), E, self.phys.L)
+        return tp, te, L
+
+    def step(self, s, time=None, as_tensor=False):
+        """s[6] (one env) or s[E,6] -> first control of the updated nominal sequence, shape [1] or [E,1]."""
+        if self.engine is None:
+            self.configure()
+        eng = self.engine
+        s_t = eng.tensor(s)
+        single = s_t.dim() == 1
+        s_t = s_t.reshape(-1, 6)
+        E = s_t.shape[0]
+        if E != self.num_envs:
+            raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
+        tp, te, L = self._attributes(E)
+        kw = {}
+        if self.noise == "sfc64":
+            from .sampling import sample_knots_sfc64
+            kw["knots"] = sample_knots_sfc64(self._rng, E, self.num_rollouts, self.cfg)
+        else:
+            kw.update(seed=self.seed, offset=self.step_counter)
+        eng.step(s_t, self.u_nom, tp, te, L=L, Q_out=self.Q, S_out=self.S, **kw)
+        self.step_counter += 1
+        if self.optimizer_logging:
+            self.logging_values = {"Q_logged": self.Q.cpu().numpy(), "J_logged": self.S.cpu().numpy(),
+                                   "u_logged": self.u_nom.cpu().numpy()}
+        if self.calculate_optimal_trajectory:
+            self.optimal_trajectory = eng.predict(s_t, self.u_nom, L=L).cpu().numpy()
+        if as_tensor:
+            return self.Q
+        q = self.Q.cpu().numpy()          # the single D2H copy float(controller.step(...)) forces (CartPole/__init__.py:509)
+        return q[:1].copy() if single else q.reshape(E, 1).copy()

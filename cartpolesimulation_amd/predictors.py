@@ -1,0 +1,149 @@
+"""Predictor seam — stand-ins with the reference's call signatures, backed by cpmppi_predict (HIP).
+
+Mirrors (paths in the reference checkout):
+  * next_state_predictor_ODE_v0   SI_Toolkit_ASF/ToolkitCustomization/predictors_customization_v0.py:22-55
+  * predictor_ODE_v0 / PredictorWrapper (absent SI_Toolkit submodule) as their in-tree callers use them:
+    Control_Toolkit_ASF/Controllers/controller_mppi_cartpole.py:51-52,63-65,191,473,566-567 and
+    SI_Toolkit_ASF/ToolkitCustomization/Modules/ODE_module.py:29-31,46-50.
+Inputs may be numpy arrays or ROCm tensors; outputs are numpy by default (what the reference returns) or device
+tensors with ``as_tensor=True``.  There is no CPU path: construction fails without the HIP library / an MI355X.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+from .configs import MPPIConfig, PhysicalParameters
+from .state_utilities import STATE_INDICES, STATE_VARIABLES, CONTROL_INPUTS, create_cartpole_state  # noqa: F401
+
+
+def _engine(horizon, dt, intermediate_steps, phys, math_mode, device):
+    from .engine import MPPIEngine
+    cfg = MPPIConfig(num_rollouts=1, mpc_horizon=max(1, int(horizon)), mpc_timestep=float(dt),
+                     intermediate_steps=int(intermediate_steps), math_mode=math_mode)
+    return MPPIEngine(1, cfg, phys, device=device)
+
+
+def _pole_length(variable_parameters, phys):
+    if variable_parameters is not None and hasattr(variable_parameters, "L"):
+        return float(np.asarray(variable_parameters.L).reshape(-1)[0])
+    return phys.L
+
+
+class next_state_predictor_ODE_v0:
+    """Per-step hook: ``step(s[B,6], Q[B,1]) -> s_next[B,6]`` (one control step = ``intermediate_steps`` Euler
+    substeps with edge bounce and angle wrap).  Honours ``variable_parameters.L`` only, like the reference (:47-50)."""
+
+    def __init__(self, dt, intermediate_steps, batch_size, variable_parameters=None, phys=None, math_mode="precise",
+                 device=0, **kwargs):
+        self.phys = phys or PhysicalParameters()
+        self.params = self.phys
+        self.variable_parameters = variable_parameters
+        self.intermediate_steps = int(intermediate_steps)
+        self.t_step = float(dt / float(self.intermediate_steps))
+        self.s = create_cartpole_state()
+        self._eng = _engine(1, dt, intermediate_steps, self.phys, math_mode, device)
+
+    def step(self, s, Q, as_tensor=False):
+        assert Q.shape[0] == s.shape[0]
+        assert Q.ndim == 2
+        assert s.ndim == 2
+        L = _pole_length(self.variable_parameters, self.phys)
+        out = self._eng.predict(s, Q[:, :1], L=L)[:, 1]
+        return out if as_tensor else out.cpu().numpy()
+
+
+class predictor_ODE_v0:
+    """``predict / predict_core(s0[B,6] | [6], Q[B,H,1] | [H,1]) -> [B,H+1,6]`` with ``out[:,0] = s0``."""
+    predictor_type = "ODE_v0"
+
+    def __init__(self, horizon, dt, intermediate_steps=10, batch_size=1, variable_parameters=None, phys=None,
+                 math_mode="precise", device=0, **kwargs):
+        self.horizon = int(horizon)
+        self.dt = float(dt)
+        self.intermediate_steps = int(intermediate_steps)
+        self.batch_size = int(batch_size)
+        self.variable_parameters = variable_parameters
+        self.phys = phys or PhysicalParameters()
+        self.params = self.phys
+        self._math_mode, self._device = math_mode, device
+        self._eng = _engine(self.horizon, dt, intermediate_steps, self.phys, math_mode, device)
+        self.next_step_predictor = SimpleNamespace(params=self.phys)
+
+    def predict_core(self, initial_state, Q, as_tensor=False):
+        eng = self._eng
+        Q = eng.tensor(Q)
+        if Q.dim() == 2:                       # [H,1] -> one rollout
+            Q = Q.unsqueeze(0)
+        if Q.dim() == 3:
+            Q = Q[:, :, 0]
+        s0 = eng.tensor(initial_state)
+        if s0.dim() == 2 and s0.shape[0] == 1 and Q.shape[0] != 1:
+            s0 = s0[0]
+        out = eng.predict(s0, Q.contiguous(), L=_pole_length(self.variable_parameters, self.phys))
+        return out if as_tensor else out.cpu().numpy()
+
+    predict = predict_core
+
+    def update(self, Q0=None, s=None):
+        """No internal state for an ODE predictor (controller_mppi_cartpole.py:566-567 calls it regardless)."""
+        return None
+
+
+class PredictorWrapper:
+    """configure / predict / predict_core / update with the attributes the in-tree callers read."""
+
+    def __init__(self, phys=None, math_mode="precise", device=0):
+        self.predictor = None
+        self.predictor_config = {"predictor_type": "ODE_v0", "model_name": None, "intermediate_steps": 10}
+        self.predictor_type = "ODE_v0"
+        self.model_name = None
+        self.batch_size = None
+        self._horizon = None
+        self.dt = None
+        self.variable_parameters = None
+        self.phys, self._math_mode, self._device = phys, math_mode, device
+
+    # the reference lets the GUI change the horizon on a live predictor (controller_mppi_cartpole.py:473)
+    @property
+    def horizon(self):
+        return self._horizon
+
+    @horizon.setter
+    def horizon(self, value):
+        if value is not None and self._horizon is not None and int(value) != self._horizon and self.predictor is not None:
+            self._horizon = int(value)
+            self._build()
+        else:
+            self._horizon = None if value is None else int(value)
+
+    def update_predictor_config_from_specification(self, predictor_specification=None, **kwargs):
+        spec = predictor_specification or "ODE_v0"
+        if str(spec).split(":")[0] not in ("ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
+            raise NotImplementedError(f"predictor_specification {spec!r}: only the ODE_v0 path is built on this tier "
+                                      "(neural predictors are SURVEY.md §8f N3)")
+        self.predictor_config = {"predictor_type": "ODE_v0", "model_name": None,
+                                 "intermediate_steps": self.predictor_config["intermediate_steps"]}
+        self.predictor_type = "ODE_v0"
+
+    def _build(self):
+        self.predictor = predictor_ODE_v0(self._horizon, self.dt, self.predictor_config["intermediate_steps"],
+                                          self.batch_size, self.variable_parameters, self.phys, self._math_mode,
+                                          self._device)
+
+    def configure(self, batch_size, horizon, dt, predictor_specification=None, variable_parameters=None, **kwargs):
+        self.update_predictor_config_from_specification(predictor_specification)
+        self.configure_with_compilation(batch_size, horizon, dt, variable_parameters=variable_parameters)
+
+    def configure_with_compilation(self, batch_size, horizon, dt, variable_parameters=None, **kwargs):
+        self.batch_size, self._horizon, self.dt = int(batch_size), int(horizon), float(dt)
+        self.variable_parameters = variable_parameters
+        self._build()
+
+    def predict(self, s, Q, **kw):
+        return self.predictor.predict(s, Q, **kw)
+
+    def predict_core(self, s, Q, **kw):
+        return self.predictor.predict_core(s, Q, **kw)
+
+    def update(self, Q0=None, s=None):
+        return self.predictor.update(Q0, s)

@@ -1,0 +1,161 @@
+"""GPU tests of the drop-in boundary: the reference's controller / optimizer / predictor / cost-function call signatures
+ on the HIP path, checked against the oracle.  They read like the reference's own usage:
+others/Tests/test_controller_mppi_tf.py:7-48, controller_mppi_cartpole.py:51-52,191, cost_function_gym.py:18-21."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+from numpy.random import SFC64, Generator
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402
+
+f32 = np.float32
+
+
+class MockSpace:                                    # others/globals_and_utils.py:236-240
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high = np.atleast_1d(low).astype(dtype), np.atleast_1d(high).astype(dtype)
+        self.dtype, self.shape = dtype, shape
+
+
+def test_controller_mpc_reference_usage():
+    """The reference's timing script, with assertions: construct, configure("mppi"), step(s0) repeatedly."""
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    from cartpolesimulation_amd.state_utilities import create_cartpole_state, ANGLE_IDX
+    ctrl = controller_mpc(environment_name="CartPole",
+                          initial_environment_attributes={"target_position": 0.0, "target_equilibrium": 1.0},
+                          action_space=MockSpace(-1.0, 1.0, (1,)), observation_space=MockSpace(-np.inf, np.inf, (6,)),
+                          config=dict(num_rollouts=512, mpc_horizon=20, seed=3))
+    ctrl.configure(optimizer_name="mppi")
+    assert ctrl.has_optimizer and ctrl.optimizer.optimizer_name == "mppi"
+    assert ctrl.optimizer.num_rollouts == 512 and ctrl.optimizer.mpc_horizon == 20
+    s0 = create_cartpole_state({"angle": 0.2, "angleD": 0.0, "position": 0.02, "positionD": 0.0})
+    u = ctrl.step(s0)
+    assert np.asarray(u).shape == (1,) and -1.0 <= float(u[0]) <= 1.0
+    # pole leaning to positive angle: the cart must be pushed to get under it -> consistent sign over repeated solves
+    us = [float(ctrl.step(s0, time=0.02 * i, updated_attributes={"target_position": 0.0, "target_equilibrium": 1.0,
+                                                                  "L": 0.395, "m_pole": 0.087, "Q_ccrc": 0.0,
+                                                                  "Q_applied_-1": 0.0})[0]) for i in range(5)]
+    assert all(abs(x) <= 1.0 for x in us) and np.sign(us[-1]) == np.sign(us[0]) != 0
+    ctrl.controller_reset()
+    assert float(ctrl.optimizer.u_nom.abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        ctrl.configure(optimizer_name="rpgd")
+    assert s0[ANGLE_IDX] == f32(0.2)
+
+
+def test_optimizer_mppi_sfc64_matches_oracle_over_steps():
+    """Identical noise seeds: three consecutive optimizer steps (shift, clip, cost, correction, update) vs the oracle."""
+    from cartpolesimulation_amd.optimizer_mppi import optimizer_mppi
+    N, H = 768, 25
+    vp = SimpleNamespace(target_position=f32(0.03), target_equilibrium=f32(1.0), L=f32(0.31))
+    opt = optimizer_mppi(control_limits=(np.array([-1.0]), np.array([1.0])), seed=5, num_rollouts=N, mpc_horizon=H,
+                         noise="sfc64", variable_parameters=vp, cost_function_specification="quadratic_boundary_grad_minimal")
+    opt.configure(dt=0.02)
+    rng = Generator(SFC64(5))
+    cfg = O.MPPIConfig(N=N, H=H)
+    u_ref = np.zeros(H, dtype=f32)
+    s = O.create_cartpole_state(0.25, -0.5, 0.01, 0.05)
+    for it in range(3):
+        u = opt.step(s, time=0.02 * it)
+        du = O.sample_delta_u(rng, N, H, np.float64(cfg.stdev))
+        ref = O.mppi_step(s, u_ref, du, vp.target_position, vp.target_equilibrium, cfg, L=vp.L)
+        u_ref = ref["u_new"]
+        np.testing.assert_allclose(opt.u_nom.cpu().numpy()[0], u_ref, atol=1e-4)
+        np.testing.assert_allclose(u, [ref["Q"]], atol=1e-4)
+        s = O.ode_v0_step(s[None], np.array([ref["Q"]], f32), L=vp.L)[0]
+    opt.optimizer_reset()
+    assert opt.step_counter == 0
+
+
+def test_optimizer_batched_envs_equal_single_env_runs():
+    """E envs in one launch == E separate single-env optimizers (same per-env Philox streams via env_offset)."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, N, H = 5, 512, 20
+    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H)
+    rng = Generator(SFC64(11))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.0)
+                   for _ in range(E)])
+    tp = rng.uniform(-0.05, 0.05, E).astype(f32)
+    Lv = rng.uniform(0.25, 0.45, E).astype(f32)
+    big = MPPIEngine(E, cfg)
+    un = big.zeros(E, H)
+    Q, _ = big.step(s0, un, tp, np.ones(E, f32), L=Lv, seed=77, offset=2, env_offset=0)
+    small = MPPIEngine(1, cfg)
+    for e in range(E):
+        u1 = small.zeros(1, H)
+        q1, _ = small.step(s0[e:e + 1], u1, tp[e:e + 1], np.ones(1, f32), L=Lv[e:e + 1], seed=77, offset=2, env_offset=e)
+        assert np.array_equal(u1.cpu().numpy()[0], un.cpu().numpy()[e])
+        assert float(q1[0]) == float(Q[e])
+
+
+def test_predictor_seam():
+    from cartpolesimulation_amd.predictors import PredictorWrapper, next_state_predictor_ODE_v0, predictor_ODE_v0
+    rng = Generator(SFC64(2))
+    B, H = 96, 12
+    s = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-8, 8), rng.uniform(-0.19, 0.19),
+                                          rng.uniform(-0.6, 0.6)) for _ in range(B)])
+    Q = rng.uniform(-1, 1, (B, H, 1)).astype(f32)
+    vp = SimpleNamespace(L=f32(0.27))
+    hook = next_state_predictor_ODE_v0(0.02, 10, B, variable_parameters=vp)
+    assert abs(hook.t_step - 0.002) < 1e-12
+    nxt = hook.step(s, Q[:, 0, :])
+    ref = O.ode_v0_step(s, Q[:, 0, 0], L=vp.L)
+    assert (np.abs(nxt - ref) <= 1e-5 + 1e-5 * np.abs(ref)).all(axis=1).mean() >= 0.97
+    with pytest.raises(AssertionError):
+        hook.step(s, Q[:, 0, 0])                               # Q must be 2-D, as the reference asserts (:43-45)
+    pw = PredictorWrapper()
+    pw.configure(batch_size=B, horizon=H, dt=0.02, predictor_specification="ODE_v0", variable_parameters=vp)
+    assert pw.predictor_config["predictor_type"] == "ODE_v0" and pw.predictor_type == "ODE_v0" and pw.horizon == H
+    traj = pw.predict(s, Q)
+    assert traj.shape == (B, H + 1, 6) and traj.dtype == np.float32 and np.array_equal(traj[:, 0], s)
+    ref_traj = O.predict_core(s, Q, L=vp.L)
+    ok = (np.abs(traj - ref_traj) <= 1e-4 + 1e-4 * np.abs(ref_traj)).all(axis=(1, 2))
+    assert ok.mean() >= 0.95
+    # one state broadcast over the batch, [H,1] controls for a single rollout, update() is a no-op
+    t1 = predictor_ODE_v0(H, 0.02).predict(s[0], Q[0])
+    assert t1.shape == (1, H + 1, 6)
+    assert pw.update(Q[:, :1], s) is None
+    pw.horizon = 6                                             # settable, as the legacy controller does (:473)
+    assert pw.predict_core(s, Q[:, :6]).shape == (B, 7, 6)
+    with pytest.raises(NotImplementedError):
+        pw.configure(batch_size=B, horizon=H, dt=0.02, predictor_specification="GRU-6IN-32H1-32H2-5OUT-0")
+
+
+def test_cost_function_seam():
+    """SURVEY.md Appendix D2 known answers + the plugin interface shapes."""
+    from cartpolesimulation_amd.cost_functions import CostFunctionWrapper, quadratic_boundary_grad_minimal, default
+    states = np.array([[[-0.320988894, -0.381744802, 0.948923886, -0.315505087, -0.095265023, 0.180272102]],
+                       [[2.861763477, -1.590178132, -0.961102605, 0.276191473, 0.190087095, -0.315414101]]], dtype=f32)
+    inputs = np.array([[[-0.24]], [[0.8]]], dtype=f32)
+    vp = SimpleNamespace(target_position=f32(0.05), target_equilibrium=f32(1.0))
+    q = quadratic_boundary_grad_minimal(vp, None)
+    stage = q.get_stage_cost(states, inputs, None)
+    assert stage.shape == (2, 1)
+    np.testing.assert_allclose(stage[:, 0], [1.883728743, 5542.100097656], rtol=1e-5)
+    assert q.get_terminal_cost(states[:, 0]).shape == (2, 1) and not q.get_terminal_cost(states[:, 0]).any()
+    d = default(vp, None)
+    np.testing.assert_allclose(d.get_stage_cost(states, inputs, None)[:, 0], [93.84038544, 6.000019456e+09], rtol=1e-5)
+    np.testing.assert_allclose(d.get_terminal_cost(states[:, 0])[:, 0], [10000.0, 10000.0])
+    # trajectory cost = sum of stage costs on state_horizon[:, :-1] + terminal on state_horizon[:, -1]
+    rng = Generator(SFC64(8))
+    traj = O.predict_core(O.create_cartpole_state(0.4, 1.0, 0.05, 0.1), rng.uniform(-1, 1, (64, 15)).astype(f32))
+    u = rng.uniform(-1, 1, (64, 15, 1)).astype(f32)
+    w = CostFunctionWrapper()
+    w.configure(batch_size=64, horizon=15, variable_parameters=vp, environment_name="CartPole",
+                cost_function_specification="default")
+    total = w.get_trajectory_cost(traj, u, None)
+    ref = O.trajectory_cost(O.COST_DEFAULT, traj, u[:, :, 0], vp.target_position, vp.target_equilibrium)
+    np.testing.assert_allclose(total, ref, rtol=1e-4)
+    np.testing.assert_allclose(w.get_summed_stage_cost(traj[:, :-1], u, None),
+                               O.default_stage_cost(traj[:, :-1], u[:, :, 0], vp.target_position, vp.target_equilibrium).sum(1),
+                               rtol=1e-4)
+    vp.target_position = f32(-0.02)                           # read at call time, like the plugins do
+    total2 = w.get_trajectory_cost(traj, u, None)
+    assert not np.allclose(total, total2)
+    with pytest.raises(ValueError):
+        w.configure(cost_function_specification="quadratic_boundary_nonconvex")

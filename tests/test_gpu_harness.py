@@ -1,0 +1,73 @@
+"""GPU: closed loop on the device (plant + MPPI for E envs in one loop) and the sharded step function."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402
+
+f32 = np.float32
+
+
+def test_plant_matches_oracle():
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    eng = MPPIEngine(1, MPPIConfig(num_rollouts=8, mpc_horizon=4))
+    rng = np.random.Generator(np.random.SFC64(4))
+    E = 64
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-8, 8), rng.uniform(-0.197, 0.197),
+                                           rng.uniform(-0.8, 0.8)) for _ in range(E)])
+    Q = rng.uniform(-1, 1, E).astype(f32)
+    Lv = rng.uniform(0.2, 0.5, E).astype(f32)
+    s = eng.tensor(s0.copy())
+    eng.plant_advance(s, Q, L=Lv, n_substeps=10, dt_sim=0.002)
+    out = s.cpu().numpy()
+    for e in range(E):
+        r = s0[e].copy()
+        add, pdd = O.plant_ode(r, Q[e], Lv[e])
+        for _ in range(10):
+            r = O.plant_substep(r, add, pdd, 0.002, Lv[e])
+            add, pdd = O.plant_ode(r, Q[e], Lv[e])
+        assert np.all(np.abs(out[e] - r) <= 2e-5 + 2e-5 * np.abs(r)), (e, out[e], r)
+
+
+@pytest.mark.parametrize("cost", ["legacy", "default"])
+def test_batched_closed_loop_stabilises(cost):
+    """32 envs at once near the reference's default problem size (2048 x 35): stabilisation succeeds for most envs.  (The costs whose
+    scale LBD=100 was tuned for: the in-tree legacy weights and `default`; quadratic_boundary_grad_minimal is two
+    orders of magnitude flatter and is paired with the gradient optimizer in the reference's shipped config.)"""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig, legacy_mppi_config
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment, generate_random_initial_states
+    E = 32
+    cfg = legacy_mppi_config(num_rollouts=2048, mpc_horizon=35) if cost == "legacy" else \
+        MPPIConfig(num_rollouts=2048, mpc_horizon=35, cost_function_specification="default")
+    eng = MPPIEngine(E, cfg)
+    rng = np.random.Generator(np.random.SFC64(0))
+    s0 = generate_random_initial_states(E, rng, init_limits=dict(angle=(0.0, 12.0), angleD=30.0, position=0.3, positionD=0.1))
+    exp = BatchedCartPoleExperiment(eng, seed=1)
+    out = exp.run(s0, n_control_steps=150, target_position=0.0, target_equilibrium=1.0)
+    states, Q = out["states"].cpu().numpy(), out["Q"].cpu().numpy()
+    assert states.shape == (151, E, 6) and Q.shape == (150, E) and np.abs(Q).max() <= 1.0
+    assert np.array_equal(states[0], s0)
+    final = states[-1]
+    upright = (np.abs(final[:, 0]) < 0.15) & (np.abs(final[:, 4]) < 0.198)
+    assert upright.mean() >= 0.8, f"only {upright.mean():.2f} of the envs stabilised; |angle| {np.abs(final[:, 0]).round(2)}"
+    assert np.allclose(final[:, 2], np.cos(final[:, 0]), atol=1e-6)
+
+
+def test_sharded_step_fn_single_rank():
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.shard import ShardedMPPI, hip_step_fn
+    E = 6
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=256, mpc_horizon=10))
+    u = eng.zeros(E, 10)
+    s0 = np.tile(O.create_cartpole_state(0.2, 0.0, 0.0, 0.0), (E, 1))
+    sh = ShardedMPPI(E, hip_step_fn(eng, u, np.zeros(E, f32), np.ones(E, f32), None, seed=9))
+    u_all, q_all = sh.step(sh.local(s0))
+    assert u_all.shape == (E, 10) and q_all.shape == (E,) and (sh.start, sh.count) == (0, E)
+    assert torch.equal(u_all[:, 0], q_all)
+    # identical states but env-keyed noise streams: different solutions per env
+    assert len(set(np.round(q_all.cpu().numpy(), 7))) == E
