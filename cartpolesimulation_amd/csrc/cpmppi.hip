@@ -81,7 +81,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
   const float L = a.L ? a.L[env] : p.L_default;
-  const EnvConst ec = make_env_const(p, L);
+  const EnvConst ec = make_env_const_uniform(p, L);
   const float x_t = a.x_t[env], te = a.te[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
 
-  auto control_step = [&](uint32_t k, F du) {
+  auto control_step = [&](uint32_t k, F du) __attribute__((always_inline)) {
     const float uk = shifted_nominal(p, un, k);
     F ur = splat<F>(uk) + du;
     if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * H;
     float* __restrict__ my_tile = tile + wave * (64 * R * TILE_STRIDE);
     float pre[NLOAD];
-    auto gload = [&](uint32_t k0) {
+    auto gload = [&](uint32_t k0) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < NLOAD; ++i) {
         const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       }
     }
   } else {
-    auto knot = [&](int i, uint32_t j) -> float {
+    auto knot = [&](int i, uint32_t j) __attribute__((always_inline)) -> float {
       const uint32_t nn = valid[i] ? n[i] : 0;
       if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
       else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);

@@ -67,6 +67,16 @@ __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
   return c;
 }
 
+// For kernels where the env (hence L) is the same for the whole wave: pin every field to an SGPR.
+__device__ __forceinline__ EnvConst make_env_const_uniform(const Params& p, float L) {
+  EnvConst c = make_env_const(p, L);
+  float* f = &c.L;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(EnvConst) / sizeof(float)); ++i)
+    f[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f[i])));
+  return c;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // float / float2 helpers
 typedef float f2 __attribute__((ext_vector_type(2)));

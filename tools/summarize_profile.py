@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into profiles/<tag>/ and profiles/pmc_traffic.json."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    if "anonymous" not in name:
+        return None
+    return name.split("::")[1].split("(")[0]
+
+
+summary = {}
+for noise in ("philox", "buffer"):
+    ks = glob.glob(os.path.join(src, f"stats_{noise}", "**", "*_kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(dst, f"kernel_stats_{noise}.csv"))
+    log = os.path.join(src, f"stats_{noise}.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"bench_line_under_rocprof_{noise}.json"), "w").write(lines[-1])
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, f"pmc_*_{noise}", "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                agg[(k, "_VGPR_Count")].append(float(r["VGPR_Count"]))
+                agg[(k, "_LDS_Block_Size")].append(float(r["LDS_Block_Size"]))
+    out = {}
+    for (k, c), v in sorted(agg.items()):
+        out.setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+    summary[noise] = out
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+
+# HBM traffic of the dominant kernel per launch: (FETCH_SIZE + WRITE_SIZE) KiB * 1024 (MI355X_MICROARCH.md §HBM).
+# The x2 FETCH_SIZE correction of that guide is calibrated for 16 B/lane streaming reads; this kernel issues 4 B/lane
+# loads in 32-byte row segments (buffer mode) or almost no loads (philox mode), so the raw value is recorded together
+# with the doubled one as an upper bound.
+rec = {}
+for noise, out in summary.items():
+    for k, c in out.items():
+        if k.startswith("rollout_cost_kernel") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = c["FETCH_SIZE"]["mean_per_launch"] * 1024, c["WRITE_SIZE"]["mean_per_launch"] * 1024
+            rec[noise] = {"kernel": k, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
+                          "hbm_bytes_per_launch_fetch_doubled": 2 * f + w}
+bench = {}
+for noise in rec:
+    p = os.path.join(dst, f"bench_line_under_rocprof_{noise}.json")
+    if os.path.exists(p):
+        cfg = json.load(open(p))["config"]
+        rec[noise].update(E=cfg["envs_per_gpu"], N=cfg["rollouts"], H=cfg["horizon"], noise=noise)
+json.dump(rec, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(rec, indent=1))
