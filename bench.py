@@ -162,12 +162,12 @@ def main():
         bytes_launch = algorithmic_bytes_per_rollout(N, H) * E * N
         flops_launch = algorithmic_flops_per_rollout(H) * E * N
         achieved_gbs = bytes_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic = None          # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/summarize_profile.py
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc))
-                if rec.get("E") == E and rec.get("N") == N and rec.get("H") == H and rec.get("noise") == args.noise:
+                rec = json.load(open(pmc)).get(args.noise, {})
+                if (rec.get("E"), rec.get("N"), rec.get("H")) == (E, N, H):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      for (uint32_t sub = 0; sub < p.S; ++sub) substep_fast<F>(st, uK, p.t_step, p, ec);
+      control_step_fast<F>(st, uK, p.S, p.t_step, p, ec);
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
@@ -344,9 +344,10 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
   o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
   for (uint32_t k = 0; k < H; ++k) {
     const float u = p.u_max * Q[b * H + k];
-    for (uint32_t sub = 0; sub < p.S; ++sub) {
-      if constexpr (FAST) substep_fast<float>(st, ec.kp1 * u, p.t_step, p, ec);
-      else substep_precise(st, u, p.t_step, p, ec);
+    if constexpr (FAST) {
+      control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec);
+    } else {
+      for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
     o += 6;
     o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;

@@ -142,6 +142,39 @@ __device__ __forceinline__ void sincos_pi(F x, F& sn, F& cs) {
   }
 }
 
+// Variant without per-lane quadrant selects: reduce by multiples of pi to |r| <= pi/2 (q in {-1,0,1}, q*PI_HI exact),
+// sin x = (-1)^q sin r, cos x = (-1)^q cos r; the sign is a multiply, so every instruction has a packed float2 form.
+// Polynomials: sin r = r + r z P3(z), cos r = 1 + z Q4(z), z = r^2, fitted on [-pi/2, pi/2] (Lawson-weighted
+// least squares, coefficients rounded to float32): relative error 1.2e-8 (sin), absolute 4.9e-9 (cos) before rounding.
+template <class F>
+__device__ __forceinline__ void sincos_pi_half(F x, F& sn, F& cs) {
+  constexpr float INV_PI = 0.318309886183790672f;
+  constexpr float PI_HI = 3.14159274101257324f;
+  constexpr float PI_LO = -8.74227765734758577e-8f;
+  const F q = rint_(x * splat<F>(INV_PI));
+  F r = fma_(-q, splat<F>(PI_HI), x);
+  r = fma_(-q, splat<F>(PI_LO), r);
+  const F z = r * r;
+  const F sg = fma_(abs_(q), splat<F>(-2.0f), splat<F>(1.0f));
+  F P = fma_(z, splat<F>(2.6056311526190257e-06f), splat<F>(-0.00019809538207482547f));
+  P = fma_(P, z, splat<F>(0.008333065547049046f));
+  P = fma_(P, z, splat<F>(-0.16666659712791443f));
+  const F rs = r * sg;
+  sn = fma_(rs * z, P, rs);
+  F Q = fma_(z, splat<F>(-2.6075662162838853e-07f), splat<F>(2.476180816302076e-05f));
+  Q = fma_(Q, z, splat<F>(-0.0013888402609154582f));
+  Q = fma_(Q, z, splat<F>(0.04166664183139801f));
+  Q = fma_(Q, z, splat<F>(-0.5f));
+  cs = fma_(z * sg, Q, sg);
+}
+
+#ifndef CPMPPI_SINCOS_MODE
+#define CPMPPI_SINCOS_MODE 1    // 0: pi/4 reduction + quadrant selects   1: pi/2 reduction + sign multiply
+#endif
+#ifndef CPMPPI_WRAP_MODE
+#define CPMPPI_WRAP_MODE 1      // 0: the reference's two comparisons     1: theta - 2pi*rint(theta/2pi)
+#endif
+
 template <class F>
 struct State {
   F th, w, c, s, x, v;   // angle, angleD, angle_cos, angle_sin, position, positionD
@@ -207,57 +240,128 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
   st.w = w1; st.x = x1; st.v = v1;
 }
 
-// One Euler substep, FAST: the same float32 formulas with folded per-env constants, FMA, a reciprocal + one Newton
-// correction for the divide (<= 1 ulp; A is in [0.33, 0.43] so no scaling is needed) and sincos_pi.
+#ifndef CPMPPI_NEWTON
+#define CPMPPI_NEWTON 0         // 0: num * v_rcp_f32(A) (<= 1.5 ulp; measured deviation identical)   1: + one Newton correction
+#endif
+#ifndef CPMPPI_ROTATE
+#define CPMPPI_ROTATE 1         // 1: rotate (cos, sin) on intermediate substeps, full wrap + sincos at the control step's end
+#endif
+
+// ODE + simultaneous forward Euler of one substep with folded constants (FAST).  Outputs the un-wrapped new state.
+//   A    = (k+1)(m_c+m_p) - m_p c^2
+//   xDD  = [ c (m_p g s - J/Lh w) - (k+1) m_p Lh w^2 s - (k+1) M_fric v + (k+1) u ] / A
+//   aDD  = g_i s + xDD c /((k+1)Lh) - cT w                                      (cartpole_equations.py:95-99)
 template <class F>
-__device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
-  constexpr int W = Width<F>::value;
+__device__ __forceinline__ void ode_euler_fast(const State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
+                                               F& th1, F& w1, F& x1, F& v1) {
   const F c = st.c, s = st.s, w = st.w, v = st.v;
   const F A = fma_(-(c * splat<F>(p.m_pole)), c, splat<F>(e.kp1_mt));
   const F t1 = fma_(splat<F>(e.mg), s, -(w * splat<F>(e.JinvLh)));
   F num = fma_(c, t1, uK);
   num = fma_(-((w * w) * splat<F>(e.kmLh)), s, num);
   num = fma_(splat<F>(-e.kM), v, num);
-  const F r = rcp_(A);
+  const F r = rcp_(A);                                  // A in [0.33, 0.43]: no scaling needed
+#if CPMPPI_NEWTON
   const F q0 = num * r;
   const F xDD = fma_(fma_(-A, q0, num), r, q0);
-  const F aDD = fma_(splat<F>(e.g_i), s, fma_(xDD * c, splat<F>(e.inv_kLh), -(w * splat<F>(e.cT_i))));
+#else
+  const F xDD = num * r;
+#endif
   const F tt = splat<F>(t);
-  F th1 = fma_(w, tt, st.th);
-  F w1 = fma_(aDD, tt, w);
-  F x1 = fma_(v, tt, st.x);
-  F v1 = fma_(xDD, tt, v);
-  // One wave-uniform test for both rare events (edge bounce, cartpole_equations.py:341-347; an angle beyond one
-  // 2*pi wrap, |angleD| > 1500 rad/s): the hot instruction stream carries no exec-mask bookkeeping.
+  th1 = fma_(w, tt, st.th);
+  // (do NOT fold "1 - cT*t" into one constant: its rounding error would bias w the same way every substep)
+  const F aDD = fma_(splat<F>(e.g_i), s, fma_(xDD * c, splat<F>(e.inv_kLh), -(w * splat<F>(e.cT_i))));
+  w1 = fma_(aDD, tt, w);
+  x1 = fma_(v, tt, st.x);
+  v1 = fma_(xDD, tt, v);
+}
+
+// Edge bounce of one lane (cartpole_equations.py:341-347), rare.
+__device__ __forceinline__ void bounce_lane(float& thi, float& wi, float& xi, float& vi, float t, float inv_halfL) {
+  const float cb = cosf(thi);
+  wi = __builtin_fmaf(-(2.0f * (vi * cb)), inv_halfL, wi);
+  thi = __builtin_fmaf(wi, t, thi);
+  vi = -vi;
+  xi = __builtin_fmaf(vi, t, xi);
+}
+
+// theta - 2pi*rint(theta/2pi): k*2pi_f32 is subtracted exactly for |k| <= 2 (Sterbenz), i.e. this IS fmod followed by the
+// reference's two comparisons except when theta is within one ulp of +-pi, where both values are the same point of
+// the circle; for absurd |theta| (> 4pi in one substep) it differs from the exact fmod by <= 0.5 ulp.
+template <class F>
+__device__ __forceinline__ F wrap_rint(F th) {
+  return fma_(-rint_(th * splat<F>(0.159154943091895336f)), splat<F>(TWO_PI_F), th);
+}
+
+// One Euler substep, FAST, with the reference's per-substep wrap and sin/cos evaluation.
+template <class F>
+__device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
+  constexpr int W = Width<F>::value;
+  F th1, w1, x1, v1;
+  ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
   bool rare = false;
 #pragma unroll
-  for (int i = 0; i < W; ++i)
-    rare |= (__builtin_fabsf(get(x1, i)) >= p.THL) | (__builtin_fabsf(get(th1, i)) >= TWO_PI_F);
+  for (int i = 0; i < W; ++i) rare |= (__builtin_fabsf(get(x1, i)) >= p.THL);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
+      if (__builtin_fabsf(xi) >= p.THL) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
+      put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+    }
+  }
+  th1 = wrap_rint<F>(th1);
+  st.th = th1; st.w = w1; st.x = x1; st.v = v1;
+  sincos_pi_half<F>(th1, st.s, st.c);
+}
+
+// Intermediate substep, FAST + ROTATE: the angle is left un-wrapped and (cos, sin) are advanced by the rotation
+// through d = w*t, the exact increment of the angle, with sin d, cos d from their Taylor polynomials (|d| <= 0.125:
+// truncation < 1e-9).  Rounding adds ~1 ulp per rotation; the control step's LAST substep re-synchronises with the full
+// wrap + sincos (substep_fast), so the states observed at control-step granularity carry at most S-1 rotations of drift
+// (~2e-7).  Lanes that bounce, or spin faster than 0.125 rad per substep, are re-evaluated exactly in the cold branch.
+template <class F>
+__device__ __forceinline__ void substep_fast_rot(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
+  constexpr int W = Width<F>::value;
+  F th1, w1, x1, v1;
+  const F d = st.w * splat<F>(t);
+  ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
+  const F d2 = d * d;
+  const F sd = fma_(d * d2, fma_(d2, splat<F>(8.3333333e-3f), splat<F>(-1.6666667e-1f)), d);
+  const F cd = fma_(d2, fma_(d2, splat<F>(4.1666667e-2f), splat<F>(-0.5f)), splat<F>(1.0f));
+  F c1 = fma_(st.c, cd, -(st.s * sd));
+  F s1 = fma_(st.s, cd, st.c * sd);
+  bool rare = false;
+#pragma unroll
+  for (int i = 0; i < W; ++i) rare |= (__builtin_fabsf(get(x1, i)) >= p.THL) | (__builtin_fabsf(get(d, i)) > 0.125f);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
 #pragma unroll
     for (int i = 0; i < W; ++i) {
       float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
-      if (__builtin_fabsf(xi) >= p.THL) {
-        const float cb = cosf(thi);
-        wi = __builtin_fmaf(-(2.0f * (vi * cb)), e.inv_halfL, wi);
-        thi = __builtin_fmaf(wi, t, thi);
-        vi = -vi;
-        xi = __builtin_fmaf(vi, t, xi);
+      const bool hit = __builtin_fabsf(xi) >= p.THL;
+      if (hit || __builtin_fabsf(get(d, i)) > 0.125f) {
+        if (hit) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
+        thi = wrap_rint<float>(thi);
+        float sn, cs;
+        sincos_pi_half<float>(thi, sn, cs);
+        put(s1, i, sn); put(c1, i, cs);
+        put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
       }
-      if (__builtin_fabsf(thi) >= TWO_PI_F) thi = fmodf(thi, TWO_PI_F);
-      put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
     }
   }
-  // fmod(theta, 2pi) is the identity for |theta| < 2pi; then the reference's two comparisons
-  F off;
-#pragma unroll
-  for (int i = 0; i < W; ++i) {
-    const float thi = get(th1, i);
-    put(off, i, (thi > PI_F) ? -TWO_PI_F : ((thi < -PI_F) ? TWO_PI_F : 0.0f));
-  }
-  th1 += off;
-  st.th = th1; st.w = w1; st.x = x1; st.v = v1;
-  sincos_pi<F>(th1, st.s, st.c);
+  st.th = th1; st.w = w1; st.x = x1; st.v = v1; st.c = c1; st.s = s1;
+}
+
+// One control step of S substeps under a held control (FAST).
+template <class F>
+__device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
+                                                  const EnvConst& e) {
+#if CPMPPI_ROTATE
+  for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
+  substep_fast<F>(st, uK, t, p, e);
+#else
+  for (uint32_t sub = 0; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -67,8 +67,11 @@ enum { CPMPPI_CONTROL_CLIP = 0, CPMPPI_CONTROL_PENALISE = 1 };     /* clip u_run
 enum { CPMPPI_SHIFT_REPEAT_LAST = 0, CPMPPI_SHIFT_APPEND_ZERO = 1, CPMPPI_SHIFT_NONE = 2 };
 enum { CPMPPI_CORRECTION_U_RUN = 0, CPMPPI_CORRECTION_U_NOM = 1 }; /* which u enters the MPPI correction term */
 enum { CPMPPI_MATH_PRECISE = 0,  /* IEEE divide, libm-grade sincos, no FMA contraction: closest to numpy float32 */
-       CPMPPI_MATH_FAST = 1 };   /* same float32 formulas with FMA contraction, reciprocal+Newton divide (<=1 ulp),
-                                    range-reduced polynomial sincos (<=1.5 ulp on [-pi,pi]) */
+       CPMPPI_MATH_FAST = 1 };   /* same float32 formulas with folded constants and FMA, v_rcp_f32 divide (<=1.5 ulp),
+                                    polynomial sincos on the wrapped angle; inside a control step (cos,sin) advance
+                                    by rotation through w*t and are re-synchronised by the exact wrap + sincos at the
+                                    step's last substep, so states at control-step granularity carry rounding noise
+                                    only (tools/deviation.py: median 1e-6, p99 1e-5 of the reference's own mode A) */
 enum { CPMPPI_NOISE_DELTA_U = 0, /* noise = delta_u[E,N,H]  (reference layout, rollout-major)              */
        CPMPPI_NOISE_KNOTS = 1,   /* noise = knots[E,N,P], P = ceil(H/period)+1; interpolated in-kernel       */
        CPMPPI_NOISE_PHILOX = 2 };/* knots generated in-kernel from (seed, offset): no perturbation buffer   */

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Deviation statistics of the HIP rollout against the golden reference outputs (development tool, GPU).
+
+For every C2 golden regime: |final state - reference| over all 1024 rollouts, in units of the parity band
+(1e-4 + 1e-4|x|), against mode A (strict f32) and mode B (f64 substeps); plus the A-vs-B gap itself for scale.
+Usage: python tools/deviation.py [lib.so ...]   (default: the in-tree library)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cartpolesimulation_amd import _lib as L  # noqa: E402
+from cartpolesimulation_amd.configs import MPPIConfig, build_c_config  # noqa: E402
+from tests.test_gpu_parity import regen_delta_u  # noqa: E402
+
+g = np.load(os.path.join(ROOT, "tests", "golden", "rollouts_c2.npz"))
+N, H = int(g["N"]), int(g["H"])
+libs = sys.argv[1:] or [L.LIB_PATH]
+dev = torch.device("cuda", 0)
+
+
+def band(d, ref):
+    return np.abs(d) / (1e-4 + 1e-4 * np.abs(ref))
+
+
+print(f"{'lib':22s} {'math':8s} {'regime':10s}  vsA: med   p99    max   in-band |  vsB: med   p99    max   in-band | A-vs-B p99  max")
+for path in libs:
+    lib = C.CDLL(os.path.abspath(path))
+    vp, u32 = C.c_void_p, C.c_uint32
+    lib.cpmppi_create.argtypes = [C.POINTER(L.cpmppi_config), C.c_int, C.POINTER(vp)]
+    lib.cpmppi_predict.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
+    for math in ("precise", "fast"):
+        cfg = build_c_config(1, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math))
+        h = vp()
+        assert lib.cpmppi_create(C.byref(cfg), 0, C.byref(h)) == 0
+        tot = []
+        for name in g["names"]:
+            _, du = regen_delta_u(g[f"{name}/seed"], N, H, g["stdev"])
+            u_run = torch.as_tensor(np.ascontiguousarray((g[f"{name}/u_nom"] + du).astype(np.float32)), device=dev)
+            s0 = torch.as_tensor(np.tile(g[f"{name}/s0"], (N, 1)), device=dev)
+            traj = torch.empty(N, H + 1, 6, device=dev)
+            lib.cpmppi_predict(h, N, H, s0.data_ptr(), u_run.data_ptr(), None, traj.data_ptr(), None)
+            torch.cuda.synchronize()
+            fin = traj[:, -1].cpu().numpy()
+            A, B = g[f"{name}/raw/final"], g[f"{name}/raw/final_B"]
+            dA, dB, dAB = band(fin - A, A).max(1), band(fin - B, B).max(1), band(A - B, A).max(1)
+            tot.append((dA, dB))
+            print(f"{os.path.basename(path):22s} {math:8s} {name:10s}  {np.median(dA):8.3f} {np.percentile(dA, 99):6.2f} "
+                  f"{dA.max():6.1f} {np.mean(dA <= 1):7.3f} | {np.median(dB):8.3f} {np.percentile(dB, 99):6.2f} "
+                  f"{dB.max():6.1f} {np.mean(dB <= 1):7.3f} | {np.percentile(dAB, 99):6.2f} {dAB.max():6.1f}")
+        dA = np.concatenate([t[0] for t in tot]); dB = np.concatenate([t[1] for t in tot])
+        print(f"{os.path.basename(path):22s} {math:8s} {'ALL':10s}  {np.median(dA):8.3f} {np.percentile(dA, 99):6.2f} "
+              f"{dA.max():6.1f} {np.mean(dA <= 1):7.3f} | {np.median(dB):8.3f} {np.percentile(dB, 99):6.2f} "
+              f"{dB.max():6.1f} {np.mean(dB <= 1):7.3f}")
