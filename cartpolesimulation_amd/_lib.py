@@ -17,7 +17,7 @@ NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX = 0, 1, 2
 EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
            "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_set_profiling", "cpmppi_get_profile",
-           "cpmppi_version")
+           "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_version")
 
 
 class cpmppi_config(C.Structure):
@@ -37,7 +37,18 @@ class cpmppi_step_args(C.Structure):
     _fields_ = [("E", C.c_uint32), ("s0", C.c_void_p), ("u_nom", C.c_void_p), ("u_prev", C.c_void_p),
                 ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p), ("L", C.c_void_p),
                 ("noise_kind", C.c_uint32), ("noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
-                ("env_offset", C.c_uint32), ("Q_out", C.c_void_p), ("S_out", C.c_void_p)]
+                ("env_offset", C.c_uint32), ("Q_out", C.c_void_p), ("S_out", C.c_void_p),
+                ("predictor", C.c_uint32), ("h0", C.c_void_p)]
+
+
+class cpmppi_gru_model(C.Structure):
+    _FP = C.POINTER(C.c_float)
+    _fields_ = [("inputs", C.c_uint32), ("hidden", C.c_uint32), ("layers", C.c_uint32), ("outputs", C.c_uint32),
+                ("w_ih", _FP * 2), ("w_hh", _FP * 2), ("b_ih", _FP * 2), ("b_hh", _FP * 2), ("w_out", _FP), ("b_out", _FP),
+                ("in_scale", _FP), ("in_shift", _FP), ("out_scale", _FP), ("out_shift", _FP)]
+
+
+PREDICTOR_ODE_V0, PREDICTOR_GRU = 0, 1
 
 
 class CpmppiError(RuntimeError):
@@ -80,6 +91,8 @@ def load():
     lib.cpmppi_plant_advance.argtypes = [vp, u32, vp, vp, vp, u32, f, vp]
     lib.cpmppi_set_profiling.argtypes = [vp, C.c_int]
     lib.cpmppi_get_profile.argtypes = [vp, C.POINTER(f), C.POINTER(f), u32, C.POINTER(u32)]
+    lib.cpmppi_set_gru.argtypes = [vp, C.POINTER(cpmppi_gru_model)]
+    lib.cpmppi_gru_predict.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

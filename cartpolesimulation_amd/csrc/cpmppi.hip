@@ -20,6 +20,7 @@
 
 #include "cpmppi.h"
 #include "cpmppi_device.hpp"
+#include "cpmppi_gru.hpp"
 
 using namespace cpmppi;
 
@@ -436,6 +437,160 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E
   se[0] = st.th; se[1] = st.w; se[2] = st.c; se[3] = st.s; se[4] = st.x; se[5] = st.v;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// GRU predictor (BASELINE configs[4]): see cpmppi_gru.hpp.  256 threads = 4 waves x 32 rollouts.
+constexpr int GRU_ROLLOUTS_PER_BLOCK = 32 * WAVES;
+
+__device__ __forceinline__ void gru_load_image(float* __restrict__ lds, const float* __restrict__ image) {
+  for (int i = threadIdx.x; i < GRU_IMAGE_FLOATS; i += BLOCK) lds[i] = image[i];
+  __syncthreads();
+}
+
+// predictor seam with the neural predictor: s0[B,6], Q[B,H], h0[2,B,32] or NULL -> traj[B,H+1,6], h_out[2,B,32] or NULL
+__global__ __launch_bounds__(BLOCK) void gru_predict_kernel(const GruNorm nm, const float* __restrict__ image, uint32_t B,
+                                                            uint32_t H, const float* __restrict__ s0,
+                                                            const float* __restrict__ Q, const float* __restrict__ h0,
+                                                            float* __restrict__ traj, float* __restrict__ h_out) {
+  extern __shared__ float lds[];
+  gru_load_image(lds, image);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, c = lane & 31u;
+  const size_t b = (size_t)blockIdx.x * GRU_ROLLOUTS_PER_BLOCK + wave * 32 + c;
+  const bool valid = b < B;
+  const size_t bb = valid ? b : 0;
+  const float* s = s0 + bb * 6;
+  f16v h1 = gru_load_hidden(h0 ? h0 + bb * 32 : nullptr, lane);
+  f16v h2 = gru_load_hidden(h0 ? h0 + ((size_t)B + bb) * 32 : nullptr, lane);
+  f16v x = gru_input_tile(nm, s, Q[bb * H], lane);
+  float* o = traj + bb * (size_t)(H + 1) * 6;
+  if (valid && lane < 32) for (int i = 0; i < 6; ++i) o[i] = s[i];
+  for (uint32_t k = 0; k < H; ++k) {
+    const f16v out = gru_step(lds, x, h1, h2, lane);
+    float st[6];
+    gru_output_state(nm, out, lane, st);
+    if (valid && lane < 32) {
+      o += 6;
+      for (int i = 0; i < 6; ++i) o[i] = st[i];
+    }
+    x = out;                                               // normalised outputs are fed back unchanged
+    if (lane >= 32 && k + 1 < H) x[1] = __builtin_fmaf(Q[bb * H + k + 1], nm.in_scale[0], nm.in_shift[0]);
+  }
+  if (h_out && valid) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      h_out[bb * 32 + gru_tile_row(v, lane >> 5)] = h1[v];
+      h_out[((size_t)B + bb) * 32 + gru_tile_row(v, lane >> 5)] = h2[v];
+    }
+  }
+}
+
+// Fused MPPI step with the GRU predictor: same contract as rollout_cost_kernel (plugin costs), h0[E,2,32] or NULL.
+template <int COST, int NOISE>
+__global__ __launch_bounds__(BLOCK) void gru_rollout_cost_kernel(const Params p, const StepPtrs a, const GruNorm nm,
+                                                                 const float* __restrict__ image,
+                                                                 const float* __restrict__ h0) {
+  extern __shared__ float lds[];                           // GRU image, then [WAVES][W] weighted sums
+  __shared__ float red[2 * WAVES];
+  gru_load_image(lds, image);
+  float* bsum = lds + GRU_IMAGE_FLOATS;
+  const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, c = lane & 31u;
+  const uint32_t row0 = blk * GRU_ROLLOUTS_PER_BLOCK + wave * 32;
+  const uint32_t n = row0 + c;
+  const bool owner = lane < 32 && n < p.N;                 // the lane that accounts for rollout n
+  const uint32_t nn = n < p.N ? n : 0;
+  const uint32_t H = p.H;
+  const float x_t = a.x_t[env], te = a.te[env];
+  const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
+  const float* __restrict__ un = a.u_nom + (size_t)env * H;
+  f16v h1 = gru_load_hidden(h0 ? h0 + (size_t)env * 64 : nullptr, lane);
+  f16v h2 = gru_load_hidden(h0 ? h0 + (size_t)env * 64 + 32 : nullptr, lane);
+
+  auto knot = [&](uint32_t j) __attribute__((always_inline)) -> float {
+    if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
+    else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
+  };
+  float z_lo = 0.0f, z_hi = 0.0f;
+  if constexpr (NOISE != NOISE_DELTA_U) { z_lo = knot(0); z_hi = knot(1); }
+  uint32_t ii = 0, j = 0;
+
+  float st[6] = {s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
+  float cost = 0.0f, corr = 0.0f;
+  f16v x;
+  for (uint32_t k = 0; k < H; ++k) {
+    float du;
+    if constexpr (NOISE == NOISE_DELTA_U) du = a.noise[((size_t)env * p.N + nn) * H + k];
+    else du = interp_knots(z_lo, z_hi, ii, p.period);
+    const float uk = shifted_nominal(p, un, k);
+    float ur = uk + du;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = fminf(fmaxf(ur, p.lo), p.hi);
+    const float cosang = cosf(st[0]);
+    if constexpr (COST == COST_QBGM) cost += stage_qbgm<float>(p, st[4], cosang, st[1], ur, x_t, te);
+    else cost += stage_default<float>(p, st[4], cosang, ur, x_t, te);
+    corr += mppi_correction<float>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
+    if (k == 0) x = gru_input_tile(nm, s0, ur, lane);
+    else if (lane >= 32) x[1] = __builtin_fmaf(ur, nm.in_scale[0], nm.in_shift[0]);
+    const f16v out = gru_step(lds, x, h1, h2, lane);
+    gru_output_state(nm, out, lane, st);
+    x = out;
+    if constexpr (NOISE != NOISE_DELTA_U) {
+      if (++ii == p.period) {
+        ii = 0; ++j;
+        z_lo = z_hi;
+        if (j + 1 < p.P) z_hi = knot(j + 1);
+      }
+    }
+  }
+  const float term = (COST == COST_DEFAULT) ? terminal_indicator<float>(p, st[0], st[4], x_t) : 0.0f;
+  float S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / (float)(H + 1);
+  S_total += corr;
+  if (a.S_out && owner) a.S_out[(size_t)env * p.N + n] = S_total;
+
+  const float m_w = wave_min(owner ? S_total : INFINITY);
+  if (lane == 0) red[wave] = m_w;
+  __syncthreads();
+  float m_b = red[0];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) m_b = fminf(m_b, red[w]);
+  const float e = owner ? expf((-1.0f / p.LBD) * (S_total - m_b)) : 0.0f;
+  const float a_w = wave_sum(e);
+  if (lane == 0) red[WAVES + wave] = a_w;
+  const uint32_t W = a.W;
+  float* __restrict__ my_bsum = bsum + wave * W;
+  if constexpr (NOISE == NOISE_PHILOX) {
+    for (uint32_t jj = 0; jj < W; ++jj) {
+      const float v = wave_sum(e * philox_knot(a.seed, a.offset, a.env_offset + env, nn, jj, p.sigma));
+      if (lane == 0) my_bsum[jj] = v;
+    }
+  } else {
+    const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * W;
+    const uint32_t rows = (row0 < p.N) ? ((p.N - row0 < 32u) ? p.N - row0 : 32u) : 0u;
+    for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+      const uint32_t col = c0 + lane;
+      float acc = 0.0f;
+      for (uint32_t r = 0; r < rows; ++r) {
+        const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
+        if (col < W) acc = __builtin_fmaf(er, src[(size_t)r * W + col], acc);
+      }
+      if (col < W) my_bsum[col] = acc;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ outp = a.partial + ((size_t)env * a.nb + blk) * (2 + W);
+  if (tid == 0) {
+    float a_b = red[WAVES];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) a_b += red[WAVES + w];
+    outp[0] = m_b;
+    outp[1] = a_b;
+  }
+  for (uint32_t cc = tid; cc < W; cc += BLOCK) {
+    float v = bsum[cc];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v += bsum[w * W + cc];
+    outp[2 + cc] = v;
+  }
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -449,6 +604,8 @@ struct cpmppi_handle {
   uint32_t nb;
   std::string err;
   // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
+  float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
+  GruNorm gru_norm;
   bool profiling = false;
   std::vector<hipEvent_t> ev;          // triples per step: before rollout, between, after finalize
   size_t ev_used = 0;
@@ -559,7 +716,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   h->cfg = *cfg;
   h->device = device;
   fill_params(*cfg, h->prm);
-  h->nb = (cfg->N + BLOCK - 1) / BLOCK;
+  h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
   const uint32_t Wmax = cfg->H > h->prm.P ? cfg->H : h->prm.P;
   h->workspace_floats = (size_t)cfg->E * h->nb * (2 + Wmax);
   h->workspace = nullptr;
@@ -580,6 +737,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
 void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
   if (h->workspace) (void)hipFree(h->workspace);
+  if (h->gru_image) (void)hipFree(h->gru_image);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
 }
@@ -706,7 +864,25 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     h->ev_used += 3;
     CPMPPI_HIP(h, hipEventRecord(ev[0], s));
   }
-  CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), (size_t)WAVES * p.W * sizeof(float), s, p));
+  if (a->predictor == CPMPPI_PREDICTOR_GRU) {
+    if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: predictor GRU requested but no model set (cpmppi_set_gru)");
+    if (h->prm.cost_id == CPMPPI_COST_LEGACY)
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports the plugin costs only");
+    p.nb = (h->cfg.N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;
+    const size_t lds = ((size_t)GRU_IMAGE_FLOATS + (size_t)WAVES * p.W) * sizeof(float);
+    const dim3 grid(a->E * p.nb);
+#define CPMPPI_GRU_LAUNCH(COST, NOISE)                                                                       \
+    hipLaunchKernelGGL((gru_rollout_cost_kernel<COST, NOISE>), grid, dim3(BLOCK), lds, s, h->prm, p, h->gru_norm, \
+                       (const float*)h->gru_image, a->h0)
+    const bool q = h->prm.cost_id == CPMPPI_COST_QBGM;
+    if (a->noise_kind == CPMPPI_NOISE_DELTA_U) { if (q) CPMPPI_GRU_LAUNCH(COST_QBGM, NOISE_DELTA_U); else CPMPPI_GRU_LAUNCH(COST_DEFAULT, NOISE_DELTA_U); }
+    else if (a->noise_kind == CPMPPI_NOISE_KNOTS) { if (q) CPMPPI_GRU_LAUNCH(COST_QBGM, NOISE_KNOTS); else CPMPPI_GRU_LAUNCH(COST_DEFAULT, NOISE_KNOTS); }
+    else { if (q) CPMPPI_GRU_LAUNCH(COST_QBGM, NOISE_PHILOX); else CPMPPI_GRU_LAUNCH(COST_DEFAULT, NOISE_PHILOX); }
+#undef CPMPPI_GRU_LAUNCH
+    CPMPPI_HIP(h, hipGetLastError());
+  } else {
+    CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), (size_t)WAVES * p.W * sizeof(float), s, p));
+  }
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
   if (a->noise_kind == CPMPPI_NOISE_DELTA_U)
     hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, p.nb,
@@ -740,6 +916,73 @@ int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, 
     if (finalize_ms) finalize_ms[i] = b;
   }
   h->ev_used = 0;
+  return CPMPPI_OK;
+}
+
+int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (!m || m->hidden != 32 || m->layers != 2 || m->inputs != 6 || m->outputs != 5)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_gru: only GRU-6IN-32H1-32H2-5OUT is built");
+  for (int l = 0; l < 2; ++l)
+    if (!m->w_ih[l] || !m->w_hh[l] || !m->b_ih[l] || !m->b_hh[l]) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_gru: null weights");
+  if (!m->w_out || !m->b_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_gru: null head weights");
+  std::vector<float> img((size_t)GRU_IMAGE_FLOATS, 0.0f);
+  auto frag = [&](int f) { return img.data() + (size_t)f * 64; };
+  // x-tile row r -> network input column: rows 0..4 = the 5 state features (inputs 1..5), row 5 = Q (input 0)
+  auto xcol = [](int r) { return r < 5 ? r + 1 : (r == 5 ? 0 : -1); };
+  for (int g = 0; g < 3; ++g) {
+    for (int s = 0; s < 4; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int col = xcol(gru_tile_row(s, l >> 5));
+        frag(GF_L1X + g * 4 + s)[l] = col < 0 ? 0.0f : m->w_ih[0][(size_t)(g * 32 + (l & 31)) * 6 + col];
+      }
+    for (int s = 0; s < 16; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int k = gru_tile_row(s, l >> 5);
+        const size_t row = (size_t)(g * 32 + (l & 31));
+        frag(GF_L1H + g * 16 + s)[l] = m->w_hh[0][row * 32 + k];
+        frag(GF_L2X + g * 16 + s)[l] = m->w_ih[1][row * 32 + k];
+        frag(GF_L2H + g * 16 + s)[l] = m->w_hh[1][row * 32 + k];
+      }
+  }
+  for (int layer = 0; layer < 2; ++layer) {
+    const int fb = layer == 0 ? GF_L1B : GF_L2B;
+    for (int l = 0; l < 32; ++l) {                           // lane-half 0 carries the bias (k = 0), half 1 zeros
+      frag(fb + 0)[l] = m->b_ih[layer][l] + m->b_hh[layer][l];
+      frag(fb + 1)[l] = m->b_ih[layer][32 + l] + m->b_hh[layer][32 + l];
+      frag(fb + 2)[l] = m->b_ih[layer][64 + l];
+      frag(fb + 3)[l] = m->b_hh[layer][64 + l];
+    }
+  }
+  for (int s = 0; s < 16; ++s)
+    for (int l = 0; l < 64; ++l)
+      frag(GF_DW + s)[l] = (l & 31) < 5 ? m->w_out[(size_t)(l & 31) * 32 + gru_tile_row(s, l >> 5)] : 0.0f;
+  for (int l = 0; l < 5; ++l) frag(GF_DB)[l] = m->b_out[l];
+  for (int i = 0; i < 6; ++i) {
+    h->gru_norm.in_scale[i] = m->in_scale ? m->in_scale[i] : 1.0f;
+    h->gru_norm.in_shift[i] = m->in_shift ? m->in_shift[i] : 0.0f;
+  }
+  for (int i = 0; i < 5; ++i) {
+    h->gru_norm.out_scale[i] = m->out_scale ? m->out_scale[i] : 1.0f;
+    h->gru_norm.out_shift[i] = m->out_shift ? m->out_shift[i] : 0.0f;
+  }
+  if (int rc = ensure_device(h)) return rc;
+  if (!h->gru_image) CPMPPI_HIP(h, hipMalloc(&h->gru_image, img.size() * sizeof(float)));
+  CPMPPI_HIP(h, hipMemcpy(h->gru_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  return CPMPPI_OK;
+}
+
+int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* h0,
+                       float* traj_out, float* h_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_gru_predict: no model set (cpmppi_set_gru)");
+  if (horizon == 0) horizon = h->cfg.H;
+  if (B == 0 || !s0 || !Q || !traj_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_gru_predict: bad argument");
+  if (int rc = ensure_device(h)) return rc;
+  hipLaunchKernelGGL(gru_predict_kernel, dim3((B + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK), dim3(BLOCK),
+                     (size_t)GRU_IMAGE_FLOATS * sizeof(float), (hipStream_t)stream, h->gru_norm,
+                     (const float*)h->gru_image, B, horizon, s0, Q, h0, traj_out, h_out);
+  CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
 

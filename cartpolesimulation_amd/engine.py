@@ -154,6 +154,52 @@ class MPPIEngine:
                                                   float(dt_sim), self._stream()))
         return s
 
+    # ------------------------------------------------------------------ GRU predictor (BASELINE configs[4])
+    GRU_KEYS = ("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "w_out", "b_out")
+
+    def set_gru(self, model):
+        """Attach a GRU-6IN-32H1-32H2-5OUT model: dict of float32 arrays in the torch.nn.GRU layout
+        (w_ih0[96,6], w_hh0[96,32], b_ih0[96], b_hh0[96], w_ih1[96,32], w_hh1, b_ih1, b_hh1, w_out[5,32], b_out[5]) and
+        optional in_scale/in_shift[6], out_scale/out_shift[5]."""
+        shapes = dict(w_ih0=(96, 6), w_hh0=(96, 32), b_ih0=(96,), b_hh0=(96,), w_ih1=(96, 32), w_hh1=(96, 32),
+                      b_ih1=(96,), b_hh1=(96,), w_out=(5, 32), b_out=(5,), in_scale=(6,), in_shift=(6,),
+                      out_scale=(5,), out_shift=(5,))
+        keep = {}
+        for k, shp in shapes.items():
+            if k in model and model[k] is not None:
+                a = np.ascontiguousarray(np.asarray(model[k].detach().cpu() if torch.is_tensor(model[k]) else model[k],
+                                                    dtype=np.float32))
+                if a.shape != shp:
+                    raise ValueError(f"GRU weight {k} must have shape {shp}, got {a.shape}")
+                keep[k] = a
+            elif k in self.GRU_KEYS:
+                raise ValueError(f"GRU weight {k} missing")
+        fp = lambda k: keep[k].ctypes.data_as(C.POINTER(C.c_float)) if k in keep else None
+        m = _L.cpmppi_gru_model()
+        m.inputs, m.hidden, m.layers, m.outputs = 6, 32, 2, 5
+        for l in range(2):
+            m.w_ih[l], m.w_hh[l], m.b_ih[l], m.b_hh[l] = fp(f"w_ih{l}"), fp(f"w_hh{l}"), fp(f"b_ih{l}"), fp(f"b_hh{l}")
+        m.w_out, m.b_out = fp("w_out"), fp("b_out")
+        m.in_scale, m.in_shift, m.out_scale, m.out_shift = fp("in_scale"), fp("in_shift"), fp("out_scale"), fp("out_shift")
+        self._check(self.lib.cpmppi_set_gru(self._h, C.byref(m)))
+        self.has_gru = True
+
+    def gru_predict(self, s0, Q, h0=None, return_hidden=False):
+        """Neural predictor seam: s0[B,6] | [6], Q[B,H], h0[2,B,32] -> traj[B,H+1,6] (and final hidden [2,B,32])."""
+        Q = self.tensor(Q)
+        if Q.dim() == 3:
+            Q = Q[:, :, 0].contiguous()
+        B, H = Q.shape
+        s0 = self.tensor(s0)
+        if s0.dim() == 1:
+            s0 = s0.unsqueeze(0).expand(B, 6).contiguous()
+        h0 = self.tensor(h0, (2, B, 32)) if h0 is not None else None
+        traj = self.empty(B, H + 1, 6)
+        h_out = self.empty(2, B, 32) if return_hidden else None
+        self._check(self.lib.cpmppi_gru_predict(self._h, B, H, _ptr(s0), _ptr(Q), _ptr(h0), _ptr(traj), _ptr(h_out),
+                                                self._stream()))
+        return (traj, h_out) if return_hidden else traj
+
     def set_profiling(self, enable=True):
         self._check(self.lib.cpmppi_set_profiling(self._h, int(bool(enable))))
 
@@ -168,7 +214,7 @@ class MPPIEngine:
 
     # ------------------------------------------------------------------ the fused hot path
     def step(self, s0, u_nom, target_position, target_equilibrium, L=None, delta_u=None, knots=None, seed=None,
-             offset=0, env_offset=0, u_prev=None, Q_out=None, S_out=None):
+             offset=0, env_offset=0, u_prev=None, Q_out=None, S_out=None, predictor="ODE_v0", h0=None):
         """One MPPI optimizer step for E envs.  ``u_nom`` [E,H] is updated IN PLACE.
 
         Exactly one noise source: ``delta_u`` [E,N,H], ``knots`` [E,N,P], or ``seed`` (in-kernel Philox).
@@ -212,6 +258,11 @@ class MPPIEngine:
         a.noise = noise.data_ptr() if noise is not None else None
         a.Q_out = Q_out.data_ptr()
         a.S_out = S_out.data_ptr() if S_out is not None else None
+        if predictor not in ("ODE_v0", "GRU"):
+            raise ValueError("predictor must be 'ODE_v0' or 'GRU'")
+        a.predictor = _L.PREDICTOR_GRU if predictor == "GRU" else _L.PREDICTOR_ODE_V0
+        h0 = self.tensor(h0, (E, 2, 32)) if h0 is not None else None
+        a.h0 = h0.data_ptr() if h0 is not None else None
         self._check(self.lib.cpmppi_step(self._h, C.byref(a), self._stream()))
         # keep the temporaries alive until the launch is enqueued (stream-ordered frees are safe in torch's allocator)
         return Q_out, S_out

@@ -106,6 +106,24 @@ typedef struct {
 
 typedef struct cpmppi_handle cpmppi_handle;
 
+enum { CPMPPI_PREDICTOR_ODE_V0 = 0, CPMPPI_PREDICTOR_GRU = 1 };
+
+/* Neural predictor of BASELINE configs[4] (model naming SI_Toolkit_ASF/config_predictors.yml:8-13): two GRU layers of
+ * 32 units and a dense head, torch.nn.GRU convention (gate rows r, z, n; b_ih and b_hh).  HOST pointers; inputs are
+ * ordered (Q, angleD, angle_cos, angle_sin, position, positionD), outputs (angleD, angle_cos, angle_sin, position,
+ * positionD) — SI_Toolkit's alphabetical feature order; normalised = x*scale + shift (NULL = identity). */
+typedef struct {
+  uint32_t inputs, hidden, layers, outputs;   /* 6, 32, 2, 5 */
+  const float* w_ih[2];                       /* [96,6], [96,32] */
+  const float* w_hh[2];                       /* [96,32] */
+  const float* b_ih[2];                       /* [96] */
+  const float* b_hh[2];                       /* [96] */
+  const float* w_out;                         /* [5,32] */
+  const float* b_out;                         /* [5] */
+  const float* in_scale;  const float* in_shift;    /* [6] */
+  const float* out_scale; const float* out_shift;   /* [5] */
+} cpmppi_gru_model;
+
 /* One optimizer step for `E` envs (E <= config.E).  All pointers are device pointers. */
 typedef struct {
   uint32_t E;                       /* active envs in this call */
@@ -124,6 +142,8 @@ typedef struct {
   uint32_t env_offset;              /* CPMPPI_NOISE_PHILOX: global index of env 0 (rank * E_local when sharded) */
   float* Q_out;                     /* [E]    first element of the updated nominal sequence */
   float* S_out;                     /* [E,N]  per-rollout total cost, or NULL */
+  uint32_t predictor;               /* CPMPPI_PREDICTOR_ODE_V0 (default, 0) or CPMPPI_PREDICTOR_GRU */
+  const float* h0;                  /* GRU only: hidden state per env [E,2,32] shared by the env's rollouts, or NULL=0 */
 } cpmppi_step_args;
 
 int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out);
@@ -166,6 +186,15 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* args, void* stream);
  * call (at most max_steps entries are written; *n_steps receives the number recorded) and resets the recorder. */
 int cpmppi_set_profiling(cpmppi_handle* h, int enable);
 int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, uint32_t max_steps, uint32_t* n_steps);
+
+/* Attach / replace the GRU model of a handle (synchronous upload; not for the launch path). */
+int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* model);
+
+/* Predictor seam with the neural predictor (predictor_autoregressive_neural; augmentation angle = atan2(sin, cos),
+ * SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:121-127): s0[B,6], Q[B,H], h0[2,B,32] or NULL ->
+ * traj[B,H+1,6], h_out[2,B,32] or NULL (device pointers). */
+int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* h0,
+                       float* traj_out, float* h_out, void* stream);
 
 /* a16 alone: S[E,N], delta_u[E,N,H] -> weighted average [E,H] (controller_mppi_cartpole.py:306-321). */
 int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S, const float* delta_u, float* out,

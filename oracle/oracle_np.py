@@ -452,3 +452,87 @@ class LegacyMPPIController:
         self.u_prev = self.u.copy()                                                    # :558
         self.u = np.concatenate([self.u[1:], np.zeros(1, dtype=f32)])                  # :561-562
         return Q
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# BASELINE config C5 / SURVEY §8f N3 — autoregressive GRU predictor (GRU-6IN-32H1-32H2-5OUT).
+# The implementing class (SI_Toolkit.Predictors.predictor_autoregressive_neural) is in the absent submodule and no GRU
+# weights ship in-tree (config_predictors.yml:10,32 point to a git-ignored Experiments folder), so what is restated
+# here is (i) the standard GRU cell in the torch.nn.GRU convention (gate order r, z, n; both bias vectors), pinned by
+# tests/golden/gru_c5.npz which oracle/gen_golden_gru.py produced with torch.nn.GRU itself, and (ii) the in-tree
+# output augmentation angle = atan2(angle_sin, angle_cos) (SI_Toolkit_ASF/ToolkitCustomization/
+# predictors_customization.py:121-127).  Feature order follows SI_Toolkit's alphabetical sorting, as visible in the
+# in-tree net-info file GymlikeCartPole/Dense-7IN-32H1-32H2-1OUT-0/Dense-7IN-32H1-32H2-1OUT-0.txt:
+GRU_INPUTS = ("Q", "angleD", "angle_cos", "angle_sin", "position", "positionD")
+GRU_OUTPUTS = ("angleD", "angle_cos", "angle_sin", "position", "positionD")
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRU cell: r,z,n = chunks of 3*hidden rows.  x[B,I], h[B,Hd] -> h'[B,Hd] (float32)."""
+    Hd = h.shape[1]
+    gi = x @ w_ih.T + b_ih
+    gh = h @ w_hh.T + b_hh
+    r = _sigmoid(gi[:, :Hd] + gh[:, :Hd])
+    z = _sigmoid(gi[:, Hd:2 * Hd] + gh[:, Hd:2 * Hd])
+    n = np.tanh(gi[:, 2 * Hd:] + r * gh[:, 2 * Hd:])
+    return ((1.0 - z) * n + z * h).astype(f32)
+
+
+def gru_features_from_state(s):
+    """state[...,6] -> the 5 state features in GRU_INPUTS order (without Q)."""
+    return np.stack([s[..., ANGLED_IDX], s[..., ANGLE_COS_IDX], s[..., ANGLE_SIN_IDX], s[..., POSITION_IDX],
+                     s[..., POSITIOND_IDX]], axis=-1).astype(f32)
+
+
+def gru_predict(model, s0, Q, h0=None):
+    """Autoregressive rollout.  model: dict of float32 arrays (w_ih0[96,6], w_hh0[96,32], b_ih0, b_hh0, w_ih1[96,32],
+    w_hh1, b_ih1, b_hh1, w_out[5,32], b_out[5], in_scale[6], in_shift[6], out_scale[5], out_shift[5]).
+    s0[B,6], Q[B,H] -> traj[B,H+1,6] (traj[:,0]=s0), final hidden [2,B,32].  The network runs on normalised features
+    (x*scale+shift), its normalised outputs are fed back unchanged; outputs are de-normalised and augmented with
+    angle = atan2(sin, cos)."""
+    s0 = np.asarray(s0, dtype=f32)
+    Q = np.asarray(Q, dtype=f32)
+    B, H = Q.shape
+    if s0.ndim == 1:
+        s0 = np.tile(s0, (B, 1))
+    Hd = model["w_hh0"].shape[1]
+    h = np.zeros((2, B, Hd), dtype=f32) if h0 is None else np.array(h0, dtype=f32)
+    feat = (gru_features_from_state(s0) * model["in_scale"][1:] + model["in_shift"][1:]).astype(f32)
+    traj = np.zeros((B, H + 1, 6), dtype=f32)
+    traj[:, 0] = s0
+    for k in range(H):
+        qn = (Q[:, k] * model["in_scale"][0] + model["in_shift"][0]).astype(f32)
+        x = np.concatenate([qn[:, None], feat], axis=1).astype(f32)
+        h[0] = gru_cell(x, h[0], model["w_ih0"], model["w_hh0"], model["b_ih0"], model["b_hh0"])
+        h[1] = gru_cell(h[0], h[1], model["w_ih1"], model["w_hh1"], model["b_ih1"], model["b_hh1"])
+        feat = (h[1] @ model["w_out"].T + model["b_out"]).astype(f32)
+        y = (feat * model["out_scale"] + model["out_shift"]).astype(f32)
+        traj[:, k + 1, ANGLED_IDX], traj[:, k + 1, ANGLE_COS_IDX], traj[:, k + 1, ANGLE_SIN_IDX] = y[:, 0], y[:, 1], y[:, 2]
+        traj[:, k + 1, POSITION_IDX], traj[:, k + 1, POSITIOND_IDX] = y[:, 3], y[:, 4]
+        traj[:, k + 1, ANGLE_IDX] = np.arctan2(y[:, 2], y[:, 1])
+    return traj, h
+
+
+def gru_mppi_step(model, s, u_nom, delta_u, target_position, target_equilibrium, cfg, h0=None, low=-1.0, high=1.0):
+    """optimizer step with the GRU predictor inside the same MPPI loop (BASELINE configs[4]); plugin costs only."""
+    u_nom = np.asarray(u_nom, dtype=f32)
+    if cfg.shift_mode == "repeat_last":
+        u_nom = np.concatenate([u_nom[1:], u_nom[-1:]])
+    elif cfg.shift_mode == "append_zero":
+        u_nom = np.concatenate([u_nom[1:], np.zeros(1, dtype=f32)])
+    u_run = u_nom[None, :] + delta_u
+    if cfg.control_mode == "clip":
+        u_run = np.clip(u_run, f32(low), f32(high))
+    h0b = None if h0 is None else np.repeat(np.asarray(h0, dtype=f32)[:, None, :], delta_u.shape[0], axis=1)
+    traj, _ = gru_predict(model, s, u_run, h0b)
+    S_cost = trajectory_cost(cfg.cost_id, traj, u_run, target_position, target_equilibrium, cfg.horizon_reduce)
+    u_corr = u_run if cfg.correction_u == "u_run" else u_nom[None, :]
+    S_cost = (S_cost + mppi_correction_cost(u_corr, delta_u, cfg.cc_weight, cfg.R, cfg.NU)).astype(f32)
+    u_new = (u_nom + reward_weighted_average(S_cost, delta_u, cfg.LBD)).astype(f32)
+    if cfg.control_mode == "clip":
+        u_new = np.clip(u_new, f32(low), f32(high))
+    return dict(S=S_cost, u_new=u_new, Q=u_new[0], traj=traj, u_run=u_run)

@@ -167,3 +167,41 @@ def test_closed_loop_c1_plumbing(golden_dir):
     assert n_match == 10
     # qualitatively stabilising afterwards
     assert abs(s[O.ANGLE_IDX]) < 0.2 and abs(s[O.POSITION_IDX]) < 0.198
+
+
+def test_gru_oracle_matches_torch_fixture(golden_dir):
+    """BASELINE configs[4]: the numpy GRU restatement is pinned to trajectories produced by torch.nn.GRU + Linear."""
+    g = load(golden_dir, "gru_c5.npz")
+    model = {k: g[k] for k in g.files if k not in ("s0", "Q", "h0", "traj", "h_final")}
+    traj, h = O.gru_predict(model, g["s0"], g["Q"], g["h0"])
+    d = np.abs(traj - g["traj"])
+    d[:, :, 0] = np.minimum(d[:, :, 0], 2 * np.pi - d[:, :, 0])
+    assert d.max() < 5e-6 and np.abs(h - g["h_final"]).max() < 5e-6
+    assert model["w_ih0"].shape == (96, 6) and model["w_out"].shape == (5, 32)
+
+
+def test_gru_oracle_against_live_torch(golden_dir):
+    """Independent check with a freshly seeded torch.nn.GRU (not the stored weights)."""
+    torch = pytest.importorskip("torch")
+    torch.manual_seed(11)
+    gru = torch.nn.GRU(6, 32, 2, batch_first=True)
+    lin = torch.nn.Linear(32, 5)
+    model = {f"{n}{l}": getattr(gru, f"{'weight' if n[0] == 'w' else 'bias'}_{n[2:]}_l{l}").detach().numpy()
+             for l in (0, 1) for n in ("w_ih", "w_hh", "b_ih", "b_hh")}
+    model.update(w_out=lin.weight.detach().numpy(), b_out=lin.bias.detach().numpy(), in_scale=np.ones(6, f32),
+                 in_shift=np.zeros(6, f32), out_scale=np.ones(5, f32), out_shift=np.zeros(5, f32))
+    rng = Generator(SFC64(1))
+    B, H = 7, 9
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-0.1, 0.1), 0.1)
+                   for _ in range(B)])
+    Q = rng.uniform(-1, 1, (B, H)).astype(f32)
+    traj, _ = O.gru_predict(model, s0, Q)
+    with torch.no_grad():
+        feat = torch.tensor(O.gru_features_from_state(s0))
+        h = torch.zeros(2, B, 32)
+        for k in range(H):
+            out, h = gru(torch.cat([torch.tensor(Q[:, k:k + 1]), feat], 1)[:, None], h)
+            feat = lin(out[:, 0])
+            y = feat.numpy()
+            ref = np.stack([np.arctan2(y[:, 2], y[:, 1]), y[:, 0], y[:, 1], y[:, 2], y[:, 3], y[:, 4]], 1)
+            assert np.abs(traj[:, k + 1] - ref).max() < 5e-6
