@@ -94,6 +94,9 @@ def main():
                          "buffer: device sampler writes delta_u[E,N,H] to HBM, rollout kernel reads it back "
                          "(the reference's tensor layout at the optimizer/predictor seam)")
     ap.add_argument("--math", choices=["fast", "precise"], default="fast")
+    ap.add_argument("--predictor", choices=["ode", "gru"], default="ode",
+                    help="ode: predictor_ODE_v0 (the headline path); gru: GRU-6IN-32H1-32H2-5OUT on the f32 matrix "
+                         "cores inside the same MPPI loop (BASELINE configs[4], synthetic weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-env", action="store_true")
     args = ap.parse_args()
@@ -103,12 +106,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if distributed:
         dist.init_process_group("nccl", device_id=device)
 
     from cartpolesimulation_amd.engine import MPPIEngine
@@ -121,20 +125,27 @@ def main():
     u_nom = eng.zeros(E, H)
     Q_out = eng.empty(E)
     du = eng.empty(E, N, H) if args.noise == "buffer" else None
-    gathered = torch.empty(world * E * H, dtype=torch.float32, device=device) if world > 1 else None
+    gathered = torch.empty(world * E * H, dtype=torch.float32, device=device) if distributed else None
     seed = 1234
+    pred_kw = {}
+    if args.predictor == "gru":
+        rng = np.random.Generator(np.random.SFC64(5))
+        u = lambda *s: rng.uniform(-1, 1, s).astype(np.float32) / np.sqrt(32.0, dtype=np.float32)
+        eng.set_gru(dict(w_ih0=u(96, 6), w_hh0=u(96, 32), b_ih0=u(96), b_hh0=u(96), w_ih1=u(96, 32), w_hh1=u(96, 32),
+                         b_ih1=u(96), b_hh1=u(96), w_out=u(5, 32), b_out=u(5)))
+        pred_kw = dict(predictor="GRU")
 
     def step(i):
         if args.noise == "buffer":
             eng._check(eng.lib.cpmppi_sample(eng._h, E, seed, i, rank * E, None, du.data_ptr(), eng._stream()))
-            eng.step(s0, u_nom, tp, te, L=L, delta_u=du, Q_out=Q_out)
+            eng.step(s0, u_nom, tp, te, L=L, delta_u=du, Q_out=Q_out, **pred_kw)
         else:
-            eng.step(s0, u_nom, tp, te, L=L, seed=seed, offset=i, env_offset=rank * E, Q_out=Q_out)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, u_nom.view(-1))
+            eng.step(s0, u_nom, tp, te, L=L, seed=seed, offset=i, env_offset=rank * E, Q_out=Q_out, **pred_kw)
+        if distributed:
+            dist.all_gather_into_tensor(gathered, u_nom.view(-1))      # the single RCCL gather of chosen controls
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +160,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rollout_ms, finalize_ms = eng.get_profile()
     eng.set_profiling(False)
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -171,6 +182,16 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if args.predictor == "gru":
+            # useful flops of the GRU-6IN-32H1-32H2-5OUT forward per rollout-step: 2 x (3*32*(6+32) + 3*32*(32+32) + 5*32)
+            gru_flops = 2.0 * (3 * 32 * 38 + 3 * 32 * 64 + 5 * 32) * H * E * N
+            roof = {"bound": "mfma", "kernel": "gru_rollout_cost_kernel", "achieved": gru_flops / (k_ms * 1e-3) / 1e12,
+                    "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": gru_flops / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
+                    "kernel_ms": k_ms, "finalize_kernel_ms": float(np.mean(finalize_ms)),
+                    "note": "f32-input MFMA (v_mfma_f32_32x32x2_f32): dense peak = the fp32 vector peak, 157.3 TFLOP/s"}
+        else:
+            roof = None
         out = {
             "metric": "MPPI rollouts/sec (1024 samples x 50-step horizon)", "value": value, "unit": "rollouts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -179,9 +200,10 @@ def main():
                                    f"{E} independent envs per GPU batched in one launch (BASELINE configs[1] shape)",
                        "envs_per_gpu": E, "rollouts": N, "horizon": H, "substeps": 10,
                        "cost": cfg.cost_function_specification, "noise": args.noise, "math": args.math,
+                       "predictor": "predictor_ODE_v0" if args.predictor == "ode" else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",
                        "parallelism": f"env-sharded x{world}, one RCCL all-gather of u_nom per step" if world > 1
                        else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": achieved_gbs,
+            "roofline": roof or {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": k_ms, "finalize_kernel_ms": float(np.mean(finalize_ms)),
                          "algorithmic_bytes_per_rollout": algorithmic_bytes_per_rollout(N, H),
@@ -194,19 +216,25 @@ def main():
         if not args.no_single_env:
             # latency of ONE problem instance (BASELINE configs[1] literally: single env), same kernels
             e1 = MPPIEngine(1, cfg, device=local_rank)
+            if args.predictor == "gru":
+                e1.lib.cpmppi_set_gru  # same synthetic model
+                e1.set_gru({k: v for k, v in zip(("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1",
+                                                  "w_out", "b_out"),
+                                                 (u(96, 6), u(96, 32), u(96), u(96), u(96, 32), u(96, 32), u(96), u(96),
+                                                  u(5, 32), u(5)))})
             u1 = e1.zeros(1, H)
             for i in range(5):
-                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=i)
+                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=i, **pred_kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             reps = 50
             for i in range(reps):
-                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=100 + i)
+                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=100 + i, **pred_kw)
             torch.cuda.synchronize()
             dt1 = (time.perf_counter() - t1) / reps
             e1.set_profiling(True)
             for i in range(20):
-                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=200 + i)
+                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=200 + i, **pred_kw)
             r1, f1 = e1.get_profile()
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": float(np.median(r1)) * 1e3,
@@ -215,7 +243,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, H)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
