@@ -97,13 +97,13 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     F ur = splat<F>(uk) + du;
     if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
     if constexpr (COST == COST_QBGM) {
-      cost += stage_qbgm<F>(p, st.x, cosang, st.w, ur, x_t, te);
+      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
-      cost += stage_default<F>(p, st.x, cosang, ur, x_t, te);
+      cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else {
-      cost += stage_legacy<F>(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
+      cost += stage_legacy<F, FAST>(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
     }
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
@@ -157,13 +157,17 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
     };
     float z_lo[R], z_hi[R];
+    double slope[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) { z_lo[i] = knot(i, 0); z_hi[i] = knot(i, 1); }
+    for (int i = 0; i < R; ++i) {
+      z_lo[i] = knot(i, 0); z_hi[i] = knot(i, 1);
+      slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
+    }
     uint32_t ii = 0, j = 0;
     for (uint32_t k = 0; k < H; ++k) {
       F du;
 #pragma unroll
-      for (int i = 0; i < R; ++i) put(du, i, interp_knots(z_lo[i], z_hi[i], ii, p.period));
+      for (int i = 0; i < R; ++i) put(du, i, interp_from_slope(slope[i], z_lo[i], ii));
       control_step(k, du);
       if (++ii == p.period) {
         ii = 0; ++j;
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         for (int i = 0; i < R; ++i) {
           z_lo[i] = z_hi[i];
           if (j + 1 < p.P) z_hi[i] = knot(i, j + 1);
+          slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
         }
       }
     }

@@ -368,17 +368,25 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
 // Stage / terminal costs (generic over float / float2).  `x_t` target position, `te` target equilibrium, `u` the
 // control applied at this stage.
 // quadratic_boundary_grad_minimal.py:64-126; w = {dd, db, ep, ekp, cc, R, permissible_track_fraction}
-template <class F>
+// x / c for a wave-uniform c: the IEEE divide (PRECISE) or a multiply by the float32-rounded reciprocal (FAST; differs
+// from the divide by <= 1 ulp).
+template <bool FAST, class F>
+__device__ __forceinline__ F div_uniform(F x, float c) {
+  if constexpr (FAST) return x * splat<F>(1.0f / c);
+  else return x / splat<F>(c);
+}
+
+template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang, F u, float x_t, float te) {
   const float THL = p.THL;
-  const F d = (x - splat<F>(x_t)) / splat<F>(2.0f * THL);
+  const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   const F dd = (d * d) * splat<F>(p.w[0]);
   const float ptf = p.w[6];
   const F ax = abs_(x);
   F near;
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) put(near, i, (get(ax, i) > ptf * THL) ? 1.0f : 0.0f);
-  const F b = (ax - splat<F>(ptf * THL)) / splat<F>((1.0f - ptf) * THL);
+  const F b = div_uniform<FAST, F>(ax - splat<F>(ptf * THL), (1.0f - ptf) * THL);
   const F db = (near * (b * b)) * splat<F>(p.w[1]);
   const F e1 = splat<F>(1.0f) - cosang * splat<F>(te);
   const F ep = (e1 * e1) * splat<F>(p.w[2]);
@@ -388,10 +396,10 @@ __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang,
 }
 
 // default.py:23-88; w = {dd, ep, cc, R}
-template <class F>
+template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_default(const Params& p, F x, F cosang, F u, float x_t, float te) {
   const float THL = p.THL;
-  const F d = (x - splat<F>(x_t)) / splat<F>(2.0f * THL);
+  const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   F ind;
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) put(ind, i, (__builtin_fabsf(get(x, i)) > 0.90f * THL) ? 1.0e7f : 0.0f);
@@ -423,11 +431,11 @@ __device__ __forceinline__ F mppi_correction(const Params& p, F u, F du) {
 }
 
 // controller_mppi_cartpole.py:227-275 (q); w = {dd, ep, ekp, ekc, cc, ccrc}; u = nominal control of the stage
-template <class F>
+template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_legacy(const Params& p, F x, F cosang, F w_ang, F v, float u, F du, float u_prev,
                                           float x_t) {
   const float THL = p.THL;
-  const F d = (x - splat<F>(x_t)) / splat<F>(2.0f * THL);
+  const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   F ind;
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) put(ind, i, (__builtin_fabsf(get(x, i)) > 0.95f * THL) ? 1.0e6f : 0.0f);
@@ -491,6 +499,19 @@ __device__ __forceinline__ float interp_knots(float z_lo, float z_hi, uint32_t i
   const float diff = z_hi - z_lo;                         // float32 difference, as numpy forms it
   const double slope = (double)diff / (double)period;
   const double prod = slope * (double)i;                  // two roundings (no FMA), as numpy
+  return (float)(prod + (double)z_lo);
+}
+
+// The same value with the slope hoisted: slope changes only when the knots change (once per `period` steps).
+__device__ __forceinline__ double knot_slope(float z_lo, float z_hi, uint32_t period) {
+#pragma clang fp contract(off)      // (else sigma*z of philox_knot is fused into this subtraction and skips a rounding)
+  const float diff = z_hi - z_lo;
+  return (double)diff / (double)period;
+}
+__device__ __forceinline__ float interp_from_slope(double slope, float z_lo, uint32_t i) {
+#pragma clang fp contract(off)
+  if (i == 0) return z_lo;
+  const double prod = slope * (double)i;
   return (float)(prod + (double)z_lo);
 }
 
