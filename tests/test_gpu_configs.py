@@ -1,0 +1,84 @@
+"""GPU: the BASELINE.json config shapes at full size.
+
+  C2  1024 x 50,  E = 1            covered fixture-by-fixture in test_gpu_parity.py
+  C3  4096 x 100, E = 64           one launch; parity on an env subset against the plain-C oracle + properties
+  C4  2048 x 50,  E = 64 per GPU   (512 envs sharded 64/GPU): the per-GPU launch; parity subset + properties
+Size-independent properties checked on the FULL launch: batching invariance (an env's result does not depend on which
+other envs share the launch), rollout-permutation invariance of the update, the soft-min update is a convex combination
+of the perturbations, and determinism."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402
+from oracle import oracle_c as OC  # noqa: E402
+
+f32 = np.float32
+
+
+def make(E, N, H, **kw):
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    return MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, **kw))
+
+
+def inputs(E, H, seed):
+    rng = np.random.Generator(np.random.SFC64(seed))
+    THL = 0.198
+    ang = np.where(rng.uniform(size=E) > 0.5, 1.0, -1.0) * rng.uniform(0, 180, E) * np.pi / 180
+    s0 = np.zeros((E, 6), f32)
+    s0[:, 0], s0[:, 1] = ang, rng.uniform(-1, 1, E) * 1200 * np.pi / 180
+    s0[:, 2], s0[:, 3] = np.cos(ang), np.sin(ang)
+    s0[:, 4], s0[:, 5] = rng.uniform(-1, 1, E) * THL * 0.8, rng.uniform(-1, 1, E) * THL * 0.5
+    return s0, (rng.uniform(-0.8, 0.8, E) * THL).astype(f32), np.ones(E, f32), rng.uniform(0.2, 0.5, E).astype(f32)
+
+
+@pytest.mark.parametrize("name,E,N,H", [("C3", 64, 4096, 100), ("C4", 64, 2048, 50)])
+def test_config_full_size(name, E, N, H):
+    eng = make(E, N, H)
+    s0, tp, te, Lv = inputs(E, H, seed=2 if name == "C3" else 3)
+    rng = np.random.Generator(np.random.SFC64(9))
+    u0 = (0.1 * rng.standard_normal((E, H))).astype(f32)
+    kn, _ = eng.sample(seed=2, offset=0)                               # device RNG knots for the whole launch
+    un = eng.tensor(u0.copy())
+    S = eng.empty(E, N)
+    Q, _ = eng.step(s0, un, tp, te, L=Lv, knots=kn, S_out=S)
+    un_h, S_h, Q_h = un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy()
+    assert np.isfinite(un_h).all() and np.isfinite(S_h).all() and np.abs(un_h).max() <= 1.0
+    assert np.array_equal(Q_h, un_h[:, 0])
+
+    # ---- parity on an env subset against the C oracle (same knots, interpolated by the oracle)
+    cfg = O.MPPIConfig(N=N, H=H)
+    sub = [0, E // 2, E - 1]
+    kn_h = kn.cpu().numpy()
+    du = np.stack([O.interpolate_knots(kn_h[e], H) for e in sub])
+    u_ref, Q_ref, S_ref = OC.step(OC.make_config(cfg), s0[sub], u0[sub], du, tp[sub], te[sub], L=Lv[sub])
+    for i, e in enumerate(sub):
+        rel = np.abs(S_h[e] - S_ref[i]) / np.abs(S_ref[i])
+        assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.95, f"{name} env {e}: median rel {np.median(rel):.2e}"
+        np.testing.assert_allclose(un_h[e], u_ref[i], atol=1e-4)
+
+    # ---- batching invariance + determinism: envs stepped alone / again give bit-identical results
+    un2 = eng.tensor(u0.copy())
+    eng.step(s0, un2, tp, te, L=Lv, knots=kn)
+    assert np.array_equal(un2.cpu().numpy(), un_h)
+    small = make(1, N, H)
+    for e in (1, E - 2):
+        u1 = small.tensor(u0[e:e + 1].copy())
+        small.step(s0[e:e + 1], u1, tp[e:e + 1], te[e:e + 1], L=Lv[e:e + 1], knots=kn[e:e + 1].contiguous())
+        np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=2e-6)       # (1 vs 2 rollouts per lane mapping)
+
+    # ---- permutation invariance: shuffling an env's rollouts leaves its update unchanged (to summation order)
+    perm = torch.randperm(N, device=kn.device)
+    u3 = eng.tensor(u0.copy())
+    eng.step(s0, u3, tp, te, L=Lv, knots=kn[:, perm].contiguous())
+    np.testing.assert_allclose(u3.cpu().numpy(), un_h, atol=5e-6)
+
+    # ---- the update is a convex combination of the perturbations (before clipping): min <= u_new - u_shift <= max
+    du0 = O.interpolate_knots(kn_h[0], H)
+    u_shift = np.concatenate([u0[0, 1:], u0[0, -1:]])
+    inc = un_h[0] - u_shift
+    free = np.abs(un_h[0]) < 1.0
+    assert np.all(inc[free] <= du0.max(0)[free] + 1e-6) and np.all(inc[free] >= du0.min(0)[free] - 1e-6)
