@@ -239,7 +239,7 @@ def main():
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": float(np.median(r1)) * 1e3,
                                  "finalize_kernel_us": float(np.median(f1)) * 1e3,
-                                 "note": "host-paced python loop, 2 launches per step; kernel times from HIP events"}
+                                 "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time from HIP events"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, H)
         print(json.dumps(out), flush=True)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -51,6 +52,9 @@ struct StepPtrs {
   uint32_t W;           // width of the weighted-sum vector (H in delta_u space, P in knot space)
   float* S_out;
   float* partial;       // [E][nb][2 + W]
+  uint32_t* counter;    // [E] arrival tickets of the env's blocks (0 between launches); NULL = separate finalize kernel
+  float* u_nom_out;     // fused finalize: where the updated nominal sequence goes (== u_nom)
+  float* Q_out;
 };
 
 // Nominal control for stage k after the configured shift (a18).
@@ -58,6 +62,52 @@ __device__ __forceinline__ float shifted_nominal(const Params& p, const float* _
   if (p.shift_mode == CPMPPI_SHIFT_NONE) return un[k];
   if (k + 1 < p.H) return un[k + 1];
   return (p.shift_mode == CPMPPI_SHIFT_REPEAT_LAST) ? un[p.H - 1] : 0.0f;
+}
+
+// Merge the per-block partials of one env (rescaled to the env-wide minimum), apply shift / update / clip, write u_nom
+// and Q.  Executed by one whole block.  COHERENT = the partials were written by other workgroups of THIS launch: read
+// them with agent-scope (sc1) loads that bypass this CU's L1.
+template <bool KNOT_SPACE, bool COHERENT>
+__device__ __forceinline__ void finalize_env(const Params& p, const float* partial, uint32_t nb, uint32_t W,
+                                             float* __restrict__ u_nom, float* __restrict__ Q_out, uint32_t env) {
+  __shared__ float u_new[CPMPPI_MAX_HORIZON];
+  __shared__ float bz[KNOT_SPACE ? (CPMPPI_MAX_HORIZON + 2) : 1];
+  const uint32_t tid = threadIdx.x, H = p.H;
+  const float* pe = partial + (size_t)env * nb * (2 + W);
+  auto ld = [&](size_t i) -> float {
+    if constexpr (COHERENT) return __hip_atomic_load(pe + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return pe[i];
+  };
+  float M = INFINITY;
+  for (uint32_t b = 0; b < nb; ++b) M = fminf(M, ld((size_t)b * (2 + W)));
+  float a = 0.0f;
+  for (uint32_t b = 0; b < nb; ++b) a += ld((size_t)b * (2 + W) + 1) * expf((-1.0f / p.LBD) * (ld((size_t)b * (2 + W)) - M));
+  auto merged = [&](uint32_t c) {
+    float v = 0.0f;
+    for (uint32_t b = 0; b < nb; ++b)
+      v = __builtin_fmaf(ld((size_t)b * (2 + W) + 2 + c), expf((-1.0f / p.LBD) * (ld((size_t)b * (2 + W)) - M)), v);
+    return v;
+  };
+  if constexpr (KNOT_SPACE) {
+    for (uint32_t c = tid; c < W; c += BLOCK) bz[c] = merged(c);
+    __syncthreads();
+  }
+  float* __restrict__ un = u_nom + (size_t)env * H;
+  for (uint32_t k = tid; k < H; k += BLOCK) {
+    float bk;
+    if constexpr (KNOT_SPACE) {
+      const uint32_t j = k / p.period, i = k % p.period;
+      bk = bz[j] + (bz[j + 1] - bz[j]) * ((float)i / (float)p.period);
+    } else {
+      bk = merged(k);
+    }
+    float v = shifted_nominal(p, un, k) + bk / a;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) v = fminf(fmaxf(v, p.lo), p.hi);
+    u_new[k] = v;
+  }
+  __syncthreads();                          // every read of the old nominal sequence is done
+  for (uint32_t k = tid; k < H; k += BLOCK) un[k] = u_new[k];
+  if (tid == 0 && Q_out) Q_out[env] = u_new[0];
 }
 
 // The hot path.  R = rollouts per lane (1: latency mapping, 2: packed float2 throughput mapping, FAST only).
@@ -257,52 +307,38 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     for (int w = 1; w < WAVES; ++w) v += bsum[w * W + c];
     out[2 + c] = v;
   }
+  // ---- fused finalize: the env's last-arriving block merges the partials (no second launch) -----------------------
+  // Placement-independent hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, the
+  // block's barrier, one lane's agent-scope release, then the ticket; the consumer block does one agent-scope acquire
+  // (invalidates this CU's L1), drains, barriers, and additionally reads the partials with sc1 loads.
+  if (a.counter) {
+    __shared__ uint32_t ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ticket = __hip_atomic_fetch_add(a.counter + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (ticket == a.nb - 1) {                               // uniform over the block
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      __syncthreads();
+      finalize_env<NOISE != NOISE_DELTA_U, true>(p, a.partial, a.nb, W, a.u_nom_out, a.Q_out, env);
+    }
+  }
 }
 
-// One block per env: merge partials, update the nominal sequence.
+// Stand-alone form: one block per env (used after the GRU rollout kernel).
 template <bool KNOT_SPACE>
 __global__ __launch_bounds__(BLOCK) void finalize_kernel(const Params p, const float* __restrict__ partial,
                                                          uint32_t nb, uint32_t W, float* __restrict__ u_nom,
                                                          float* __restrict__ Q_out) {
-  __shared__ float u_new[CPMPPI_MAX_HORIZON];
-  __shared__ float bz[KNOT_SPACE ? (CPMPPI_MAX_HORIZON + 2) : 1];
-  const uint32_t env = blockIdx.x, tid = threadIdx.x, H = p.H;
-  const float* __restrict__ pe = partial + (size_t)env * nb * (2 + W);
-  float M = INFINITY;
-  for (uint32_t b = 0; b < nb; ++b) M = fminf(M, pe[(size_t)b * (2 + W)]);
-  float a = 0.0f;
-  for (uint32_t b = 0; b < nb; ++b) {
-    const float* pb = pe + (size_t)b * (2 + W);
-    a += pb[1] * expf((-1.0f / p.LBD) * (pb[0] - M));
-  }
-  auto merged = [&](uint32_t c) {
-    float v = 0.0f;
-    for (uint32_t b = 0; b < nb; ++b) {
-      const float* pb = pe + (size_t)b * (2 + W);
-      v = __builtin_fmaf(pb[2 + c], expf((-1.0f / p.LBD) * (pb[0] - M)), v);
-    }
-    return v;
-  };
-  if constexpr (KNOT_SPACE) {
-    for (uint32_t c = tid; c < W; c += BLOCK) bz[c] = merged(c);
-    __syncthreads();
-  }
-  float* __restrict__ un = u_nom + (size_t)env * H;
-  for (uint32_t k = tid; k < H; k += BLOCK) {
-    float bk;
-    if constexpr (KNOT_SPACE) {
-      const uint32_t j = k / p.period, i = k % p.period;
-      bk = bz[j] + (bz[j + 1] - bz[j]) * ((float)i / (float)p.period);
-    } else {
-      bk = merged(k);
-    }
-    float v = shifted_nominal(p, un, k) + bk / a;
-    if (p.control_mode == CPMPPI_CONTROL_CLIP) v = fminf(fmaxf(v, p.lo), p.hi);
-    u_new[k] = v;
-  }
-  __syncthreads();                          // every read of the old nominal sequence is done
-  for (uint32_t k = tid; k < H; k += BLOCK) un[k] = u_new[k];
-  if (tid == 0 && Q_out) Q_out[env] = u_new[0];
+  finalize_env<KNOT_SPACE, false>(p, partial, nb, W, u_nom, Q_out, blockIdx.x);
 }
 
 // a17: knots[E,N,P] and/or delta_u[E,N,H].  One lane draws (or loads) the knots of one rollout into LDS; the wave then
@@ -609,8 +645,10 @@ struct cpmppi_handle {
   uint32_t nb;
   std::string err;
   // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
+  uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
   GruNorm gru_norm;
+  bool fuse_finalize = true;           // ODE path: the env's last block finalizes in-kernel (CPMPPI_FUSE_FINALIZE=0 disables)
   bool profiling = false;
   std::vector<hipEvent_t> ev;          // triples per step: before rollout, between, after finalize
   size_t ev_used = 0;
@@ -722,6 +760,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   h->device = device;
   fill_params(*cfg, h->prm);
   h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
+  if (const char* ev = getenv("CPMPPI_FUSE_FINALIZE")) h->fuse_finalize = ev[0] != '0';
   const uint32_t Wmax = cfg->H > h->prm.P ? cfg->H : h->prm.P;
   h->workspace_floats = (size_t)cfg->E * h->nb * (2 + Wmax);
   h->workspace = nullptr;
@@ -729,6 +768,8 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   hipError_t e = hipGetDevice(&cur);
   if (e == hipSuccess) e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&h->workspace, h->workspace_floats * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&h->counters, (size_t)cfg->E * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(h->counters, 0, (size_t)cfg->E * sizeof(uint32_t));
   if (e == hipSuccess) e = hipSetDevice(cur);
   if (e != hipSuccess) {
     std::string msg = std::string("cpmppi_create: hipMalloc workspace: ") + hipGetErrorString(e);
@@ -743,6 +784,7 @@ void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
   if (h->workspace) (void)hipFree(h->workspace);
   if (h->gru_image) (void)hipFree(h->gru_image);
+  if (h->counters) (void)hipFree(h->counters);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
 }
@@ -855,6 +897,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = (a->noise_kind == CPMPPI_NOISE_DELTA_U) ? h->cfg.H : h->prm.P;
   p.S_out = a->S_out; p.partial = h->workspace;
+  p.counter = nullptr; p.u_nom_out = a->u_nom; p.Q_out = a->Q_out;
   const hipStream_t s = (hipStream_t)stream;
   hipEvent_t* ev = nullptr;
   if (h->profiling) {
@@ -886,15 +929,19 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
 #undef CPMPPI_GRU_LAUNCH
     CPMPPI_HIP(h, hipGetLastError());
   } else {
+    p.counter = h->fuse_finalize ? h->counters : nullptr;
     CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), (size_t)WAVES * p.W * sizeof(float), s, p));
   }
+  const bool separate_finalize = (p.counter == nullptr);
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
-  if (a->noise_kind == CPMPPI_NOISE_DELTA_U)
-    hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, p.nb,
-                       p.W, a->u_nom, a->Q_out);
-  else
-    hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace, p.nb,
-                       p.W, a->u_nom, a->Q_out);
+  if (separate_finalize) {
+    if (a->noise_kind == CPMPPI_NOISE_DELTA_U)
+      hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
+                         p.nb, p.W, a->u_nom, a->Q_out);
+    else
+      hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
+                         p.nb, p.W, a->u_nom, a->Q_out);
+  }
   CPMPPI_HIP(h, hipGetLastError());
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[2], s));
   return CPMPPI_OK;
