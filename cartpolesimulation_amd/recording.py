@@ -1,0 +1,155 @@
+"""Experiment recordings in the reference's CSV format and a batched data generator (N1 + N2).
+
+Format (CartPole/csv_logger.py:10-33,125-159): comment block of ``# `` lines — title, git revision, ``#``, header with
+the time intervals, controller, optimizer and physical parameters, ``# Data:`` — then one row with the column names and
+one row per saved time step.  Column set and order = ``CartPole.variables_to_log`` (CartPole/__init__.py:221-259).
+Downstream tooling reads these files with ``pandas.read_csv(path, comment='#')``.
+
+``generate_dataset`` is the counterpart of ``run_data_generator.py`` -> ``CartPole/data_generator.py:259-367``: instead
+of ``number_of_experiments`` sequential single-env runs it steps E envs at once on the GPU (plant + MPPI in one device
+loop, harness.py) and writes one recording per env.
+"""
+import csv
+import os
+from datetime import datetime
+
+import numpy as np
+
+COLUMNS = ["time", "angle", "angleD", "angleDD", "angle_cos", "angle_sin", "position", "positionD", "positionDD",
+           "Q_calculated", "Q_applied", "Q_ccrc", "u", "target_position", "target_equilibrium", "L", "L_for_controller",
+           "m_pole", "m_pole_for_controller", "vertical_angle_offset", "vertical_angle_offset_cos",
+           "vertical_angle_offset_sin", "Q_update_time"]
+
+
+def create_csv_file_name(controller_name="mpc", optimizer_name="mppi", prefix="CPS", with_date=True, title=""):
+    """CartPole/csv_logger.py:96-116."""
+    date = datetime.now().strftime("_%Y-%m-%d_%H-%M-%S") if with_date else ""
+    name_controller = "" if controller_name == "" else "_" + controller_name + ("_" + optimizer_name if optimizer_name else "")
+    return prefix + ("_" + title if title else "") + name_controller + date + ".csv"
+
+
+def _unique_path(folder, csv_name):
+    """CartPole/csv_logger.py:61-91: never overwrite, append -1, -2, ..."""
+    os.makedirs(folder, exist_ok=True)
+    if not csv_name.endswith(".csv"):
+        csv_name += ".csv"
+    path = os.path.join(folder, csv_name)
+    base, idx = path[:-4], 1
+    while os.path.isfile(path):
+        path = f"{base}-{idx}.csv"
+        idx += 1
+    return path
+
+
+def create_csv_header(length_of_experiment, dt_simulation, dt_controller, dt_save, controller_name, optimizer_name, phys):
+    """CartPole/csv_logger.py:125-159."""
+    header = [f"Length of experiment: {length_of_experiment} s", "", "Time intervals dt:",
+              f"Simulation: {dt_simulation} s", f"Controller update: {dt_controller} s", f"Saving: {dt_save} s", "",
+              f"Controller: {controller_name}"]
+    if optimizer_name:
+        header.append(f"MPC Optimizer: {optimizer_name}")
+    header.append("Parameters:")
+    for k, v in vars(phys).items():
+        header.append(f"{k}: {v}")
+    header += ["", "Data:"]
+    return header
+
+
+def write_recording(path, columns, title=None, header=(), revision="cartpolesimulation_amd"):
+    """columns: dict name -> 1-D array (all the same length), written in dict order."""
+    title = title or (f"This is CartPole simulation from {datetime.now().strftime('%d.%m.%Y')}"
+                      f" at time {datetime.now().strftime('%H:%M:%S')}")
+    with open(path, "a", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# " + title])
+        w.writerow(["# Done with git-revision: {}".format(revision)])
+        w.writerow(["#"])
+        for line in header:
+            w.writerow(["# " + line])
+        w.writerow(list(columns.keys()))
+        w.writerows(zip(*[np.asarray(v).tolist() for v in columns.values()]))
+    return path
+
+
+def second_derivatives(states, Q, L, phys):
+    """angleDD, positionDD of the logged states under the logged control (CartPole/cartpole_equations.py:44-105), as
+    torch ops on whatever device the tensors live on."""
+    import torch
+    ca, sa, w, v = states[..., 2], states[..., 3], states[..., 1], states[..., 5]
+    u = phys.u_max * Q
+    kp1, Lh = phys.k + 1.0, L / 2.0
+    A = kp1 * (phys.m_cart + phys.m_pole) - phys.m_pole * ca * ca
+    T = -phys.J_fric * w
+    xDD = (phys.m_pole * phys.g * sa * ca + T * ca / Lh + kp1 * (-(phys.m_pole * Lh * w * w * sa) - phys.M_fric * v + u)) / A
+    aDD = (phys.g * sa + xDD * ca + T / (phys.m_pole * Lh)) / (kp1 * Lh)
+    return aDD, xDD, torch.as_tensor(u)
+
+
+def experiment_columns(result, env, dt_control, target_position, target_equilibrium, L, phys):
+    """One env of a harness.BatchedCartPoleExperiment.run(record=True) result -> the reference's column dict."""
+    import torch
+    states = result["states"][:-1, env]                     # state at the time each control was computed
+    Q = result["Q"][:, env]
+    T = states.shape[0]
+    Lt = torch.full((T,), float(L), device=states.device)
+    aDD, xDD, u = second_derivatives(states, Q, Lt, phys)
+    c = lambda t: t.detach().cpu().numpy()
+    zeros, ones = np.zeros(T), np.ones(T)
+    s = c(states)
+    cols = {"time": np.arange(T) * dt_control, "angle": s[:, 0], "angleD": s[:, 1], "angleDD": c(aDD), "angle_cos": s[:, 2],
+            "angle_sin": s[:, 3], "position": s[:, 4], "positionD": s[:, 5], "positionDD": c(xDD), "Q_calculated": c(Q),
+            "Q_applied": c(Q), "Q_ccrc": np.concatenate([[0.0], c(Q)[:-1]]), "u": c(u),
+            "target_position": ones * float(target_position), "target_equilibrium": ones * float(target_equilibrium),
+            "L": ones * float(L), "L_for_controller": ones * float(L), "m_pole": ones * phys.m_pole,
+            "m_pole_for_controller": ones * phys.m_pole, "vertical_angle_offset": zeros,
+            "vertical_angle_offset_cos": ones, "vertical_angle_offset_sin": zeros, "Q_update_time": zeros}
+    assert list(cols) == COLUMNS
+    return cols
+
+
+def generate_dataset(engine, num_envs, length_of_experiment, out_dir, seed=0, target_position=None, L=None,
+                     dt_simulation=0.002, dt_control=0.02, init_limits=None, prefix="CPS"):
+    """Batched run_data_generator: ``num_envs`` experiments of ``length_of_experiment`` seconds -> one CSV each."""
+    from .harness import BatchedCartPoleExperiment, generate_random_initial_states
+    rng = np.random.Generator(np.random.SFC64(seed))
+    phys = engine.phys
+    s0 = generate_random_initial_states(num_envs, rng, phys.TrackHalfLength, init_limits)
+    tp = np.zeros(num_envs, np.float32) if target_position is None else \
+        np.broadcast_to(np.asarray(target_position, np.float32), (num_envs,)).copy()
+    Lv = np.full(num_envs, phys.L, np.float32) if L is None else np.broadcast_to(np.asarray(L, np.float32), (num_envs,)).copy()
+    steps = int(round(length_of_experiment / dt_control))
+    exp = BatchedCartPoleExperiment(engine, dt_simulation, dt_control, seed=seed)
+    res = exp.run(s0, steps, target_position=tp, target_equilibrium=1.0, L=Lv, record=True)
+    header = create_csv_header(length_of_experiment, dt_simulation, dt_control, dt_control, "mpc", "mppi", phys)
+    paths = []
+    for e in range(num_envs):
+        cols = experiment_columns(res, e, dt_control, tp[e], 1.0, Lv[e], phys)
+        name = create_csv_file_name("mpc", "mppi", prefix=prefix, with_date=False, title=f"env{e:05d}")
+        paths.append(write_recording(_unique_path(out_dir, name), cols, header=header))
+    return paths
+
+
+def main(argv=None):
+    """python -m cartpolesimulation_amd.recording --envs 64 --length 10 --out ./Experiment_Recordings/"""
+    import argparse
+    from .configs import MPPIConfig, legacy_mppi_config
+    from .engine import MPPIEngine
+    ap = argparse.ArgumentParser(description="Batched CartPole data generator on MI355X (reference: run_data_generator.py)")
+    ap.add_argument("--envs", type=int, default=64)
+    ap.add_argument("--length", type=float, default=10.0, help="length of each experiment in seconds")
+    ap.add_argument("--out", default="./Experiment_Recordings/")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rollouts", type=int, default=3500)
+    ap.add_argument("--horizon", type=int, default=35)
+    ap.add_argument("--cost", default="legacy_mppi_cartpole",
+                    choices=["legacy_mppi_cartpole", "default", "quadratic_boundary_grad_minimal"])
+    args = ap.parse_args(argv)
+    cfg = legacy_mppi_config(num_rollouts=args.rollouts, mpc_horizon=args.horizon) if args.cost == "legacy_mppi_cartpole" \
+        else MPPIConfig(num_rollouts=args.rollouts, mpc_horizon=args.horizon, cost_function_specification=args.cost)
+    eng = MPPIEngine(args.envs, cfg)
+    paths = generate_dataset(eng, args.envs, args.length, args.out, seed=args.seed)
+    print(f"wrote {len(paths)} recordings to {args.out}")
+
+
+if __name__ == "__main__":
+    main()

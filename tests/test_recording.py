@@ -1,0 +1,63 @@
+"""The recording writer: file layout as CartPole/csv_logger.py writes it, column set as
+CartPole/__init__.py:221-259 logs it; readable the way the reference's loaders read it (pandas, comment='#')."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from cartpolesimulation_amd import recording as R
+from cartpolesimulation_amd.configs import PhysicalParameters
+
+REFERENCE_COLUMNS = ["time", "angle", "angleD", "angleDD", "angle_cos", "angle_sin", "position", "positionD",
+                     "positionDD", "Q_calculated", "Q_applied", "Q_ccrc", "u", "target_position", "target_equilibrium",
+                     "L", "L_for_controller", "m_pole", "m_pole_for_controller", "vertical_angle_offset",
+                     "vertical_angle_offset_cos", "vertical_angle_offset_sin", "Q_update_time"]
+
+
+def test_columns_match_reference_order():
+    assert R.COLUMNS == REFERENCE_COLUMNS
+
+
+def test_write_and_read_back(tmp_path):
+    T = 7
+    cols = {k: np.arange(T) * (i + 1) * 0.5 for i, k in enumerate(R.COLUMNS)}
+    header = R.create_csv_header(0.14, 0.002, 0.02, 0.02, "mpc", "mppi", PhysicalParameters())
+    path = R.write_recording(R._unique_path(str(tmp_path), "CPS_test"), cols, header=header)
+    lines = open(path).read().splitlines()
+    assert lines[0].startswith("# This is CartPole simulation from ") and lines[1].startswith("# Done with git-revision: ")
+    assert lines[2] == "#" and "# Length of experiment: 0.14 s" in lines and "# MPC Optimizer: mppi" in lines
+    assert "# Saving: 0.02 s" in lines and "# Data:" in lines
+    first_data = lines.index("# Data:") + 1
+    assert lines[first_data].split(",") == REFERENCE_COLUMNS
+    df = pd.read_csv(path, comment="#")
+    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == T
+    np.testing.assert_allclose(df["angleD"].to_numpy(), cols["angleD"])
+    # never overwrite an existing recording (csv_logger.py:76-88)
+    p2 = R._unique_path(str(tmp_path), "CPS_test")
+    assert p2 != path and p2.endswith("CPS_test-1.csv")
+    assert R.create_csv_file_name("mpc", "mppi", with_date=False) == "CPS_mpc_mppi.csv"
+
+
+@pytest.mark.gpu
+def test_generate_dataset_on_device(tmp_path):
+    torch = pytest.importorskip("torch")
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    E = 4
+    eng = MPPIEngine(E, legacy_mppi_config(num_rollouts=512, mpc_horizon=20))
+    paths = R.generate_dataset(eng, E, 0.4, str(tmp_path), seed=3,
+                               init_limits=dict(angle=(0.0, 10.0), angleD=20.0, position=0.3, positionD=0.1))
+    assert len(paths) == E and all(os.path.isfile(p) for p in paths)
+    df = pd.read_csv(paths[1], comment="#")
+    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == 20
+    np.testing.assert_allclose(np.diff(df["time"]), 0.02, atol=1e-9)
+    np.testing.assert_allclose(df["angle_cos"], np.cos(df["angle"]), atol=1e-5)
+    np.testing.assert_allclose(df["u"], 1.77 * df["Q_applied"], rtol=1e-6)
+    assert np.abs(df["Q_applied"]).max() <= 1.0 and np.isfinite(df.to_numpy()).all()
+    # second derivatives are those of the logged state under the logged control (cartpole_equations.py:44-105)
+    from oracle import oracle_np as O
+    r = df.iloc[5]
+    add, pdd = O.cartpole_ode(np.float32(r.angle_cos), np.float32(r.angle_sin), np.float32(r.angleD),
+                              np.float32(r.positionD), np.float32(1.77 * r.Q_applied), np.float32(r.L))
+    assert abs(add - r.angleDD) < 1e-3 * max(1, abs(add)) and abs(pdd - r.positionDD) < 1e-3 * max(1, abs(pdd))
