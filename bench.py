@@ -97,9 +97,17 @@ def main():
     ap.add_argument("--predictor", choices=["ode", "gru"], default="ode",
                     help="ode: predictor_ODE_v0 (the headline path); gru: GRU-6IN-32H1-32H2-5OUT on the f32 matrix "
                          "cores inside the same MPPI loop (BASELINE configs[4], synthetic weights)")
+    ap.add_argument("--config", choices=["C2", "C3", "C4"], default=None,
+                    help="BASELINE.json config presets: C2 = 1024x50 (the metric's shape, default: 2048 envs per GPU); "
+                         "C3 = 64 envs x 4096 x 100 in one launch; C4 = 64 envs per GPU x 2048 x 50 (512 envs over 8 GPUs)")
+    ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane: 0 auto, 1, 2 (tuning knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-env", action="store_true")
     args = ap.parse_args()
+    if args.config == "C3":
+        args.envs, args.rollouts, args.horizon = 64, 4096, 100
+    elif args.config == "C4":
+        args.envs, args.rollouts, args.horizon = 64, 2048, 50
 
     import torch
     import torch.distributed as dist
@@ -119,7 +127,7 @@ def main():
     from cartpolesimulation_amd.configs import MPPIConfig
 
     E, N, H = args.envs, args.rollouts, args.horizon
-    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=args.math)
+    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=args.math, rollouts_per_lane=args.rpl)
     eng = MPPIEngine(E, cfg, device=local_rank)
     s0, tp, te, L = synthetic_inputs(E, H, seed=2 + rank, device=device)
     u_nom = eng.zeros(E, H)
@@ -193,11 +201,12 @@ def main():
         else:
             roof = None
         out = {
-            "metric": "MPPI rollouts/sec (1024 samples x 50-step horizon)", "value": value, "unit": "rollouts/s",
+            "metric": f"MPPI rollouts/sec ({N} samples x {H}-step horizon)", "value": value, "unit": "rollouts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2-shape MPPI problems: {N} samples x {H}-step horizon x 10 Euler substeps, "
-                                   f"{E} independent envs per GPU batched in one launch (BASELINE configs[1] shape)",
+            "config": {"workload": f"{args.config or 'C2'}-shape MPPI problems: {N} samples x {H}-step horizon x 10 Euler "
+                                   f"substeps, {E} independent envs per GPU batched in one launch"
+                                   + ("" if args.config in ("C3", "C4") else " (BASELINE configs[1] shape)"),
                        "envs_per_gpu": E, "rollouts": N, "horizon": H, "substeps": 10,
                        "cost": cfg.cost_function_specification, "noise": args.noise, "math": args.math,
                        "predictor": "predictor_ODE_v0" if args.predictor == "ode" else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",

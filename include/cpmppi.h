@@ -100,7 +100,7 @@ typedef struct {
   uint32_t correction_u;         /* CPMPPI_CORRECTION_*  */
   uint32_t math_mode;            /* CPMPPI_MATH_* */
   uint32_t rollouts_per_lane;    /* lane mapping of the FAST rollout kernel: 0 = automatic (2 for launches of
-                                    >= 262144 rollouts, else 1), 1 = one rollout per lane (lowest latency),
+                                    >= 393216 rollouts, else 1; measured crossover), 1 = one rollout per lane (lowest latency),
                                     2 = two rollouts per lane as packed float2 (highest throughput) */
 } cpmppi_config;
 
