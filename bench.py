@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=2048, help="independent MPPI problem instances per GPU")
+    ap.add_argument("--envs", type=int, default=8192, help="independent MPPI problem instances per GPU")
     ap.add_argument("--rollouts", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--noise", choices=["buffer", "philox"], default="philox",

@@ -17,7 +17,8 @@ NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX = 0, 1, 2
 EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
            "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_set_profiling", "cpmppi_get_profile",
-           "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_version")
+           "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
+           "cpmppi_version")
 
 
 class cpmppi_config(C.Structure):
@@ -93,6 +94,9 @@ def load():
     lib.cpmppi_get_profile.argtypes = [vp, C.POINTER(f), C.POINTER(f), u32, C.POINTER(u32)]
     lib.cpmppi_set_gru.argtypes = [vp, C.POINTER(cpmppi_gru_model)]
     lib.cpmppi_gru_predict.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
+    lib.cpmppi_rollout_cost.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    lib.cpmppi_cem_sample.argtypes = [vp, u32, vp, vp, u64, u64, u32, vp, vp]
+    lib.cpmppi_cem_update.argtypes = [vp, u32, vp, vp, u32, f, vp, vp, vp, vp]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

@@ -11,6 +11,7 @@ import numpy as np
 
 from .configs import MPPIConfig, PhysicalParameters
 from .cost_functions import CostFunctionWrapper
+from .optimizer_cem import optimizer_cem
 from .optimizer_mppi import optimizer_mppi
 from .predictors import PredictorWrapper
 
@@ -60,9 +61,11 @@ class controller_mpc(template_controller):
     def configure(self, optimizer_name=None, predictor_specification=None, cost_function_specification=None,
                   controller_logging=False, **kwargs):
         optimizer_name = optimizer_name or "mppi"
+        if optimizer_name in ("cem", "cem-tf"):
+            return self._configure_cem(predictor_specification, cost_function_specification, controller_logging, **kwargs)
         if optimizer_name != "mppi":
-            raise NotImplementedError(f"optimizer {optimizer_name!r}: only 'mppi' is on the built hot path "
-                                      "(cem / rpgd are SURVEY.md §8f N4)")
+            raise NotImplementedError(f"optimizer {optimizer_name!r}: 'mppi' (the hot path) and 'cem' are built; the "
+                                      "gradient-based optimizers (rpgd, ...) need an adjoint kernel")
         cfg = dict(self.config_optimizer)
         cfg.update(kwargs)
         cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
@@ -84,6 +87,23 @@ class controller_mpc(template_controller):
                                         phys=self.phys, device=self.device, num_envs=self.num_envs,
                                         variable_parameters=self.variable_parameters, **cfg)
         self.optimizer.configure(dt=opt_probe.mpc_timestep, predictor_specification="ODE_v0")
+
+    def _configure_cem(self, predictor_specification, cost_function_specification, controller_logging, **kwargs):
+        cfg = dict(self.config_optimizer)
+        cfg.update(kwargs)
+        cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
+            "quadratic_boundary_grad_minimal"
+        self.controller_logging = controller_logging
+        self.cost_function_wrapper = CostFunctionWrapper()
+        self.cost_function_wrapper.configure(variable_parameters=self.variable_parameters,
+                                             environment_name=self.environment_name,
+                                             cost_function_specification=cost_name, weights=cfg.get("cost_weights"),
+                                             phys=self.phys, device=self.device)
+        self.optimizer = optimizer_cem(cost_function=self.cost_function_wrapper.cost_function,
+                                       control_limits=self.control_limits, optimizer_logging=controller_logging,
+                                       phys=self.phys, device=self.device, num_envs=self.num_envs,
+                                       variable_parameters=self.variable_parameters, **cfg)
+        self.optimizer.configure()
 
     def step(self, s, time=None, updated_attributes=None):
         self.update_attributes(updated_attributes)

@@ -632,6 +632,70 @@ __global__ __launch_bounds__(BLOCK) void gru_rollout_cost_kernel(const Params p,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// CEM (hyper-parameters Control_Toolkit_ASF/config_optimizers.yml:1-11 "cem-tf"): the same rollout +
+// cost kernel, a different sampler and a top-k reduction instead of the soft-min.
+// Q[e,n,k] = clip(mean[e,k] + stdev[e,k] * z), z ~ N(0,1) from Philox (rollout, env, step pair, offset).
+__global__ __launch_bounds__(BLOCK) void cem_sample_kernel(const Params p, uint32_t E, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdev, uint64_t seed, uint64_t offset,
+                                                           uint32_t env_offset, float* __restrict__ Q) {
+  const size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= (size_t)E * p.N) return;
+  const uint32_t env = (uint32_t)(r / p.N), n = (uint32_t)(r % p.N);
+  const float* m = mean + (size_t)env * p.H;
+  const float* sd = stdev + (size_t)env * p.H;
+  float* q = Q + r * p.H;
+  for (uint32_t k = 0; k < p.H; k += 2) {
+    float z0, z1;
+    philox_normal_pair(seed, offset, env_offset + env, n, k >> 1, z0, z1);
+    q[k] = fminf(fmaxf(__builtin_fmaf(sd[k], z0, m[k]), p.lo), p.hi);
+    if (k + 1 < p.H) q[k + 1] = fminf(fmaxf(__builtin_fmaf(sd[k + 1], z1, m[k + 1]), p.lo), p.hi);
+  }
+}
+
+// One block per env: sort (S, index) ascending with a bitonic network in LDS (ties by index = stable argsort), then
+// mean and population standard deviation of the best_k input sequences per time-step, stdev floored at stdev_min.
+__global__ __launch_bounds__(BLOCK) void cem_update_kernel(const Params p, const float* __restrict__ S,
+                                                           const float* __restrict__ Q, uint32_t best_k, float stdev_min,
+                                                           uint32_t Np, float* __restrict__ mean_out,
+                                                           float* __restrict__ stdev_out, uint32_t* __restrict__ elite_out) {
+  extern __shared__ float cem_lds[];                     // keys[Np], idx[Np]
+  float* key = cem_lds;
+  uint32_t* idx = reinterpret_cast<uint32_t*>(cem_lds + Np);
+  const uint32_t env = blockIdx.x, tid = threadIdx.x;
+  for (uint32_t i = tid; i < Np; i += BLOCK) {
+    key[i] = i < p.N ? S[(size_t)env * p.N + i] : INFINITY;
+    idx[i] = i;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= Np; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < Np; i += BLOCK) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const float ki = key[i], kl = key[l];
+          const uint32_t ii = idx[i], il = idx[l];
+          const bool gt = (ki > kl) || (ki == kl && ii > il);
+          if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (elite_out) for (uint32_t i = tid; i < best_k; i += BLOCK) elite_out[(size_t)env * best_k + i] = idx[i];
+  const float* Qe = Q + (size_t)env * p.N * p.H;
+  for (uint32_t k = tid; k < p.H; k += BLOCK) {
+    float m = 0.0f;
+    for (uint32_t i = 0; i < best_k; ++i) m += Qe[(size_t)idx[i] * p.H + k];
+    m /= (float)best_k;
+    float v = 0.0f;
+    for (uint32_t i = 0; i < best_k; ++i) { const float d = Qe[(size_t)idx[i] * p.H + k] - m; v = __builtin_fmaf(d, d, v); }
+    mean_out[(size_t)env * p.H + k] = m;
+    stdev_out[(size_t)env * p.H + k] = fmaxf(sqrtf(v / (float)best_k), stdev_min);
+  }
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -646,6 +710,7 @@ struct cpmppi_handle {
   std::string err;
   // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
   uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
+  float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
   GruNorm gru_norm;
   bool fuse_finalize = true;           // ODE path: the env's last block finalizes in-kernel (CPMPPI_FUSE_FINALIZE=0 disables)
@@ -770,6 +835,8 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->workspace, h->workspace_floats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->counters, (size_t)cfg->E * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(h->counters, 0, (size_t)cfg->E * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&h->zeros_H, (size_t)cfg->E * cfg->H * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(h->zeros_H, 0, (size_t)cfg->E * cfg->H * sizeof(float));
   if (e == hipSuccess) e = hipSetDevice(cur);
   if (e != hipSuccess) {
     std::string msg = std::string("cpmppi_create: hipMalloc workspace: ") + hipGetErrorString(e);
@@ -785,6 +852,7 @@ void cpmppi_destroy(cpmppi_handle* h) {
   if (h->workspace) (void)hipFree(h->workspace);
   if (h->gru_image) (void)hipFree(h->gru_image);
   if (h->counters) (void)hipFree(h->counters);
+  if (h->zeros_H) (void)hipFree(h->zeros_H);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
 }
@@ -1034,6 +1102,63 @@ int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const flo
   hipLaunchKernelGGL(gru_predict_kernel, dim3((B + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK), dim3(BLOCK),
                      (size_t)GRU_IMAGE_FLOATS * sizeof(float), (hipStream_t)stream, h->gru_norm,
                      (const float*)h->gru_image, B, horizon, s0, Q, h0, traj_out, h_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const float* inputs, const float* target_position,
+                        const float* target_equilibrium, const float* L, float* S_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !s0 || !inputs || !target_position || !target_equilibrium || !S_out)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost: bad argument");
+  if (h->prm.cost_id == CPMPPI_COST_LEGACY)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost: plugin costs only");
+  if (int rc = ensure_device(h)) return rc;
+  Params prm = h->prm;
+  prm.shift_mode = CPMPPI_SHIFT_NONE;
+  prm.cc_weight = 0.0f;
+  StepPtrs p;
+  p.s0 = s0; p.u_nom = h->zeros_H; p.u_prev = nullptr; p.x_t = target_position; p.te = target_equilibrium; p.L = L;
+  p.noise = inputs; p.seed = 0; p.offset = 0; p.env_offset = 0;
+  uint32_t rpl = h->cfg.rollouts_per_lane;
+  if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
+  else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N >= 393216ull) ? 2 : 1;
+  p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
+  p.W = h->cfg.H;
+  p.S_out = S_out; p.partial = h->workspace; p.counter = nullptr; p.u_nom_out = nullptr; p.Q_out = nullptr;
+  cpmppi_handle* hh = h;
+  const Params saved = hh->prm;
+  hh->prm = prm;
+  hipError_t e = launch_rollout(hh, rpl, CPMPPI_NOISE_DELTA_U, dim3(E * p.nb), (size_t)WAVES * p.W * sizeof(float),
+                                (hipStream_t)stream, p);
+  hh->prm = saved;
+  CPMPPI_HIP(h, e);
+  return CPMPPI_OK;
+}
+
+int cpmppi_cem_sample(cpmppi_handle* h, uint32_t E, const float* mean, const float* stdev, uint64_t seed, uint64_t offset,
+                      uint32_t env_offset, float* Q_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !mean || !stdev || !Q_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_cem_sample: bad argument");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t rows = (size_t)E * h->cfg.N;
+  hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     h->prm, E, mean, stdev, seed, offset, env_offset, Q_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_cem_update(cpmppi_handle* h, uint32_t E, const float* S, const float* Q, uint32_t best_k, float stdev_min,
+                      float* mean_out, float* stdev_out, uint32_t* elite_idx_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || !S || !Q || !mean_out || !stdev_out || best_k == 0 || best_k > h->cfg.N)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_cem_update: bad argument (0 < best_k <= N)");
+  uint32_t Np = 1;
+  while (Np < h->cfg.N) Np <<= 1;
+  if ((size_t)Np * 8 > 160 * 1024 - 1024) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_cem_update: N too large for the LDS sort (<= 16384)");
+  if (int rc = ensure_device(h)) return rc;
+  hipLaunchKernelGGL(cem_update_kernel, dim3(E), dim3(BLOCK), (size_t)Np * 8, (hipStream_t)stream, h->prm, S, Q, best_k,
+                     stdev_min, Np, mean_out, stdev_out, elite_idx_out);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }

@@ -200,6 +200,42 @@ class MPPIEngine:
                                                 self._stream()))
         return (traj, h_out) if return_hidden else traj
 
+    # ------------------------------------------------------------------ cost-only launch and CEM
+    def _per_env(self, x, E):
+        x = self.tensor(x).reshape(-1)
+        return x.expand(E).contiguous() if x.numel() == 1 else x
+
+    def rollout_cost(self, s0, inputs, target_position, target_equilibrium, L=None):
+        """inputs[E,N,H] -> S[E,N]: trajectory cost of given control sequences (no update)."""
+        inputs = self.tensor(inputs)
+        E = inputs.shape[0]
+        if inputs.shape != (E, self.N, self.H):
+            raise ValueError(f"inputs must be [E,{self.N},{self.H}]")
+        s0 = self.tensor(s0, (E, 6))
+        tp, te = self._per_env(target_position, E), self._per_env(target_equilibrium, E)
+        Lt = self._per_env(L, E) if L is not None else None
+        S = self.empty(E, self.N)
+        self._check(self.lib.cpmppi_rollout_cost(self._h, E, _ptr(s0), _ptr(inputs), _ptr(tp), _ptr(te), _ptr(Lt), _ptr(S),
+                                                 self._stream()))
+        return S
+
+    def cem_sample(self, mean, stdev, seed, offset=0, env_offset=0):
+        mean, stdev = self.tensor(mean), self.tensor(stdev)
+        E = mean.shape[0]
+        Q = self.empty(E, self.N, self.H)
+        self._check(self.lib.cpmppi_cem_sample(self._h, E, _ptr(mean), _ptr(stdev), int(seed), int(offset), int(env_offset),
+                                               _ptr(Q), self._stream()))
+        return Q
+
+    def cem_update(self, S, Q, best_k, stdev_min, return_elites=False):
+        S, Q = self.tensor(S), self.tensor(Q)
+        E = S.shape[0]
+        mean, stdev = self.empty(E, self.H), self.empty(E, self.H)
+        elites = torch.empty(E, best_k, dtype=torch.int32, device=self.device) if return_elites else None
+        self._check(self.lib.cpmppi_cem_update(self._h, E, _ptr(S), _ptr(Q), int(best_k), float(stdev_min), _ptr(mean),
+                                               _ptr(stdev), _ptr(elites), self._stream()))
+        return (mean, stdev, elites) if return_elites else (mean, stdev)
+
     def set_profiling(self, enable=True):
         self._check(self.lib.cpmppi_set_profiling(self._h, int(bool(enable))))
 

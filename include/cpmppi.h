@@ -196,6 +196,21 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* model);
 int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* h0,
                        float* traj_out, float* h_out, void* stream);
 
+/* Rollout + cost only (no update): per-rollout trajectory cost S[E,N] of GIVEN input sequences inputs[E,N,H] under the
+ * handle's plugin cost — cost_function.get_trajectory_cost(predictor.predict_core(s, Q), Q) fused; the building block of
+ * the sampling optimizers that are not MPPI. */
+int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const float* inputs, const float* target_position,
+                        const float* target_equilibrium, const float* L, float* S_out, void* stream);
+
+/* CEM (hyper-parameters: Control_Toolkit_ASF/config_optimizers.yml:1-11, section cem-tf).
+ * cpmppi_cem_sample: Q[E,N,H] = clip(mean[E,H] + stdev[E,H] * z), z ~ N(0,1) from Philox(seed, offset, env, rollout).
+ * cpmppi_cem_update: per env, the best_k sequences by cost (stable ascending order) -> their mean and population
+ * standard deviation per time-step, the latter floored at stdev_min; elite_idx_out[E,best_k] (may be NULL). */
+int cpmppi_cem_sample(cpmppi_handle* h, uint32_t E, const float* mean, const float* stdev, uint64_t seed, uint64_t offset,
+                      uint32_t env_offset, float* Q_out, void* stream);
+int cpmppi_cem_update(cpmppi_handle* h, uint32_t E, const float* S, const float* Q, uint32_t best_k, float stdev_min,
+                      float* mean_out, float* stdev_out, uint32_t* elite_idx_out, void* stream);
+
 /* a16 alone: S[E,N], delta_u[E,N,H] -> weighted average [E,H] (controller_mppi_cartpole.py:306-321). */
 int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S, const float* delta_u, float* out,
                                    void* stream);

@@ -536,3 +536,13 @@ def gru_mppi_step(model, s, u_nom, delta_u, target_position, target_equilibrium,
     if cfg.control_mode == "clip":
         u_new = np.clip(u_new, f32(low), f32(high))
     return dict(S=S_cost, u_new=u_new, Q=u_new[0], traj=traj, u_run=u_run)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# SURVEY §8f N4 — CEM distribution update (the optimizer class is in the absent Control_Toolkit; hyper-parameters
+# Control_Toolkit_ASF/config_optimizers.yml:1-11).  Unpinned in-tree: this is the textbook update the config keys name.
+def cem_update(S, Q, best_k, stdev_min):
+    """S[N], Q[N,H] -> (mean[H], stdev[H], elite indices): best_k lowest costs (stable order), population std."""
+    idx = np.argsort(S, kind="stable")[:best_k]
+    elite = Q[idx].astype(np.float64)
+    return elite.mean(0).astype(f32), np.maximum(elite.std(0), stdev_min).astype(f32), idx

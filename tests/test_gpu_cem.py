@@ -1,0 +1,93 @@
+"""GPU: CEM over the same rollout + cost kernel — sampler, cost-only launch, top-k refit, optimizer."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402
+
+f32 = np.float32
+
+
+def make(E, N, H, **kw):
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    return MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, shift_mode="none", **kw))
+
+
+def test_cem_sample_cost_update_vs_oracle():
+    E, N, H, K = 3, 200, 35, 40                                   # the shipped cem-tf sizes, 3 envs
+    eng = make(E, N, H)
+    rng = np.random.Generator(np.random.SFC64(4))
+    mean = (0.2 * rng.standard_normal((E, H))).astype(f32)
+    stdev = rng.uniform(0.05, 0.6, (E, H)).astype(f32)
+    Q = eng.cem_sample(mean, stdev, seed=8, offset=2)
+    Qh = Q.cpu().numpy()
+    assert Qh.shape == (E, N, H) and np.abs(Qh).max() <= 1.0
+    # far from the limits nothing is clipped: the samples are mean + stdev * N(0,1)
+    m0, sd0 = np.zeros((E, H), f32) + 0.1, np.zeros((E, H), f32) + 0.05
+    z = (eng.cem_sample(m0, sd0, seed=8, offset=9).cpu().numpy() - 0.1) / 0.05
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1.0) < 0.03 and abs((z ** 3).mean()) < 0.1
+    assert np.array_equal(eng.cem_sample(mean, stdev, seed=8, offset=2).cpu().numpy(), Qh)
+    assert not np.array_equal(eng.cem_sample(mean, stdev, seed=8, offset=3).cpu().numpy(), Qh)
+    # cost-only launch == cost_function.get_trajectory_cost(predictor.predict_core(s, Q), Q)
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.0)
+                   for _ in range(E)])
+    tp = rng.uniform(-0.05, 0.05, E).astype(f32)
+    Lv = rng.uniform(0.25, 0.45, E).astype(f32)
+    S = eng.rollout_cost(s0, Q, tp, np.ones(E, f32), L=Lv)
+    Sh = S.cpu().numpy()
+    for e in range(E):
+        traj = O.predict_core(s0[e], Qh[e], L=Lv[e])
+        ref = O.trajectory_cost(O.COST_QBGM, traj, Qh[e], tp[e], f32(1.0))
+        rel = np.abs(Sh[e] - ref) / np.abs(ref)
+        assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.97
+    # top-k refit on the device's own costs: exact elite set, mean/std to rounding
+    m2, s2, el = eng.cem_update(S, Q, K, 0.01, return_elites=True)
+    for e in range(E):
+        mr, sr, idx = O.cem_update(Sh[e], Qh[e], K, 0.01)
+        assert np.array_equal(el.cpu().numpy()[e], idx)
+        np.testing.assert_allclose(m2.cpu().numpy()[e], mr, atol=1e-6)
+        np.testing.assert_allclose(s2.cpu().numpy()[e], sr, atol=2e-6)
+    # ties and N not a power of two: equal costs keep index order
+    St = torch.zeros(E, N, device=S.device)
+    _, _, el2 = eng.cem_update(St, Q, 7, 0.0, return_elites=True)
+    assert np.array_equal(el2.cpu().numpy(), np.tile(np.arange(7), (E, 1)))
+
+
+def test_optimizer_cem_improves_and_controls():
+    from types import SimpleNamespace
+    from cartpolesimulation_amd.optimizer_cem import optimizer_cem
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    vp = SimpleNamespace(target_position=f32(0.0), target_equilibrium=f32(1.0))
+    opt = optimizer_cem(control_limits=(np.array([-1.0]), np.array([1.0])), seed=2, mpc_horizon=35, num_rollouts=200,
+                        cem_outer_it=3, cem_best_k=40, variable_parameters=vp, cost_function_specification="default",
+                        optimizer_logging=True)
+    opt.configure(dt=0.02)
+    s = O.create_cartpole_state(0.25, 0.0, 0.02, 0.0)
+    u = opt.step(s)
+    assert u.shape == (1,) and abs(float(u[0])) <= 1.0
+    assert float(opt.stdev[0, -1]) == pytest.approx(np.sqrt(0.5)) and float(opt.dist_mue[0, -1]) == 0.0
+    assert (opt.stdev[0, :-1] >= 0.01 - 1e-7).all() and float(opt.stdev[0, :5].mean()) < 0.5        # refit tightened it
+    # the refit distribution is better than the prior: mean cost of fresh samples drops over the outer iterations
+    eng = opt.engine
+    prior = eng.rollout_cost(s[None], eng.cem_sample(eng.zeros(1, 35), eng.zeros(1, 35) + 0.5, 5), 0.0, 1.0).mean()
+    opt.optimizer_reset()
+    opt.step(s)
+    mue = torch.cat([opt.dist_mue[:, -1:], opt.dist_mue[:, :-1]], 1)                                # undo the shift
+    sd = torch.cat([opt.stdev[:, -1:] * 0 + 0.01, opt.stdev[:, :-1]], 1)
+    post = eng.rollout_cost(s[None], eng.cem_sample(mue.contiguous(), sd.contiguous(), 5), 0.0, 1.0).mean()
+    assert float(post) < float(prior)
+    # through the controller seam, closed loop with the device plant: stays upright
+    ctrl = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0},
+                          (np.array([-1.0], f32), np.array([1.0], f32)),
+                          config=dict(num_rollouts=256, mpc_horizon=35, seed=1, cost_function_specification="default"))
+    ctrl.configure("cem")
+    assert ctrl.optimizer.optimizer_name == "cem"
+    st = eng.tensor(O.create_cartpole_state(0.1, 0.0, 0.0, 0.0)[None].copy())
+    for t in range(60):
+        q = ctrl.step(st.cpu().numpy()[0], time=0.02 * t)
+        eng.plant_advance(st, q.astype(f32), n_substeps=10, dt_sim=0.002)
+    fin = st.cpu().numpy()[0]
+    assert abs(fin[0]) < 0.3 and abs(fin[4]) < 0.198
