@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpmppi.so")
 
 ABI_VERSION = 1
-COST_QBGM, COST_DEFAULT, COST_LEGACY = 0, 1, 2
+COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG = 0, 1, 2, 3
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 CONTROL_CLIP, CONTROL_PENALISE = 0, 1
 SHIFT_REPEAT_LAST, SHIFT_APPEND_ZERO, SHIFT_NONE = 0, 1, 2
@@ -27,7 +27,7 @@ class cpmppi_config(C.Structure):
                 ("k", C.c_float), ("m_cart", C.c_float), ("m_pole", C.c_float), ("g", C.c_float),
                 ("J_fric", C.c_float), ("M_fric", C.c_float), ("u_max", C.c_float), ("track_half_length", C.c_float),
                 ("L_default", C.c_float),
-                ("cost_id", C.c_uint32), ("cost_w", C.c_float * 16),
+                ("cost_id", C.c_uint32), ("cost_w", C.c_float * 24),
                 ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("cc_weight", C.c_float),
                 ("sigma", C.c_float), ("period", C.c_uint32), ("action_low", C.c_float), ("action_high", C.c_float),
                 ("horizon_reduce", C.c_uint32), ("control_mode", C.c_uint32), ("shift_mode", C.c_uint32),
@@ -39,7 +39,7 @@ class cpmppi_step_args(C.Structure):
                 ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p), ("L", C.c_void_p),
                 ("noise_kind", C.c_uint32), ("noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("env_offset", C.c_uint32), ("Q_out", C.c_void_p), ("S_out", C.c_void_p),
-                ("predictor", C.c_uint32), ("h0", C.c_void_p)]
+                ("predictor", C.c_uint32), ("h0", C.c_void_p), ("previous_input", C.c_void_p)]
 
 
 class cpmppi_gru_model(C.Structure):

@@ -45,6 +45,22 @@ COST_WEIGHTS = {
                                              permissible_track_fraction=0.85)),
     "default": (L.COST_DEFAULT, ["dd_weight", "ep_weight", "cc_weight", "R"],
                 dict(dd_weight=600.0, ep_weight=20000.0, cc_weight=1.0, R=1.0, ccrc_weight=1.0)),
+    # config_cost_function.yml:12-36; "cos_admissible_angle" is derived from admissible_angle (degrees in the YAML)
+    "quadratic_boundary_grad": (L.COST_QBG,
+                                ["dd_quadratic_weight_up", "dd_linear_weight_up", "db_weight_up", "ep_weight_up",
+                                 "ekp_weight_up", "cc_weight_up", "ccrc_weight_up",
+                                 "dd_quadratic_weight_down", "dd_linear_weight_down", "db_weight_down", "ep_weight_down",
+                                 "ekp_weight_down", "cc_weight_down", "ccrc_weight_down",
+                                 "target_angular_speed_sqr_max_correction_up",
+                                 "target_angular_speed_sqr_max_correction_down", "permissible_track_fraction",
+                                 "cos_admissible_angle", "R"],
+                                dict(dd_quadratic_weight_up=500.0, dd_linear_weight_up=0.0, ep_weight_up=6000.0,
+                                     target_angular_speed_sqr_max_correction_up=0.0, ekp_weight_up=30.0,
+                                     db_weight_up=10000.0, cc_weight_up=5.0, ccrc_weight_up=0.0,
+                                     dd_quadratic_weight_down=500.0, dd_linear_weight_down=0.0, ep_weight_down=6000.0,
+                                     target_angular_speed_sqr_max_correction_down=100.0, ekp_weight_down=30.0,
+                                     db_weight_down=10000.0, cc_weight_down=5.0, ccrc_weight_down=0.0,
+                                     permissible_track_fraction=0.85, admissible_angle=0.0, R=1.0)),
     "legacy_mppi_cartpole": (L.COST_LEGACY,
                              ["dd_weight", "ep_weight", "ekp_weight", "ekc_weight", "cc_weight", "ccrc_weight"],
                              dict(dd_weight=120.0, ep_weight=50000.0, ekp_weight=0.01, ekc_weight=5.0, cc_weight=1.0,
@@ -100,7 +116,10 @@ def cost_vector(name, overrides=None):
         raise ValueError(f"unknown cost_function_specification {name!r}; available: {sorted(COST_WEIGHTS)}")
     cost_id, keys, defaults = COST_WEIGHTS[name]
     vals = dict(defaults)
-    vals.update(overrides or {})
+    vals.update({k: v for k, v in (overrides or {}).items() if k in defaults or k in keys})
+    if "admissible_angle" in vals and "cos_admissible_angle" not in (overrides or {}):
+        rad = f32(np.float32(np.pi) * vals["admissible_angle"] / 180.0)      # quadratic_boundary_grad.py:33 (float32)
+        vals["cos_admissible_angle"] = float(np.cos(rad))
     return cost_id, [float(vals[k]) for k in keys]
 
 

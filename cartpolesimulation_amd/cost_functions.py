@@ -65,7 +65,8 @@ class cost_function_base:
         traj[:, :H] = st
         traj[:, H] = st[:, H - 1]
         tp, te = self._targets()
-        stage, _, _ = eng.trajectory_cost(traj, inputs, tp, te, want=("stage",))
+        prev = None if previous_input is None else eng.tensor(np.full(H, _scalar(previous_input, 0.0), np.float32))
+        stage, _, _ = eng.trajectory_cost(traj, inputs, tp, te, u_prev=prev, want=("stage",))
         return self._out(stage, as_tensor)
 
     def get_terminal_cost(self, terminal_states, as_tensor=False):
@@ -79,7 +80,9 @@ class cost_function_base:
     def get_trajectory_cost(self, state_horizon, inputs, previous_input=None, as_tensor=False):
         H = state_horizon.shape[1] - 1
         tp, te = self._targets()
-        _, _, total = self._engine(H).trajectory_cost(state_horizon, inputs, tp, te, want=("total",))
+        eng = self._engine(H)
+        prev = None if previous_input is None else eng.tensor(np.full(H, _scalar(previous_input, 0.0), np.float32))
+        _, _, total = eng.trajectory_cost(state_horizon, inputs, tp, te, u_prev=prev, want=("total",))
         return self._out(total, as_tensor)
 
     def get_summed_stage_cost(self, states, inputs, previous_input=None, as_tensor=False):
@@ -96,7 +99,14 @@ class default(cost_function_base):
     MAX_COST = 600.0 * 1.0e7 + 20000.0 + 1.0 * 1.0 * (1.77 ** 2)      # default.py:20
 
 
-COST_FUNCTIONS = {"quadratic_boundary_grad_minimal": quadratic_boundary_grad_minimal, "default": default}
+class quadratic_boundary_grad(cost_function_base):
+    """Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad.py (up/down weight sets by target_equilibrium,
+    energy-based angular-speed target, control-change-rate term against ``previous_input``)."""
+    cost_name = "quadratic_boundary_grad"
+
+
+COST_FUNCTIONS = {"quadratic_boundary_grad_minimal": quadratic_boundary_grad_minimal, "default": default,
+                  "quadratic_boundary_grad": quadratic_boundary_grad}
 
 
 class CostFunctionWrapper:

@@ -46,6 +46,7 @@ struct StepPtrs {
   const float* te;
   const float* L;
   const float* noise;
+  const float* prev_in; // [E] control applied before this step (quadratic_boundary_grad ccrc) or NULL
   uint64_t seed, offset;
   uint32_t env_offset;
   uint32_t nb;          // blocks per env
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   State<F> st{splat<F>(s0[0]), splat<F>(s0[1]), splat<F>(s0[2]), splat<F>(s0[3]), splat<F>(s0[4]), splat<F>(s0[5])};
 
   F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
+  F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
 
   auto control_step = [&](uint32_t k, F du) __attribute__((always_inline)) {
@@ -152,6 +154,10 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     } else if constexpr (COST == COST_DEFAULT) {
       cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
+    } else if constexpr (COST == COST_QBG) {
+      cost += stage_qbg<F, FAST>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
+      corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
+      u_before = ur;
     } else {
       cost += stage_legacy<F, FAST>(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
     }
@@ -415,11 +421,13 @@ __global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, 
     float c;
     if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm<float>(p, t[4], cosang, t[1], in, x_t, te);
     else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default<float>(p, t[4], cosang, in, x_t, te);
+    else if (p.cost_id == CPMPPI_COST_QBG)
+      c = stage_qbg<float>(p, t[4], cosang, t[1], in, k == 0 ? (u_prev ? u_prev[0] : 0.0f) : inputs[b * H + k - 1], x_t, te);
     else c = stage_legacy<float>(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
     if (stage_out) stage_out[b * H + k] = c;
     sum += c;
   }
-  const float term = (p.cost_id == CPMPPI_COST_QBGM) ? 0.0f : terminal_indicator<float>(p, t[0], t[4], x_t);
+  const float term = (p.cost_id == CPMPPI_COST_QBGM || p.cost_id == CPMPPI_COST_QBG) ? 0.0f : terminal_indicator<float>(p, t[0], t[4], x_t);
   if (terminal_out) terminal_out[b] = term;
   if (total_out)
     total_out[b] = (p.cost_id == CPMPPI_COST_LEGACY || p.horizon_reduce == CPMPPI_REDUCE_SUM)
@@ -787,6 +795,7 @@ hipError_t launch_rollout(const cpmppi_handle* h, uint32_t rpl, uint32_t noise, 
   switch (h->prm.cost_id) {
     case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
     case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
+    case CPMPPI_COST_QBG: return launch_rollout_math<COST_QBG>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
     default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
   }
 }
@@ -808,7 +817,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: E, N, H, S, period must be > 0 and H <= 1024");
   if (!(cfg->dt > 0.0f) || !(cfg->LBD > 0.0f) || !(cfg->NU > 0.0f) || !(cfg->L_default > 0.0f))
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: dt, LBD, NU, L_default must be > 0");
-  if (cfg->cost_id > CPMPPI_COST_LEGACY || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
+  if (cfg->cost_id > CPMPPI_COST_QBG || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
       cfg->correction_u > 1 || cfg->math_mode > 1 || cfg->rollouts_per_lane > 2)
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: unknown enum value");
   int count = 0;
@@ -864,7 +873,7 @@ int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out) {
 }
 
 int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cost_w, uint32_t n) {
-  if (!h || !cost_w || n > 16 || cost_id > CPMPPI_COST_LEGACY)
+  if (!h || !cost_w || n > 24 || cost_id > CPMPPI_COST_QBG)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_cost_weights: bad argument");
   h->cfg.cost_id = cost_id;
   h->prm.cost_id = cost_id;
@@ -956,7 +965,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   if (int rc = ensure_device(h)) return rc;
   StepPtrs p;
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
-  p.L = a->L; p.noise = a->noise; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
+  p.L = a->L; p.noise = a->noise; p.prev_in = a->previous_input; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
   // lane mapping: two rollouts per lane (packed float2) once the launch is big enough to keep >= 2 such waves on
   // every SIMD; one rollout per lane (shortest critical path) for small launches
   uint32_t rpl = h->cfg.rollouts_per_lane;
@@ -982,8 +991,8 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   }
   if (a->predictor == CPMPPI_PREDICTOR_GRU) {
     if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: predictor GRU requested but no model set (cpmppi_set_gru)");
-    if (h->prm.cost_id == CPMPPI_COST_LEGACY)
-      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports the plugin costs only");
+    if (h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT)
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports quadratic_boundary_grad_minimal and default");
     p.nb = (h->cfg.N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;
     const size_t lds = ((size_t)GRU_IMAGE_FLOATS + (size_t)WAVES * p.W) * sizeof(float);
     const dim3 grid(a->E * p.nb);
@@ -1119,7 +1128,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   prm.cc_weight = 0.0f;
   StepPtrs p;
   p.s0 = s0; p.u_nom = h->zeros_H; p.u_prev = nullptr; p.x_t = target_position; p.te = target_equilibrium; p.L = L;
-  p.noise = inputs; p.seed = 0; p.offset = 0; p.env_offset = 0;
+  p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.env_offset = 0;
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
   else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N >= 393216ull) ? 2 : 1;

@@ -24,7 +24,7 @@ namespace cpmppi {
 constexpr float PI_F = 3.14159274101257324f;       // float32(np.pi)
 constexpr float TWO_PI_F = 6.28318548202514648f;   // float32(2*np.pi)
 
-enum : int { COST_QBGM = 0, COST_DEFAULT = 1, COST_LEGACY = 2 };
+enum : int { COST_QBGM = 0, COST_DEFAULT = 1, COST_LEGACY = 2, COST_QBG = 3 };
 enum : int { NOISE_DELTA_U = 0, NOISE_KNOTS = 1, NOISE_PHILOX = 2 };
 
 // Kernel-argument block (passed by value -> kernarg segment -> SGPRs).
@@ -34,7 +34,7 @@ struct Params {
   float t_step;                      // dt / S
   float k, m_cart, m_pole, g, J_fric, M_fric, u_max, THL, L_default;
   uint32_t cost_id;
-  float w[16];
+  float w[24];
   float R, LBD, NU, cc_weight, sigma;
   float lo, hi;
   uint32_t horizon_reduce, control_mode, shift_mode, correction_u;
@@ -393,6 +393,40 @@ __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang,
   const F ekp = (w_ang * w_ang) * splat<F>(p.w[3]);
   const F cc = ((u * u) * splat<F>(p.w[5])) * splat<F>(p.w[4]);
   return dd + db + ep + ekp + cc;
+}
+
+// quadratic_boundary_grad.py:64-232; w = {up: ddq, ddl, db, ep, ekp, cc, ccrc | down: the same 7 | tas_corr_up,
+// tas_corr_down, permissible_track_fraction, cos(admissible_angle), R}; u_before = the control of the previous stage
+// (previous_input at stage 0); terminal cost zero.
+template <class F, bool FAST = false>
+__device__ __forceinline__ F stage_qbg(const Params& p, F x, F cosang, F w_ang, F u, F u_before, float x_t, float te) {
+  const bool up = (te == 1.0f);
+  const float* w = p.w + (up ? 0 : 7);
+  const float corr = up ? p.w[14] : p.w[15];
+  const float ptf = p.w[16], cos_adm = p.w[17], R = p.w[18], THL = p.THL;
+  const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
+  const F dd_quadratic = (d * d) * splat<F>(w[0]);
+  const F dd_linear = abs_(d) * splat<F>(w[1]);
+  const F ax = abs_(x);
+  F near;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) put(near, i, (get(ax, i) > ptf * THL) ? 1.0f : 0.0f);
+  const F b = div_uniform<FAST, F>(ax - splat<F>(ptf * THL), (1.0f - ptf) * THL);
+  const F db = (near * (b * b)) * splat<F>(w[2]);
+  const F tc = cosang * splat<F>(te);
+  const F e2 = splat<F>(2.0f) - tc;
+  const F ep = (e2 * e2 - splat<F>(1.0f)) * splat<F>(w[3]);
+  const float tas_max = __builtin_fabsf(120.0f * (1.0f + te) / 2.0f + corr);
+  const F basic = (splat<F>(1.0f) - tc) * splat<F>(0.5f);
+  F scaling;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i)
+    put(scaling, i, (te * (get(cosang, i) - cos_adm) > 0.0f) ? 0.0f : get(basic, i));
+  const F ekp = abs_(w_ang * w_ang - scaling * splat<F>(tas_max)) * splat<F>(w[4]);
+  const F cc = ((u * u) * splat<F>(R)) * splat<F>(w[5]);
+  const F dc = u - u_before;
+  const F ccrc = (dc * dc) * splat<F>(w[6]);
+  return dd_linear + dd_quadratic + db + ep + ekp + cc + ccrc;
 }
 
 // default.py:23-88; w = {dd, ep, cc, R}

@@ -58,8 +58,12 @@ enum {
   CPMPPI_COST_QBGM = 0,    /* quadratic_boundary_grad_minimal.py:64-126 ; cost_w = {dd_quadratic_weight, db_weight,
                               ep_weight, ekp_weight, cc_weight, R, permissible_track_fraction} */
   CPMPPI_COST_DEFAULT = 1, /* default.py:23-88 ; cost_w = {dd_weight, ep_weight, cc_weight, R} */
-  CPMPPI_COST_LEGACY = 2   /* controller_mppi_cartpole.py:119-161,227-303 (q + phi); cost_w = {dd_weight, ep_weight,
+  CPMPPI_COST_LEGACY = 2,  /* controller_mppi_cartpole.py:119-161,227-303 (q + phi); cost_w = {dd_weight, ep_weight,
                               ekp_weight, ekc_weight, cc_weight, ccrc_weight}; the MPPI correction term is part of q */
+  CPMPPI_COST_QBG = 3      /* quadratic_boundary_grad.py:64-232; cost_w = {up: dd_quadratic, dd_linear, db, ep, ekp, cc,
+                              ccrc | down: the same seven | target_angular_speed_sqr_max_correction up, down |
+                              permissible_track_fraction | cos(admissible_angle) | R}; the set is chosen per env by
+                              target_equilibrium == 1 */
 };
 
 enum { CPMPPI_REDUCE_SUM = 0, CPMPPI_REDUCE_MEAN = 1 };            /* horizon aggregation of the plugin costs */
@@ -88,7 +92,7 @@ typedef struct {
   float L_default;               /* used where the per-env L pointer is NULL */
   /* cost */
   uint32_t cost_id;
-  float cost_w[16];
+  float cost_w[24];
   /* MPPI — config_optimizers.yml:92-97 */
   float R, LBD, NU, cc_weight;
   float sigma;                   /* knot std-dev = SQRTRHOINV / sqrt(dt) */
@@ -144,6 +148,8 @@ typedef struct {
   float* S_out;                     /* [E,N]  per-rollout total cost, or NULL */
   uint32_t predictor;               /* CPMPPI_PREDICTOR_ODE_V0 (default, 0) or CPMPPI_PREDICTOR_GRU */
   const float* h0;                  /* GRU only: hidden state per env [E,2,32] shared by the env's rollouts, or NULL=0 */
+  const float* previous_input;      /* [E] control applied before this step (Q_ccrc of CartPole/__init__.py:517): the
+                                       control-change-rate term of quadratic_boundary_grad at stage 0; NULL = 0 */
 } cpmppi_step_args;
 
 int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out);
@@ -172,7 +178,8 @@ int cpmppi_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* 
 /* Cost seam (a12-a14): trajectories traj[B,H+1,6], inputs[B,H] -> stage_out[B,H] (may be NULL), terminal_out[B]
  * (may be NULL), total_out[B] (may be NULL; sum or mean per config.horizon_reduce, plugin costs only).
  * target_position / target_equilibrium are host scalars here (the plugin reads them from variable_parameters).
- * Legacy cost additionally needs u_nom[H], u_prev[H] (device) and interprets `inputs` as delta_u. */
+ * Legacy cost additionally needs u_nom[H], u_prev[H] (device) and interprets `inputs` as delta_u;
+ * quadratic_boundary_grad reads its previous_input from u_prev[0] (NULL = 0). */
 int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* traj, const float* inputs,
                            float target_position, float target_equilibrium, const float* u_nom, const float* u_prev,
                            float* stage_out, float* terminal_out, float* total_out, void* stream);

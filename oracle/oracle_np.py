@@ -255,6 +255,10 @@ def trajectory_cost(cost_id, traj, inputs, target_position, target_equilibrium, 
     elif cost_id == COST_DEFAULT:
         stage = default_stage_cost(traj[:, :-1], inputs, target_position, target_equilibrium, p, c)
         term = default_terminal_cost(traj[:, -1], target_position, p)
+    elif cost_id == 3:                   # COST_QBG (defined further down)
+        stage = qbg_stage_cost(traj[:, :-1], inputs, getattr(c, "qbg_previous_input", f32(0.0)), target_position,
+                               target_equilibrium, getattr(c, "qbg_weights", None), p)
+        term = np.zeros(traj.shape[0], dtype=f32)
     else:
         raise ValueError(cost_id)
     if horizon_reduce == "sum":
@@ -546,3 +550,42 @@ def cem_update(S, Q, best_k, stdev_min):
     idx = np.argsort(S, kind="stable")[:best_k]
     elite = Q[idx].astype(np.float64)
     return elite.mean(0).astype(f32), np.maximum(elite.std(0), stdev_min).astype(f32), idx
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# SURVEY §8f N4 — cost plugin quadratic_boundary_grad
+# (Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad.py:64-232; weights config_cost_function.yml:12-36)
+COST_QBG = 3
+QBG_DEFAULT_WEIGHTS = dict(
+    dd_quadratic_weight_up=500.0, dd_linear_weight_up=0.0, ep_weight_up=6000.0,
+    target_angular_speed_sqr_max_correction_up=0.0, ekp_weight_up=30.0, db_weight_up=10000.0, cc_weight_up=5.0,
+    ccrc_weight_up=0.0,
+    dd_quadratic_weight_down=500.0, dd_linear_weight_down=0.0, ep_weight_down=6000.0,
+    target_angular_speed_sqr_max_correction_down=100.0, ekp_weight_down=30.0, db_weight_down=10000.0, cc_weight_down=5.0,
+    ccrc_weight_down=0.0,
+    permissible_track_fraction=0.85, admissible_angle=0.0, R=1.0)   # admissible_angle in RADIANS here
+
+
+def qbg_stage_cost(states, inputs, previous_input, target_position, target_equilibrium, w=None, p=DEFAULT_PARAMS):
+    """states[N,H,6], inputs[N,H], previous_input scalar -> [N,H] float32; terminal cost is zero (:163-164)."""
+    w = dict(QBG_DEFAULT_WEIGHTS, **(w or {}))
+    sfx = "_up" if target_equilibrium == 1.0 else "_down"                                   # :190-209 (weights())
+    g = lambda k: f32(w[k + sfx])
+    THL, te = p.TrackHalfLength, f32(target_equilibrium)
+    x, ang, angD = states[:, :, POSITION_IDX], states[:, :, ANGLE_IDX], states[:, :, ANGLED_IDX]
+    d = (x - target_position) / (2 * THL)
+    dd_quadratic = g("dd_quadratic_weight") * d ** 2                                        # :64-71
+    dd_linear = g("dd_linear_weight") * np.abs((x - target_position) / (2.0 * THL))         # :73-78
+    ptf = f32(w["permissible_track_fraction"])
+    near = (np.abs(x) > ptf * THL).astype(f32)
+    db = g("db_weight") * (near * ((np.abs(x) - ptf * THL) / ((1 - ptf) * THL)) ** 2)       # :98-105
+    ep = g("ep_weight") * (((2.0 - te * np.cos(ang)) ** 2) - 1.0)                           # :108-110
+    tas_max = np.abs(f32(120.0) * (f32(1.0) + te) / f32(2.0) + g("target_angular_speed_sqr_max_correction"))   # :123-129
+    basic = (1.0 - te * np.cos(ang)) / 2
+    cond = te * (np.cos(ang) - np.cos(f32(w["admissible_angle"]))) > 0
+    tas = tas_max * np.where(cond, f32(0.0), basic)
+    ekp = g("ekp_weight") * np.abs(angD ** 2 - tas)                                         # :133-141
+    cc = g("cc_weight") * (f32(w["R"]) * inputs ** 2)                                       # :144-145
+    u_before = np.concatenate([np.full((inputs.shape[0], 1), previous_input, dtype=f32), inputs[:, :-1]], axis=1)
+    ccrc = g("ccrc_weight") * (inputs - u_before) ** 2                                      # :178-183
+    return (dd_linear + dd_quadratic + db + ep + ekp + cc + ccrc).astype(f32)               # :232

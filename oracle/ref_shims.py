@@ -117,8 +117,24 @@ class NumpyLibrary:
         return np.zeros(shape, dtype=dtype)
 
     @staticmethod
-    def cond(pred, t, f):
-        return t() if pred else f()
+    def cond(pred, true_fn=None, false_fn=None):
+        return true_fn() if pred else false_fn()
+
+    @staticmethod
+    def equal(a, b):
+        return np.equal(a, b)
+
+    @staticmethod
+    def stop_gradient(x):
+        return x
+
+    @staticmethod
+    def min(a, b):
+        return np.minimum(a, b)
+
+    @staticmethod
+    def norm(x, axis=None):
+        return np.linalg.norm(x, axis=axis)
 
     @staticmethod
     def create_rng(seed):

@@ -40,7 +40,7 @@ def test_struct_layout_matches_header():
         names = decl.split(None, 1)[1]
         fields += [re.sub(r"\[.*\]", "", x).strip() for x in names.split(",")]
     assert fields == [f[0] for f in _lib.cpmppi_config._fields_]
-    assert C.sizeof(_lib.cpmppi_config) == 4 * (len(fields) - 1) + 64
+    assert C.sizeof(_lib.cpmppi_config) == 4 * (len(fields) - 1) + 96
 
 
 def test_no_cpu_fallback():

@@ -159,3 +159,51 @@ def test_cost_function_seam():
     assert not np.allclose(total, total2)
     with pytest.raises(ValueError):
         w.configure(cost_function_specification="quadratic_boundary_nonconvex")
+
+
+@pytest.mark.parametrize("case", ["up_shipped", "down_shipped", "up_all_terms", "down_all_terms"])
+def test_quadratic_boundary_grad_seam_and_fused(golden_dir, case):
+    """The in-tree plugin quadratic_boundary_grad: cost seam against the reference's own outputs, then the fused step
+    (rollout + this cost + update) against the oracle, both weight sets (target_equilibrium = +-1)."""
+    import os
+    from cartpolesimulation_amd.cost_functions import quadratic_boundary_grad
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    g = np.load(os.path.join(golden_dir, "qbg_costs.npz"))
+    w = dict(zip(g[f"{case}/weight_names"], g[f"{case}/weight_values"]))
+    w["cos_admissible_angle"] = float(np.cos(f32(w.pop("admissible_angle"))))          # the fixture holds radians
+    vp = SimpleNamespace(target_position=g[f"{case}/target_position"], target_equilibrium=g[f"{case}/target_equilibrium"])
+    c = quadratic_boundary_grad(vp, None, weights=w)
+    traj, Qin, prev = g[f"{case}/traj"], g[f"{case}/Q"], g[f"{case}/previous_input"]
+    stage = c.get_stage_cost(traj[:, :-1], Qin[..., None], prev)
+    np.testing.assert_allclose(stage, g[f"{case}/stage"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(c.get_trajectory_cost(traj, Qin[..., None], prev), g[f"{case}/total"], rtol=1e-4)
+    assert not c.get_terminal_cost(traj[:, -1]).any()
+    # fused step
+    N, H = Qin.shape
+    for rpl in (1, 2):
+        eng = MPPIEngine(1, MPPIConfig(num_rollouts=N, mpc_horizon=H, cost_function_specification="quadratic_boundary_grad",
+                                       cost_weights=w, rollouts_per_lane=rpl))
+        rng = Generator(SFC64(3))
+        u0 = (0.2 * rng.standard_normal(H)).astype(f32)
+        du = O.sample_delta_u(rng, N, H, np.float64(eng.mppi.sigma))
+        un = eng.tensor(u0[None].copy())
+        S = eng.empty(1, N)
+        eng.step(g[f"{case}/s0"][None], un, vp.target_position, vp.target_equilibrium, delta_u=du[None], S_out=S,
+                 previous_input=prev)
+        cfg = O.MPPIConfig(N=N, H=H, cost_id=O.COST_QBG)
+        cfg.cost.qbg_weights = {k: v for k, v in zip(g[f"{case}/weight_names"], g[f"{case}/weight_values"])
+                                if k in O.QBG_DEFAULT_WEIGHTS}
+        cfg.cost.qbg_previous_input = prev
+        ref = O.mppi_step(g[f"{case}/s0"], u0, du, vp.target_position, vp.target_equilibrium, cfg)
+        Sd = S.cpu().numpy()[0]
+        rel = np.abs(Sd - ref["S"]) / np.abs(ref["S"])
+        assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.97, f"{case} rpl={rpl}: median {np.median(rel):.2e}"
+        # costs here are ~5e4 against LBD = 100, so the soft-min weights amplify 1e-5 relative cost differences; the
+        # update is therefore checked on the device's own costs (exactness of the reduction) ...
+        u_shift = np.concatenate([u0[1:], u0[-1:]])
+        u_chk = np.clip(u_shift + O.reward_weighted_average(Sd, du), -1, 1)
+        np.testing.assert_allclose(un.cpu().numpy()[0], u_chk, atol=1e-4)
+        # ... and end to end with the tolerance scaled by that amplification
+        # (a relative cost difference r changes a weight by r*|S|/LBD; the perturbations are O(1))
+        np.testing.assert_allclose(un.cpu().numpy()[0], ref["u_new"], atol=max(1e-4, np.abs(ref["S"]).max() * 1e-5 / 100.0))

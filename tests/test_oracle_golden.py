@@ -205,3 +205,14 @@ def test_gru_oracle_against_live_torch(golden_dir):
             y = feat.numpy()
             ref = np.stack([np.arctan2(y[:, 2], y[:, 1]), y[:, 0], y[:, 1], y[:, 2], y[:, 3], y[:, 4]], 1)
             assert np.abs(traj[:, k + 1] - ref).max() < 5e-6
+
+
+@pytest.mark.parametrize("case", ["up_shipped", "down_shipped", "up_all_terms", "down_all_terms"])
+def test_qbg_cost_oracle_matches_reference(golden_dir, case):
+    """quadratic_boundary_grad (in-tree plugin): stage and trajectory cost against the reference's own outputs."""
+    g = load(golden_dir, "qbg_costs.npz")
+    w = {k: v for k, v in zip(g[f"{case}/weight_names"], g[f"{case}/weight_values"]) if k in O.QBG_DEFAULT_WEIGHTS}
+    stage = O.qbg_stage_cost(g[f"{case}/traj"][:, :-1], g[f"{case}/Q"], g[f"{case}/previous_input"],
+                             g[f"{case}/target_position"], g[f"{case}/target_equilibrium"], w)
+    np.testing.assert_allclose(stage, g[f"{case}/stage"], rtol=2e-6)
+    np.testing.assert_allclose(stage.sum(1), g[f"{case}/total"], rtol=1e-5)
