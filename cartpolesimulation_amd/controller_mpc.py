@@ -43,13 +43,21 @@ class controller_mpc(template_controller):
     ``step`` = update_attributes -> optimizer.step -> logging.  Only the MPPI optimizer is built on this tier."""
 
     def __init__(self, environment_name="CartPole", initial_environment_attributes=None, control_limits=None,
-                 action_space=None, observation_space=None, config=None, phys=None, device=0, num_envs=1, **kwargs):
+                 action_space=None, observation_space=None, config=None, phys=None, device=0, num_envs=1,
+                 config_root=None, **kwargs):
         if control_limits is None and action_space is not None:          # the gym-style ctor of others/Tests/*.py
             control_limits = (np.asarray(action_space.low, dtype=np.float32), np.asarray(action_space.high, dtype=np.float32))
         super().__init__(environment_name, initial_environment_attributes, control_limits)
         if environment_name != "CartPole":
             raise ValueError("only the CartPole environment is built")
         self.config_optimizer = dict(config or {})     # overrides of config_optimizers.yml:87-97 + glue flags
+        if config_root is not None:                    # read a CartPoleSimulation checkout's YAML files
+            from .configs import as_dict, load_reference_yaml, mppi_config_from_yaml
+            yaml_phys, cfgs = load_reference_yaml(config_root)
+            base = as_dict(mppi_config_from_yaml(cfgs))
+            base.update(self.config_optimizer)
+            self.config_optimizer = base
+            phys = phys or yaml_phys
         self.phys = phys or PhysicalParameters()
         self.device, self.num_envs = device, num_envs
         self.has_optimizer = True

@@ -33,7 +33,8 @@ class optimizer_mppi:
                  period_interpolation_inducing_points=10, optimizer_logging=False, calculate_optimal_trajectory=False,
                  mpc_timestep=0.02, num_envs=1, noise="philox", cost_function_specification=None, cost_weights=None,
                  horizon_reduce="sum", control_mode="clip", shift_mode="repeat_last", correction_u="u_run",
-                 math_mode="fast", intermediate_steps=10, phys=None, device=0, variable_parameters=None, **kwargs):
+                 math_mode="fast", intermediate_steps=10, phys=None, device=0, variable_parameters=None, gru_model=None,
+                 **kwargs):
         self.predictor, self.cost_function = predictor, cost_function
         low, high = (-1.0, 1.0) if control_limits is None else (float(np.asarray(control_limits[0]).reshape(-1)[0]),
                                                                   float(np.asarray(control_limits[1]).reshape(-1)[0]))
@@ -73,6 +74,8 @@ class optimizer_mppi:
         self.engine = None
         self.u_nom = None
         self.step_counter = 0
+        self.gru_model = gru_model           # dict of GRU-6IN-32H1-32H2-5OUT weights -> neural predictor in the loop
+        self.h = None                        # its memory per env [E,2,32] (controller_mppi_cartpole.py:566-567 update)
 
     # ------------------------------------------------------------------
     def configure(self, dt=None, predictor_specification=None, num_envs=None, **kwargs):
@@ -81,10 +84,18 @@ class optimizer_mppi:
             self.cfg.mpc_timestep = float(dt)
         if num_envs is not None:
             self.num_envs = int(num_envs)
-        if predictor_specification not in (None, "ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
-            raise NotImplementedError("only the ODE_v0 predictor is built into the fused kernel on this tier")
+        neural = predictor_specification is not None and str(predictor_specification).startswith("GRU-6IN-32H1-32H2-5OUT")
+        if neural and self.gru_model is None:
+            raise ValueError("a GRU predictor_specification needs gru_model=dict(weights) (no model files ship in-tree)")
+        if not neural and predictor_specification not in (None, "ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
+            raise NotImplementedError("built predictors: ODE_v0 and GRU-6IN-32H1-32H2-5OUT-*")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         E, N, H = self.num_envs, self.num_rollouts, self.mpc_horizon
+        if self.gru_model is not None and (neural or predictor_specification is None):
+            self.engine.set_gru(self.gru_model)
+            self.h = self.engine.zeros(E, 2, 32)
+        else:
+            self.h = None
         self.u_nom = self.engine.zeros(E, H)
         self.Q = self.engine.empty(E)
         self.S = self.engine.empty(E, N) if self.optimizer_logging else None
@@ -95,6 +106,8 @@ class optimizer_mppi:
         """u_nom = midpoint of the control limits; restart the noise stream."""
         if self.u_nom is not None:
             self.u_nom.fill_(0.5 * (self.action_low + self.action_high))
+        if self.h is not None:
+            self.h.zero_()
         self.step_counter = 0
         self._rng = np.random.Generator(np.random.SFC64(self.seed))
 
@@ -124,8 +137,15 @@ class optimizer_mppi:
             kw["knots"] = sample_knots_sfc64(self._rng, E, self.num_rollouts, self.cfg)
         else:
             kw.update(seed=self.seed, offset=self.step_counter)
+        if self.h is not None:
+            kw.update(predictor="GRU", h0=self.h)
         eng.step(s_t, self.u_nom, tp, te, L=L, Q_out=self.Q, S_out=self.S, **kw)
         self.step_counter += 1
+        if self.h is not None:
+            # advance the network's memory with the state just seen and the control just chosen (update_internal_state)
+            _, h_new = eng.gru_predict(s_t, self.Q.reshape(E, 1), h0=self.h.transpose(0, 1).contiguous(),
+                                       return_hidden=True)
+            self.h = h_new.transpose(0, 1).contiguous()
         if self.optimizer_logging:
             self.logging_values = {"Q_logged": self.Q.cpu().numpy(), "J_logged": self.S.cpu().numpy(),
                                    "u_logged": self.u_nom.cpu().numpy()}

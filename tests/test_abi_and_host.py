@@ -126,3 +126,14 @@ def test_sfc64_knots_match_the_reference_sampler(golden_dir):
     cfg = MPPIConfig(num_rollouts=int(h["N"]), mpc_horizon=int(h["H"]), SQRTRHOINV=0.02)
     kn = sample_knots_sfc64(rng, 1, cfg.num_rollouts, cfg)[0]
     assert np.array_equal(kn[0][:4], h["du_row0"][::10]) and np.array_equal(kn[-1][:4], h["du_row3499"][::10])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Control_Toolkit_ASF"), reason="reference checkout not mounted")
+def test_controller_reads_a_checkout():
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    c = controller_mpc("CartPole", {"target_position": 0.0}, config_root="/root/reference", config=dict(num_rollouts=512))
+    assert c.config_optimizer["mpc_horizon"] == 35 and c.config_optimizer["num_rollouts"] == 512
+    assert c.config_optimizer["cost_function_specification"] == "quadratic_boundary_grad_minimal"
+    assert c.config_optimizer["cost_weights"]["db_weight_up"] == 10000 and c.has_optimizer
+    with pytest.raises(ValueError):
+        controller_mpc("Pendulum")

@@ -289,3 +289,42 @@ def test_closed_loop_c1_plumbing(golden_dir):
         eng.plant_advance(s, np.array([Q], dtype=f32), n_substeps=10, dt_sim=0.002)
     s_host = s.cpu().numpy()[0]
     assert abs(s_host[O.ANGLE_IDX]) < 0.2 and abs(s_host[O.POSITION_IDX]) < 0.198
+
+
+def test_limits_and_bad_arguments():
+    """Maximum horizon, many envs, unsupported knot counts, misaligned pointers."""
+    import ctypes as C
+    from cartpolesimulation_amd import _lib as L
+    # H = CPMPPI_MAX_HORIZON (1024) with one knot period per 32 steps; a single block per env
+    H = 1024
+    eng = engine(1, 64, H, period_interpolation_inducing_points=32, intermediate_steps=1, mpc_timestep=0.002)
+    rng = Generator(SFC64(1))
+    du = (0.1 * rng.standard_normal((1, 64, H))).astype(f32)
+    s0 = O.create_cartpole_state(0.1, 0.0, 0.0, 0.0)[None]
+    un = eng.zeros(1, H)
+    S = eng.empty(1, 64)
+    eng.step(s0, un, 0.0, 1.0, delta_u=du, S_out=S)
+    cfg = O.MPPIConfig(N=64, H=H, S=1, dt=0.002, period=32)
+    ref = O.mppi_step(s0[0], np.zeros(H, f32), du[0], f32(0), f32(1), cfg)
+    np.testing.assert_allclose(S.cpu().numpy()[0], ref["S"], rtol=2e-4)
+    np.testing.assert_allclose(un.cpu().numpy()[0], ref["u_new"], atol=1e-4)
+    with pytest.raises(L.CpmppiError):
+        engine(1, 8, 1025)                                                    # beyond the maximum horizon
+    # many small envs in one launch; every env gets its own noise stream and a finite answer
+    E = 5000
+    e2 = engine(E, 64, 10)
+    u2 = e2.zeros(E, 10)
+    Q, _ = e2.step(np.tile(s0, (E, 1)), u2, 0.0, 1.0, seed=3)
+    q = Q.cpu().numpy()
+    assert np.isfinite(q).all() and len(np.unique(np.round(q, 7))) > E * 0.9
+    # more than 63 knots per rollout is outside the device sampler's LDS budget -> clean error, not a crash
+    e3 = engine(1, 8, 100, period_interpolation_inducing_points=1)
+    with pytest.raises(L.CpmppiError):
+        e3.sample(seed=1)
+    # a pointer that is not 4-byte aligned is refused
+    a = L.cpmppi_step_args()
+    buf = e2.zeros(64)
+    a.E, a.s0, a.u_nom = 1, buf.data_ptr() + 1, buf.data_ptr()
+    a.target_position = a.target_equilibrium = buf.data_ptr()
+    a.noise_kind = L.NOISE_PHILOX
+    assert e2.lib.cpmppi_step(e2._h, C.byref(a), None) == -5
