@@ -212,18 +212,24 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
       else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
     };
-    float z_lo[R], z_hi[R];
+    constexpr bool F32_INTERP = FAST && NOISE == NOISE_PHILOX;       // our own noise: one FMA instead of the f64 form
+    const float inv_period = 1.0f / (float)p.period;
+    float z_lo[R], z_hi[R], slope32[R];
     double slope[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       z_lo[i] = knot(i, 0); z_hi[i] = knot(i, 1);
-      slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
+      if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
+      else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
     }
     uint32_t ii = 0, j = 0;
     for (uint32_t k = 0; k < H; ++k) {
       F du;
 #pragma unroll
-      for (int i = 0; i < R; ++i) put(du, i, interp_from_slope(slope[i], z_lo[i], ii));
+      for (int i = 0; i < R; ++i) {
+        if constexpr (F32_INTERP) put(du, i, interp_from_slope32(slope32[i], z_lo[i], ii));
+        else put(du, i, interp_from_slope(slope[i], z_lo[i], ii));
+      }
       control_step(k, du);
       if (++ii == p.period) {
         ii = 0; ++j;
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         for (int i = 0; i < R; ++i) {
           z_lo[i] = z_hi[i];
           if (j + 1 < p.P) z_hi[i] = knot(i, j + 1);
-          slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
+          if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
+          else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
         }
       }
     }
@@ -373,7 +380,10 @@ __global__ __launch_bounds__(BLOCK) void sample_kernel(const Params p, uint32_t 
   for (uint32_t row = 0; row < 64 && wave_row0 + row < total; ++row) {
     for (uint32_t k = lane; k < p.H; k += 64) {
       const uint32_t j = k / p.period, i = k % p.period;
-      du_out[(wave_row0 + row) * p.H + k] = interp_knots(wk[row * stride + j], wk[row * stride + j + 1], i, p.period);
+      const float zl = wk[row * stride + j], zh = wk[row * stride + j + 1];
+      du_out[(wave_row0 + row) * p.H + k] = (p.interp_f32 && !knots_in)
+          ? interp_from_slope32(knot_slope32(zl, zh, 1.0f / (float)p.period), zl, i)      // what the FAST Philox kernel forms
+          : interp_knots(zl, zh, i, p.period);
     }
   }
 }
@@ -756,6 +766,7 @@ void fill_params(const cpmppi_config& c, Params& p) {
   p.lo = c.action_low; p.hi = c.action_high;
   p.horizon_reduce = c.horizon_reduce; p.control_mode = c.control_mode; p.shift_mode = c.shift_mode;
   p.correction_u = c.correction_u;
+  p.interp_f32 = (c.math_mode == CPMPPI_MATH_FAST) ? 1u : 0u;
 }
 
 int ensure_device(cpmppi_handle* h) {

@@ -38,6 +38,8 @@ struct Params {
   float R, LBD, NU, cc_weight, sigma;
   float lo, hi;
   uint32_t horizon_reduce, control_mode, shift_mode, correction_u;
+  uint32_t interp_f32;               // FAST + device-generated knots: interpolate with one float32 FMA (<= 1 ulp of the
+                                     // float64 scipy form, which stays in force for caller-provided knots)
 };
 
 // Per-env constants.  PRECISE keeps the reference's operands; FAST folds them (all wave-uniform).
@@ -541,6 +543,15 @@ __device__ __forceinline__ double knot_slope(float z_lo, float z_hi, uint32_t pe
 #pragma clang fp contract(off)      // (else sigma*z of philox_knot is fused into this subtraction and skips a rounding)
   const float diff = z_hi - z_lo;
   return (double)diff / (double)period;
+}
+// float32 form for the FAST path's own Philox noise: slope rounded to float, then ONE fma per control step.
+__device__ __forceinline__ float knot_slope32(float z_lo, float z_hi, float inv_period) {
+#pragma clang fp contract(off)      // same reason: the knots must be the rounded float32 values the sampler stores
+  const float diff = z_hi - z_lo;
+  return diff * inv_period;
+}
+__device__ __forceinline__ float interp_from_slope32(float slope, float z_lo, uint32_t i) {
+  return __builtin_fmaf(slope, (float)i, z_lo);
 }
 __device__ __forceinline__ float interp_from_slope(double slope, float z_lo, uint32_t i) {
 #pragma clang fp contract(off)

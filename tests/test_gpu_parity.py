@@ -145,19 +145,30 @@ def test_noise_sources_agree(math_mode, rpl):
     Lv = rng.uniform(0.2, 0.5, E).astype(f32)
     u0 = (0.2 * rng.standard_normal((E, H))).astype(f32)
     kn, du = eng.sample(seed=1234, offset=5, env_offset=11, knots=True, delta_u=True)
-    # device interpolation == oracle interpolation (bit-exact: float64 slope, float32 store)
-    assert np.array_equal(du.cpu().numpy().reshape(E * N, H), O.interpolate_knots(kn.cpu().numpy().reshape(E * N, -1), H))
-    assert np.array_equal(eng.interpolate(kn).cpu().numpy(), du.cpu().numpy())
+    # interpolation of CALLER knots == oracle interpolation (bit-exact: float64 slope, float32 store, as scipy does)
+    du64 = eng.interpolate(kn)
+    assert np.array_equal(du64.cpu().numpy().reshape(E * N, H), O.interpolate_knots(kn.cpu().numpy().reshape(E * N, -1), H))
+    # the sampler's own delta_u: PRECISE uses the same float64 form; FAST uses one float32 FMA (<= 1 ulp away)
+    if math_mode == "precise":
+        assert np.array_equal(du64.cpu().numpy(), du.cpu().numpy())
+    else:
+        np.testing.assert_allclose(du.cpu().numpy(), du64.cpu().numpy(), rtol=0, atol=1.2e-7)
     outs = []
     for kw in (dict(delta_u=du), dict(knots=kn), dict(seed=1234, offset=5, env_offset=11)):
         un = eng.tensor(u0.copy())
         S = eng.empty(E, N)
         Q, _ = eng.step(s0, un, tp, te, L=Lv, S_out=S, **kw)
         outs.append((un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy()))
+    # identical perturbations -> identical costs: sampler buffer == in-kernel Philox always; caller knots (float64
+    # interpolation) == both in PRECISE, and within the 1-ulp interpolation difference in FAST
+    assert np.array_equal(outs[2][1], outs[0][1])
+    if math_mode == "precise":
+        assert np.array_equal(outs[1][1], outs[0][1])
+    else:
+        np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5)
     for o in outs[1:]:
-        assert np.array_equal(o[1], outs[0][1])                    # identical perturbations -> identical costs
-        np.testing.assert_allclose(o[0], outs[0][0], atol=2e-6)    # knot-space vs delta_u-space reduction order
-        np.testing.assert_allclose(o[2], outs[0][2], atol=2e-6)
+        np.testing.assert_allclose(o[0], outs[0][0], atol=5e-6)    # knot-space vs delta_u-space reduction order
+        np.testing.assert_allclose(o[2], outs[0][2], atol=5e-6)
 
 
 def test_philox_sampler_statistics():
