@@ -47,6 +47,7 @@ struct EnvConst {
   float L, Lh;
   float kp1, kp1_mt;                 // (k+1), (k+1)*(m_cart+m_pole)
   float mg, JinvLh, kmLh, kM, g_i, cT_i, inv_kLh, inv_halfL;
+  float tg_i, tcT_i, tinv_kLh;       // the same three angleDD coefficients times the substep length t
 };
 
 __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
@@ -66,6 +67,10 @@ __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
   c.g_i = (float)((double)p.g * inv_kLh);
   c.cT_i = (float)((double)p.J_fric / ((double)p.m_pole * Lh) * inv_kLh);
   c.inv_halfL = (float)(1.0 / (0.5 * (double)L));
+  const double t = (double)p.t_step;
+  c.tg_i = (float)(t * (double)p.g * inv_kLh);
+  c.tcT_i = (float)(t * ((double)p.J_fric / ((double)p.m_pole * Lh) * inv_kLh));
+  c.tinv_kLh = (float)(t * inv_kLh);
   return c;
 }
 
@@ -102,12 +107,22 @@ template <> __device__ __forceinline__ f2 splat<f2>(float x) { return f2{x, x}; 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
-__device__ __forceinline__ f2 rcp_(f2 a) { return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+#ifndef CPMPPI_RCP_SHARED
+#define CPMPPI_RCP_SHARED 0     // float2: one v_rcp_f32 (a quarter-rate instruction) for both lanes, 1/(ab) * (b, a)
+#endif
+__device__ __forceinline__ f2 rcp_(f2 a) {
+#if CPMPPI_RCP_SHARED
+  const float r = __builtin_amdgcn_rcpf(a.x * a.y);
+  return f2{r, r} * a.yx;
+#else
+  return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+#endif
+}
 __device__ __forceinline__ float rint_(float a) { return __builtin_rintf(a); }
 __device__ __forceinline__ f2 rint_(f2 a) { return f2{__builtin_rintf(a.x), __builtin_rintf(a.y)}; }
 __device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ f2 abs_(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
-__device__ __forceinline__ float clamp_(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
+__device__ __forceinline__ float clamp_(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
 __device__ __forceinline__ f2 clamp_(f2 a, float lo, float hi) { return f2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
 __device__ __forceinline__ float cos_(float a) { return cosf(a); }
 __device__ __forceinline__ f2 cos_(f2 a) { return f2{cosf(a.x), cosf(a.y)}; }
@@ -245,6 +260,12 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
 #ifndef CPMPPI_NEWTON
 #define CPMPPI_NEWTON 0         // 0: num * v_rcp_f32(A) (<= 1.5 ulp; measured deviation identical)   1: + one Newton correction
 #endif
+#ifndef CPMPPI_FOLD_T
+#define CPMPPI_FOLD_T 0         // 1: fold t into the angleDD coefficients (-1 instruction; measured: 2.4x the deviation, so off)
+#endif
+#ifndef CPMPPI_HOIST_SPIN
+#define CPMPPI_HOIST_SPIN 1     // test |w t| once per control step (<= 0.1) instead of every substep (<= 0.125)
+#endif
 #ifndef CPMPPI_ROTATE
 #define CPMPPI_ROTATE 1         // 1: rotate (cos, sin) on intermediate substeps, full wrap + sincos at the control step's end
 #endif
@@ -272,8 +293,13 @@ __device__ __forceinline__ void ode_euler_fast(const State<F>& st, F uK, float t
   const F tt = splat<F>(t);
   th1 = fma_(w, tt, st.th);
   // (do NOT fold "1 - cT*t" into one constant: its rounding error would bias w the same way every substep)
+#if CPMPPI_FOLD_T
+  // w + t*aDD with t folded into the three coefficients (each product still rounds relative to its own size)
+  w1 = fma_(splat<F>(e.tg_i), s, fma_(xDD * c, splat<F>(e.tinv_kLh), fma_(w, splat<F>(-e.tcT_i), w)));
+#else
   const F aDD = fma_(splat<F>(e.g_i), s, fma_(xDD * c, splat<F>(e.inv_kLh), -(w * splat<F>(e.cT_i))));
   w1 = fma_(aDD, tt, w);
+#endif
   x1 = fma_(v, tt, st.x);
   v1 = fma_(xDD, tt, v);
 }
@@ -322,8 +348,8 @@ __device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const 
 // truncation < 1e-9).  Rounding adds ~1 ulp per rotation; the control step's LAST substep re-synchronises with the full
 // wrap + sincos (substep_fast), so the states observed at control-step granularity carry at most S-1 rotations of drift
 // (~2e-7).  Lanes that bounce, or spin faster than 0.125 rad per substep, are re-evaluated exactly in the cold branch.
-template <class F>
-__device__ __forceinline__ void substep_fast_rot(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
+template <class F, bool CHECK_SPIN = true>
+__device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   const F d = st.w * splat<F>(t);
@@ -335,13 +361,17 @@ __device__ __forceinline__ void substep_fast_rot(State<F>& st, F uK, float t, co
   F s1 = fma_(st.s, cd, st.c * sd);
   bool rare = false;
 #pragma unroll
-  for (int i = 0; i < W; ++i) rare |= (__builtin_fabsf(get(x1, i)) >= p.THL) | (__builtin_fabsf(get(d, i)) > 0.125f);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+  for (int i = 0; i < W; ++i) {
+    rare |= (__builtin_fabsf(get(x1, i)) >= p.THL);
+    if constexpr (CHECK_SPIN) rare |= (__builtin_fabsf(get(d, i)) > 0.125f);
+  }
+  const bool fired = __builtin_amdgcn_ballot_w64(rare) != 0;
+  if (__builtin_expect(fired, 0)) {
 #pragma unroll
     for (int i = 0; i < W; ++i) {
       float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
       const bool hit = __builtin_fabsf(xi) >= p.THL;
-      if (hit || __builtin_fabsf(get(d, i)) > 0.125f) {
+      if (hit || (CHECK_SPIN && __builtin_fabsf(get(d, i)) > 0.125f)) {
         if (hit) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
         thi = wrap_rint<float>(thi);
         float sn, cs;
@@ -352,13 +382,30 @@ __device__ __forceinline__ void substep_fast_rot(State<F>& st, F uK, float t, co
     }
   }
   st.th = th1; st.w = w1; st.x = x1; st.v = v1; st.c = c1; st.s = s1;
+  return fired;
 }
 
 // One control step of S substeps under a held control (FAST).
 template <class F>
 __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e) {
-#if CPMPPI_ROTATE
+#if CPMPPI_ROTATE && CPMPPI_HOIST_SPIN
+  // The Taylor rotation needs |w t| <= 0.125 (its cos error reaches half an ulp only at ~0.18).  Tested once here with
+  // the margin 0.1: without a bounce w cannot gain 12 rad/s within one control step; a bounce can change w abruptly,
+  // so after one the rest of the control step runs the exact substep.  Everything is wave-uniform.
+  bool spin = false;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) spin |= __builtin_fabsf(get(st.w, i)) * t > 0.1f;
+  bool exact = __builtin_amdgcn_ballot_w64(spin) != 0;
+  uint32_t sub = 0;
+  if (__builtin_expect(!exact, 1)) {
+    while (sub + 1 < S) {
+      ++sub;
+      if (__builtin_expect(substep_fast_rot<F, false>(st, uK, t, p, e), 0)) break;
+    }
+  }
+  for (; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);       // the last substep always; all remaining after a bounce
+#elif CPMPPI_ROTATE
   for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
   substep_fast<F>(st, uK, t, p, e);
 #else

@@ -71,10 +71,10 @@ def test_config_full_size(name, E, N, H):
         np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=2e-6)       # (1 vs 2 rollouts per lane mapping)
 
     # ---- permutation invariance: shuffling an env's rollouts leaves its update unchanged (to summation order)
-    perm = torch.randperm(N, device=kn.device)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).to(kn.device)
     u3 = eng.tensor(u0.copy())
     eng.step(s0, u3, tp, te, L=Lv, knots=kn[:, perm].contiguous())
-    np.testing.assert_allclose(u3.cpu().numpy(), un_h, atol=5e-6)
+    np.testing.assert_allclose(u3.cpu().numpy(), un_h, atol=2e-5)      # float32 weighted sums over 4096 rollouts
 
     # ---- the update is a convex combination of the perturbations (before clipping): min <= u_new - u_shift <= max
     du0 = O.interpolate_knots(kn_h[0], H)
