@@ -16,4 +16,6 @@ for NOISE in philox buffer; do
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq_$NOISE -- python3 $B2 > $OUT/pmc_sq_$NOISE.log 2>&1
   timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq2_$NOISE -- python3 $B2 > $OUT/pmc_sq2_$NOISE.log 2>&1
 done
+# GRU predictor (MFMA) kernel: kernel-trace stats only
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_gru -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single-env --predictor gru --envs 256 > $OUT/stats_gru.log 2>&1
 find $OUT -name "*.csv" | wc -l

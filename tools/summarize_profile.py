@@ -43,6 +43,12 @@ for noise in ("philox", "buffer"):
     for (k, c), v in sorted(agg.items()):
         out.setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
     summary[noise] = out
+ks = glob.glob(os.path.join(src, "stats_gru", "**", "*_kernel_stats.csv"), recursive=True)
+if ks:
+    shutil.copy(ks[0], os.path.join(dst, "kernel_stats_gru.csv"))
+    lines = [l for l in open(os.path.join(src, "stats_gru.log")) if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, "bench_line_under_rocprof_gru.json"), "w").write(lines[-1])
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 
 # HBM traffic of the dominant kernel per launch: (FETCH_SIZE + WRITE_SIZE) KiB * 1024 (MI355X_MICROARCH.md §HBM).
