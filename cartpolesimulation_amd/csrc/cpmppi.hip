@@ -22,6 +22,7 @@
 #include "cpmppi.h"
 #include "cpmppi_device.hpp"
 #include "cpmppi_gru.hpp"
+#include "cpmppi_grad.hpp"
 
 using namespace cpmppi;
 
@@ -716,6 +717,118 @@ __global__ __launch_bounds__(BLOCK) void cem_update_kernel(const Params p, const
 
 thread_local std::string g_create_error;
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rollout + plugin cost + its gradient w.r.t. the inputs (cpmppi_grad.hpp).  One lane = one (env, rollout) of the
+// flattened [E*N] axis (the gradient optimizers run 16-40 rollouts per env, config_optimizers.yml:60,75: a block per
+// env would idle), so per-env quantities are per-lane here.  Check-points ckpt[H][6][E*N] (lane-contiguous) hold the
+// state at every control step; sub[S][6][BLOCK] in LDS holds the sub-states of the control step being reversed.
+struct GradPtrs {
+  const float* s0; const float* Q; const float* x_t; const float* te; const float* L; const float* prev_in;
+  float* ckpt; float* S_out; float* grad; uint32_t E;
+};
+
+template <int COST>
+__global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, const GradPtrs a) {
+  extern __shared__ float sub_states[];            // [S][6][BLOCK]
+  const uint32_t tid = threadIdx.x;
+  const size_t B = (size_t)a.E * p.N;
+  const size_t g = (size_t)blockIdx.x * BLOCK + tid;
+  if (g >= B) return;                               // (no block-level barrier below)
+  const uint32_t env = (uint32_t)(g / p.N);
+  const uint32_t H = p.H, S = p.S;
+  const float t = p.t_step;
+  const EnvConst ec = make_env_const(p, a.L ? a.L[env] : p.L_default);
+  const float x_t = a.x_t[env], te = a.te[env];
+  const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
+  const float* __restrict__ Q = a.Q + g * H;
+  const float cos0 = cosf(s0[0]), sin0 = sinf(s0[0]);   // the plugins take cos(angle) of the given state at stage 0
+  const float ub0 = a.prev_in ? a.prev_in[env] : 0.0f;
+  const bool clip = p.control_mode == CPMPPI_CONTROL_CLIP;
+  const float scale = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? 1.0f : 1.0f / (float)(H + 1);
+
+  // ---- forward, check-pointing every control step -------------------------------------------------------------
+  State<float> st{s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
+  float cost = 0.0f, cosang = cos0, u_before = ub0;
+  for (uint32_t k = 0; k < H; ++k) {
+    float* __restrict__ ck = a.ckpt + ((size_t)k * 6) * B + g;
+    ck[0] = st.th; ck[B] = st.w; ck[2 * B] = st.c; ck[3 * B] = st.s; ck[4 * B] = st.x; ck[5 * B] = st.v;
+    float ur = Q[k];
+    if (clip) ur = clamp_(ur, p.lo, p.hi);
+    if constexpr (COST == COST_QBGM) cost += stage_qbgm<float, true>(p, st.x, cosang, st.w, ur, x_t, te);
+    else if constexpr (COST == COST_DEFAULT) cost += stage_default<float, true>(p, st.x, cosang, ur, x_t, te);
+    else cost += stage_qbg<float, true>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
+    u_before = ur;
+    const float uK = (ur * p.u_max) * ec.kp1;
+    for (uint32_t s = 0; s < S; ++s) substep_fast<float>(st, uK, t, p, ec);
+    cosang = st.c;
+  }
+  const float term = (COST == COST_DEFAULT) ? terminal_indicator<float>(p, st.th, st.x, x_t) : 0.0f;
+  if (a.S_out) a.S_out[g] = (cost + term) * scale;
+
+  // ---- backward --------------------------------------------------------------------------------------------------
+  Adjoint lam{0.0f, 0.0f, 0.0f, 0.0f};              // the terminal indicator has zero derivative
+  float carry = 0.0f;                               // d stage_{k+1} / d u_k through u_before (quadratic_boundary_grad)
+  float* __restrict__ my = sub_states + tid;
+  for (uint32_t k = H; k-- > 0;) {
+    const float* __restrict__ ck = a.ckpt + ((size_t)k * 6) * B + g;
+    const State<float> st0{ck[0], ck[B], ck[2 * B], ck[3 * B], ck[4 * B], ck[5 * B]};
+    const float q = Q[k];
+    const bool clipped = clip && (q < p.lo || q > p.hi);
+    const float ur = clip ? clamp_(q, p.lo, p.hi) : q;
+    const float uK = (ur * p.u_max) * ec.kp1;
+    State<float> s = st0;
+    for (uint32_t i = 0; i < S; ++i) {
+      float* __restrict__ d = my + (size_t)i * 6 * BLOCK;
+      d[0] = s.th; d[BLOCK] = s.w; d[2 * BLOCK] = s.c; d[3 * BLOCK] = s.s; d[4 * BLOCK] = s.x; d[5 * BLOCK] = s.v;
+      substep_fast<float>(s, uK, t, p, ec);
+    }
+    float guK = 0.0f;
+    for (uint32_t i = S; i-- > 0;) {
+      const float* __restrict__ d = my + (size_t)i * 6 * BLOCK;
+      const State<float> si{d[0], d[BLOCK], d[2 * BLOCK], d[3 * BLOCK], d[4 * BLOCK], d[5 * BLOCK]};
+      substep_reverse(si, uK, t, p, ec, lam, guK);
+    }
+    // stage k: its own state and control
+    const float ca = (k == 0) ? cos0 : st0.c, sa = (k == 0) ? sin0 : st0.s;
+    float ub = ub0;
+    if (COST == COST_QBG && k > 0) { ub = Q[k - 1]; if (clip) ub = clamp_(ub, p.lo, p.hi); }
+    StageGrad sg;
+    if constexpr (COST == COST_QBGM) sg = stage_qbgm_grad(p, st0.x, ca, st0.w, ur, x_t, te);
+    else if constexpr (COST == COST_DEFAULT) sg = stage_default_grad(p, st0.x, ca, ur, x_t, te);
+    else sg = stage_qbg_grad(p, st0.x, ca, st0.w, ur, ub, x_t, te);
+    lam.x = __builtin_fmaf(scale, sg.x, lam.x);
+    lam.w = __builtin_fmaf(scale, sg.w, lam.w);
+    lam.th = __builtin_fmaf(scale * sg.cosang, -sa, lam.th);
+    const float gk = __builtin_fmaf(guK, ec.kp1 * p.u_max, scale * sg.u + carry);
+    carry = scale * sg.u_before;
+    a.grad[g * H + k] = clipped ? 0.0f : gk;
+  }
+}
+
+// Adam on input sequences with per-rollout gradient-norm clipping (tf.clip_by_norm over the horizon) and the final
+// clip to the action limits; hyper-parameters config_optimizers.yml:52-58,69-73.  One lane = one (env, rollout) row.
+__global__ __launch_bounds__(BLOCK) void adam_step_kernel(size_t rows, uint32_t H, float* __restrict__ Q,
+                                                          const float* __restrict__ grad, float* __restrict__ m,
+                                                          float* __restrict__ v, float lr_t, float beta1, float beta2,
+                                                          float eps, float gradmax_clip, float lo, float hi) {
+  const size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= rows) return;
+  const float* __restrict__ gr = grad + r * H;
+  float ss = 0.0f;
+  for (uint32_t k = 0; k < H; ++k) ss = __builtin_fmaf(gr[k], gr[k], ss);
+  const float nrm = sqrtf(ss);
+  const float sc = (gradmax_clip > 0.0f && nrm > gradmax_clip) ? gradmax_clip / nrm : 1.0f;
+  for (uint32_t k = 0; k < H; ++k) {
+    const size_t i = r * H + k;
+    const float gk = gr[k] * sc;
+    const float mk = beta1 * m[i] + (1.0f - beta1) * gk;
+    const float vk = beta2 * v[i] + (1.0f - beta2) * gk * gk;
+    m[i] = mk; v[i] = vk;
+    Q[i] = clamp_(Q[i] - lr_t * mk / (sqrtf(vk) + eps), lo, hi);
+  }
+}
+
 }  // namespace
 
 struct cpmppi_handle {
@@ -730,6 +843,8 @@ struct cpmppi_handle {
   uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
   float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
+  float* grad_ckpt = nullptr;          // [H][6][E*N] check-points of cpmppi_rollout_cost_grad (allocated on first use)
+  size_t grad_ckpt_floats = 0;
   GruNorm gru_norm;
   bool fuse_finalize = true;           // ODE path: the env's last block finalizes in-kernel (CPMPPI_FUSE_FINALIZE=0 disables)
   bool profiling = false;
@@ -871,6 +986,7 @@ void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
   if (h->workspace) (void)hipFree(h->workspace);
   if (h->gru_image) (void)hipFree(h->gru_image);
+  if (h->grad_ckpt) (void)hipFree(h->grad_ckpt);
   if (h->counters) (void)hipFree(h->counters);
   if (h->zeros_H) (void)hipFree(h->zeros_H);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -1153,6 +1269,55 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
                                 (hipStream_t)stream, p);
   hh->prm = saved;
   CPMPPI_HIP(h, e);
+  return CPMPPI_OK;
+}
+
+int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, const float* inputs,
+                             const float* target_position, const float* target_equilibrium, const float* L,
+                             const float* previous_input, float* S_out, float* grad_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !s0 || !inputs || !target_position || !target_equilibrium || !grad_out)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: bad argument");
+  if (h->prm.cost_id == CPMPPI_COST_LEGACY)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: plugin costs only");
+  if (h->cfg.math_mode != CPMPPI_MATH_FAST)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for the FAST arithmetic");
+  const size_t lds = (size_t)h->cfg.S * 6 * BLOCK * sizeof(float);
+  if (lds > 150 * 1024) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: S too large for the LDS sub-state buffer (<= 25)");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t B = (size_t)E * h->cfg.N;
+  const size_t need = (size_t)h->cfg.H * 6 * (size_t)h->cfg.E * h->cfg.N;
+  if (h->grad_ckpt_floats < need) {
+    if (h->grad_ckpt) (void)hipFree(h->grad_ckpt);
+    h->grad_ckpt = nullptr; h->grad_ckpt_floats = 0;
+    CPMPPI_HIP(h, hipMalloc(&h->grad_ckpt, need * sizeof(float)));
+    h->grad_ckpt_floats = need;
+  }
+  GradPtrs a{s0, inputs, target_position, target_equilibrium, L, previous_input, h->grad_ckpt, S_out, grad_out, E};
+  const dim3 grid((unsigned)((B + BLOCK - 1) / BLOCK));
+  hipStream_t st = (hipStream_t)stream;
+  switch (h->prm.cost_id) {
+    case CPMPPI_COST_QBGM: hipLaunchKernelGGL(rollout_grad_kernel<COST_QBGM>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+    case CPMPPI_COST_DEFAULT: hipLaunchKernelGGL(rollout_grad_kernel<COST_DEFAULT>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+    default: hipLaunchKernelGGL(rollout_grad_kernel<COST_QBG>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+  }
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_adam_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, float* m, float* v, uint32_t iteration,
+                     float learning_rate, float beta1, float beta2, float epsilon, float gradmax_clip, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !Q || !grad || !m || !v || iteration == 0)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_adam_step: bad argument (iteration counts from 1)");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t rows = (size_t)E * h->cfg.N;
+  // Keras Adam: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), epsilon outside the square root
+  const double lr_t = (double)learning_rate * sqrt(1.0 - pow((double)beta2, (double)iteration)) /
+                      (1.0 - pow((double)beta1, (double)iteration));
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     rows, h->cfg.H, Q, grad, m, v, (float)lr_t, beta1, beta2, epsilon, gradmax_clip, h->prm.lo, h->prm.hi);
+  CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
 

@@ -219,6 +219,31 @@ class MPPIEngine:
                                                  self._stream()))
         return S
 
+    def rollout_cost_grad(self, s0, inputs, target_position, target_equilibrium, L=None, previous_input=None):
+        """inputs[E,N,H] -> (S[E,N], grad[E,N,H]): trajectory cost and its derivative w.r.t. the inputs."""
+        inputs = self.tensor(inputs)
+        E = inputs.shape[0]
+        if inputs.shape != (E, self.N, self.H):
+            raise ValueError(f"inputs must be [E,{self.N},{self.H}]")
+        s0 = self.tensor(s0, (E, 6))
+        tp, te = self._per_env(target_position, E), self._per_env(target_equilibrium, E)
+        Lt = self._per_env(L, E) if L is not None else None
+        pi = self._per_env(previous_input, E) if previous_input is not None else None
+        S, grad = self.empty(E, self.N), self.empty(E, self.N, self.H)
+        self._check(self.lib.cpmppi_rollout_cost_grad(self._h, E, _ptr(s0), _ptr(inputs), _ptr(tp), _ptr(te), _ptr(Lt),
+                                                      _ptr(pi), _ptr(S), _ptr(grad), self._stream()))
+        return S, grad
+
+    def adam_step(self, Q, grad, m, v, iteration, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, gradmax_clip=0.0):
+        """One Adam iteration on Q[E,N,H] in place (m, v: caller-owned moments, zero before iteration 1)."""
+        for x in (Q, grad, m, v):
+            if not (isinstance(x, torch.Tensor) and x.is_contiguous() and x.dtype == torch.float32 and x.shape == Q.shape):
+                raise ValueError("Q, grad, m, v must be contiguous float32 device tensors of one shape [E,N,H]")
+        self._check(self.lib.cpmppi_adam_step(self._h, Q.shape[0], _ptr(Q), _ptr(grad), _ptr(m), _ptr(v), int(iteration),
+                                              float(learning_rate), float(beta1), float(beta2), float(epsilon),
+                                              float(gradmax_clip), self._stream()))
+        return Q
+
     def cem_sample(self, mean, stdev, seed, offset=0, env_offset=0):
         mean, stdev = self.tensor(mean), self.tensor(stdev)
         E = mean.shape[0]

@@ -209,6 +209,22 @@ int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const flo
 int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const float* inputs, const float* target_position,
                         const float* target_equilibrium, const float* L, float* S_out, void* stream);
 
+/* Rollout + plugin cost + its gradient with respect to the inputs: S[E,N] (may be NULL) and
+ * grad[E,N,H] = d get_trajectory_cost(predict_core(s, Q), Q, previous_input) / d Q — what TensorFlow's GradientTape
+ * hands to the gradient-based optimizers of the absent Control_Toolkit (Control_Toolkit_ASF/config_optimizers.yml:49-86,
+ * sections gradient-tf and rpgd; :21-48 the CEM+gradient hybrids).  FAST arithmetic, plugin costs only; the edge bounce
+ * is differentiated along the branch taken, indicators and a clipped control contribute zero.  previous_input[E] may be
+ * NULL (0).  Allocates H*6*E*N floats of check-points on first use. */
+int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, const float* inputs,
+                             const float* target_position, const float* target_equilibrium, const float* L,
+                             const float* previous_input, float* S_out, float* grad_out, void* stream);
+
+/* One Adam iteration on the input sequences Q[E,N,H] (in place; m, v are the caller-owned moment buffers, zero before
+ * iteration 1): per-rollout gradient-norm clipping to gradmax_clip (<= 0: off), Keras-style bias correction, then the
+ * clip to [action_low, action_high] (config_optimizers.yml:52-58,69-73). */
+int cpmppi_adam_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, float* m, float* v, uint32_t iteration,
+                     float learning_rate, float beta1, float beta2, float epsilon, float gradmax_clip, void* stream);
+
 /* CEM (hyper-parameters: Control_Toolkit_ASF/config_optimizers.yml:1-11, section cem-tf).
  * cpmppi_cem_sample: Q[E,N,H] = clip(mean[E,H] + stdev[E,H] * z), z ~ N(0,1) from Philox(seed, offset, env, rollout).
  * cpmppi_cem_update: per env, the best_k sequences by cost (stable ascending order) -> their mean and population
