@@ -12,6 +12,7 @@ import numpy as np
 from .configs import MPPIConfig, PhysicalParameters
 from .cost_functions import CostFunctionWrapper
 from .optimizer_cem import optimizer_cem
+from .optimizer_gradient import optimizer_gradient, optimizer_rpgd
 from .optimizer_mppi import optimizer_mppi
 from .predictors import PredictorWrapper
 
@@ -69,11 +70,14 @@ class controller_mpc(template_controller):
     def configure(self, optimizer_name=None, predictor_specification=None, cost_function_specification=None,
                   controller_logging=False, **kwargs):
         optimizer_name = optimizer_name or "mppi"
-        if optimizer_name in ("cem", "cem-tf"):
-            return self._configure_cem(predictor_specification, cost_function_specification, controller_logging, **kwargs)
+        others = {"cem": optimizer_cem, "cem-tf": optimizer_cem, "gradient": optimizer_gradient,
+                  "gradient-tf": optimizer_gradient, "rpgd": optimizer_rpgd, "rpgd-tf": optimizer_rpgd}
+        if optimizer_name in others:
+            return self._configure_other(others[optimizer_name], predictor_specification, cost_function_specification,
+                                         controller_logging, **kwargs)
         if optimizer_name != "mppi":
-            raise NotImplementedError(f"optimizer {optimizer_name!r}: 'mppi' (the hot path) and 'cem' are built; the "
-                                      "gradient-based optimizers (rpgd, ...) need an adjoint kernel")
+            raise NotImplementedError(f"optimizer {optimizer_name!r}: built are 'mppi' (the hot path), 'cem', 'gradient' "
+                                      "and 'rpgd'")
         cfg = dict(self.config_optimizer)
         cfg.update(kwargs)
         cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
@@ -96,7 +100,7 @@ class controller_mpc(template_controller):
                                         variable_parameters=self.variable_parameters, **cfg)
         self.optimizer.configure(dt=opt_probe.mpc_timestep, predictor_specification="ODE_v0")
 
-    def _configure_cem(self, predictor_specification, cost_function_specification, controller_logging, **kwargs):
+    def _configure_other(self, cls, predictor_specification, cost_function_specification, controller_logging, **kwargs):
         cfg = dict(self.config_optimizer)
         cfg.update(kwargs)
         cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
@@ -107,7 +111,7 @@ class controller_mpc(template_controller):
                                              environment_name=self.environment_name,
                                              cost_function_specification=cost_name, weights=cfg.get("cost_weights"),
                                              phys=self.phys, device=self.device)
-        self.optimizer = optimizer_cem(cost_function=self.cost_function_wrapper.cost_function,
+        self.optimizer = cls(cost_function=self.cost_function_wrapper.cost_function,
                                        control_limits=self.control_limits, optimizer_logging=controller_logging,
                                        phys=self.phys, device=self.device, num_envs=self.num_envs,
                                        variable_parameters=self.variable_parameters, **cfg)
