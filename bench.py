@@ -118,10 +118,17 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (development aid: CPMPPI_BENCH_BACKEND=gloo CPMPPI_BENCH_ONE_DEVICE=1 runs the N>1 code path on a 1-GPU box)
+    backend = os.environ.get("CPMPPI_BENCH_BACKEND", "nccl")
+    if os.environ.get("CPMPPI_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from cartpolesimulation_amd.engine import MPPIEngine
     from cartpolesimulation_amd.configs import MPPIConfig
@@ -133,7 +140,12 @@ def main():
     u_nom = eng.zeros(E, H)
     Q_out = eng.empty(E)
     du = eng.empty(E, N, H) if args.noise == "buffer" else None
-    gathered = torch.empty(world * E * H, dtype=torch.float32, device=device) if distributed else None
+    # the one collective of the path: all-gather of the updated nominal sequences.  Envs are independent,
+    # so step i+1 does not need step i's gathered result: the gather of a snapshot runs asynchronously on RCCL's stream
+    # while the next step's kernel computes (two snapshot/result buffers, each waited on before it is reused).
+    gathered = [torch.empty(world * E * H, dtype=torch.float32, device=device) for _ in range(2)] if distributed else None
+    snapshot = [torch.empty(E * H, dtype=torch.float32, device=device) for _ in range(2)] if distributed else None
+    pending = [None, None]
     seed = 1234
     pred_kw = {}
     if args.predictor == "gru":
@@ -150,10 +162,19 @@ def main():
         else:
             eng.step(s0, u_nom, tp, te, L=L, seed=seed, offset=i, env_offset=rank * E, Q_out=Q_out, **pred_kw)
         if distributed:
-            dist.all_gather_into_tensor(gathered, u_nom.view(-1))      # the single RCCL gather of chosen controls
+            b = i & 1
+            if pending[b] is not None:
+                pending[b].wait()                                   # stream-level wait: the buffers are free again
+            snapshot[b].copy_(u_nom.view(-1))
+            pending[b] = dist.all_gather_into_tensor(gathered[b], snapshot[b], async_op=True)
 
     def barrier():
         if distributed:
+            for b in range(2):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,6 +194,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(u_nom).all(), "non-finite nominal controls"
+    if distributed:      # the last gather delivered this rank's block (and finite blocks from every other rank)
+        last = gathered[(args.warmup + args.steps - 1) & 1].view(world, E * H)
+        assert torch.equal(last[rank], u_nom.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
