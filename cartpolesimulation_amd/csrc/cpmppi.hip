@@ -33,6 +33,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_TK
 #define CPMPPI_TK 8
 #endif
+#ifndef CPMPPI_GRU_MIN_WAVES
+#define CPMPPI_GRU_MIN_WAVES 2      // waves per SIMD the GRU kernels are compiled for (register budget 512 / this)
+#endif
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
 #endif
@@ -507,7 +510,7 @@ __device__ __forceinline__ void gru_load_image(float* __restrict__ lds, const fl
 }
 
 // predictor seam with the neural predictor: s0[B,6], Q[B,H], h0[2,B,32] or NULL -> traj[B,H+1,6], h_out[2,B,32] or NULL
-__global__ __launch_bounds__(BLOCK) void gru_predict_kernel(const GruNorm nm, const float* __restrict__ image, uint32_t B,
+__global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_predict_kernel(const GruNorm nm, const float* __restrict__ image, uint32_t B,
                                                             uint32_t H, const float* __restrict__ s0,
                                                             const float* __restrict__ Q, const float* __restrict__ h0,
                                                             float* __restrict__ traj, float* __restrict__ h_out) {
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(BLOCK) void gru_predict_kernel(const GruNorm nm, co
 
 // Fused MPPI step with the GRU predictor: same contract as rollout_cost_kernel (plugin costs), h0[E,2,32] or NULL.
 template <int COST, int NOISE>
-__global__ __launch_bounds__(BLOCK) void gru_rollout_cost_kernel(const Params p, const StepPtrs a, const GruNorm nm,
+__global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_kernel(const Params p, const StepPtrs a, const GruNorm nm,
                                                                  const float* __restrict__ image,
                                                                  const float* __restrict__ h0) {
   extern __shared__ float lds[];                           // GRU image, then [WAVES][W] weighted sums
@@ -575,23 +578,31 @@ __global__ __launch_bounds__(BLOCK) void gru_rollout_cost_kernel(const Params p,
 
   float st[6] = {s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
   float cost = 0.0f, corr = 0.0f;
+  float cosang = cosf(s0[0]);               // the plugins take cos(angle) of the given state at stage 0
   f16v x;
+  GruCarry carry;
+  gru_carry_init(lds, h1, lane, carry);
+  const bool half1 = lane >= 32;
   for (uint32_t k = 0; k < H; ++k) {
     float du;
     if constexpr (NOISE == NOISE_DELTA_U) du = a.noise[((size_t)env * p.N + nn) * H + k];
     else du = interp_knots(z_lo, z_hi, ii, p.period);
     const float uk = shifted_nominal(p, un, k);
     float ur = uk + du;
-    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = fminf(fmaxf(ur, p.lo), p.hi);
-    const float cosang = cosf(st[0]);
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
     if constexpr (COST == COST_QBGM) cost += stage_qbgm<float>(p, st[4], cosang, st[1], ur, x_t, te);
     else cost += stage_default<float>(p, st[4], cosang, ur, x_t, te);
     corr += mppi_correction<float>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
     if (k == 0) x = gru_input_tile(nm, s0, ur, lane);
-    else if (lane >= 32) x[1] = __builtin_fmaf(ur, nm.in_scale[0], nm.in_shift[0]);
-    const f16v out = gru_step(lds, x, h1, h2, lane);
-    gru_output_state(nm, out, lane, st);
-    x = out;
+    else if (half1) x[1] = __builtin_fmaf(ur, nm.in_scale[0], nm.in_shift[0]);
+    float out[5];
+    gru_step_pipelined(lds, x, h1, h2, carry, lane, out);
+    gru_output_state_fast(nm, out, st, cosang);
+    // normalised outputs are fed back unchanged: rows 0..3 on lane-half 0, row 4 (and Q, row 5) on lane-half 1
+    x[0] = half1 ? out[4] : out[0];
+    x[1] = half1 ? 0.0f : out[1];
+    x[2] = half1 ? 0.0f : out[2];
+    x[3] = half1 ? 0.0f : out[3];
     if constexpr (NOISE != NOISE_DELTA_U) {
       if (++ii == p.period) {
         ii = 0; ++j;
@@ -600,6 +611,7 @@ __global__ __launch_bounds__(BLOCK) void gru_rollout_cost_kernel(const Params p,
       }
     }
   }
+  st[0] = atan2f(st[3], st[2]);             // predictors_customization.py:121-127, needed for the terminal cost only
   const float term = (COST == COST_DEFAULT) ? terminal_indicator<float>(p, st[0], st[4], x_t) : 0.0f;
   float S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / (float)(H + 1);
   S_total += corr;
@@ -1214,6 +1226,22 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
     for (int l = 0; l < 64; ++l)
       frag(GF_DW + s)[l] = (l & 31) < 5 ? m->w_out[(size_t)(l & 31) * 32 + gru_tile_row(s, l >> 5)] : 0.0f;
   for (int l = 0; l < 5; ++l) frag(GF_DB)[l] = m->b_out[l];
+  // plain vectors of the fused rollout kernel (biases as accumulator tiles, dense head on the VALU)
+  for (int layer = 0; layer < 2; ++layer)
+    for (int hf = 0; hf < 2; ++hf)
+      for (int v = 0; v < 16; ++v) {
+        const int r = gru_tile_row(v, hf);
+        float* b = img.data() + GV_BIAS + (size_t)layer * 4 * 32 + hf * 16 + v;
+        b[0 * 32] = m->b_ih[layer][r] + m->b_hh[layer][r];
+        b[1 * 32] = m->b_ih[layer][32 + r] + m->b_hh[layer][32 + r];
+        b[2 * 32] = m->b_ih[layer][64 + r];
+        b[3 * 32] = m->b_hh[layer][64 + r];
+      }
+  for (int hf = 0; hf < 2; ++hf)
+    for (int o = 0; o < 5; ++o)
+      for (int v = 0; v < 16; ++v)
+        img[GV_HEAD + (size_t)hf * 80 + o * 16 + v] = m->w_out[(size_t)o * 32 + gru_tile_row(v, hf)];
+  for (int o = 0; o < 5; ++o) img[GV_HEADB + o] = m->b_out[o];
   for (int i = 0; i < 6; ++i) {
     h->gru_norm.in_scale[i] = m->in_scale ? m->in_scale[i] : 1.0f;
     h->gru_norm.in_shift[i] = m->in_shift ? m->in_shift[i] : 0.0f;

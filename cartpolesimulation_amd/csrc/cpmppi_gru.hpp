@@ -35,7 +35,13 @@ enum : int {
   GF_DB = 180,           // 1
   GF_COUNT = 181
 };
-constexpr int GRU_IMAGE_FLOATS = GF_COUNT * 64;
+// After the fragments: plain vectors for the fused rollout kernel, which takes biases and the 5-row dense head off the
+// matrix pipe (25 of 181 MFMAs per step).  Layout [lane half][register v] so that a lane reads 16 consecutive floats
+// (4 x ds_read_b128, same address across a half = broadcast).
+constexpr int GV_BIAS = GF_COUNT * 64;          // 8 vectors (layer 1: r, z, n_x, n_h; layer 2: the same) x [2][16]
+constexpr int GV_HEAD = GV_BIAS + 8 * 32;       // [2][5][16]: w_out[o][row(v, half)]
+constexpr int GV_HEADB = GV_HEAD + 2 * 5 * 16;  // b_out[5] (+3 pad)
+constexpr int GRU_IMAGE_FLOATS = GV_HEADB + 8;
 
 struct GruNorm {         // normalised = x*scale + shift ; order Q, angleD, angle_cos, angle_sin, position, positionD
   float in_scale[6], in_shift[6], out_scale[5], out_shift[5];
@@ -91,6 +97,108 @@ __device__ __forceinline__ f16v gru_step(const float* __restrict__ lds, const f1
   gru_layer<4>(lds, GF_L1X, GF_L1H, GF_L1B, x, h1, lane);
   gru_layer<16>(lds, GF_L2X, GF_L2H, GF_L2B, h1, h2, lane);
   return gru_mm<16>(gru_bias(lds + GF_DB * 64, lane), lds + GF_DW * 64, h2, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined step for the fused rollout kernel.  A wave's MFMAs run in the matrix pipe while its VALU executes
+// independent instructions, but within one autoregressive step the gate non-linearities (VALU: exp, rcp) depend on all
+// products of their layer.  The products that do NOT depend on them are therefore issued interleaved with the gates:
+//   * layer-2 hidden products  W_hh2 h2(t-1)          during the layer-1 gates of step t,
+//   * layer-1 hidden products  W_hh1 h1(t) for step t+1  during the layer-2 gates of step t  (carried in GruCarry),
+// three MFMAs (one k-step of the r, z, n accumulators) per gate register, A fragments fetched one chunk ahead; a
+// scheduling barrier after every chunk keeps the compiler from clumping them again.  Summation order differs from
+// gru_step only in that the hidden products enter an accumulator before the input products.
+struct GruCarry {
+  f16v ar, az, anh;      // layer-1 pre-activations so far: bias + W_hh1 h1 for the coming step
+};
+
+// bias vector b (0..7) as an accumulator tile: acc[v] = bias[row(v, lane half)]
+__device__ __forceinline__ f16v gru_bias_v(const float* __restrict__ lds, int b, uint32_t lane) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* __restrict__ src = reinterpret_cast<const f4*>(lds + GV_BIAS + b * 32 + (lane >> 5) * 16);
+  f16v z;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4 t = src[q];
+    z[4 * q + 0] = t.x; z[4 * q + 1] = t.y; z[4 * q + 2] = t.z; z[4 * q + 3] = t.w;
+  }
+  return z;
+}
+
+// dense head on the VALU: every lane sums its 16 rows, the two halves are added across lanes; out[0..4] on ALL lanes
+__device__ __forceinline__ void gru_head_valu(const float* __restrict__ lds, const f16v& h2, uint32_t lane, float out[5]) {
+  const float* __restrict__ w = lds + GV_HEAD + (lane >> 5) * 80;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc = __builtin_fmaf(w[o * 16 + v], h2[v], acc);
+    out[o] = acc + __shfl_xor(acc, 32, 64) + lds[GV_HEADB + o];
+  }
+}
+
+__device__ __forceinline__ void gru_carry_init(const float* __restrict__ lds, const f16v& h1, uint32_t lane, GruCarry& c) {
+  c.ar = gru_mm<16>(gru_bias_v(lds, 0, lane), lds + (GF_L1H + 0) * 64, h1, lane);
+  c.az = gru_mm<16>(gru_bias_v(lds, 1, lane), lds + (GF_L1H + 16) * 64, h1, lane);
+  c.anh = gru_mm<16>(gru_bias_v(lds, 3, lane), lds + (GF_L1H + 32) * 64, h1, lane);
+}
+
+// gates of one layer (registers ar, az, anx, anh -> h in place) interleaved with the hidden products
+// pr/pz/pn += W[fh + {0,16,32} + s] * X[s] of ANOTHER layer / step.
+__device__ __forceinline__ void gru_gates_overlapped(const f16v& ar, const f16v& az, const f16v& anx, const f16v& anh,
+                                                     f16v& h, const float* __restrict__ lds, int fh, const f16v& X,
+                                                     f16v& pr, f16v& pz, f16v& pn, uint32_t lane) {
+  const float* __restrict__ f = lds + fh * 64 + lane;
+  float a0 = f[0], a1 = f[16 * 64], a2 = f[32 * 64];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+    if (v + 1 < 16) { n0 = f[(v + 1) * 64]; n1 = f[(16 + v + 1) * 64]; n2 = f[(32 + v + 1) * 64]; }
+    pr = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, X[v], pr, 0, 0, 0);
+    pz = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, X[v], pz, 0, 0, 0);
+    pn = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, X[v], pn, 0, 0, 0);
+    const float r = gru_sigmoid(ar[v]);
+    const float z = gru_sigmoid(az[v]);
+    const float n = gru_tanh(__builtin_fmaf(r, anh[v], anx[v]));
+    h[v] = __builtin_fmaf(z, h[v] - n, n);                    // (1-z)*n + z*h
+    a0 = n0; a1 = n1; a2 = n2;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void gru_step_pipelined(const float* __restrict__ lds, const f16v& x, f16v& h1, f16v& h2,
+                                                   GruCarry& c, uint32_t lane, float out[5]) {
+  // layer 1: input products on top of the carried hidden products
+  const f16v ar = gru_mm<4>(c.ar, lds + (GF_L1X + 0) * 64, x, lane);
+  const f16v az = gru_mm<4>(c.az, lds + (GF_L1X + 4) * 64, x, lane);
+  const f16v anx = gru_mm<4>(gru_bias_v(lds, 2, lane), lds + (GF_L1X + 8) * 64, x, lane);
+  f16v br = gru_bias_v(lds, 4, lane);
+  f16v bz = gru_bias_v(lds, 5, lane);
+  f16v bnx = gru_bias_v(lds, 6, lane);
+  f16v bnh = gru_bias_v(lds, 7, lane);
+  gru_gates_overlapped(ar, az, anx, c.anh, h1, lds, GF_L2H, h2, br, bz, bnh, lane);       // gates 1 || W_hh2 h2
+  // layer 2: input products with the new h1
+  br = gru_mm<16>(br, lds + (GF_L2X + 0) * 64, h1, lane);
+  bz = gru_mm<16>(bz, lds + (GF_L2X + 16) * 64, h1, lane);
+  bnx = gru_mm<16>(bnx, lds + (GF_L2X + 32) * 64, h1, lane);
+  c.ar = gru_bias_v(lds, 0, lane);
+  c.az = gru_bias_v(lds, 1, lane);
+  c.anh = gru_bias_v(lds, 3, lane);
+  gru_gates_overlapped(br, bz, bnx, bnh, h2, lds, GF_L1H, h1, c.ar, c.az, c.anh, lane);   // gates 2 || W_hh1 h1 (next step)
+  gru_head_valu(lds, h2, lane, out);
+}
+
+// Next state (without the angle) from head outputs held on every lane; cos(atan2(s, c)) = c / |(c, s)| spares the
+// per-step atan2f + cosf of the augmentation (the angle itself is needed only for the terminal cost).
+__device__ __forceinline__ void gru_output_state_fast(const GruNorm& nm, const float out[5], float st[6], float& cosang) {
+  st[1] = __builtin_fmaf(out[0], nm.out_scale[0], nm.out_shift[0]);
+  st[2] = __builtin_fmaf(out[1], nm.out_scale[1], nm.out_shift[1]);
+  st[3] = __builtin_fmaf(out[2], nm.out_scale[2], nm.out_shift[2]);
+  st[4] = __builtin_fmaf(out[3], nm.out_scale[3], nm.out_shift[3]);
+  st[5] = __builtin_fmaf(out[4], nm.out_scale[4], nm.out_shift[4]);
+  const float r2 = __builtin_fmaf(st[2], st[2], st[3] * st[3]);
+  cosang = r2 > 0.0f ? st[2] * __builtin_amdgcn_rsqf(r2) : 1.0f;
 }
 
 // Hidden state of one rollout/env: hsrc[32] -> tile registers of this lane.
