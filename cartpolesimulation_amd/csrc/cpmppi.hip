@@ -22,6 +22,7 @@
 #include "cpmppi.h"
 #include "cpmppi_device.hpp"
 #include "cpmppi_gru.hpp"
+#include "cpmppi_gru16.hpp"
 #include "cpmppi_grad.hpp"
 
 using namespace cpmppi;
@@ -32,6 +33,9 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_TK
 #define CPMPPI_TK 8
+#endif
+#ifndef CPMPPI_GRU_STAGGER
+#define CPMPPI_GRU_STAGGER 0
 #endif
 #ifndef CPMPPI_GRU_MIN_WAVES
 #define CPMPPI_GRU_MIN_WAVES 2      // waves per SIMD the GRU kernels are compiled for (register budget 512 / this)
@@ -547,14 +551,19 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_predict_kerne
 }
 
 // Fused MPPI step with the GRU predictor: same contract as rollout_cost_kernel (plugin costs), h0[E,2,32] or NULL.
-template <int COST, int NOISE>
+template <int COST, int NOISE, bool F16>
 __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_kernel(const Params p, const StepPtrs a, const GruNorm nm,
                                                                  const float* __restrict__ image,
                                                                  const float* __restrict__ h0) {
   extern __shared__ float lds[];                           // GRU image, then [WAVES][W] weighted sums
   __shared__ float red[2 * WAVES];
-  gru_load_image(lds, image);
-  float* bsum = lds + GRU_IMAGE_FLOATS;
+  constexpr int IMAGE_FLOATS = F16 ? G16_IMAGE_BYTES / 4 : GRU_IMAGE_FLOATS;
+  for (int i = threadIdx.x; i < IMAGE_FLOATS; i += BLOCK) lds[i] = image[i];
+  __syncthreads();
+#if CPMPPI_GRU_STAGGER
+  if ((blockIdx.x >> 8) & 1u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(CPMPPI_GRU_STAGGER); }
+#endif
+  float* bsum = lds + IMAGE_FLOATS;
   const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, c = lane & 31u;
   const uint32_t row0 = blk * GRU_ROLLOUTS_PER_BLOCK + wave * 32;
@@ -581,8 +590,20 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
   float cosang = cosf(s0[0]);               // the plugins take cos(angle) of the given state at stage 0
   f16v x;
   GruCarry carry;
-  gru_carry_init(lds, h1, lane, carry);
+  Gru16Carry carry16;
+  Gru16State gs;
+  const char* __restrict__ ldsb = reinterpret_cast<const char*>(lds);
+  if constexpr (F16) {
+    gs.h1 = h1; gs.h2 = h2;
+    gru16_carry_init(ldsb, gs, lane, carry16);
+  } else {
+    gru_carry_init(lds, h1, lane, carry);
+  }
   const bool half1 = lane >= 32;
+#ifdef CPMPPI_GRU_STAMPS
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (uint32_t k = 0; k < H; ++k) {
     float du;
     if constexpr (NOISE == NOISE_DELTA_U) du = a.noise[((size_t)env * p.N + nn) * H + k];
@@ -596,7 +617,22 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
     if (k == 0) x = gru_input_tile(nm, s0, ur, lane);
     else if (half1) x[1] = __builtin_fmaf(ur, nm.in_scale[0], nm.in_shift[0]);
     float out[5];
-    gru_step_pipelined(lds, x, h1, h2, carry, lane, out);
+    if constexpr (F16) {
+#ifdef CPMPPI_GRU_STAMPS
+      const f16v o = gru16_step(ldsb, x, gs, carry16, lane, stamp_acc, stamp_prev);
+#else
+      const f16v o = gru16_step(ldsb, x, gs, carry16, lane);
+#endif
+      out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3];
+      out[4] = __shfl(o[0], (int)(c + 32u), 64);           // positionD (row 4) lives on the partner lane-half
+      if (half1) out[4] = o[0];
+    } else {
+#ifdef CPMPPI_GRU_STAMPS
+      gru_step_pipelined(lds, x, h1, h2, carry, lane, out, stamp_acc, stamp_prev);
+#else
+      gru_step_pipelined(lds, x, h1, h2, carry, lane, out);
+#endif
+    }
     gru_output_state_fast(nm, out, st, cosang);
     // normalised outputs are fed back unchanged: rows 0..3 on lane-half 0, row 4 (and Q, row 5) on lane-half 1
     x[0] = half1 ? out[4] : out[0];
@@ -612,6 +648,11 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
     }
   }
   st[0] = atan2f(st[3], st[2]);             // predictors_customization.py:121-127, needed for the terminal cost only
+#ifdef CPMPPI_GRU_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_gru_stamp_sum[i], stamp_acc[i]);
+  if (lane == 0) atomicAdd(&g_gru_stamp_sum[6], 1ull);
+#endif
   const float term = (COST == COST_DEFAULT) ? terminal_indicator<float>(p, st[0], st[4], x_t) : 0.0f;
   float S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / (float)(H + 1);
   S_total += corr;
@@ -855,6 +896,7 @@ struct cpmppi_handle {
   uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
   float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
+  void* gru16_image = nullptr;         // device copy of the f16 split image (cpmppi_gru16.hpp)
   float* grad_ckpt = nullptr;          // [H][6][E*N] check-points of cpmppi_rollout_cost_grad (allocated on first use)
   size_t grad_ckpt_floats = 0;
   GruNorm gru_norm;
@@ -998,6 +1040,7 @@ void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
   if (h->workspace) (void)hipFree(h->workspace);
   if (h->gru_image) (void)hipFree(h->gru_image);
+  if (h->gru16_image) (void)hipFree(h->gru16_image);
   if (h->grad_ckpt) (void)hipFree(h->grad_ckpt);
   if (h->counters) (void)hipFree(h->counters);
   if (h->zeros_H) (void)hipFree(h->zeros_H);
@@ -1133,11 +1176,17 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     if (h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT)
       return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports quadratic_boundary_grad_minimal and default");
     p.nb = (h->cfg.N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;
-    const size_t lds = ((size_t)GRU_IMAGE_FLOATS + (size_t)WAVES * p.W) * sizeof(float);
+    // FAST: float32-equivalent split products on the f16 matrix cores (cpmppi_gru16.hpp); PRECISE: exact f32 MFMA chains
+    const bool f16 = h->cfg.math_mode == CPMPPI_MATH_FAST && h->gru16_image != nullptr;
+    const size_t lds = ((f16 ? (size_t)G16_IMAGE_BYTES / 4 : (size_t)GRU_IMAGE_FLOATS) + (size_t)WAVES * p.W) * sizeof(float);
     const dim3 grid(a->E * p.nb);
-#define CPMPPI_GRU_LAUNCH(COST, NOISE)                                                                       \
-    hipLaunchKernelGGL((gru_rollout_cost_kernel<COST, NOISE>), grid, dim3(BLOCK), lds, s, h->prm, p, h->gru_norm, \
-                       (const float*)h->gru_image, a->h0)
+#define CPMPPI_GRU_LAUNCH(COST, NOISE)                                                                                  \
+    do {                                                                                                                \
+      if (f16) hipLaunchKernelGGL((gru_rollout_cost_kernel<COST, NOISE, true>), grid, dim3(BLOCK), lds, s, h->prm, p,  \
+                                  h->gru_norm, (const float*)h->gru16_image, a->h0);                                    \
+      else hipLaunchKernelGGL((gru_rollout_cost_kernel<COST, NOISE, false>), grid, dim3(BLOCK), lds, s, h->prm, p,     \
+                              h->gru_norm, (const float*)h->gru_image, a->h0);                                          \
+    } while (0)
     const bool q = h->prm.cost_id == CPMPPI_COST_QBGM;
     if (a->noise_kind == CPMPPI_NOISE_DELTA_U) { if (q) CPMPPI_GRU_LAUNCH(COST_QBGM, NOISE_DELTA_U); else CPMPPI_GRU_LAUNCH(COST_DEFAULT, NOISE_DELTA_U); }
     else if (a->noise_kind == CPMPPI_NOISE_KNOTS) { if (q) CPMPPI_GRU_LAUNCH(COST_QBGM, NOISE_KNOTS); else CPMPPI_GRU_LAUNCH(COST_DEFAULT, NOISE_KNOTS); }
@@ -1250,9 +1299,49 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
     h->gru_norm.out_scale[i] = m->out_scale ? m->out_scale[i] : 1.0f;
     h->gru_norm.out_shift[i] = m->out_shift ? m->out_shift[i] : 0.0f;
   }
+  // ---- f16 split image (cpmppi_gru16.hpp): fragment f holds, for lane l and t = 0..7, the weight of output row l%32
+  // against k-slot (block b, lane half l/32, t) = tile register v = 8b + t of that half
+  std::vector<unsigned char> img16((size_t)G16_IMAGE_BYTES, 0);
+  bool in_range = true;
+  auto put16 = [&](int f, int lane, int t, float w) {
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
+    if (!(fabsf(w) < 60000.0f)) in_range = false;
+    reinterpret_cast<_Float16*>(img16.data() + (size_t)f * G16_FRAG_BYTES + lane * 16)[t] = hi;
+    reinterpret_cast<_Float16*>(img16.data() + (size_t)(f + 1) * G16_FRAG_BYTES + lane * 16)[t] = lo;
+  };
+  for (int g = 0; g < 3; ++g)
+    for (int l = 0; l < 64; ++l)
+      for (int tt = 0; tt < 8; ++tt) {
+        const size_t row = (size_t)(g * 32 + (l & 31));
+        const int col = xcol(gru_tile_row(tt, l >> 5));                       // x tile registers 0..7
+        put16(HF_L1X + g * 2, l, tt, (col < 0 || tt >= 4) ? 0.0f : m->w_ih[0][row * 6 + col]);
+        for (int b = 0; b < 2; ++b) {
+          const int k = gru_tile_row(8 * b + tt, l >> 5);
+          put16(HF_L1H + (g * 2 + b) * 2, l, tt, m->w_hh[0][row * 32 + k]);
+          put16(HF_L2X + (g * 2 + b) * 2, l, tt, m->w_ih[1][row * 32 + k]);
+          put16(HF_L2H + (g * 2 + b) * 2, l, tt, m->w_hh[1][row * 32 + k]);
+        }
+      }
+  for (int b = 0; b < 2; ++b)
+    for (int l = 0; l < 64; ++l)
+      for (int tt = 0; tt < 8; ++tt)
+        put16(HF_HEAD + b * 2, l, tt, (l & 31) < 5 ? m->w_out[(size_t)(l & 31) * 32 + gru_tile_row(8 * b + tt, l >> 5)] : 0.0f);
+  if (!in_range) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_gru: weights beyond the f16 range");
+  {
+    float* bv = reinterpret_cast<float*>(img16.data() + G16_BIAS_OFF);
+    for (int i = 0; i < 8 * 32; ++i) bv[i] = img[GV_BIAS + i];               // the same 8 gate-bias tiles
+    for (int hf = 0; hf < 2; ++hf)
+      for (int v = 0; v < 16; ++v) {
+        const int r = gru_tile_row(v, hf);
+        bv[8 * 32 + hf * 16 + v] = r < 5 ? m->b_out[r] : 0.0f;
+      }
+  }
   if (int rc = ensure_device(h)) return rc;
   if (!h->gru_image) CPMPPI_HIP(h, hipMalloc(&h->gru_image, img.size() * sizeof(float)));
   CPMPPI_HIP(h, hipMemcpy(h->gru_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!h->gru16_image) CPMPPI_HIP(h, hipMalloc(&h->gru16_image, img16.size()));
+  CPMPPI_HIP(h, hipMemcpy(h->gru16_image, img16.data(), img16.size(), hipMemcpyHostToDevice));
   return CPMPPI_OK;
 }
 
@@ -1299,6 +1388,17 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   CPMPPI_HIP(h, e);
   return CPMPPI_OK;
 }
+
+#ifdef CPMPPI_GRU_STAMPS
+extern "C" int cpmppi_debug_gru_stamps(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gru_stamp_sum), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gru_stamp_sum), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, const float* inputs,
                              const float* target_position, const float* target_equilibrium, const float* L,

@@ -109,6 +109,21 @@ __device__ __forceinline__ f16v gru_step(const float* __restrict__ lds, const f1
 // three MFMAs (one k-step of the r, z, n accumulators) per gate register, A fragments fetched one chunk ahead; a
 // scheduling barrier after every chunk keeps the compiler from clumping them again.  Summation order differs from
 // gru_step only in that the hidden products enter an accumulator before the input products.
+// development aid (-DCPMPPI_GRU_STAMPS): s_memtime at the phase boundaries of a step, summed per wave
+#ifdef CPMPPI_GRU_STAMPS
+__device__ unsigned long long g_gru_stamp_sum[8];
+#define GRU_STAMP(i)                                                                   \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+    stamp_acc[i] += now_ - stamp_prev;                                                 \
+    stamp_prev = now_;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define GRU_STAMP(i) do {} while (0)
+#endif
+
 struct GruCarry {
   f16v ar, az, anh;      // layer-1 pre-activations so far: bias + W_hh1 h1 for the coming step
 };
@@ -155,20 +170,33 @@ __device__ __forceinline__ void gru_gates_overlapped(const f16v& ar, const f16v&
   for (int v = 0; v < 16; ++v) {
     float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
     if (v + 1 < 16) { n0 = f[(v + 1) * 64]; n1 = f[(16 + v + 1) * 64]; n2 = f[(32 + v + 1) * 64]; }
+#ifndef GRU_EXP_NOMFMA
     pr = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, X[v], pr, 0, 0, 0);
     pz = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, X[v], pz, 0, 0, 0);
     pn = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, X[v], pn, 0, 0, 0);
+#else
+    pr[v] += a0; pz[v] += a1; pn[v] += a2;
+#endif
+#ifndef GRU_EXP_NOGATES
     const float r = gru_sigmoid(ar[v]);
     const float z = gru_sigmoid(az[v]);
     const float n = gru_tanh(__builtin_fmaf(r, anh[v], anx[v]));
     h[v] = __builtin_fmaf(z, h[v] - n, n);                    // (1-z)*n + z*h
+#else
+    h[v] = __builtin_fmaf(ar[v], az[v], anx[v] + anh[v]) * 1e-3f;
+#endif
     a0 = n0; a1 = n1; a2 = n2;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 __device__ __forceinline__ void gru_step_pipelined(const float* __restrict__ lds, const f16v& x, f16v& h1, f16v& h2,
-                                                   GruCarry& c, uint32_t lane, float out[5]) {
+                                                   GruCarry& c, uint32_t lane, float out[5]
+#ifdef CPMPPI_GRU_STAMPS
+                                                   , unsigned long long* stamp_acc, unsigned long long& stamp_prev
+#endif
+                                                   ) {
+  GRU_STAMP(0);
   // layer 1: input products on top of the carried hidden products
   const f16v ar = gru_mm<4>(c.ar, lds + (GF_L1X + 0) * 64, x, lane);
   const f16v az = gru_mm<4>(c.az, lds + (GF_L1X + 4) * 64, x, lane);
@@ -177,7 +205,9 @@ __device__ __forceinline__ void gru_step_pipelined(const float* __restrict__ lds
   f16v bz = gru_bias_v(lds, 5, lane);
   f16v bnx = gru_bias_v(lds, 6, lane);
   f16v bnh = gru_bias_v(lds, 7, lane);
+  GRU_STAMP(1);
   gru_gates_overlapped(ar, az, anx, c.anh, h1, lds, GF_L2H, h2, br, bz, bnh, lane);       // gates 1 || W_hh2 h2
+  GRU_STAMP(2);
   // layer 2: input products with the new h1
   br = gru_mm<16>(br, lds + (GF_L2X + 0) * 64, h1, lane);
   bz = gru_mm<16>(bz, lds + (GF_L2X + 16) * 64, h1, lane);
@@ -185,8 +215,11 @@ __device__ __forceinline__ void gru_step_pipelined(const float* __restrict__ lds
   c.ar = gru_bias_v(lds, 0, lane);
   c.az = gru_bias_v(lds, 1, lane);
   c.anh = gru_bias_v(lds, 3, lane);
+  GRU_STAMP(3);
   gru_gates_overlapped(br, bz, bnx, bnh, h2, lds, GF_L1H, h1, c.ar, c.az, c.anh, lane);   // gates 2 || W_hh1 h1 (next step)
+  GRU_STAMP(4);
   gru_head_valu(lds, h2, lane, out);
+  GRU_STAMP(5);
 }
 
 // Next state (without the angle) from head outputs held on every lane; cos(atan2(s, c)) = c / |(c, s)| spares the

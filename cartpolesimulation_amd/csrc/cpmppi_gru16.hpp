@@ -1,0 +1,177 @@
+// cpmppi_gru16.hpp — the GRU predictor of the FAST arithmetic: float32-equivalent products on the f16 matrix cores.
+//
+// Why.  Measured on MI355X (tools/gru_stamps.py, SQ_VALU_MFMA_COEXEC_CYCLES = 0): v_mfma_f32_32x32x2_f32 does not
+// co-execute with vector instructions — its time and the gate math's time simply add (9 984 + ~3 800 cycles per
+// 32-rollout tile step), so the exact-f32 kernel of cpmppi_gru.hpp sits at its floor.  The f16 matrix cores run
+// 16 x more multiply-adds per cycle AND overlap with the VALU.  Every float32 operand is therefore split into two
+// halves, x = hi + lo with hi = f16(x), lo = f16(x - hi)  (x - hi is exact in float32), and a product W X becomes
+//      Whi Xhi + Whi Xlo + Wlo Xhi                                   (three v_mfma_f32_32x32x16_f16, f32 accumulate)
+// — the dropped Wlo Xlo term is 2^-22 relative, and lo parts that fall into f16's subnormal range are rounded with an
+// absolute error <= 3e-8, i.e. at the level of float32 rounding of the O(1) pre-activations.  Per 16 hidden units:
+// 3 x 32 cycles instead of 8 x 64.  PRECISE math keeps the exact-f32 kernel.
+//
+// Mapping (same idea as cpmppi_gru.hpp).  Rollouts are the tile's columns (col = lane & 31), hidden units its rows,
+// which live in the 16 accumulator registers: row = (v&3) + 8(v>>2) + 4(lane>>5).  The f16 MFMA takes 8 consecutive
+// k-values per lane (k = 8(lane>>5) + t); the weights are stored with the k order permuted so that k-slot
+// (block b, lane half, t) IS accumulator register v = 8b + t of that lane half: a result tile becomes the next
+// product's B operand by conversion alone — registers 0..7 feed block 0, registers 8..15 block 1, no data movement.
+// (operand layout checked on the device by tools/dev/mfma16_layout.hip)
+#pragma once
+#include "cpmppi_gru.hpp"
+
+namespace cpmppi {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// LDS image, in 16-byte units per lane: fragment f = 64 lanes x 8 f16 = 1 KiB.  A (gate, block) pair owns two
+// consecutive fragments: hi, lo.
+enum : int {
+  HF_L1X = 0,                   // 3 gates x 1 block  (x tile registers 0..7: 5 state features, Q, zeros)
+  HF_L1H = HF_L1X + 3 * 1 * 2,  // 3 x 2
+  HF_L2X = HF_L1H + 3 * 2 * 2,
+  HF_L2H = HF_L2X + 3 * 2 * 2,
+  HF_HEAD = HF_L2H + 3 * 2 * 2, // 1 x 2  (rows 0..4 real)
+  HF_COUNT = HF_HEAD + 1 * 2 * 2
+};
+constexpr int G16_FRAG_BYTES = 64 * 16;
+constexpr int G16_BIAS_OFF = HF_COUNT * G16_FRAG_BYTES;        // 9 vectors x [2][16] floats: 8 gate biases + head
+constexpr int G16_IMAGE_BYTES = G16_BIAS_OFF + 9 * 32 * 4;
+
+struct HSplit { h8 hi, lo; };      // one k-block of a tile as B operand
+
+// registers [8b, 8b+8) of a float32 tile -> (hi, lo)
+__device__ __forceinline__ HSplit gru16_split(const f16v& t, int b) {
+  HSplit s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = t[8 * b + i];
+    const _Float16 hi = (_Float16)x;
+    s.hi[i] = hi;
+    s.lo[i] = (_Float16)(x - (float)hi);
+  }
+  return s;
+}
+
+__device__ __forceinline__ const h8* gru16_frag(const char* __restrict__ lds, int f, uint32_t lane) {
+  return reinterpret_cast<const h8*>(lds + (size_t)f * G16_FRAG_BYTES + lane * 16);
+}
+
+// acc += W X for one (gate, block): fragments f (hi), f+1 (lo)
+__device__ __forceinline__ f16v gru16_mm(f16v acc, const char* __restrict__ lds, int f, const HSplit& X, uint32_t lane) {
+  const h8 whi = *gru16_frag(lds, f, lane), wlo = *gru16_frag(lds, f + 1, lane);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, X.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, X.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, X.hi, acc, 0, 0, 0);
+  return acc;
+}
+
+// bias vector b (0..8) as an accumulator tile
+__device__ __forceinline__ f16v gru16_bias(const char* __restrict__ lds, int b, uint32_t lane) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* __restrict__ src = reinterpret_cast<const f4*>(lds + G16_BIAS_OFF + (b * 32 + (lane >> 5) * 16) * 4);
+  f16v z;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4 t = src[q];
+    z[4 * q + 0] = t.x; z[4 * q + 1] = t.y; z[4 * q + 2] = t.z; z[4 * q + 3] = t.w;
+  }
+  return z;
+}
+
+struct Gru16Carry {
+  f16v ar, az, anh;        // layer-1 pre-activations so far: bias + W_hh1 h1 for the coming step
+};
+
+struct Gru16State {
+  f16v h1, h2;             // float32 hidden tiles
+  HSplit h1s[2], h2s[2];   // their two k-blocks as B operands
+};
+
+__device__ __forceinline__ void gru16_resplit(const f16v& h, HSplit s[2]) {
+  s[0] = gru16_split(h, 0);
+  s[1] = gru16_split(h, 1);
+}
+
+// hidden products of layer `fh` (HF_L1H / HF_L2H) into (r, z, n_h)
+__device__ __forceinline__ void gru16_hidden_products(const char* __restrict__ lds, int fh, const HSplit hs[2], f16v& pr,
+                                                      f16v& pz, f16v& pn, uint32_t lane) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    pr = gru16_mm(pr, lds, fh + (0 * 2 + b) * 2, hs[b], lane);
+    pz = gru16_mm(pz, lds, fh + (1 * 2 + b) * 2, hs[b], lane);
+    pn = gru16_mm(pn, lds, fh + (2 * 2 + b) * 2, hs[b], lane);
+  }
+}
+
+__device__ __forceinline__ void gru16_gates(const f16v& ar, const f16v& az, const f16v& anx, const f16v& anh, f16v& h) {
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const float r = gru_sigmoid(ar[v]);
+    const float z = gru_sigmoid(az[v]);
+    const float n = gru_tanh(__builtin_fmaf(r, anh[v], anx[v]));
+    h[v] = __builtin_fmaf(z, h[v] - n, n);                    // (1-z)*n + z*h
+  }
+}
+
+__device__ __forceinline__ void gru16_carry_init(const char* __restrict__ lds, Gru16State& s, uint32_t lane, Gru16Carry& c) {
+  gru16_resplit(s.h1, s.h1s);
+  gru16_resplit(s.h2, s.h2s);
+  c.ar = gru16_bias(lds, 0, lane); c.az = gru16_bias(lds, 1, lane); c.anh = gru16_bias(lds, 3, lane);
+  gru16_hidden_products(lds, HF_L1H, s.h1s, c.ar, c.az, c.anh, lane);
+}
+
+// One autoregressive step.  x: feature tile (registers 0..7 meaningful).  Returns the head tile (rows 0..3 in registers
+// 0..3 of lane-half 0, row 4 in register 0 of lane-half 1).  The products that do not depend on a layer's gates are
+// issued just before them (layer-2 hidden products before the layer-1 gates, the NEXT step's layer-1 hidden products
+// before the layer-2 gates) so that the matrix pipe works while the VALU evaluates exp / rcp.
+__device__ __forceinline__ f16v gru16_step(const char* __restrict__ lds, const f16v& x, Gru16State& s, Gru16Carry& c,
+                                           uint32_t lane
+#ifdef CPMPPI_GRU_STAMPS
+                                           , unsigned long long* stamp_acc, unsigned long long& stamp_prev
+#endif
+                                           ) {
+  __builtin_amdgcn_sched_barrier(0);
+  GRU_STAMP(0);
+  const HSplit xs = gru16_split(x, 0);
+  // (scheduling barriers between the phases: without them the compiler hoists every fragment load of the step to
+  // its top and spills)
+  // layer 1: input products on top of the carried hidden products
+  const f16v ar = gru16_mm(c.ar, lds, HF_L1X + 0, xs, lane);
+  const f16v az = gru16_mm(c.az, lds, HF_L1X + 2, xs, lane);
+  const f16v anx = gru16_mm(gru16_bias(lds, 2, lane), lds, HF_L1X + 4, xs, lane);
+  const f16v anh = c.anh;
+  __builtin_amdgcn_sched_barrier(0);
+  GRU_STAMP(1);
+  f16v br = gru16_bias(lds, 4, lane), bz = gru16_bias(lds, 5, lane), bnh = gru16_bias(lds, 7, lane);
+  gru16_hidden_products(lds, HF_L2H, s.h2s, br, bz, bnh, lane);        // W_hh2 h2(t-1): independent of the gates below
+  __builtin_amdgcn_sched_barrier(0);
+  gru16_gates(ar, az, anx, anh, s.h1);
+  gru16_resplit(s.h1, s.h1s);
+  __builtin_amdgcn_sched_barrier(0);
+  GRU_STAMP(2);
+  // layer 2: input products with the new h1
+  f16v bnx = gru16_bias(lds, 6, lane);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    br = gru16_mm(br, lds, HF_L2X + (0 * 2 + b) * 2, s.h1s[b], lane);
+    bz = gru16_mm(bz, lds, HF_L2X + (1 * 2 + b) * 2, s.h1s[b], lane);
+    bnx = gru16_mm(bnx, lds, HF_L2X + (2 * 2 + b) * 2, s.h1s[b], lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  GRU_STAMP(3);
+  c.ar = gru16_bias(lds, 0, lane); c.az = gru16_bias(lds, 1, lane); c.anh = gru16_bias(lds, 3, lane);
+  gru16_hidden_products(lds, HF_L1H, s.h1s, c.ar, c.az, c.anh, lane);  // W_hh1 h1(t) for step t+1
+  __builtin_amdgcn_sched_barrier(0);
+  gru16_gates(br, bz, bnx, bnh, s.h2);
+  gru16_resplit(s.h2, s.h2s);
+  __builtin_amdgcn_sched_barrier(0);
+  GRU_STAMP(4);
+  f16v out = gru16_bias(lds, 8, lane);
+  out = gru16_mm(out, lds, HF_HEAD + 0, s.h2s[0], lane);
+  out = gru16_mm(out, lds, HF_HEAD + 2, s.h2s[1], lane);
+  __builtin_amdgcn_sched_barrier(0);
+  GRU_STAMP(5);
+  return out;
+}
+
+}  // namespace cpmppi
