@@ -607,12 +607,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
   for (uint32_t k = 0; k < H; ++k) {
     float du;
     if constexpr (NOISE == NOISE_DELTA_U) du = a.noise[((size_t)env * p.N + nn) * H + k];
+    else if constexpr (F16 && NOISE == NOISE_PHILOX)      // FAST + own noise: one float32 FMA, as the ODE kernel and the sampler
+      du = interp_from_slope32(knot_slope32(z_lo, z_hi, 1.0f / (float)p.period), z_lo, ii);
     else du = interp_knots(z_lo, z_hi, ii, p.period);
     const float uk = shifted_nominal(p, un, k);
     float ur = uk + du;
     if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
-    if constexpr (COST == COST_QBGM) cost += stage_qbgm<float>(p, st[4], cosang, st[1], ur, x_t, te);
-    else cost += stage_default<float>(p, st[4], cosang, ur, x_t, te);
+    if constexpr (COST == COST_QBGM) cost += stage_qbgm<float, F16>(p, st[4], cosang, st[1], ur, x_t, te);
+    else cost += stage_default<float, F16>(p, st[4], cosang, ur, x_t, te);
     corr += mppi_correction<float>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : uk, du);
     if (k == 0) x = gru_input_tile(nm, s0, ur, lane);
     else if (half1) x[1] = __builtin_fmaf(ur, nm.in_scale[0], nm.in_shift[0]);
@@ -1310,17 +1312,21 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
     reinterpret_cast<_Float16*>(img16.data() + (size_t)f * G16_FRAG_BYTES + lane * 16)[t] = hi;
     reinterpret_cast<_Float16*>(img16.data() + (size_t)(f + 1) * G16_FRAG_BYTES + lane * 16)[t] = lo;
   };
+  // gate rows pre-scaled so that the gates need no multiply before v_exp_f32 (gru16_gates): r, z by -log2(e), n by 2 log2(e)
+  const double LOG2E = 1.4426950408889634;
+  const double gate_scale[3] = {-LOG2E, -LOG2E, 2.0 * LOG2E};
+  auto sc = [&](int g, float w) { return (float)(gate_scale[g] * (double)w); };
   for (int g = 0; g < 3; ++g)
     for (int l = 0; l < 64; ++l)
       for (int tt = 0; tt < 8; ++tt) {
         const size_t row = (size_t)(g * 32 + (l & 31));
         const int col = xcol(gru_tile_row(tt, l >> 5));                       // x tile registers 0..7
-        put16(HF_L1X + g * 2, l, tt, (col < 0 || tt >= 4) ? 0.0f : m->w_ih[0][row * 6 + col]);
+        put16(HF_L1X + g * 2, l, tt, (col < 0 || tt >= 4) ? 0.0f : sc(g, m->w_ih[0][row * 6 + col]));
         for (int b = 0; b < 2; ++b) {
           const int k = gru_tile_row(8 * b + tt, l >> 5);
-          put16(HF_L1H + (g * 2 + b) * 2, l, tt, m->w_hh[0][row * 32 + k]);
-          put16(HF_L2X + (g * 2 + b) * 2, l, tt, m->w_ih[1][row * 32 + k]);
-          put16(HF_L2H + (g * 2 + b) * 2, l, tt, m->w_hh[1][row * 32 + k]);
+          put16(HF_L1H + (g * 2 + b) * 2, l, tt, sc(g, m->w_hh[0][row * 32 + k]));
+          put16(HF_L2X + (g * 2 + b) * 2, l, tt, sc(g, m->w_ih[1][row * 32 + k]));
+          put16(HF_L2H + (g * 2 + b) * 2, l, tt, sc(g, m->w_hh[1][row * 32 + k]));
         }
       }
   for (int b = 0; b < 2; ++b)
@@ -1330,7 +1336,10 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
   if (!in_range) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_gru: weights beyond the f16 range");
   {
     float* bv = reinterpret_cast<float*>(img16.data() + G16_BIAS_OFF);
-    for (int i = 0; i < 8 * 32; ++i) bv[i] = img[GV_BIAS + i];               // the same 8 gate-bias tiles
+    for (int i = 0; i < 8 * 32; ++i) {                                        // the same 8 gate-bias tiles, scaled alike
+      const int kind = (i / 32) % 4;                                          // r, z, n_x, n_h
+      bv[i] = (float)(gate_scale[kind < 2 ? kind : 2] * (double)img[GV_BIAS + i]);
+    }
     for (int hf = 0; hf < 2; ++hf)
       for (int v = 0; v < 16; ++v) {
         const int r = gru_tile_row(v, hf);

@@ -103,12 +103,16 @@ __device__ __forceinline__ void gru16_hidden_products(const char* __restrict__ l
   }
 }
 
+// Gates on pre-activations that the image builder has pre-scaled: the r and z rows of every weight matrix and bias by
+// -log2(e), the n rows by 2 log2(e), so sigmoid(a) = 1 / (1 + 2^a') and tanh(y) = 1 - 2 / (2^y' + 1) need no multiply
+// in front of v_exp_f32.
 __device__ __forceinline__ void gru16_gates(const f16v& ar, const f16v& az, const f16v& anx, const f16v& anh, f16v& h) {
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
-    const float r = gru_sigmoid(ar[v]);
-    const float z = gru_sigmoid(az[v]);
-    const float n = gru_tanh(__builtin_fmaf(r, anh[v], anx[v]));
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ar[v]));
+    const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(az[v]));
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(r, anh[v], anx[v]));
+    const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
     h[v] = __builtin_fmaf(z, h[v] - n, n);                    // (1-z)*n + z*h
   }
 }
