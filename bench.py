@@ -77,9 +77,15 @@ def cpu_baseline(N, H, budget_s=12.0):
     reps = int(max(1, min(64, budget_s / max(t1, 1e-3))))
     E = threads * reps
     t = run(E)
-    return {"value": E * N / t, "unit": "rollouts/s", "cores": threads, "kind": "port",
+    all_threads = threads
+    threads = 1                            # the reference's own situation: one process, one core
+    k1 = int(max(2, min(64, 2 * 1.5 / max(run(2), 1e-3))))      # ~1.5 s of one core
+    ts = run(k1)
+    return {"value": E * N / t, "unit": "rollouts/s", "cores": all_threads, "kind": "port",
             "sample": f"{E} envs x {N} rollouts x {H} steps x 10 substeps in {t:.2f} s; oracle/cpmppi_oracle.c "
-                      f"(gcc -O2, no fast-math, OpenMP over envs x rollouts)"}
+                      f"(gcc -O2, no fast-math, OpenMP over envs x rollouts)",
+            "single_thread": {"value": k1 * N / ts, "unit": "rollouts/s", "cores": 1,
+                              "sample": f"{k1} envs x {N} rollouts x {H} steps in {ts:.2f} s"}}
 
 
 def main():
