@@ -260,7 +260,12 @@ def main():
             "roofline_valu": {"bound": "fp32-valu", "achieved": flops_launch / (k_ms * 1e-3) / 1e12,
                               "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": flops_launch / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                              "algorithmic_flops_per_rollout": algorithmic_flops_per_rollout(H)},
+                              "algorithmic_flops_per_rollout": algorithmic_flops_per_rollout(H),
+                              # the same peak with every substep's sincos costed at ~30 flop-equivalents
+                              # (the algebraic count above leaves the 2 transcendental evaluations + fmod per substep out)
+                              "survey_ceiling_rollouts_per_s": FP32_VALU_PEAK_TFLOPS * 1e12 /
+                              (algorithmic_flops_per_rollout(H) + 2.0 * 10 * H * 30.0),
+                              "kernel_rollouts_per_s": E * N / (k_ms * 1e-3)},
         }
         if not args.no_single_env:
             # latency of ONE problem instance (BASELINE configs[1] literally: single env), same kernels
