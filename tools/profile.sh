@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r1}
-OUT=$R/gpurun_out/prof_$TAG
+OUT=$R/gpurun_out/prof_$TAG/run_$(date +%Y%m%d_%H%M%S)     # one sub-directory per run: gpurun merges, it never deletes
 mkdir -p $OUT
 for NOISE in philox buffer; do
   B="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single-env --noise $NOISE"

@@ -11,6 +11,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+runs = sorted(d for d in glob.glob(os.path.join(src, "run_*")) if os.path.isdir(d))
+if runs:                      # tools/profile.sh writes one sub-directory per run; take the latest
+    src = runs[-1]
+print("summarising", src)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
