@@ -18,7 +18,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_set_profiling", "cpmppi_get_profile",
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
-           "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_version")
+           "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version")
 
 
 class cpmppi_config(C.Structure):
@@ -97,6 +97,7 @@ def load():
     lib.cpmppi_rollout_cost.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp]
     lib.cpmppi_rollout_cost_grad.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpmppi_adam_step.argtypes = [vp, u32, vp, vp, vp, vp, u32, f, f, f, f, f, vp]
+    lib.cpmppi_sgd_step.argtypes = [vp, u32, vp, vp, f, f, vp]
     lib.cpmppi_cem_sample.argtypes = [vp, u32, vp, vp, u64, u64, u32, vp, vp]
     lib.cpmppi_cem_update.argtypes = [vp, u32, vp, vp, u32, f, vp, vp, vp, vp]
     lib.cpmppi_version.restype = C.c_char_p

@@ -11,7 +11,7 @@ import numpy as np
 
 from .configs import MPPIConfig, PhysicalParameters
 from .cost_functions import CostFunctionWrapper
-from .optimizer_cem import optimizer_cem
+from .optimizer_cem import optimizer_cem, optimizer_cem_grad_bharadhwaj, optimizer_cem_naive_grad, optimizer_random_action
 from .optimizer_gradient import optimizer_gradient, optimizer_rpgd
 from .optimizer_mppi import optimizer_mppi
 from .predictors import PredictorWrapper
@@ -71,13 +71,16 @@ class controller_mpc(template_controller):
                   controller_logging=False, **kwargs):
         optimizer_name = optimizer_name or "mppi"
         others = {"cem": optimizer_cem, "cem-tf": optimizer_cem, "gradient": optimizer_gradient,
-                  "gradient-tf": optimizer_gradient, "rpgd": optimizer_rpgd, "rpgd-tf": optimizer_rpgd}
+                  "gradient-tf": optimizer_gradient, "rpgd": optimizer_rpgd, "rpgd-tf": optimizer_rpgd,
+                  "cem-naive-grad": optimizer_cem_naive_grad, "cem-naive-grad-tf": optimizer_cem_naive_grad,
+                  "cem-grad-bharadhwaj": optimizer_cem_grad_bharadhwaj, "cem-grad-bharadhwaj-tf": optimizer_cem_grad_bharadhwaj,
+                  "random-action": optimizer_random_action, "random-action-tf": optimizer_random_action}
         if optimizer_name in others:
             return self._configure_other(others[optimizer_name], predictor_specification, cost_function_specification,
                                          controller_logging, **kwargs)
         if optimizer_name != "mppi":
-            raise NotImplementedError(f"optimizer {optimizer_name!r}: built are 'mppi' (the hot path), 'cem', 'gradient' "
-                                      "and 'rpgd'")
+            raise NotImplementedError(f"optimizer {optimizer_name!r}: built are 'mppi' (the hot path) and "
+                                      f"{sorted(k for k in others if not k.endswith('-tf'))}")
         cfg = dict(self.config_optimizer)
         cfg.update(kwargs)
         cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \

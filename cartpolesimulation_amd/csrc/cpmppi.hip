@@ -884,6 +884,20 @@ __global__ __launch_bounds__(BLOCK) void adam_step_kernel(size_t rows, uint32_t 
   }
 }
 
+// Plain gradient step with the same per-rollout norm clipping and limit clip (cem-naive-grad-tf, config_optimizers.yml:21-31).
+__global__ __launch_bounds__(BLOCK) void sgd_step_kernel(size_t rows, uint32_t H, float* __restrict__ Q,
+                                                         const float* __restrict__ grad, float lr, float gradmax_clip,
+                                                         float lo, float hi) {
+  const size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= rows) return;
+  const float* __restrict__ gr = grad + r * H;
+  float ss = 0.0f;
+  for (uint32_t k = 0; k < H; ++k) ss = __builtin_fmaf(gr[k], gr[k], ss);
+  const float nrm = sqrtf(ss);
+  const float sc = (gradmax_clip > 0.0f && nrm > gradmax_clip) ? gradmax_clip / nrm : 1.0f;
+  for (uint32_t k = 0; k < H; ++k) Q[r * H + k] = clamp_(Q[r * H + k] - lr * (gr[k] * sc), lo, hi);
+}
+
 }  // namespace
 
 struct cpmppi_handle {
@@ -1454,6 +1468,18 @@ int cpmppi_adam_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, 
                       (1.0 - pow((double)beta1, (double)iteration));
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      rows, h->cfg.H, Q, grad, m, v, (float)lr_t, beta1, beta2, epsilon, gradmax_clip, h->prm.lo, h->prm.hi);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_sgd_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, float learning_rate, float gradmax_clip,
+                    void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !Q || !grad) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sgd_step: bad argument");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t rows = (size_t)E * h->cfg.N;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     rows, h->cfg.H, Q, grad, learning_rate, gradmax_clip, h->prm.lo, h->prm.hi);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }

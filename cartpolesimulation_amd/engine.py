@@ -244,6 +244,15 @@ class MPPIEngine:
                                               float(gradmax_clip), self._stream()))
         return Q
 
+    def sgd_step(self, Q, grad, learning_rate, gradmax_clip=0.0):
+        """Q <- clip(Q - lr * clip_by_norm(grad)) in place."""
+        for x in (Q, grad):
+            if not (isinstance(x, torch.Tensor) and x.is_contiguous() and x.dtype == torch.float32 and x.shape == Q.shape):
+                raise ValueError("Q, grad must be contiguous float32 device tensors of one shape [E,N,H]")
+        self._check(self.lib.cpmppi_sgd_step(self._h, Q.shape[0], _ptr(Q), _ptr(grad), float(learning_rate),
+                                             float(gradmax_clip), self._stream()))
+        return Q
+
     def cem_sample(self, mean, stdev, seed, offset=0, env_offset=0):
         mean, stdev = self.tensor(mean), self.tensor(stdev)
         E = mean.shape[0]

@@ -64,6 +64,10 @@ class optimizer_cem:
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         self.optimizer_reset()
 
+    def _refine(self, Q, s_t, tp, te, L):
+        """Hook of the CEM + gradient hybrids: improve the samples before they are ranked."""
+        return Q
+
     def optimizer_reset(self):
         E, H = self.num_envs, self.mpc_horizon
         self.dist_mue = self.engine.zeros(E, H) + 0.5 * (self.action_low + self.action_high)
@@ -89,6 +93,7 @@ class optimizer_cem:
         self._first = False
         for _ in range(iters):
             Q = eng.cem_sample(self.dist_mue, self.stdev, self.seed, offset=self.step_counter)
+            Q = self._refine(Q, s_t, tp, te, L)
             S = eng.rollout_cost(s_t, Q, tp, te, L=L)
             self.dist_mue, self.stdev = eng.cem_update(S, Q, self.cem_best_k, self.cem_stdev_min)
             self.step_counter += 1
@@ -103,3 +108,95 @@ class optimizer_cem:
             return u
         q = u.cpu().numpy()
         return q[:1].copy() if single else q.reshape(E, 1).copy()
+
+
+class optimizer_cem_naive_grad(optimizer_cem):
+    """``cem-naive-grad-tf`` (config_optimizers.yml:21-31): CEM whose samples take ONE plain gradient step
+    ``Q <- clip(Q - learning_rate * clip_by_norm(dJ/dQ, gradmax_clip))`` (cpmppi_rollout_cost_grad + cpmppi_sgd_step)
+    before the elites are chosen.  [recalled semantics, class absent from the tree]"""
+    optimizer_name = "cem-naive-grad"
+
+    def __init__(self, *args, learning_rate=0.1, gradmax_clip=10, cem_outer_it=1, cem_stdev_min=0.1, **kwargs):
+        super().__init__(*args, cem_outer_it=cem_outer_it, cem_stdev_min=cem_stdev_min, **kwargs)
+        self.learning_rate, self.gradmax_clip = float(learning_rate), float(gradmax_clip)
+
+    def _refine(self, Q, s_t, tp, te, L):
+        _, G = self.engine.rollout_cost_grad(s_t, Q, tp, te, L=L)
+        return self.engine.sgd_step(Q, G, self.learning_rate, self.gradmax_clip)
+
+
+class optimizer_cem_grad_bharadhwaj(optimizer_cem):
+    """``cem-grad-bharadhwaj-tf`` (config_optimizers.yml:32-48; Bharadhwaj et al. 2020, "Model-predictive control via
+    cross-entropy and gradient-based optimization"): every CEM sample takes an Adam step on dJ/dQ before the elites
+    are chosen; the Adam moments belong to the sample slots and persist over the outer iterations of a control step.
+    [recalled semantics, class absent from the tree]"""
+    optimizer_name = "cem-grad-bharadhwaj"
+
+    def __init__(self, *args, learning_rate=0.05, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1.0e-8, num_rollouts=32,
+                 cem_best_k=8, cem_outer_it=2, cem_initial_action_stdev=2, cem_stdev_min=1.0e-6, gradmax_clip=5, **kwargs):
+        super().__init__(*args, num_rollouts=num_rollouts, cem_best_k=cem_best_k, cem_outer_it=cem_outer_it,
+                         cem_initial_action_stdev=cem_initial_action_stdev, cem_stdev_min=cem_stdev_min, **kwargs)
+        self.learning_rate, self.adam_beta_1, self.adam_beta_2 = float(learning_rate), float(adam_beta_1), float(adam_beta_2)
+        self.adam_epsilon, self.gradmax_clip = float(adam_epsilon), float(gradmax_clip)
+
+    def step(self, s, time=None, as_tensor=False):
+        self._m = self._v = None                    # fresh moments every control step
+        self._it = 0
+        return super().step(s, time, as_tensor)
+
+    def _refine(self, Q, s_t, tp, te, L):
+        if self._m is None:
+            self._m, self._v = torch.zeros_like(Q), torch.zeros_like(Q)
+        _, G = self.engine.rollout_cost_grad(s_t, Q, tp, te, L=L)
+        self._it += 1
+        return self.engine.adam_step(Q, G, self._m, self._v, self._it, self.learning_rate, self.adam_beta_1, self.adam_beta_2,
+                                     self.adam_epsilon, self.gradmax_clip)
+
+
+class optimizer_random_action(optimizer_cem):
+    """``random-action-tf`` (config_optimizers.yml:98-102): ``num_rollouts`` input plans drawn uniformly from the control
+    limits every control step, the first input of the cheapest one is applied; nothing is carried over.
+    [recalled semantics, class absent from the tree]"""
+    optimizer_name = "random-action"
+
+    def __init__(self, *args, num_rollouts=640, **kwargs):
+        kwargs.pop("cem_outer_it", None)
+        super().__init__(*args, num_rollouts=num_rollouts, cem_outer_it=1, cem_best_k=1, **kwargs)
+
+    def step(self, s, time=None, as_tensor=False):
+        import math
+        if self.engine is None:
+            self.configure()
+        eng = self.engine
+        s_t = eng.tensor(s)
+        single = s_t.dim() == 1
+        s_t = s_t.reshape(-1, 6)
+        E = s_t.shape[0]
+        if E != self.num_envs:
+            raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
+        vp = self.variable_parameters
+        tp = _vec(getattr(vp, "target_position", None), E, 0.0)
+        te = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
+        L = _vec(getattr(vp, "L", None), E, self.phys.L)
+        # N(0,1) from the device Philox sampler (clip limits far away), mapped to U(low, high) through the normal CDF
+        wide = eng.zeros(E, self.mpc_horizon)
+        z = self._normal(wide, self.step_counter)
+        lo, hi = self.action_low, self.action_high
+        Q = (lo + (hi - lo) * 0.5 * (1.0 + torch.erf(z * (1.0 / math.sqrt(2.0))))).clamp_(lo, hi).contiguous()
+        self.step_counter += 1
+        S = eng.rollout_cost(s_t, Q, tp, te, L=L)
+        best = torch.argmin(S, dim=1)
+        u = Q[torch.arange(E, device=S.device), best, 0].clone()
+        if self.optimizer_logging:
+            self.logging_values = {"Q_logged": u.cpu().numpy(), "J_logged": S.cpu().numpy()}
+        if as_tensor:
+            return u
+        q = u.cpu().numpy()
+        return q[:1].copy() if single else q.reshape(E, 1).copy()
+
+    def _normal(self, zeros_EH, offset):
+        # the sampler clips to the control limits, so draw with a small stdev and rescale: z = (x / 0.01), |x| <= 1 keeps
+        # |z| <= 100, i.e. no clipping of a standard normal
+        x = self.engine.cem_sample(zeros_EH + 0.5 * (self.action_low + self.action_high),
+                                   zeros_EH + 0.01 * 0.5 * (self.action_high - self.action_low), self.seed, offset=offset)
+        return (x - 0.5 * (self.action_low + self.action_high)) / (0.01 * 0.5 * (self.action_high - self.action_low))

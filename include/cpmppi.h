@@ -225,6 +225,11 @@ int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, cons
 int cpmppi_adam_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, float* m, float* v, uint32_t iteration,
                      float learning_rate, float beta1, float beta2, float epsilon, float gradmax_clip, void* stream);
 
+/* Plain gradient step Q <- clip(Q - learning_rate * clip_by_norm(grad, gradmax_clip)) on Q[E,N,H] in place
+ * (cem-naive-grad-tf, config_optimizers.yml:21-31). */
+int cpmppi_sgd_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, float learning_rate, float gradmax_clip,
+                    void* stream);
+
 /* CEM (hyper-parameters: Control_Toolkit_ASF/config_optimizers.yml:1-11, section cem-tf).
  * cpmppi_cem_sample: Q[E,N,H] = clip(mean[E,H] + stdev[E,H] * z), z ~ N(0,1) from Philox(seed, offset, env, rollout).
  * cpmppi_cem_update: per env, the best_k sequences by cost (stable ascending order) -> their mean and population

@@ -43,7 +43,7 @@ def test_controller_mpc_reference_usage():
     ctrl.controller_reset()
     assert float(ctrl.optimizer.u_nom.abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
-        ctrl.configure(optimizer_name="random-action-tf")
+        ctrl.configure(optimizer_name="cem-gmm-tf")
     assert s0[ANGLE_IDX] == f32(0.2)
 
 
