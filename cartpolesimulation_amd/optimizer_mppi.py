@@ -139,6 +139,14 @@ class optimizer_mppi:
             kw.update(seed=self.seed, offset=self.step_counter)
         if self.h is not None:
             kw.update(predictor="GRU", h0=self.h)
+        # the control applied last, which the simulator hands over as "Q_applied_-1" / "Q_ccrc" (CartPole/__init__.py:517-518):
+        # the previous_input of the control-change-rate term of quadratic_boundary_grad
+        vp = self.variable_parameters
+        prev = getattr(vp, "Q_applied_-1", None)
+        if prev is None:
+            prev = getattr(vp, "Q_ccrc", None)
+        if prev is not None and self.cfg.cost_function_specification == "quadratic_boundary_grad":
+            kw["previous_input"] = _vec(prev, E, 0.0)
         eng.step(s_t, self.u_nom, tp, te, L=L, Q_out=self.Q, S_out=self.S, **kw)
         self.step_counter += 1
         if self.h is not None:

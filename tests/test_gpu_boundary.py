@@ -207,3 +207,25 @@ def test_quadratic_boundary_grad_seam_and_fused(golden_dir, case):
         # ... and end to end with the tolerance scaled by that amplification
         # (a relative cost difference r changes a weight by r*|S|/LBD; the perturbations are O(1))
         np.testing.assert_allclose(un.cpu().numpy()[0], ref["u_new"], atol=max(1e-4, np.abs(ref["S"]).max() * 1e-5 / 100.0))
+
+
+def test_previous_input_reaches_the_cost_through_updated_attributes():
+    """CartPole.Update_Q hands the control applied last as "Q_applied_-1" / "Q_ccrc" (CartPole/__init__.py:517-518); with
+    quadratic_boundary_grad's control-change-rate weight switched on it must change the optimizer's choice."""
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    s = O.create_cartpole_state(0.15, 0.0, 0.0, 0.0)
+    J = []
+    for prev in (None, 0.9, -0.9):
+        ctrl = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
+                              control_limits=([-1.0], [1.0]),
+                              config=dict(seed=5, num_rollouts=1024, mpc_horizon=35, cost_function_specification="quadratic_boundary_grad",
+                                          cost_weights=dict(ccrc_weight_up=50.0)))
+        ctrl.configure("mppi", controller_logging=True)
+        upd = {} if prev is None else {"Q_applied_-1": prev, "Q_ccrc": prev}
+        ctrl.step(s, 0.0, upd)
+        J.append(np.asarray(ctrl.controller_data_for_csv["J_logged"], dtype=np.float64).reshape(-1))
+    # stage 0 adds w (u_0 - prev)^2 instead of w u_0^2: the same rollouts, costs shifted by w (prev^2 - 2 prev u_0)
+    d_pos, d_neg = J[1] - J[0], J[2] - J[0]
+    np.testing.assert_allclose(0.5 * (d_pos + d_neg), 50.0 * 0.81, rtol=2e-3)          # w prev^2
+    u0 = (d_neg - d_pos) / (4.0 * 50.0 * 0.9)                                            # the rollouts' first controls
+    assert np.abs(u0).max() <= 1.0 + 1e-3 and u0.std() > 0.05
