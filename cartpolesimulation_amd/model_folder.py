@@ -1,0 +1,121 @@
+"""Reading SI_Toolkit model folders: net-info file, normalisation vectors, weights.
+
+Format evidence in the reference tree: ``GymlikeCartPole/Dense-7IN-32H1-32H2-1OUT-0/`` — ``<net full name>.txt`` with
+``KEY:`` lines followed by their value (INPUTS / OUTPUTS as comma-separated feature names, NET NAME, TYPE, LIBRARY,
+NORMALIZE ...), ``normalization_vec_a.csv`` / ``normalization_vec_b.csv`` (one row, one value per INPUT: normalised =
+a*x + b) and ``denormalization_vec_A.csv`` / ``denormalization_vec_B.csv`` (one value per OUTPUT: y = A*y_norm + B).
+Model names of the neural predictor: ``SI_Toolkit_ASF/config_predictors.yml:8-13`` (``GRU-6IN-32H1-32H2-5OUT-*``).
+
+Weights: the reference's folders carry TensorFlow checkpoints / ``.keras`` archives, which need TensorFlow or h5py —
+neither exists on this image, and no GRU folder is in the tree.  What can be read here: a ``torch`` state_dict
+(``ckpt.pt``, the layout of ``torch.nn.GRU`` + a ``Linear`` head) or ``weights.npz`` with the keys of
+``MPPIEngine.set_gru``.  Anything else raises with the reason; there is no silent fallback.
+"""
+import os
+import re
+
+import numpy as np
+
+# the kernel's fixed feature order (cpmppi_gru.hpp): inputs and outputs of GRU-6IN-32H1-32H2-5OUT
+KERNEL_INPUTS = ("Q", "angleD", "angle_cos", "angle_sin", "position", "positionD")
+KERNEL_OUTPUTS = ("angleD", "angle_cos", "angle_sin", "position", "positionD")
+
+
+def read_net_info(folder):
+    """-> dict of the net-info file: keys lower-cased with spaces -> '_'; 'inputs' / 'outputs' are lists of names."""
+    folder = os.path.abspath(folder)
+    name = os.path.basename(folder.rstrip(os.sep))
+    path = os.path.join(folder, name + ".txt")
+    if not os.path.exists(path):
+        cands = [f for f in os.listdir(folder) if f.endswith(".txt") and not f.startswith("terminal")]
+        if len(cands) != 1:
+            raise FileNotFoundError(f"{folder}: no net-info file {name}.txt")
+        path = os.path.join(folder, cands[0])
+    info, key, buf = {}, None, []
+
+    def flush():
+        if key is not None:
+            info[key] = "\n".join(buf).strip()
+
+    for line in open(path):
+        m = re.match(r"^([A-Z][A-Z _\[\]a-z]*):\s*$", line.rstrip("\n"))
+        if m and m.group(1).upper() == m.group(1).upper() and line[0].isupper() and line.strip().endswith(":"):
+            flush()
+            key, buf = re.sub(r"[^a-z0-9]+", "_", m.group(1).lower()).strip("_"), []
+        else:
+            buf.append(line.rstrip("\n"))
+    flush()
+    for k in ("inputs", "outputs"):
+        info[k] = [x.strip() for x in info.get(k, "").split(",") if x.strip()]
+    info["path"] = path
+    return info
+
+
+def _row(path):
+    return np.atleast_1d(np.loadtxt(path, delimiter=",", dtype=np.float64)).astype(np.float32)
+
+
+def read_normalization(folder, info=None):
+    """-> dict(a, b, A, B): normalised input = a*x + b per INPUT, output = A*y + B per OUTPUT (identity if files absent)."""
+    info = info or read_net_info(folder)
+    out = {}
+    for key, fname, n in (("a", "normalization_vec_a.csv", len(info["inputs"])), ("b", "normalization_vec_b.csv", len(info["inputs"])),
+                          ("A", "denormalization_vec_A.csv", len(info["outputs"])),
+                          ("B", "denormalization_vec_B.csv", len(info["outputs"]))):
+        p = os.path.join(folder, fname)
+        if os.path.exists(p):
+            v = _row(p)
+            if v.size != n:
+                raise ValueError(f"{p}: {v.size} values for {n} features")
+        else:
+            v = np.ones(n, np.float32) if key in ("a", "A") else np.zeros(n, np.float32)
+        out[key] = v
+    return out
+
+
+def _weights(folder):
+    npz, pt = os.path.join(folder, "weights.npz"), os.path.join(folder, "ckpt.pt")
+    if os.path.exists(npz):
+        return dict(np.load(npz))
+    if os.path.exists(pt):
+        import torch
+        sd = torch.load(pt, map_location="cpu", weights_only=True)
+        sd = {k: v.numpy() for k, v in sd.items()}
+        pick = lambda *subs: next(v for k, v in sd.items() if all(s in k for s in subs))  # noqa: E731
+        w = {}
+        for l in range(2):
+            w[f"w_ih{l}"], w[f"w_hh{l}"] = pick(f"weight_ih_l{l}"), pick(f"weight_hh_l{l}")
+            w[f"b_ih{l}"], w[f"b_hh{l}"] = pick(f"bias_ih_l{l}"), pick(f"bias_hh_l{l}")
+        heads = [(k, v) for k, v in sd.items() if v.ndim == 2 and v.shape[0] == 5]
+        w["w_out"] = heads[-1][1]
+        w["b_out"] = next(v for k, v in sd.items() if v.ndim == 1 and v.shape[0] == 5)
+        return w
+    tf_like = [f for f in os.listdir(folder) if f.endswith((".keras", ".h5", ".index")) or ".ckpt" in f]
+    if tf_like:
+        raise NotImplementedError(f"{folder}: only TensorFlow/Keras weights found ({', '.join(sorted(tf_like)[:3])}); reading them "
+                                  "needs TensorFlow or h5py, which this image does not have - export weights.npz")
+    raise FileNotFoundError(f"{folder}: no weights.npz or ckpt.pt")
+
+
+def load_gru_model(folder):
+    """A ``GRU-6IN-32H1-32H2-5OUT-*`` folder -> the dict ``MPPIEngine.set_gru`` takes (weights permuted to the kernel's
+    feature order, normalisation as in_scale/in_shift/out_scale/out_shift)."""
+    info = read_net_info(folder)
+    net = info.get("net_name", "")
+    if not net.startswith("GRU-32H1-32H2"):
+        raise NotImplementedError(f"{folder}: net {net!r}; the HIP predictor is built for GRU-32H1-32H2 (6 inputs, 5 outputs)")
+    if sorted(info["inputs"]) != sorted(KERNEL_INPUTS) or sorted(info["outputs"]) != sorted(KERNEL_OUTPUTS):
+        raise NotImplementedError(f"{folder}: features {info['inputs']} -> {info['outputs']}; built for {KERNEL_INPUTS} -> {KERNEL_OUTPUTS}")
+    pin = [info["inputs"].index(f) for f in KERNEL_INPUTS]          # kernel column i  <- model column pin[i]
+    pout = [info["outputs"].index(f) for f in KERNEL_OUTPUTS]
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in _weights(folder).items()}
+    model = dict(w)
+    model["w_ih0"] = w["w_ih0"][:, pin]
+    model["w_out"], model["b_out"] = w["w_out"][pout], w["b_out"][pout]
+    if str(info.get("normalize", "True")).strip().lower() != "false":
+        nm = read_normalization(folder, info)
+        model.update(in_scale=nm["a"][pin], in_shift=nm["b"][pin], out_scale=nm["A"][pout], out_shift=nm["B"][pout])
+    for k in ("in_scale", "in_shift", "out_scale", "out_shift"):
+        if k in w:                                                  # weights.npz may carry them directly (kernel order)
+            model[k] = w[k]
+    return model

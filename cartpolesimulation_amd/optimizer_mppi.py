@@ -85,8 +85,12 @@ class optimizer_mppi:
         if num_envs is not None:
             self.num_envs = int(num_envs)
         neural = predictor_specification is not None and str(predictor_specification).startswith("GRU-6IN-32H1-32H2-5OUT")
+        if isinstance(self.gru_model, (str, bytes)) or hasattr(self.gru_model, "__fspath__"):
+            from .model_folder import load_gru_model          # an SI_Toolkit model folder (net-info, normalisation, weights)
+            self.gru_model = load_gru_model(self.gru_model)
         if neural and self.gru_model is None:
-            raise ValueError("a GRU predictor_specification needs gru_model=dict(weights) (no model files ship in-tree)")
+            raise ValueError("a GRU predictor_specification needs gru_model=dict(weights) or a model folder path "
+                             "(no GRU model files ship in-tree)")
         if not neural and predictor_specification not in (None, "ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
             raise NotImplementedError("built predictors: ODE_v0 and GRU-6IN-32H1-32H2-5OUT-*")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
