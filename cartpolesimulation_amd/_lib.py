@@ -39,7 +39,7 @@ class cpmppi_step_args(C.Structure):
                 ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p), ("L", C.c_void_p),
                 ("noise_kind", C.c_uint32), ("noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("env_offset", C.c_uint32), ("Q_out", C.c_void_p), ("S_out", C.c_void_p),
-                ("predictor", C.c_uint32), ("h0", C.c_void_p), ("previous_input", C.c_void_p)]
+                ("predictor", C.c_uint32), ("h0", C.c_void_p), ("previous_input", C.c_void_p), ("offset_dev", C.c_void_p)]
 
 
 class cpmppi_gru_model(C.Structure):

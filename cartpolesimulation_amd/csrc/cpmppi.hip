@@ -56,6 +56,7 @@ struct StepPtrs {
   const float* noise;
   const float* prev_in; // [E] control applied before this step (quadratic_boundary_grad ccrc) or NULL
   uint64_t seed, offset;
+  const unsigned long long* offset_dev;   // if set: the Philox step counter lives in device memory (graph replay)
   uint32_t env_offset;
   uint32_t nb;          // blocks per env
   uint32_t W;           // width of the weighted-sum vector (H in delta_u space, P in knot space)
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #pragma unroll
   for (int i = 0; i < R; ++i) { n[i] = row0 + i * 64 + lane; valid[i] = n[i] < p.N; }
   const uint32_t H = p.H;
+  const uint64_t step_offset = a.offset_dev ? (uint64_t)*a.offset_dev : a.offset;
 
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
   const float L = a.L ? a.L[env] : p.L_default;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     auto knot = [&](int i, uint32_t j) __attribute__((always_inline)) -> float {
       const uint32_t nn = valid[i] ? n[i] : 0;
       if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
-      else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
+      else return philox_knot(a.seed, step_offset, a.env_offset + env, nn, j, p.sigma);
     };
     constexpr bool F32_INTERP = FAST && NOISE == NOISE_PHILOX;       // our own noise: one FMA instead of the f64 form
     const float inv_period = 1.0f / (float)p.period;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       float v = 0.0f;
 #pragma unroll
       for (int i = 0; i < R; ++i)
-        v += e[i] * philox_knot(a.seed, a.offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma);
+        v += e[i] * philox_knot(a.seed, step_offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma);
       v = wave_sum(v);
       if (lane == 0) my_bsum[j] = v;
     }
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
   const bool owner = lane < 32 && n < p.N;                 // the lane that accounts for rollout n
   const uint32_t nn = n < p.N ? n : 0;
   const uint32_t H = p.H;
+  const uint64_t step_offset = a.offset_dev ? (uint64_t)*a.offset_dev : a.offset;
   const float x_t = a.x_t[env], te = a.te[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
 
   auto knot = [&](uint32_t j) __attribute__((always_inline)) -> float {
     if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
-    else return philox_knot(a.seed, a.offset, a.env_offset + env, nn, j, p.sigma);
+    else return philox_knot(a.seed, step_offset, a.env_offset + env, nn, j, p.sigma);
   };
   float z_lo = 0.0f, z_hi = 0.0f;
   if constexpr (NOISE != NOISE_DELTA_U) { z_lo = knot(0); z_hi = knot(1); }
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
   float* __restrict__ my_bsum = bsum + wave * W;
   if constexpr (NOISE == NOISE_PHILOX) {
     for (uint32_t jj = 0; jj < W; ++jj) {
-      const float v = wave_sum(e * philox_knot(a.seed, a.offset, a.env_offset + env, nn, jj, p.sigma));
+      const float v = wave_sum(e * philox_knot(a.seed, step_offset, a.env_offset + env, nn, jj, p.sigma));
       if (lane == 0) my_bsum[jj] = v;
     }
   } else {
@@ -883,6 +886,9 @@ __global__ __launch_bounds__(BLOCK) void adam_step_kernel(size_t rows, uint32_t 
     Q[i] = clamp_(Q[i] - lr_t * mk / (sqrtf(vk) + eps), lo, hi);
   }
 }
+
+// advances a device-resident Philox step counter after a step that used it (stream-ordered; graph-replayable)
+__global__ void bump_counter_kernel(unsigned long long* c) { *c += 1ull; }
 
 // Plain gradient step with the same per-rollout norm clipping and limit clip (cem-naive-grad-tf, config_optimizers.yml:21-31).
 __global__ __launch_bounds__(BLOCK) void sgd_step_kernel(size_t rows, uint32_t H, float* __restrict__ Q,
@@ -1164,6 +1170,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   StepPtrs p;
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
   p.L = a->L; p.noise = a->noise; p.prev_in = a->previous_input; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
+  p.offset_dev = (a->noise_kind == CPMPPI_NOISE_PHILOX) ? (const unsigned long long*)a->offset_dev : nullptr;
   // lane mapping: two rollouts per lane (packed float2) once the launch is big enough to keep >= 2 such waves on
   // every SIMD; one rollout per lane (shortest critical path) for small launches
   uint32_t rpl = h->cfg.rollouts_per_lane;
@@ -1224,6 +1231,10 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
                          p.nb, p.W, a->u_nom, a->Q_out);
   }
   CPMPPI_HIP(h, hipGetLastError());
+  if (p.offset_dev) {
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)a->offset_dev);
+    CPMPPI_HIP(h, hipGetLastError());
+  }
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[2], s));
   return CPMPPI_OK;
 }
@@ -1395,7 +1406,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   prm.cc_weight = 0.0f;
   StepPtrs p;
   p.s0 = s0; p.u_nom = h->zeros_H; p.u_prev = nullptr; p.x_t = target_position; p.te = target_equilibrium; p.L = L;
-  p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.env_offset = 0;
+  p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.offset_dev = nullptr; p.env_offset = 0;
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
   else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N >= 262144ull) ? 2 : 1;

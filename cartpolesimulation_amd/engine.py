@@ -285,7 +285,7 @@ class MPPIEngine:
     # ------------------------------------------------------------------ the fused hot path
     def step(self, s0, u_nom, target_position, target_equilibrium, L=None, delta_u=None, knots=None, seed=None,
              offset=0, env_offset=0, u_prev=None, Q_out=None, S_out=None, predictor="ODE_v0", h0=None,
-             previous_input=None):
+             previous_input=None, offset_dev=None):
         """One MPPI optimizer step for E envs.  ``u_nom`` [E,H] is updated IN PLACE.
 
         Exactly one noise source: ``delta_u`` [E,N,H], ``knots`` [E,N,P], or ``seed`` (in-kernel Philox).
@@ -336,6 +336,10 @@ class MPPIEngine:
         a.h0 = h0.data_ptr() if h0 is not None else None
         previous_input = self._per_env(previous_input, E) if previous_input is not None else None
         a.previous_input = previous_input.data_ptr() if previous_input is not None else None
+        if offset_dev is not None:           # int64 device scalar: Philox step counter kept on the device (graph replay)
+            if not (torch.is_tensor(offset_dev) and offset_dev.is_cuda and offset_dev.dtype == torch.int64 and offset_dev.numel() == 1):
+                raise ValueError("offset_dev must be a one-element int64 ROCm tensor")
+            a.offset_dev = offset_dev.data_ptr()
         self._check(self.lib.cpmppi_step(self._h, C.byref(a), self._stream()))
         # keep the temporaries alive until the launch is enqueued (stream-ordered frees are safe in torch's allocator)
         return Q_out, S_out

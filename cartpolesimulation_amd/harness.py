@@ -36,7 +36,7 @@ class BatchedCartPoleExperiment:
         self.seed = int(seed)
 
     def run(self, s0, n_control_steps, target_position=0.0, target_equilibrium=1.0, L=None, record=True,
-            env_offset=0):
+            env_offset=0, graph=False, steps_per_graph=10):
         """-> dict(states[T+1,E,6], Q[T,E]) as device tensors (only if ``record``), final state, final u_nom."""
         eng = self.engine
         s = eng.tensor(s0).clone()
@@ -50,10 +50,44 @@ class BatchedCartPoleExperiment:
         Qs = eng.empty(n_control_steps, E) if record else None
         if record:
             states[0] = s
+        if graph:
+            return self._run_graph(s, u_nom, Q, tp, te, Lt, states, Qs, n_control_steps, env_offset, int(steps_per_graph))
         for t in range(n_control_steps):
             eng.step(s, u_nom, tp, te, L=Lt, seed=self.seed, offset=t, env_offset=env_offset, Q_out=Q)
             eng.plant_advance(s, Q, L=Lt, n_substeps=self.n_sub, dt_sim=self.dt_simulation)
             if record:
                 Qs[t] = Q
                 states[t + 1] = s
+        return dict(states=states, Q=Qs, final_state=s, u_nom=u_nom)
+
+    def _run_graph(self, s, u_nom, Q, tp, te, Lt, states, Qs, n_control_steps, env_offset, per_graph):
+        """The same loop as ONE captured HIP graph of `per_graph` control steps, replayed: controller step (Philox counter in device
+        memory, `offset_dev`), plant, recording by a device-side index — no launch argument changes between steps, the
+        host only enqueues replays (the launch-bound case: few envs, ~70 us of GPU work per control step)."""
+        eng = self.engine
+        counter = torch.zeros(1, dtype=torch.int64, device=s.device)          # Philox step counter = control step index
+        slot = torch.zeros(1, dtype=torch.int64, device=s.device)             # recording row
+        record = states is not None
+
+        def one_step():
+            eng.step(s, u_nom, tp, te, L=Lt, seed=self.seed, offset_dev=counter, env_offset=env_offset, Q_out=Q)
+            eng.plant_advance(s, Q, L=Lt, n_substeps=self.n_sub, dt_sim=self.dt_simulation)
+            if record:
+                Qs.index_copy_(0, slot, Q.unsqueeze(0))
+                slot.add_(1)
+                states.index_copy_(0, slot, s.unsqueeze(0))
+
+        side = torch.cuda.Stream(device=s.device)
+        side.wait_stream(torch.cuda.current_stream(s.device))
+        g = torch.cuda.CUDAGraph()
+        per_graph = max(1, min(per_graph, n_control_steps))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(per_graph):
+                    one_step()
+        torch.cuda.current_stream(s.device).wait_stream(side)
+        for _ in range(n_control_steps // per_graph):
+            g.replay()
+        for _ in range(n_control_steps % per_graph):          # the remainder, launched directly with the same device counter
+            one_step()
         return dict(states=states, Q=Qs, final_state=s, u_nom=u_nom)

@@ -150,6 +150,10 @@ typedef struct {
   const float* h0;                  /* GRU only: hidden state per env [E,2,32] shared by the env's rollouts, or NULL=0 */
   const float* previous_input;      /* [E] control applied before this step (Q_ccrc of CartPole/__init__.py:517): the
                                        control-change-rate term of quadratic_boundary_grad at stage 0; NULL = 0 */
+  uint64_t* offset_dev;             /* CPMPPI_NOISE_PHILOX, optional: the step counter in DEVICE memory — read by the kernel
+                                       instead of `offset` and incremented by one after the step, stream-ordered.  With it a
+                                       captured HIP graph of (step, plant, ...) can be replayed: no launch argument changes
+                                       between control steps.  NULL = use `offset`. */
 } cpmppi_step_args;
 
 int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out);
