@@ -276,7 +276,7 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
 //   aDD  = g_i s + xDD c /((k+1)Lh) - cT w                                      (cartpole_equations.py:95-99)
 template <class F>
 __device__ __forceinline__ void ode_euler_fast(const State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
-                                               F& th1, F& w1, F& x1, F& v1) {
+                                               F& th1, F& w1, F& x1, F& v1, F* aDD_out = nullptr) {
   const F c = st.c, s = st.s, w = st.w, v = st.v;
   const F A = fma_(-(c * splat<F>(p.m_pole)), c, splat<F>(e.kp1_mt));
   const F t1 = fma_(splat<F>(e.mg), s, -(w * splat<F>(e.JinvLh)));
@@ -299,6 +299,7 @@ __device__ __forceinline__ void ode_euler_fast(const State<F>& st, F uK, float t
 #else
   const F aDD = fma_(splat<F>(e.g_i), s, fma_(xDD * c, splat<F>(e.inv_kLh), -(w * splat<F>(e.cT_i))));
   w1 = fma_(aDD, tt, w);
+  if (aDD_out) *aDD_out = aDD;
 #endif
   x1 = fma_(v, tt, st.x);
   v1 = fma_(xDD, tt, v);
@@ -385,6 +386,68 @@ __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, co
   return fired;
 }
 
+#ifndef CPMPPI_INCR_ROT
+#define CPMPPI_INCR_ROT 1       // packed path: (cos d, sin d) of d = w t advanced by d' - d = angleDD t^2 instead of re-evaluated
+#endif
+
+// Intermediate substep of the packed path with the rotation's (cos d, sin d) carried along: d = w t changes by
+// eps = angleDD t^2 (up to ~1e-3 for a fast-spinning pole) per substep, so
+//     (cd, sd) <- (cd - eps sd - eps^2/2, sd + eps cd)
+// replaces the two Taylor polynomials (4 instead of 7 instructions; truncation O(eps^3) in cd, eps^2 sd / 2 <= 7e-8 in
+// sd).  The pair is seeded from the polynomials at every control step, and the control step's last substep
+// re-synchronises (cos, sin) exactly as before.  Rare lanes are handled PER LANE in the wave-uniform cold branch — a
+// lane that hits the track edge bounces, gets the exact wrap + sincos and re-seeds its pair from its new angular
+// velocity; a lane whose |w t| exceeded 0.1 at the start of the control step (`spin`: its edge limit `xlim` is set to
+// -1, so the one comparison per lane covers both events) gets the exact sincos on every substep — so a rollout's
+// arithmetic never depends on what its wave partners do.  Measured (tools/cost_deviation.py,
+// all golden rollouts): relative cost deviation median 1.9e-7 / p99 7.5e-6 / max 2.8e-5 with it, 1.9e-7 / 6.9e-6 /
+// 2.3e-5 without.  (Tried on the one-rollout-per-lane path too: no gain there, left as it was.)
+template <class F>
+__device__ __forceinline__ void rot_seed(F d, F& cd, F& sd) {
+  const F d2 = d * d;
+  sd = fma_(d * d2, fma_(d2, splat<F>(8.3333333e-3f), splat<F>(-1.6666667e-1f)), d);
+  cd = fma_(d2, fma_(d2, splat<F>(4.1666667e-2f), splat<F>(-0.5f)), splat<F>(1.0f));
+}
+
+template <class F>
+__device__ __forceinline__ void substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
+                                                         F& cd, F& sd, F& xlim) {
+  constexpr int W = Width<F>::value;
+  F th1, w1, x1, v1, aDD;
+  ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1, &aDD);
+  F c1 = fma_(st.c, cd, -(st.s * sd));
+  F s1 = fma_(st.s, cd, st.c * sd);
+  const F eps = aDD * splat<F>(t * t);
+  F cd1 = fma_(-eps, fma_(eps, splat<F>(0.5f), sd), cd);            // cd - eps sd - eps^2/2  (cd ~ 1: the eps^2 term matters)
+  F sd1 = fma_(cd, eps, sd);                                         // sd + eps cd
+  bool rare = false;
+#pragma unroll
+  for (int i = 0; i < W; ++i) rare |= __builtin_fabsf(get(x1, i)) >= get(xlim, i);      // edge, or a lane flagged `spin`
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
+      const bool hit = __builtin_fabsf(xi) >= p.THL, spin = get(xlim, i) < 0.0f;
+      if (hit || spin) {
+        if (hit) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
+        thi = wrap_rint<float>(thi);
+        float sn, cs;
+        sincos_pi_half<float>(thi, sn, cs);
+        put(s1, i, sn); put(c1, i, cs);
+        put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+        if (hit) {                                                  // the angular velocity jumped: new pair, new range test
+          float cdn, sdn;
+          rot_seed<float>(wi * t, cdn, sdn);
+          put(cd1, i, cdn); put(sd1, i, sdn);
+          if (__builtin_fabsf(wi) * t > 0.1f) put(xlim, i, -1.0f);
+        }
+      }
+    }
+  }
+  cd = cd1; sd = sd1;
+  st.th = th1; st.w = w1; st.x = x1; st.v = v1; st.c = c1; st.s = s1;
+}
+
 // One control step of S substeps under a held control (FAST).
 template <class F>
 __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
@@ -397,9 +460,18 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
     substep_fast<F>(st, uK, t, p, e);
     return;
   }
-  // The Taylor rotation needs |w t| <= 0.125 (its cos error reaches half an ulp only at ~0.18).  Tested once here with
-  // the margin 0.1: without a bounce w cannot gain 12 rad/s within one control step; a bounce can change w abruptly,
-  // so after one the rest of the control step runs the exact substep.  Everything is wave-uniform.
+  // The Taylor seed needs |w t| <= 0.125 (its cos error reaches half an ulp only at ~0.18).  Tested once per control
+  // step with the margin 0.1: without a bounce w cannot gain 12 rad/s within one control step, and a lane that bounces
+  // is re-tested.  Lanes beyond the range are flagged and take the exact sincos on every substep.
+#if CPMPPI_INCR_ROT
+  F xlim;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) * t > 0.1f) ? -1.0f : p.THL);
+  F cd, sd;
+  rot_seed<F>(st.w * splat<F>(t), cd, sd);
+  for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F>(st, uK, t, p, e, cd, sd, xlim);
+  substep_fast<F>(st, uK, t, p, e);
+#else
   bool spin = false;
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) spin |= __builtin_fabsf(get(st.w, i)) * t > 0.1f;
@@ -412,6 +484,7 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
     }
   }
   for (; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);       // the last substep always; all remaining after a bounce
+#endif
 #elif CPMPPI_ROTATE
   for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
   substep_fast<F>(st, uK, t, p, e);

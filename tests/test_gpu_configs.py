@@ -64,11 +64,18 @@ def test_config_full_size(name, E, N, H):
     un2 = eng.tensor(u0.copy())
     eng.step(s0, un2, tp, te, L=Lv, knots=kn)
     assert np.array_equal(un2.cpu().numpy(), un_h)
-    small = make(1, N, H)
-    for e in (1, E - 2):
-        u1 = small.tensor(u0[e:e + 1].copy())
-        small.step(s0[e:e + 1], u1, tp[e:e + 1], te[e:e + 1], L=Lv[e:e + 1], knots=kn[e:e + 1].contiguous())
-        np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=2e-6)       # (1 vs 2 rollouts per lane mapping)
+    # stepped alone with the SAME lane mapping: bit-identical; with the other mapping (its intermediate substeps carry
+    # the rotation differently): the same update to within the parity tolerance
+    rpl_batch = 2 if E * N >= 262144 else 1
+    for rpl, exact in ((rpl_batch, True), (3 - rpl_batch, False)):
+        small = make(1, N, H, rollouts_per_lane=rpl)
+        for e in (1, E - 2):
+            u1 = small.tensor(u0[e:e + 1].copy())
+            small.step(s0[e:e + 1], u1, tp[e:e + 1], te[e:e + 1], L=Lv[e:e + 1], knots=kn[e:e + 1].contiguous())
+            if exact:
+                assert np.array_equal(u1.cpu().numpy()[0], un_h[e])
+            else:
+                np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=1e-4)
 
     # ---- permutation invariance: shuffling an env's rollouts leaves its update unchanged (to summation order)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).to(kn.device)

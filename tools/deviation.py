@@ -20,6 +20,7 @@ from tests.test_gpu_parity import regen_delta_u  # noqa: E402
 
 g = np.load(os.path.join(ROOT, "tests", "golden", "rollouts_c2.npz"))
 N, H = int(g["N"]), int(g["H"])
+RPL = int(os.environ.get("CPMPPI_DEV_RPL", "0"))          # 0 auto (one rollout per lane at this size), 2 = the packed mapping
 libs = sys.argv[1:] or [L.LIB_PATH]
 dev = torch.device("cuda", 0)
 
@@ -35,7 +36,8 @@ for path in libs:
     lib.cpmppi_create.argtypes = [C.POINTER(L.cpmppi_config), C.c_int, C.POINTER(vp)]
     lib.cpmppi_predict.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
     for math in ("precise", "fast"):
-        cfg = build_c_config(1, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math))
+        cfg = build_c_config(1, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math,
+                                             rollouts_per_lane=(RPL if math == "fast" else 0)))
         h = vp()
         assert lib.cpmppi_create(C.byref(cfg), 0, C.byref(h)) == 0
         tot = []
