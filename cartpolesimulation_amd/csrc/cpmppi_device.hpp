@@ -401,7 +401,9 @@ __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, co
 // -1, so the one comparison per lane covers both events) gets the exact sincos on every substep — so a rollout's
 // arithmetic never depends on what its wave partners do.  Measured (tools/cost_deviation.py,
 // all golden rollouts): relative cost deviation median 1.9e-7 / p99 7.5e-6 / max 2.8e-5 with it, 1.9e-7 / 6.9e-6 /
-// 2.3e-5 without.  (Tried on the one-rollout-per-lane path too: no gain there, left as it was.)
+// 2.3e-5 without.  The one-rollout-per-lane path keeps the per-substep polynomials: it is bound by the LATENCY of a
+// single wave's dependency chain, and carrying the pair makes the next rotation wait for this substep's angleDD (measured:
+// 79 us instead of 67 us per single-env step).
 template <class F>
 __device__ __forceinline__ void rot_seed(F d, F& cd, F& sd) {
   const F d2 = d * d;
