@@ -1175,7 +1175,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   // every SIMD; one rollout per lane (shortest critical path) for small launches
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
-  else if (rpl == 0) rpl = ((uint64_t)a->E * h->cfg.N >= 262144ull) ? 2 : 1;
+  else if (rpl == 0) rpl = ((uint64_t)a->E * h->cfg.N > 262144ull) ? 2 : 1;
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = (a->noise_kind == CPMPPI_NOISE_DELTA_U) ? h->cfg.H : h->prm.P;
   p.S_out = a->S_out; p.partial = h->workspace;
@@ -1409,7 +1409,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.offset_dev = nullptr; p.env_offset = 0;
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
-  else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N >= 262144ull) ? 2 : 1;
+  else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N > 262144ull) ? 2 : 1;
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = h->cfg.H;
   p.S_out = S_out; p.partial = h->workspace; p.counter = nullptr; p.u_nom_out = nullptr; p.Q_out = nullptr;
