@@ -57,6 +57,7 @@ struct StepPtrs {
   const float* prev_in; // [E] control applied before this step (quadratic_boundary_grad ccrc) or NULL
   uint64_t seed, offset;
   const unsigned long long* offset_dev;   // if set: the Philox step counter lives in device memory (graph replay)
+  uint32_t stash;       // NOISE_PHILOX: the generated knots are parked in LDS ([P][R][BLOCK] after the weighted sums) for the reduction
   uint32_t env_offset;
   uint32_t nb;          // blocks per env
   uint32_t W;           // width of the weighted-sum vector (H in delta_u space, P in knot space)
@@ -217,10 +218,27 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       }
     }
   } else {
+    // Philox: one block yields the knots of a PAIR (2q, 2q+1); the odd one is kept until it is needed.  Every knot is
+    // also parked in LDS (when it fits) so that the soft-min reduction below does not generate the sequence again.
+    float z_odd[R];
+    float* __restrict__ kstash = bsum + WAVES * a.W + tid;
     auto knot = [&](int i, uint32_t j) __attribute__((always_inline)) -> float {
       const uint32_t nn = valid[i] ? n[i] : 0;
-      if constexpr (NOISE == NOISE_KNOTS) return a.noise[((size_t)env * p.N + nn) * p.P + j];
-      else return philox_knot(a.seed, step_offset, a.env_offset + env, nn, j, p.sigma);
+      if constexpr (NOISE == NOISE_KNOTS) {
+        return a.noise[((size_t)env * p.N + nn) * p.P + j];
+      } else {
+        float z;
+        if ((j & 1u) == 0u) {
+          float z0, z1;
+          philox_normal_pair(a.seed, step_offset, a.env_offset + env, nn, j >> 1, z0, z1);
+          z_odd[i] = p.sigma * z1;
+          z = p.sigma * z0;
+        } else {
+          z = z_odd[i];
+        }
+        if (a.stash) kstash[(j * R + i) * BLOCK] = z;
+        return z;
+      }
     };
     constexpr bool F32_INTERP = FAST && NOISE == NOISE_PHILOX;       // our own noise: one FMA instead of the f64 form
     const float inv_period = 1.0f / (float)p.period;
@@ -289,11 +307,13 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const uint32_t W = a.W;
   float* __restrict__ my_bsum = bsum + wave * W;
   if constexpr (NOISE == NOISE_PHILOX) {
+    const float* __restrict__ kstash = bsum + WAVES * W + tid;         // each lane reads back what it wrote itself
     for (uint32_t j = 0; j < W; ++j) {
       float v = 0.0f;
 #pragma unroll
       for (int i = 0; i < R; ++i)
-        v += e[i] * philox_knot(a.seed, step_offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma);
+        v += e[i] * (a.stash ? kstash[(j * R + i) * BLOCK]
+                             : philox_knot(a.seed, step_offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma));
       v = wave_sum(v);
       if (lane == 0) my_bsum[j] = v;
     }
@@ -1218,7 +1238,13 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     CPMPPI_HIP(h, hipGetLastError());
   } else {
     p.counter = h->fuse_finalize ? h->counters : nullptr;
-    CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), (size_t)WAVES * p.W * sizeof(float), s, p));
+    size_t lds = (size_t)WAVES * p.W * sizeof(float);
+    p.stash = 0;
+    if (a->noise_kind == CPMPPI_NOISE_PHILOX) {                 // park the generated knots in LDS when they fit
+      const size_t park = (size_t)p.W * rpl * BLOCK * sizeof(float);
+      if (lds + park <= 32 * 1024) { p.stash = 1; lds += park; }
+    }
+    CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), lds, s, p));
   }
   const bool separate_finalize = (p.counter == nullptr);
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
@@ -1406,7 +1432,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   prm.cc_weight = 0.0f;
   StepPtrs p;
   p.s0 = s0; p.u_nom = h->zeros_H; p.u_prev = nullptr; p.x_t = target_position; p.te = target_equilibrium; p.L = L;
-  p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.offset_dev = nullptr; p.env_offset = 0;
+  p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.offset_dev = nullptr; p.env_offset = 0; p.stash = 0;
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
   else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N > 262144ull) ? 2 : 1;

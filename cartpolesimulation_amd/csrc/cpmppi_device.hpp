@@ -635,17 +635,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
   }
 }
 
+// Two standard normals per Philox block (Box-Muller) on the hardware transcendentals: ln u1 = ln2 * v_log_f32(u1),
+// v_sin_f32 / v_cos_f32 take their argument in revolutions, so sin(2 pi u2) is v_sin_f32(u2) (abs. error ~1e-6: this
+// is the library's OWN noise stream, the same function feeds the sampler kernel and the in-kernel generation).
 __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint64_t offset, uint32_t env, uint32_t rollout,
                                                    uint32_t pair, float& z0, float& z1) {
   uint32_t c0 = rollout, c1 = env, c2 = pair, c3 = (uint32_t)offset;
   philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32));
   const float u1 = (float)((c0 >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
   const float u2 = (float)(c1 >> 8) * 5.9604644775390625e-8f;          // [0, 1)
-  const float r = sqrtf(-2.0f * logf(u1));
-  float sn, cs;
-  sincosf(TWO_PI_F * u2, &sn, &cs);
-  z0 = r * cs;
-  z1 = r * sn;
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // Knot j of (env, rollout) scaled by sigma.
