@@ -514,11 +514,12 @@ __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang,
   const F dd = (d * d) * splat<F>(p.w[0]);
   const float ptf = p.w[6];
   const F ax = abs_(x);
-  F near;
+  // indicator(|x| > ptf THL) * b^2 == (max(|x| - ptf THL, 0) / ...)^2: the same value without compare + select
+  F over = ax - splat<F>(ptf * THL);
 #pragma unroll
-  for (int i = 0; i < Width<F>::value; ++i) put(near, i, (get(ax, i) > ptf * THL) ? 1.0f : 0.0f);
-  const F b = div_uniform<FAST, F>(ax - splat<F>(ptf * THL), (1.0f - ptf) * THL);
-  const F db = (near * (b * b)) * splat<F>(p.w[1]);
+  for (int i = 0; i < Width<F>::value; ++i) put(over, i, __builtin_fmaxf(get(over, i), 0.0f));
+  const F b = div_uniform<FAST, F>(over, (1.0f - ptf) * THL);
+  const F db = (b * b) * splat<F>(p.w[1]);
   const F e1 = splat<F>(1.0f) - cosang * splat<F>(te);
   const F ep = (e1 * e1) * splat<F>(p.w[2]);
   const F ekp = (w_ang * w_ang) * splat<F>(p.w[3]);
@@ -539,11 +540,11 @@ __device__ __forceinline__ F stage_qbg(const Params& p, F x, F cosang, F w_ang, 
   const F dd_quadratic = (d * d) * splat<F>(w[0]);
   const F dd_linear = abs_(d) * splat<F>(w[1]);
   const F ax = abs_(x);
-  F near;
+  F over = ax - splat<F>(ptf * THL);
 #pragma unroll
-  for (int i = 0; i < Width<F>::value; ++i) put(near, i, (get(ax, i) > ptf * THL) ? 1.0f : 0.0f);
-  const F b = div_uniform<FAST, F>(ax - splat<F>(ptf * THL), (1.0f - ptf) * THL);
-  const F db = (near * (b * b)) * splat<F>(w[2]);
+  for (int i = 0; i < Width<F>::value; ++i) put(over, i, __builtin_fmaxf(get(over, i), 0.0f));
+  const F b = div_uniform<FAST, F>(over, (1.0f - ptf) * THL);
+  const F db = (b * b) * splat<F>(w[2]);
   const F tc = cosang * splat<F>(te);
   const F e2 = splat<F>(2.0f) - tc;
   const F ep = (e2 * e2 - splat<F>(1.0f)) * splat<F>(w[3]);
