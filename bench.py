@@ -137,6 +137,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if not os.path.exists(os.path.join(ROOT, "cartpolesimulation_amd", "libcpmppi.so")):     # (git-ignored artefact)
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if distributed:
+            dist.barrier()
     from cartpolesimulation_amd.engine import MPPIEngine
     from cartpolesimulation_amd.configs import MPPIConfig
 
