@@ -327,10 +327,19 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       for (int i = 0; i < R; ++i) {
         const uint32_t base = row0 + i * 64;
         const uint32_t rows = (base < p.N) ? ((p.N - base < 64u) ? p.N - base : 64u) : 0u;
-        for (uint32_t r = 0; r < rows; ++r) {
-          const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), r));
-          if (col < W) acc = __builtin_fmaf(er, src[(size_t)(i * 64 + r) * W + col], acc);
+        // eight independent row loads in flight per batch: the pass is bound by load latency, not by its arithmetic
+        const float* __restrict__ colp = src + (size_t)(i * 64) * W + (col < W ? col : 0u);
+        uint32_t r = 0;
+        for (; r + 8 <= rows; r += 8) {
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = colp[(size_t)(r + u) * W];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), r + u)), x[u], acc);
         }
+        for (; r < rows; ++r)
+          acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), r)), colp[(size_t)r * W], acc);
       }
       if (col < W) my_bsum[col] = acc;
     }
@@ -705,10 +714,18 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
     for (uint32_t c0 = 0; c0 < W; c0 += 64) {
       const uint32_t col = c0 + lane;
       float acc = 0.0f;
-      for (uint32_t r = 0; r < rows; ++r) {
-        const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
-        if (col < W) acc = __builtin_fmaf(er, src[(size_t)r * W + col], acc);
+      const float* __restrict__ colp = src + (col < W ? col : 0u);
+      uint32_t r = 0;
+      for (; r + 8 <= rows; r += 8) {                      // eight independent row loads in flight (latency-bound pass)
+        float xr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xr[u] = colp[(size_t)(r + u) * W];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r + u)), xr[u], acc);
       }
+      for (; r < rows; ++r)
+        acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r)), colp[(size_t)r * W], acc);
       if (col < W) my_bsum[col] = acc;
     }
   }
