@@ -1204,7 +1204,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
       misaligned(a->Q_out))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_step: misaligned pointer");
   if (int rc = ensure_device(h)) return rc;
-  StepPtrs p;
+  StepPtrs p{};
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
   p.L = a->L; p.noise = a->noise; p.prev_in = a->previous_input; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
   p.offset_dev = (a->noise_kind == CPMPPI_NOISE_PHILOX) ? (const unsigned long long*)a->offset_dev : nullptr;
@@ -1447,7 +1447,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   Params prm = h->prm;
   prm.shift_mode = CPMPPI_SHIFT_NONE;
   prm.cc_weight = 0.0f;
-  StepPtrs p;
+  StepPtrs p{};
   p.s0 = s0; p.u_nom = h->zeros_H; p.u_prev = nullptr; p.x_t = target_position; p.te = target_equilibrium; p.L = L;
   p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.offset_dev = nullptr; p.env_offset = 0; p.stash = 0;
   uint32_t rpl = h->cfg.rollouts_per_lane;
