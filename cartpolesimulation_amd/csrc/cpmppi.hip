@@ -218,9 +218,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       }
     }
   } else {
-    // Philox: one block yields the knots of a PAIR (2q, 2q+1); the odd one is kept until it is needed.  Every knot is
+    // Philox: one block yields FOUR consecutive knots (4q .. 4q+3); the other three are kept until needed.  Every knot is
     // also parked in LDS (when it fits) so that the soft-min reduction below does not generate the sequence again.
-    float z_odd[R];
+    float z_next[R][3];
     float* __restrict__ kstash = bsum + WAVES * a.W + tid;
     auto knot = [&](int i, uint32_t j) __attribute__((always_inline)) -> float {
       const uint32_t nn = valid[i] ? n[i] : 0;
@@ -228,13 +228,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         return a.noise[((size_t)env * p.N + nn) * p.P + j];
       } else {
         float z;
-        if ((j & 1u) == 0u) {
-          float z0, z1;
-          philox_normal_pair(a.seed, step_offset, a.env_offset + env, nn, j >> 1, z0, z1);
-          z_odd[i] = p.sigma * z1;
-          z = p.sigma * z0;
+        const uint32_t s = j & 3u;
+        if (s == 0u) {
+          float zq[4];
+          philox_normal_quad(a.seed, step_offset, a.env_offset + env, nn, j >> 2, zq);
+          z = p.sigma * zq[0];
+          z_next[i][0] = p.sigma * zq[1]; z_next[i][1] = p.sigma * zq[2]; z_next[i][2] = p.sigma * zq[3];
         } else {
-          z = z_odd[i];
+          z = (s == 1u) ? z_next[i][0] : ((s == 2u) ? z_next[i][1] : z_next[i][2]);
         }
         if (a.stash) kstash[(j * R + i) * BLOCK] = z;
         return z;
@@ -407,10 +408,18 @@ __global__ __launch_bounds__(BLOCK) void sample_kernel(const Params p, uint32_t 
   float* __restrict__ mine = kn_lds + (wave * 64 + lane) * stride;
   if (r < total) {
     const uint32_t env = (uint32_t)(r / p.N), n = (uint32_t)(r % p.N);
-    for (uint32_t j = 0; j < p.P; ++j) {
-      const float z = knots_in ? knots_in[r * p.P + j] : philox_knot(seed, offset, env_offset + env, n, j, p.sigma);
-      mine[j] = z;
-      if (knots_out) knots_out[r * p.P + j] = z;
+    for (uint32_t j0 = 0; j0 < p.P; j0 += 4) {
+      float zq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!knots_in) philox_normal_quad(seed, offset, env_offset + env, n, j0 >> 2, zq);
+#pragma unroll
+      for (uint32_t s = 0; s < 4; ++s) {
+        const uint32_t j = j0 + s;
+        if (j < p.P) {
+          const float z = knots_in ? knots_in[r * p.P + j] : p.sigma * zq[s];
+          mine[j] = z;
+          if (knots_out) knots_out[r * p.P + j] = z;
+        }
+      }
     }
   }
   if (!du_out) return;

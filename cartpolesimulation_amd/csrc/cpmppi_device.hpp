@@ -172,7 +172,10 @@ __device__ __forceinline__ void sincos_pi_half(F x, F& sn, F& cs) {
   F r = fma_(-q, splat<F>(PI_HI), x);
   r = fma_(-q, splat<F>(PI_LO), r);
   const F z = r * r;
-  const F sg = fma_(abs_(q), splat<F>(-2.0f), splat<F>(1.0f));
+  // (-1)^q for q in {-1, 0, 1}: 1 - 2|q|; packed float2 has no abs modifier, there q*q is one instruction instead of two
+  F sg;
+  if constexpr (Width<F>::value == 2) sg = fma_(q * q, splat<F>(-2.0f), splat<F>(1.0f));
+  else sg = fma_(abs_(q), splat<F>(-2.0f), splat<F>(1.0f));
   F P = fma_(z, splat<F>(2.6056311526190257e-06f), splat<F>(-0.00019809538207482547f));
   P = fma_(P, z, splat<F>(0.008333065547049046f));
   P = fma_(P, z, splat<F>(-0.16666659712791443f));
@@ -591,9 +594,9 @@ __device__ __forceinline__ F terminal_indicator(const Params& p, F angle, F x, f
 // MPPI correction term, algebra of controller_mppi_cartpole.py:261-263
 template <class F>
 __device__ __forceinline__ F mppi_correction(const Params& p, F u, F du) {
-  const float half_nu = 0.5f * (1.0f - 1.0f / p.NU) * p.R;
-  return ((du * du) * splat<F>(half_nu) + (u * du) * splat<F>(p.R) + (u * u) * splat<F>(0.5f * p.R)) *
-         splat<F>(p.cc_weight);
+  // cc_weight (0.5 (1 - 1/NU) R du^2 + R u du + 0.5 R u^2)  =  du (a du + b u) + c u^2   with the weight folded in
+  const float a = p.cc_weight * (0.5f * (1.0f - 1.0f / p.NU) * p.R), b = p.cc_weight * p.R, c = p.cc_weight * (0.5f * p.R);
+  return fma_(u * splat<F>(c), u, du * fma_(du, splat<F>(a), u * splat<F>(b)));
 }
 
 // controller_mppi_cartpole.py:227-275 (q); w = {dd, ep, ekp, ekc, cc, ccrc}; u = nominal control of the stage
@@ -650,12 +653,28 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint64_t offse
   z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-// Knot j of (env, rollout) scaled by sigma.
+// All four words of a Philox block: two Box-Muller pairs = the four consecutive knots 4q .. 4q+3 of (env, rollout).
+__device__ __forceinline__ void philox_normal_quad(uint64_t seed, uint64_t offset, uint32_t env, uint32_t rollout,
+                                                   uint32_t quad, float z[4]) {
+  uint32_t c0 = rollout, c1 = env, c2 = quad, c3 = (uint32_t)offset;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed ^ 0x51ed270bu, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32));
+  const float ua = (float)((c0 >> 8) + 1u) * 5.9604644775390625e-8f, ub = (float)(c1 >> 8) * 5.9604644775390625e-8f;
+  const float uc = (float)((c2 >> 8) + 1u) * 5.9604644775390625e-8f, ud = (float)(c3 >> 8) * 5.9604644775390625e-8f;
+  const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ua));
+  const float rc = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(uc));
+  z[0] = ra * __builtin_amdgcn_cosf(ub);
+  z[1] = ra * __builtin_amdgcn_sinf(ub);
+  z[2] = rc * __builtin_amdgcn_cosf(ud);
+  z[3] = rc * __builtin_amdgcn_sinf(ud);
+}
+
+// Knot j of (env, rollout) scaled by sigma (random access; sequential consumers keep the other three of the block).
 __device__ __forceinline__ float philox_knot(uint64_t seed, uint64_t offset, uint32_t env, uint32_t rollout,
                                              uint32_t j, float sigma) {
-  float z0, z1;
-  philox_normal_pair(seed, offset, env, rollout, j >> 1, z0, z1);
-  return sigma * ((j & 1u) ? z1 : z0);
+  float z[4];
+  philox_normal_quad(seed, offset, env, rollout, j >> 2, z);
+  const uint32_t s = j & 3u;
+  return sigma * (s == 0u ? z[0] : (s == 1u ? z[1] : (s == 2u ? z[2] : z[3])));
 }
 
 // Linear interpolation between knots as scipy interp1d does it at controller_mppi_cartpole.py:444-445:

