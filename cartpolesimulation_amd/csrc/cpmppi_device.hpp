@@ -470,8 +470,9 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
   // is re-tested.  Lanes beyond the range are flagged and take the exact sincos on every substep.
 #if CPMPPI_INCR_ROT
   F xlim;
+  const float wlim = 0.1f / t;                  // |w t| > 0.1 as one compare with a free abs modifier per lane
 #pragma unroll
-  for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) * t > 0.1f) ? -1.0f : p.THL);
+  for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
   F cd, sd;
   rot_seed<F>(st.w * splat<F>(t), cd, sd);
   for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F>(st, uK, t, p, e, cd, sd, xlim);
