@@ -273,7 +273,7 @@ def main():
                               (algorithmic_flops_per_rollout(H) + 2.0 * 10 * H * 30.0),
                               "kernel_rollouts_per_s": E * N / (k_ms * 1e-3)},
         }
-        if not args.no_single_env:
+        if not args.no_single_env and world == 1:
             # latency of ONE problem instance (BASELINE configs[1] literally: single env), same kernels
             e1 = MPPIEngine(1, cfg, device=local_rank)
             if args.predictor == "gru":
@@ -300,7 +300,7 @@ def main():
                                  "rollout_kernel_us": float(np.median(r1)) * 1e3,
                                  "finalize_kernel_us": float(np.median(f1)) * 1e3,
                                  "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time from HIP events"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             out["cpu_baseline"] = cpu_baseline(N, H)
         print(json.dumps(out), flush=True)
     if distributed:
