@@ -170,3 +170,55 @@ def test_cem_family_bookkeeping(fake_engine):
     assert u.shape == (E, 1) and J.shape == (E, 16) and np.abs(u).max() <= 1.0
     with pytest.raises(ValueError):
         ra.step(_states(E + 1))
+
+
+def _fake_step(self, s0, u_nom, tp, te, L=None, delta_u=None, knots=None, seed=None, offset=0, env_offset=0, u_prev=None,
+               Q_out=None, S_out=None, predictor="ODE_v0", h0=None, previous_input=None, offset_dev=None):
+    """MPPIEngine.step on the numpy oracle (default flags of MPPIConfig), in-place on u_nom like the real one."""
+    E = u_nom.shape[0]
+    s0 = self.tensor(s0).reshape(E, 6).numpy()
+    tp = np.broadcast_to(np.asarray(tp, dtype=np.float32).reshape(-1), (E,)) if np.size(tp) in (1, E) else tp
+    te = np.broadcast_to(np.asarray(te, dtype=np.float32).reshape(-1), (E,))
+    cfg = O.MPPIConfig(N=self.N, H=self.H)
+    if Q_out is None:
+        Q_out = self.empty(E)
+    for e in range(E):
+        rng = np.random.Generator(np.random.SFC64([int(seed), int(offset), int(env_offset) + e]))
+        du = O.sample_delta_u(rng, self.N, self.H, np.float64(cfg.stdev))
+        out = O.mppi_step(s0[e], u_nom[e].numpy(), du, float(tp[e]), float(te[e]), cfg,
+                          L=None if L is None else float(np.asarray(L).reshape(-1)[e]))
+        u_nom[e] = torch.as_tensor(out["u_new"])
+        Q_out[e] = float(out["Q"])
+        if S_out is not None:
+            S_out[e] = torch.as_tensor(out["S"])
+    self.calls["step"] = self.calls.get("step", 0) + 1
+    self.last_kwargs = dict(previous_input=previous_input, L=L, tp=np.array(tp), te=np.array(te))
+    return Q_out, S_out
+
+
+def test_controller_mpc_and_optimizer_mppi_host_logic(fake_engine, monkeypatch):
+    """The controller seam end to end on CPU: attribute updates reach the optimizer, the nominal sequence is carried and
+    shifted by the step, logging mirrors the reference's keys, reset clears the plan."""
+    monkeypatch.setattr(FakeEngine, "step", _fake_step, raising=False)
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    ctrl = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
+                          control_limits=(np.array([-1.0], np.float32), np.array([1.0], np.float32)),
+                          config=dict(seed=9, num_rollouts=64, mpc_horizon=10))
+    ctrl.configure("mppi", controller_logging=True)
+    opt = ctrl.optimizer
+    assert ctrl.has_optimizer and opt.optimizer_name == "mppi" and opt.num_rollouts == 64 and opt.mpc_horizon == 10
+    s = O.create_cartpole_state(0.2, 0.0, 0.0, 0.0)
+    q1 = ctrl.step(s, 0.0, {"target_position": 0.05, "L": 0.3})
+    assert np.asarray(q1).shape == (1,) and abs(float(q1[0])) <= 1.0
+    assert np.allclose(opt.engine.last_kwargs["tp"], 0.05) and np.allclose(np.asarray(opt.engine.last_kwargs["L"]), 0.3)
+    assert set(ctrl.controller_data_for_csv) >= {"Q_logged", "J_logged", "u_logged"}
+    assert ctrl.controller_data_for_csv["J_logged"].shape == (1, 64)
+    u_after_1 = opt.u_nom.clone()
+    q2 = ctrl.step(s, 0.02, {})
+    assert opt.engine.calls["step"] == 2 and opt.step_counter == 2
+    assert float(q2[0]) == float(opt.u_nom[0, 0]) and not torch.equal(opt.u_nom, u_after_1)
+    assert np.allclose(opt.engine.last_kwargs["tp"], 0.05)            # attributes persist until updated again
+    ctrl.controller_reset()
+    assert float(opt.u_nom.abs().max()) == 0.0 and opt.step_counter == 0
+    with pytest.raises(ValueError):
+        opt.step(np.zeros((3, 6), np.float32))                        # configured for one env
