@@ -1,0 +1,40 @@
+"""GPU: randomised differential parity of the fused step against the C oracle (a small cut of tools/fuzz_parity.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402
+from oracle import oracle_c as OC  # noqa: E402
+
+
+@pytest.mark.parametrize("math,rpl", [("fast", 1), ("fast", 2), ("precise", 1)])
+def test_random_instances_against_the_c_oracle(math, rpl):
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, N, H, THL = 32, 1024, 50, 0.198
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=rpl))
+    cfg_c = OC.make_config(O.MPPIConfig(N=N, H=H))
+    rng = np.random.Generator(np.random.SFC64(2024))
+    rels, devs = [], []
+    for b in range(2):
+        ang = rng.uniform(-np.pi, np.pi, E)
+        s0 = np.zeros((E, 6), np.float32)
+        s0[:, 0], s0[:, 1] = ang, rng.uniform(-12, 12, E)
+        s0[:, 2], s0[:, 3] = np.cos(ang), np.sin(ang)
+        s0[:, 4], s0[:, 5] = rng.uniform(-0.9, 0.9, E) * THL, rng.uniform(-0.6, 0.6, E)
+        tp = (rng.uniform(-0.8, 0.8, E) * THL).astype(np.float32)
+        te = np.where(rng.uniform(size=E) < 0.8, 1.0, -1.0).astype(np.float32)
+        Lv = rng.uniform(0.2, 0.5, E).astype(np.float32)
+        u0 = np.clip(0.3 * rng.standard_normal((E, H)), -1, 1).astype(np.float32)
+        _, du = eng.sample(seed=50 + b, offset=b, knots=False, delta_u=True)
+        un = eng.tensor(u0.copy())
+        S = eng.empty(E, N)
+        eng.step(s0, un, tp, te, L=Lv, delta_u=du, S_out=S)
+        u_ref, _, S_ref = OC.step(cfg_c, s0, u0, du.cpu().numpy(), tp, te, L=Lv)
+        rels.append((np.abs(S.cpu().numpy() - S_ref) / np.abs(S_ref)).reshape(-1))
+        devs.append(np.abs(un.cpu().numpy() - u_ref).max(axis=1))
+    r, d = np.concatenate(rels), np.concatenate(devs)
+    assert np.median(r) < 1e-6 and np.percentile(r, 99) < 5e-5 and np.mean(r < 1e-4) >= 0.999, (np.median(r), np.percentile(r, 99))
+    assert (d < 1e-4).mean() >= 0.95 and np.median(d) < 1e-5, d.max()
