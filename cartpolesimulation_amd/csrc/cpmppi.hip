@@ -43,6 +43,7 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
 #endif
+constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
 constexpr int TK = CPMPPI_TK;                // time-steps per LDS perturbation tile
 constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
 
@@ -1083,6 +1084,9 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   fill_params(*cfg, h->prm);
   h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
   if (const char* ev = getenv("CPMPPI_FUSE_FINALIZE")) h->fuse_finalize = ev[0] != '0';
+  (void)hipSetDevice(device);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)SAMPLER_LDS_MAX);
   const uint32_t Wmax = cfg->H > h->prm.P ? cfg->H : h->prm.P;
   h->workspace_floats = (size_t)cfg->E * h->nb * (2 + Wmax);
   h->workspace = nullptr;
@@ -1137,8 +1141,8 @@ int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, 
   if (E == 0 || E > h->cfg.E || (!knots_out && !delta_u_out))
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: E out of range or no output buffer");
   if (misaligned(knots_out) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_sample: misaligned");
-  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > 65536)
-    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: more than 63 knots per rollout are not supported");
+  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > SAMPLER_LDS_MAX)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: more than 154 knots per rollout are not supported");
   if (int rc = ensure_device(h)) return rc;
   const size_t rows = (size_t)E * h->cfg.N;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK),
@@ -1153,8 +1157,8 @@ int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* 
   if (E == 0 || E > h->cfg.E || !knots || !delta_u_out)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: bad argument");
   if (misaligned(knots) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_interpolate: misaligned");
-  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > 65536)
-    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: more than 63 knots per rollout are not supported");
+  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > SAMPLER_LDS_MAX)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: more than 154 knots per rollout are not supported");
   if (int rc = ensure_device(h)) return rc;
   const size_t rows = (size_t)E * h->cfg.N;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK),

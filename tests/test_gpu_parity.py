@@ -328,10 +328,14 @@ def test_limits_and_bad_arguments():
     Q, _ = e2.step(np.tile(s0, (E, 1)), u2, 0.0, 1.0, seed=3)
     q = Q.cpu().numpy()
     assert np.isfinite(q).all() and len(np.unique(np.round(q, 7))) > E * 0.9
-    # more than 63 knots per rollout is outside the device sampler's LDS budget -> clean error, not a crash
+    # the device sampler stages [256][P+1] knots in LDS: 101 knots (H = 100, one per step) fit the 160 KB of gfx950 and
+    # match the oracle's interpolation; more than 154 per rollout -> clean error, not a crash
     e3 = engine(1, 8, 100, period_interpolation_inducing_points=1)
+    kn3, du3 = e3.sample(seed=1, knots=True, delta_u=True)
+    np.testing.assert_allclose(du3.cpu().numpy()[0], O.interpolate_knots(kn3.cpu().numpy()[0], 100, period=1), atol=2e-7)
+    e4 = engine(1, 8, 200, period_interpolation_inducing_points=1)
     with pytest.raises(L.CpmppiError):
-        e3.sample(seed=1)
+        e4.sample(seed=1)
     # a pointer that is not 4-byte aligned is refused
     a = L.cpmppi_step_args()
     buf = e2.zeros(64)
