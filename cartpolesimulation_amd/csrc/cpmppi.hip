@@ -1087,6 +1087,13 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   (void)hipSetDevice(device);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)SAMPLER_LDS_MAX);
+  // the adjoint kernel parks S x 6 x 256 sub-states in LDS (61 KB at S = 10; more substeps need the opt-in as well)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_QBGM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_DEFAULT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_QBG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
   const uint32_t Wmax = cfg->H > h->prm.P ? cfg->H : h->prm.P;
   h->workspace_floats = (size_t)cfg->E * h->nb * (2 + Wmax);
   h->workspace = nullptr;

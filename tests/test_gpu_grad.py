@@ -144,3 +144,16 @@ def test_gradient_optimizers_through_the_controller_seam(name):
         eng.plant_advance(s, Q, L=Lv, n_substeps=10)
     sh = s.cpu().numpy()
     assert (np.abs(sh[:, O.ANGLE_IDX]) < 0.35).mean() >= 0.75 and np.abs(sh[:, O.POSITION_IDX]).max() < 0.198
+
+
+def test_gradient_with_more_substeps_than_the_default_lds_budget():
+    """intermediate_steps = 20 needs 120 KB of LDS for the sub-states: launches (160 KB opt-in) and matches autograd."""
+    E, N, H = 1, 8, 6
+    eng = make(E, N, H, intermediate_steps=20)
+    s0, tp, Lv, rng = envs(E, 5)
+    Q = (0.4 * rng.standard_normal((E, N, H))).astype(f32)
+    S, G = eng.rollout_cost_grad(s0, Q, tp, np.ones(E, f32), L=Lv)
+    J, g = OT.cost_and_grad(O.COST_QBGM, s0[0], Q[0], tp[0], 1.0, L=Lv[0], S=20)
+    np.testing.assert_allclose(S.cpu().numpy()[0], J, rtol=5e-4)
+    scale = np.abs(g).max(axis=1, keepdims=True) + 1e-6
+    assert (np.abs(G.cpu().numpy()[0] - g) / scale).max() < 2e-3
