@@ -1262,6 +1262,12 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     const dim3 grid(a->E * p.nb);
 #define CPMPPI_GRU_LAUNCH(COST, NOISE)                                                                                  \
     do {                                                                                                                \
+      if (lds > 64 * 1024) {   /* long horizons with a perturbation buffer: weights image + [WAVES][H] sums */          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_rollout_cost_kernel<COST, NOISE, true>),          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_rollout_cost_kernel<COST, NOISE, false>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);                    \
+      }                                                                                                                 \
       if (f16) hipLaunchKernelGGL((gru_rollout_cost_kernel<COST, NOISE, true>), grid, dim3(BLOCK), lds, s, h->prm, p,  \
                                   h->gru_norm, (const float*)h->gru16_image, a->h0);                                    \
       else hipLaunchKernelGGL((gru_rollout_cost_kernel<COST, NOISE, false>), grid, dim3(BLOCK), lds, s, h->prm, p,     \
