@@ -96,3 +96,33 @@ def test_other_discretisations(S, dt, period, H, rpl):
     for o in outs[1:]:                                     # the three noise sources describe the same perturbations
         np.testing.assert_allclose(o[0], outs[0][0], rtol=3e-5)
         np.testing.assert_allclose(o[1], outs[0][1], atol=1e-5)
+
+
+@pytest.mark.parametrize("rpl", [1, 2])
+def test_other_physical_parameters(rpl):
+    """A different cart (heavier pole, lighter friction, stronger motor, longer track, another inertia factor): the
+    folded per-env constants of the FAST path must follow (cartpole_physical_parameters.yml values are not baked in)."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig, PhysicalParameters
+    f = lambda v: float(np.float32(v))  # noqa: E731
+    phys = PhysicalParameters(k=f(0.4), m_cart=f(0.31), m_pole=f(0.15), g=f(9.81), J_fric=f(2.0e-4), M_fric=f(1.1), L=f(0.5),
+                              u_max=f(2.5), TrackHalfLength=f(0.25))
+    p = O.CartPoleParams(k=np.float32(0.4), m_cart=np.float32(0.31), m_pole=np.float32(0.15), g=np.float32(9.81),
+                         J_fric=np.float32(2.0e-4), M_fric=np.float32(1.1), L=np.float32(0.5), u_max=np.float32(2.5),
+                         TrackHalfLength=np.float32(0.25))
+    E, N, H = 3, 512, 40
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=rpl), phys)
+    rng = np.random.Generator(np.random.SFC64(12))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1.5, 1.5), rng.uniform(-4, 4), rng.uniform(-0.2, 0.2), rng.uniform(-0.4, 0.4))
+                   for _ in range(E)])
+    tp, te = rng.uniform(-0.1, 0.1, E).astype(np.float32), np.ones(E, np.float32)
+    Lv = np.asarray([0.5, 0.35, 0.6], np.float32)
+    u0 = (0.2 * rng.standard_normal((E, H))).astype(np.float32)
+    _, du = eng.sample(seed=2, offset=0, knots=False, delta_u=True)
+    un = eng.tensor(u0.copy())
+    S = eng.empty(E, N)
+    eng.step(s0, un, tp, te, L=Lv, S_out=S, delta_u=du)
+    u_ref, _, S_ref = OC.step(OC.make_config(O.MPPIConfig(N=N, H=H), p), s0, u0, du.cpu().numpy(), tp, te, L=Lv)
+    rel = np.abs(S.cpu().numpy() - S_ref) / np.abs(S_ref)
+    assert np.median(rel) < 1e-5 and (rel < 1e-3).mean() > 0.98, (np.median(rel), rel.max())
+    np.testing.assert_allclose(un.cpu().numpy(), u_ref, atol=1e-4)
