@@ -55,17 +55,17 @@ if ks:
         open(os.path.join(dst, "bench_line_under_rocprof_gru.json"), "w").write(lines[-1])
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 
-# HBM traffic of the dominant kernel per launch: (FETCH_SIZE + WRITE_SIZE) KiB * 1024 (MI355X_MICROARCH.md §HBM).
-# The x2 FETCH_SIZE correction of that guide is calibrated for 16 B/lane streaming reads; this kernel issues 4 B/lane
-# loads in 32-byte row segments (buffer mode) or almost no loads (philox mode), so the raw value is recorded together
-# with the doubled one as an upper bound.
+# HBM-side traffic of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+# one half of the bytes of a coalesced read (MI355X_MICROARCH.md, HBM).  tools/dev/fetch_calib.hip confirmed the same
+# factor for this library's 4-byte-per-lane loads (1 GiB read once -> FETCH_SIZE 0.5 GiB), so the reported figure is
+# 2 x FETCH_SIZE + WRITE_SIZE; the raw sum is kept beside it.
 rec = {}
 for noise, out in summary.items():
     for k, c in out.items():
         if k.startswith("rollout_cost_kernel") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             f, w = c["FETCH_SIZE"]["mean_per_launch"] * 1024, c["WRITE_SIZE"]["mean_per_launch"] * 1024
-            rec[noise] = {"kernel": k, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
-                          "hbm_bytes_per_launch_fetch_doubled": 2 * f + w}
+            rec[noise] = {"kernel": k, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
+                          "hbm_bytes_per_launch_uncorrected": f + w}
 bench = {}
 for noise in rec:
     p = os.path.join(dst, f"bench_line_under_rocprof_{noise}.json")
