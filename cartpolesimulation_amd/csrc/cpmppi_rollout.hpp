@@ -1,0 +1,376 @@
+// cpmppi_rollout.hpp — the hot path: rollout_cost_kernel and what it shares with the other kernels (launch
+// descriptor, nominal-sequence shift, the per-env finalize).  A header because the kernel is instantiated in two
+// translation units compiled with different instruction-scheduling strategies (see cpmppi_rollout_r1.hip /
+// cpmppi_rollout_r2.hip): the one-rollout-per-lane mapping is bound by the latency of a single wave's instruction
+// stream, the packed two-rollout mapping by issue throughput, and the compiler's schedulers differ measurably on them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cpmppi.h"
+#include "cpmppi_device.hpp"
+
+namespace cpmppi_k {
+using namespace cpmppi;
+
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+#ifndef CPMPPI_TK
+#define CPMPPI_TK 8
+#endif
+#ifndef CPMPPI_GRU_STAGGER
+#define CPMPPI_GRU_STAGGER 0
+#endif
+#ifndef CPMPPI_GRU_MIN_WAVES
+#define CPMPPI_GRU_MIN_WAVES 2      // waves per SIMD the GRU kernels are compiled for (register budget 512 / this)
+#endif
+#ifndef CPMPPI_MIN_WAVES
+#define CPMPPI_MIN_WAVES 1
+#endif
+constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
+constexpr int TK = CPMPPI_TK;                // time-steps per LDS perturbation tile
+constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
+
+struct StepPtrs {
+  const float* s0;
+  const float* u_nom;
+  const float* u_prev;
+  const float* x_t;
+  const float* te;
+  const float* L;
+  const float* noise;
+  const float* prev_in; // [E] control applied before this step (quadratic_boundary_grad ccrc) or NULL
+  uint64_t seed, offset;
+  const unsigned long long* offset_dev;   // if set: the Philox step counter lives in device memory (graph replay)
+  uint32_t stash;       // NOISE_PHILOX: the generated knots are parked in LDS ([P][R][BLOCK] after the weighted sums) for the reduction
+  uint32_t env_offset;
+  uint32_t nb;          // blocks per env
+  uint32_t W;           // width of the weighted-sum vector (H in delta_u space, P in knot space)
+  float* S_out;
+  float* partial;       // [E][nb][2 + W]
+  uint32_t* counter;    // [E] arrival tickets of the env's blocks (0 between launches); NULL = separate finalize kernel
+  float* u_nom_out;     // fused finalize: where the updated nominal sequence goes (== u_nom)
+  float* Q_out;
+};
+
+// Nominal control for stage k after the configured shift (a18).
+__device__ __forceinline__ float shifted_nominal(const Params& p, const float* __restrict__ un, uint32_t k) {
+  if (p.shift_mode == CPMPPI_SHIFT_NONE) return un[k];
+  if (k + 1 < p.H) return un[k + 1];
+  return (p.shift_mode == CPMPPI_SHIFT_REPEAT_LAST) ? un[p.H - 1] : 0.0f;
+}
+
+// Merge the per-block partials of one env (rescaled to the env-wide minimum), apply shift / update / clip, write u_nom
+// and Q.  Executed by one whole block.  COHERENT = the partials were written by other workgroups of THIS launch: read
+// them with agent-scope (sc1) loads that bypass this CU's L1.
+template <bool KNOT_SPACE, bool COHERENT>
+__device__ __forceinline__ void finalize_env(const Params& p, const float* partial, uint32_t nb, uint32_t W,
+                                             float* __restrict__ u_nom, float* __restrict__ Q_out, uint32_t env) {
+  __shared__ float u_new[CPMPPI_MAX_HORIZON];
+  __shared__ float bz[KNOT_SPACE ? (CPMPPI_MAX_HORIZON + 2) : 1];
+  const uint32_t tid = threadIdx.x, H = p.H;
+  const float* pe = partial + (size_t)env * nb * (2 + W);
+  auto ld = [&](size_t i) -> float {
+    if constexpr (COHERENT) return __hip_atomic_load(pe + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return pe[i];
+  };
+  float M = INFINITY;
+  for (uint32_t b = 0; b < nb; ++b) M = fminf(M, ld((size_t)b * (2 + W)));
+  float a = 0.0f;
+  for (uint32_t b = 0; b < nb; ++b) a += ld((size_t)b * (2 + W) + 1) * expf((-1.0f / p.LBD) * (ld((size_t)b * (2 + W)) - M));
+  auto merged = [&](uint32_t c) {
+    float v = 0.0f;
+    for (uint32_t b = 0; b < nb; ++b)
+      v = __builtin_fmaf(ld((size_t)b * (2 + W) + 2 + c), expf((-1.0f / p.LBD) * (ld((size_t)b * (2 + W)) - M)), v);
+    return v;
+  };
+  if constexpr (KNOT_SPACE) {
+    for (uint32_t c = tid; c < W; c += BLOCK) bz[c] = merged(c);
+    __syncthreads();
+  }
+  float* __restrict__ un = u_nom + (size_t)env * H;
+  for (uint32_t k = tid; k < H; k += BLOCK) {
+    float bk;
+    if constexpr (KNOT_SPACE) {
+      const uint32_t j = k / p.period, i = k % p.period;
+      bk = bz[j] + (bz[j + 1] - bz[j]) * ((float)i / (float)p.period);
+    } else {
+      bk = merged(k);
+    }
+    float v = shifted_nominal(p, un, k) + bk / a;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) v = fminf(fmaxf(v, p.lo), p.hi);
+    u_new[k] = v;
+  }
+  __syncthreads();                          // every read of the old nominal sequence is done
+  for (uint32_t k = tid; k < H; k += BLOCK) un[k] = u_new[k];
+  if (tid == 0 && Q_out) Q_out[env] = u_new[0];
+}
+
+// The hot path.  R = rollouts per lane (1: latency mapping, 2: packed float2 throughput mapping, FAST only).
+// A block of 256 threads owns 256*R consecutive rollouts of one env; wave w owns rows [w*64*R, (w+1)*64*R) and lane l
+// integrates rows l (component 0) and l+64 (component 1).
+template <int COST, bool FAST, int NOISE, int R>
+__global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
+  using F = typename Lanes<R>::F;
+  static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");
+  __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * R * TILE_STRIDE : 1];
+  __shared__ float red[2 * WAVES];
+  extern __shared__ float bsum[];            // [WAVES][W]
+
+  const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t row0 = blk * (BLOCK * R) + wave * (64 * R);     // first rollout of this wave
+  uint32_t n[R];
+  bool valid[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) { n[i] = row0 + i * 64 + lane; valid[i] = n[i] < p.N; }
+  const uint32_t H = p.H;
+  const uint64_t step_offset = a.offset_dev ? (uint64_t)*a.offset_dev : a.offset;
+
+  // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
+  const float L = a.L ? a.L[env] : p.L_default;
+  const EnvConst ec = make_env_const_uniform(p, L);
+  const float x_t = a.x_t[env], te = a.te[env];
+  const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
+  const float* __restrict__ un = a.u_nom + (size_t)env * H;
+  const float* __restrict__ up = (a.u_prev ? a.u_prev : a.u_nom) + (size_t)env * H;
+  State<F> st{splat<F>(s0[0]), splat<F>(s0[1]), splat<F>(s0[2]), splat<F>(s0[3]), splat<F>(s0[4]), splat<F>(s0[5])};
+
+  F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
+  F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
+  F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+
+  auto control_step = [&](uint32_t k, F du) __attribute__((always_inline)) {
+    const float uk = shifted_nominal(p, un, k);
+    F ur = splat<F>(uk) + du;
+    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
+    if constexpr (COST == COST_QBGM) {
+      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te);
+      corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
+    } else if constexpr (COST == COST_DEFAULT) {
+      cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
+      corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
+    } else if constexpr (COST == COST_QBG) {
+      cost += stage_qbg<F, FAST>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
+      corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
+      u_before = ur;
+    } else {
+      cost += stage_legacy<F, FAST>(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
+    }
+    const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
+    if constexpr (FAST) {
+      const F uK = u * splat<F>(ec.kp1);
+      control_step_fast<F>(st, uK, p.S, p.t_step, p, ec);
+    } else {
+      for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
+    }
+    cosang = st.c;
+  };
+
+  // ---- rollout over the horizon ----------------------------------------------------------------------------------
+  if constexpr (NOISE == NOISE_DELTA_U) {
+    // The 64*R rollouts of a wave are one contiguous span of 64*R*H floats in delta_u[E,N,H]; a tile of TK time-steps
+    // is fetched in whole row segments (TK*4 bytes per row), parked in registers while the previous tile is
+    // integrated, then written to LDS and read back one row per lane (odd row stride: conflict-free).
+    constexpr int NLOAD = R * TK;            // elements per lane per tile
+    const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * H;
+    float* __restrict__ my_tile = tile + wave * (64 * R * TILE_STRIDE);
+    float pre[NLOAD];
+    auto gload = [&](uint32_t k0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
+        const uint32_t k = k0 + col;
+        pre[i] = (row0 + row < p.N && k < H) ? src[(size_t)row * H + k] : 0.0f;
+      }
+    };
+    gload(0);
+    for (uint32_t k0 = 0; k0 < H; k0 += TK) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
+        my_tile[row * TILE_STRIDE + col] = pre[i];
+      }
+      __syncthreads();
+      if (k0 + TK < H) gload(k0 + TK);
+      const uint32_t kend = (H - k0 < (uint32_t)TK) ? (H - k0) : (uint32_t)TK;
+      for (uint32_t kk = 0; kk < kend; ++kk) {
+        F du;
+#pragma unroll
+        for (int i = 0; i < R; ++i) put(du, i, my_tile[(i * 64 + lane) * TILE_STRIDE + kk]);
+        control_step(k0 + kk, du);
+      }
+    }
+  } else {
+    // Philox: one block yields FOUR consecutive knots (4q .. 4q+3); the other three are kept until needed.  Every knot is
+    // also parked in LDS (when it fits) so that the soft-min reduction below does not generate the sequence again.
+    float z_next[R][3];
+    float* __restrict__ kstash = bsum + WAVES * a.W + tid;
+    auto knot = [&](int i, uint32_t j) __attribute__((always_inline)) -> float {
+      const uint32_t nn = valid[i] ? n[i] : 0;
+      if constexpr (NOISE == NOISE_KNOTS) {
+        return a.noise[((size_t)env * p.N + nn) * p.P + j];
+      } else {
+        float z;
+        const uint32_t s = j & 3u;
+        if (s == 0u) {
+          float zq[4];
+          philox_normal_quad(a.seed, step_offset, a.env_offset + env, nn, j >> 2, zq);
+          z = p.sigma * zq[0];
+          z_next[i][0] = p.sigma * zq[1]; z_next[i][1] = p.sigma * zq[2]; z_next[i][2] = p.sigma * zq[3];
+        } else {
+          z = (s == 1u) ? z_next[i][0] : ((s == 2u) ? z_next[i][1] : z_next[i][2]);
+        }
+        if (a.stash) kstash[(j * R + i) * BLOCK] = z;
+        return z;
+      }
+    };
+    constexpr bool F32_INTERP = FAST && NOISE == NOISE_PHILOX;       // our own noise: one FMA instead of the f64 form
+    const float inv_period = 1.0f / (float)p.period;
+    float z_lo[R], z_hi[R], slope32[R];
+    double slope[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      z_lo[i] = knot(i, 0); z_hi[i] = knot(i, 1);
+      if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
+      else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
+    }
+    uint32_t ii = 0, j = 0;
+    for (uint32_t k = 0; k < H; ++k) {
+      F du;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        if constexpr (F32_INTERP) put(du, i, interp_from_slope32(slope32[i], z_lo[i], ii));
+        else put(du, i, interp_from_slope(slope[i], z_lo[i], ii));
+      }
+      control_step(k, du);
+      if (++ii == p.period) {
+        ii = 0; ++j;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          z_lo[i] = z_hi[i];
+          if (j + 1 < p.P) z_hi[i] = knot(i, j + 1);
+          if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
+          else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
+        }
+      }
+    }
+  }
+
+  // ---- per-rollout total cost ------------------------------------------------------------------------------------
+  F S_total;
+  if constexpr (COST == COST_LEGACY) {
+    S_total = cost + terminal_indicator<F>(p, st.th, st.x, x_t);     // sum_k q + phi  (:197-199)
+  } else {
+    const F term = (COST == COST_DEFAULT) ? terminal_indicator<F>(p, st.th, st.x, x_t) : splat<F>(0.0f);
+    S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / splat<F>((float)(H + 1));
+    S_total += corr;
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (a.S_out && valid[i]) a.S_out[(size_t)env * p.N + n[i]] = get(S_total, i);
+
+  // ---- block-level soft-min partials (a16) -----------------------------------------------------------------------
+  float m_l = INFINITY;
+#pragma unroll
+  for (int i = 0; i < R; ++i) m_l = fminf(m_l, valid[i] ? get(S_total, i) : INFINITY);
+  const float m_w = wave_min(m_l);
+  if (lane == 0) red[wave] = m_w;
+  __syncthreads();
+  float m_b = red[0];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) m_b = fminf(m_b, red[w]);
+  float e[R], e_l = 0.0f;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    e[i] = valid[i] ? expf((-1.0f / p.LBD) * (get(S_total, i) - m_b)) : 0.0f;
+    e_l += e[i];
+  }
+  const float a_w = wave_sum(e_l);
+  if (lane == 0) red[WAVES + wave] = a_w;
+
+  const uint32_t W = a.W;
+  float* __restrict__ my_bsum = bsum + wave * W;
+  if constexpr (NOISE == NOISE_PHILOX) {
+    const float* __restrict__ kstash = bsum + WAVES * W + tid;         // each lane reads back what it wrote itself
+    for (uint32_t j = 0; j < W; ++j) {
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        v += e[i] * (a.stash ? kstash[(j * R + i) * BLOCK]
+                             : philox_knot(a.seed, step_offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma));
+      v = wave_sum(v);
+      if (lane == 0) my_bsum[j] = v;
+    }
+  } else {
+    // transposed pass: lane = column (time-step or knot), loop over the wave's rows, rows read coalesced (cache-hot)
+    const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * W;
+    for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+      const uint32_t col = c0 + lane;
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const uint32_t base = row0 + i * 64;
+        const uint32_t rows = (base < p.N) ? ((p.N - base < 64u) ? p.N - base : 64u) : 0u;
+        // eight independent row loads in flight per batch: the pass is bound by load latency, not by its arithmetic
+        const float* __restrict__ colp = src + (size_t)(i * 64) * W + (col < W ? col : 0u);
+        uint32_t r = 0;
+        for (; r + 8 <= rows; r += 8) {
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = colp[(size_t)(r + u) * W];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), r + u)), x[u], acc);
+        }
+        for (; r < rows; ++r)
+          acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[i]), r)), colp[(size_t)r * W], acc);
+      }
+      if (col < W) my_bsum[col] = acc;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ out = a.partial + ((size_t)env * a.nb + blk) * (2 + W);
+  if (tid == 0) {
+    float a_b = red[WAVES];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) a_b += red[WAVES + w];
+    out[0] = m_b;
+    out[1] = a_b;
+  }
+  for (uint32_t c = tid; c < W; c += BLOCK) {
+    float v = bsum[c];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v += bsum[w * W + c];
+    out[2 + c] = v;
+  }
+  // ---- fused finalize: the env's last-arriving block merges the partials (no second launch) -----------------------
+  // Placement-independent hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, the
+  // block's barrier, one lane's agent-scope release, then the ticket; the consumer block does one agent-scope acquire
+  // (invalidates this CU's L1), drains, barriers, and additionally reads the partials with sc1 loads.
+  if (a.counter) {
+    __shared__ uint32_t ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ticket = __hip_atomic_fetch_add(a.counter + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (ticket == a.nb - 1) {                               // uniform over the block
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      __syncthreads();
+      finalize_env<NOISE != NOISE_DELTA_U, true>(p, a.partial, a.nb, W, a.u_nom_out, a.Q_out, env);
+    }
+  }
+}
+
+// Stand-alone form: one block per env (used after the GRU rollout kernel).
+
+}  // namespace cpmppi_k
