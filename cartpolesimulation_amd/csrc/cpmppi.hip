@@ -31,44 +31,56 @@ using namespace cpmppi;
 
 using namespace cpmppi_k;
 
-// rollout_cost_kernel is instantiated in cpmppi_rollout_r1.hip (R = 1) and cpmppi_rollout_r2.hip (R = 2)
+// rollout_cost_kernel is instantiated in cpmppi_rollout_latency.hip (VARIANT 0) and cpmppi_rollout_throughput.hip (1)
 namespace cpmppi_k {
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_DELTA_U, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_KNOTS, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 2>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_PHILOX, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 2>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
 }  // namespace cpmppi_k
 
 namespace {
@@ -701,27 +713,31 @@ int ensure_device(cpmppi_handle* h) {
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
-template <int COST, bool FAST, int R>
+template <int COST, bool FAST, int R, int V>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                 const StepPtrs& a) {
   switch (noise) {
     case CPMPPI_NOISE_DELTA_U:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, R>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_KNOTS:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
     default:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
   }
   return hipGetLastError();
 }
 
+// latency build for launches of at most one wave per SIMD (1024 SIMDs x 64 lanes), throughput build above
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                                const Params& p, const StepPtrs& a) {
-  if (math == CPMPPI_MATH_FAST)
-    return rpl == 2 ? launch_rollout_noise<COST, true, 2>(noise, grid, lds, s, p, a)
-                    : launch_rollout_noise<COST, true, 1>(noise, grid, lds, s, p, a);
-  return launch_rollout_noise<COST, false, 1>(noise, grid, lds, s, p, a);
+  if (math == CPMPPI_MATH_FAST) {
+    if (rpl == 2) return launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
+    const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
+    return small ? launch_rollout_noise<COST, true, 1, 0>(noise, grid, lds, s, p, a)
+                 : launch_rollout_noise<COST, true, 1, 1>(noise, grid, lds, s, p, a);
+  }
+  return launch_rollout_noise<COST, false, 1, 1>(noise, grid, lds, s, p, a);
 }
 
 hipError_t launch_rollout(const cpmppi_handle* h, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,

@@ -1,8 +1,8 @@
 // cpmppi_rollout.hpp — the hot path: rollout_cost_kernel and what it shares with the other kernels (launch
 // descriptor, nominal-sequence shift, the per-env finalize).  A header because the kernel is instantiated in two
-// translation units compiled with different instruction-scheduling strategies (see cpmppi_rollout_r1.hip /
-// cpmppi_rollout_r2.hip): the one-rollout-per-lane mapping is bound by the latency of a single wave's instruction
-// stream, the packed two-rollout mapping by issue throughput, and the compiler's schedulers differ measurably on them.
+// translation units compiled with different instruction-scheduling strategies (cpmppi_rollout_latency.hip /
+// cpmppi_rollout_throughput.hip): a launch of at most one wave per SIMD is bound by the latency of a single wave's
+// instruction stream, larger ones by issue throughput, and the compiler's schedulers differ measurably on the two.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -109,7 +109,9 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
 // The hot path.  R = rollouts per lane (1: latency mapping, 2: packed float2 throughput mapping, FAST only).
 // A block of 256 threads owns 256*R consecutive rollouts of one env; wave w owns rows [w*64*R, (w+1)*64*R) and lane l
 // integrates rows l (component 0) and l+64 (component 1).
-template <int COST, bool FAST, int NOISE, int R>
+// VARIANT only selects the translation unit (hence the scheduling strategy) an instantiation is compiled in:
+// 0 = latency build (launches of at most one wave per SIMD), 1 = throughput build.  The code is the same.
+template <int COST, bool FAST, int NOISE, int R, int VARIANT>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
   using F = typename Lanes<R>::F;
   static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");

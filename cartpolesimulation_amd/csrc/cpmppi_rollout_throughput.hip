@@ -1,0 +1,42 @@
+// Explicit instantiations of the rollout kernel, throughput build (VARIANT 1: both lane mappings and the PRECISE
+// arithmetic); compiled with -amdgpu-sched-strategy=max-ilp (see __graft_entry__.build).
+#include "cpmppi_rollout.hpp"
+
+namespace cpmppi_k {
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+}  // namespace cpmppi_k

@@ -20,9 +20,11 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    if "anonymous" not in name:
-        return None
-    return name.split("::")[1].split("(")[0]
+    """'void (anonymous namespace)::kernel<...>(args)' / 'void cpmppi_k::kernel<...>(args)' -> 'kernel<...>'"""
+    for ns in ("(anonymous namespace)::", "cpmppi_k::"):
+        if ns in name:
+            return name.split(ns, 1)[1].split("(")[0]
+    return None
 
 
 summary = {}
