@@ -5,26 +5,32 @@ A "step" = one full MPPI optimizer step for a batch of E independent problem ins
 (1024 samples x 50-step horizon x 10 Euler substeps, BASELINE.json configs[1]): perturbation sampling (a17) +
 rollout (a3-a11) + cost (a12, a15) + importance-weighted update (a16) + shift/clip (a18).  One rollout = one sampled
 control sequence integrated over the horizon + its cost + its share of the update.  Inputs are synthetic and resident
-in HBM before the timed region.  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank owns
-E envs (weak scaling, no data-path collective) and the chosen control sequences are gathered with ONE RCCL all-gather
-per step.
+in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` and `cpu_baseline` objects.
+`python bench.py --gpus N` with N > 1 starts N ranks itself (one fresh `torch.distributed.run` child, before this
+process has touched torch or the GPU, never an exec) and forwards rank 0's line; launched by `torch.distributed.run`
+directly (RANK / WORLD_SIZE in the environment) it is one of those ranks.  Every rank owns E envs (weak scaling, no
+data-path collective) and the chosen control sequences are gathered with ONE RCCL all-gather per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` and `cpu_baseline` objects, plus
+side objects for BASELINE's other configurations (`configs.C3`, `configs.C4`, `configs.C5_gru`, `single_env`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16/bf16 MFMA, MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+
+PRESETS = {"C2": (8192, 1024, 50), "C3": (64, 4096, 100), "C4": (64, 2048, 50)}
 
 
 def algorithmic_bytes_per_rollout(N, H):
@@ -37,8 +43,55 @@ def algorithmic_flops_per_rollout(H, S=10):
     return H * (S * 38.0 + 30.0) + 2.0 * H
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=8192, help="independent MPPI problem instances per GPU")
+    ap.add_argument("--rollouts", type=int, default=1024)
+    ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--noise", choices=["buffer", "philox"], default="philox",
+                    help="philox: perturbation knots generated in-kernel from a counter-based RNG (no buffer); "
+                         "buffer: device sampler writes delta_u[E,N,H] to HBM, rollout kernel reads it back "
+                         "(the reference's tensor layout at the optimizer/predictor seam)")
+    ap.add_argument("--math", choices=["fast", "precise"], default="fast")
+    ap.add_argument("--predictor", choices=["ode", "gru"], default="ode",
+                    help="ode: predictor_ODE_v0 (the headline path); gru: GRU-6IN-32H1-32H2-5OUT on the matrix "
+                         "cores inside the same MPPI loop (BASELINE configs[4], synthetic weights)")
+    ap.add_argument("--config", choices=["C2", "C3", "C4"], default=None,
+                    help="BASELINE.json config presets: C2 = 1024x50 (the metric's shape, 8192 envs per GPU, the default); "
+                         "C3 = 64 envs x 4096 x 100 in one launch; C4 = 64 envs per GPU x 2048 x 50 (512 envs over 8 GPUs)")
+    ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane: 0 auto, 1, 2 (tuning knob)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-env", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the C3 / C4 / GRU side measurements")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective plumbing only (CPU, gloo): no kernel runs and `value` is null; what the "
+                         "CPU test of the N > 1 entry point uses")
+    args = ap.parse_args(argv)
+    if args.config:
+        args.envs, args.rollouts, args.horizon = PRESETS[args.config]
+    return args
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 and not yet inside torch.distributed.run: start N ranks as a CHILD process (this process has not
+    imported torch nor touched the GPU), forward its output, return its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def synthetic_inputs(E, H, seed, device):
     """s0 as data_generator.py:221-256 / config_data_gen.yml:14-18; targets and L per env."""
+    import numpy as np
     import torch
     rng = np.random.Generator(np.random.SFC64(seed))
     THL = 0.198
@@ -56,82 +109,223 @@ def synthetic_inputs(E, H, seed, device):
     return t(s0), t(tp), t(te), t(L)
 
 
-def cpu_baseline(N, H, budget_s=12.0):
-    """The plain-C oracle (validated against the golden vectors) timed on this host's cores: same step, same shape."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N, H, budget_s=8.0):
+    """The plain-C oracle (validated against the golden vectors) timed on this host's cores: same step, same shape.
+    Three builds of the same source (oracle/Makefile): the checker itself (-O2, strict float32, sin/cos through double)
+    and two timing-only builds compiled here for this host (-O3 -march=native with libm float trig, without and with
+    -ffast-math: the reference's numba kernels are fastmath=True), each on all cores and on one."""
+    import numpy as np
     from oracle import oracle_np as O
     from oracle import oracle_c as OC
     cfg = O.MPPIConfig(N=N, H=H)
     c = OC.make_config(cfg)
     threads = OC.max_threads()
     rng = np.random.Generator(np.random.SFC64(4))
+    variants = {"checker_O2": (None, "-O2 -ffp-contract=off, float32 sin/cos evaluated in double (the validated checker)")}
+    try:
+        variants.update(OC.build_bench_variants())
+    except Exception as e:                                   # no compiler on this host: report the checker only
+        variants["_build_error"] = (None, repr(e))
 
-    def run(E):
+    def run(E, n_threads, lib):
         s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-5, 5), rng.uniform(-0.15, 0.15),
                                                rng.uniform(-0.3, 0.3)) for _ in range(E)])
         du = (cfg.stdev * rng.standard_normal((E, N, H))).astype(np.float32)
         t0 = time.perf_counter()
-        OC.step(c, s0, np.zeros((E, H), np.float32), du, 0.0, 1.0, n_threads=threads, want_S=False)
+        OC.step(c, s0, np.zeros((E, H), np.float32), du, 0.0, 1.0, n_threads=n_threads, want_S=False, use_lib=lib)
         return time.perf_counter() - t0
 
-    t1 = run(threads)                      # one env per core: calibrates the sample size
-    reps = int(max(1, min(64, budget_s / max(t1, 1e-3))))
-    E = threads * reps
-    t = run(E)
-    all_threads = threads
-    threads = 1                            # the reference's own situation: one process, one core (SURVEY.md 8d)
-    k1 = int(max(2, min(64, 2 * 1.5 / max(run(2), 1e-3))))      # ~1.5 s of one core
-    ts = run(k1)
-    return {"value": E * N / t, "unit": "rollouts/s", "cores": all_threads, "kind": "port",
-            "sample": f"{E} envs x {N} rollouts x {H} steps x 10 substeps in {t:.2f} s; oracle/cpmppi_oracle.c "
-                      f"(gcc -O2, no fast-math, OpenMP over envs x rollouts)",
-            "single_thread": {"value": k1 * N / ts, "unit": "rollouts/s", "cores": 1,
-                              "sample": f"{k1} envs x {N} rollouts x {H} steps in {ts:.2f} s"}}
+    table = {}
+    for name, (lib, flags) in variants.items():
+        if name.startswith("_"):
+            table[name] = flags
+            continue
+        t1 = run(threads, threads, lib)                     # one env per core: calibrates the sample size
+        reps = int(max(1, min(64, budget_s / 3.0 / max(t1, 1e-3))))
+        E = threads * reps
+        t = run(E, threads, lib)
+        k1 = int(max(2, min(64, 2 * 1.0 / max(run(2, 1, lib), 1e-3))))      # ~1 s of one core
+        ts = run(k1, 1, lib)
+        table[name] = {"flags": flags, "all_cores": {"value": E * N / t, "cores": threads,
+                                                     "sample": f"{E} envs x {N} x {H} x 10 substeps in {t:.2f} s"},
+                       "one_core": {"value": k1 * N / ts, "cores": 1, "sample": f"{k1} envs x {N} x {H} in {ts:.2f} s"}}
+    best = max((v for v in table.values() if isinstance(v, dict)), key=lambda v: v["all_cores"]["value"])
+    return {"value": best["all_cores"]["value"], "unit": "rollouts/s", "cores": threads, "kind": "port",
+            "sample": best["all_cores"]["sample"] + f"; oracle/cpmppi_oracle.c ({best['flags']}), OpenMP over envs x "
+                                                    f"rollouts; the fastest of the builds in `builds`",
+            "cpu": cpu_model(), "builds": table}
+
+
+class Workload:
+    """One engine + its synthetic inputs; `run(steps, warmup)` times K steps between barriers (max over ranks)."""
+
+    def __init__(self, ctx, E, N, H, noise="philox", math="fast", predictor="ode", rpl=0):
+        import numpy as np
+        import torch
+        from cartpolesimulation_amd.engine import MPPIEngine
+        from cartpolesimulation_amd.configs import MPPIConfig
+        self.ctx, self.E, self.N, self.H, self.noise, self.predictor = ctx, E, N, H, noise, predictor
+        self.cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=rpl)
+        self.eng = MPPIEngine(E, self.cfg, device=ctx["local_rank"])
+        dev = ctx["device"]
+        self.s0, self.tp, self.te, self.L = synthetic_inputs(E, H, seed=2 + ctx["rank"], device=dev)
+        self.u_nom = self.eng.zeros(E, H)
+        self.Q_out = self.eng.empty(E)
+        self.du = self.eng.empty(E, N, H) if noise == "buffer" else None
+        self.seed = 1234
+        self.pred_kw = {}
+        if predictor == "gru":
+            rng = np.random.Generator(np.random.SFC64(5))
+            u = lambda *s: rng.uniform(-1, 1, s).astype(np.float32) / np.sqrt(32.0, dtype=np.float32)
+            self.eng.set_gru(dict(w_ih0=u(96, 6), w_hh0=u(96, 32), b_ih0=u(96), b_hh0=u(96), w_ih1=u(96, 32),
+                                  w_hh1=u(96, 32), b_ih1=u(96), b_hh1=u(96), w_out=u(5, 32), b_out=u(5)))
+            self.pred_kw = dict(predictor="GRU")
+        # the one collective of the path (SURVEY.md 8e): all-gather of the updated nominal sequences.  Envs are
+        # independent, so step i+1 does not need step i's gathered result: the gather of a snapshot runs asynchronously on
+        # RCCL's stream while the next step's kernel computes (two snapshot/result buffers, each waited on before reuse).
+        W = ctx["world"]
+        self.gathered = [torch.empty(W * E * H, dtype=torch.float32, device=dev) for _ in range(2)] if W > 1 else None
+        self.snapshot = [torch.empty(E * H, dtype=torch.float32, device=dev) for _ in range(2)] if W > 1 else None
+        self.pending = [None, None]
+
+    def step(self, i):
+        import torch.distributed as dist
+        e, rank = self.eng, self.ctx["rank"]
+        if self.noise == "buffer":
+            e._check(e.lib.cpmppi_sample(e._h, self.E, self.seed, i, rank * self.E, None, self.du.data_ptr(), e._stream()))
+            e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=self.Q_out, **self.pred_kw)
+        else:
+            e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, seed=self.seed, offset=i, env_offset=rank * self.E,
+                   Q_out=self.Q_out, **self.pred_kw)
+        if self.ctx["world"] > 1:
+            b = i & 1
+            if self.pending[b] is not None:
+                self.pending[b].wait()                              # stream-level wait: the buffers are free again
+            self.snapshot[b].copy_(self.u_nom.view(-1))
+            self.pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.snapshot[b], async_op=True)
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.ctx["world"] > 1:
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+            torch.cuda.synchronize()
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        for i in range(warmup):
+            self.step(i)
+        self.barrier()
+        self.eng.set_profiling(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(warmup + i)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        rollout_ms, finalize_ms = self.eng.get_profile()
+        self.eng.set_profiling(False)
+        W, rank = self.ctx["world"], self.ctx["rank"]
+        if W > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.ctx["device"])
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert torch.isfinite(self.u_nom).all(), "non-finite nominal controls"
+        if W > 1:        # the last gather delivered this rank's block (and finite blocks from every other rank)
+            last = self.gathered[(warmup + steps - 1) & 1].view(W, self.E * self.H)
+            assert torch.equal(last[rank], self.u_nom.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
+        k_ms = float(np.mean(rollout_ms))
+        E, N, H = self.E, self.N, self.H
+        return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
+                "kernel_ms": k_ms, "kernel_ms_min": float(np.min(rollout_ms)), "finalize_kernel_ms": float(np.mean(finalize_ms)),
+                "valu_tflops": algorithmic_flops_per_rollout(H) * E * N / (k_ms * 1e-3) / 1e12,
+                "alg_gbs": algorithmic_bytes_per_rollout(N, H) * E * N / (k_ms * 1e-3) / 1e9}
+
+    def close(self):
+        self.eng.close()
+
+
+def roofline_valu(r, E, N, H):
+    return {"bound": "fp32-valu", "achieved": r["valu_tflops"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": r["valu_tflops"] / FP32_VALU_PEAK_TFLOPS, "algorithmic_flops_per_rollout": algorithmic_flops_per_rollout(H),
+            "kernel_rollouts_per_s": E * N / (r["kernel_ms"] * 1e-3)}
+
+
+def profiled_traffic(noise, E, N, H):
+    """HBM bytes per launch of the rollout kernel from an EARLIER rocprofv3 --pmc run of this command (FETCH_SIZE and
+    WRITE_SIZE in separate passes, tools/profile.sh -> tools/summarize_profile.py -> profiles/<round>/pmc_traffic.json,
+    committed).  PMC counters cannot be collected from inside the run; the figure is labelled with its source."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path)).get(noise, {})
+        except Exception:
+            continue
+        if (rec.get("E"), rec.get("N"), rec.get("H")) == (E, N, H):
+            return rec.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT), rec.get("collected")
+    return None, None, None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=8192, help="independent MPPI problem instances per GPU")
-    ap.add_argument("--rollouts", type=int, default=1024)
-    ap.add_argument("--horizon", type=int, default=50)
-    ap.add_argument("--noise", choices=["buffer", "philox"], default="philox",
-                    help="philox: perturbation knots generated in-kernel from a counter-based RNG (no buffer); "
-                         "buffer: device sampler writes delta_u[E,N,H] to HBM, rollout kernel reads it back "
-                         "(the reference's tensor layout at the optimizer/predictor seam)")
-    ap.add_argument("--math", choices=["fast", "precise"], default="fast")
-    ap.add_argument("--predictor", choices=["ode", "gru"], default="ode",
-                    help="ode: predictor_ODE_v0 (the headline path); gru: GRU-6IN-32H1-32H2-5OUT on the f32 matrix "
-                         "cores inside the same MPPI loop (BASELINE configs[4], synthetic weights)")
-    ap.add_argument("--config", choices=["C2", "C3", "C4"], default=None,
-                    help="BASELINE.json config presets: C2 = 1024x50 (the metric's shape, default: 2048 envs per GPU); "
-                         "C3 = 64 envs x 4096 x 100 in one launch; C4 = 64 envs per GPU x 2048 x 50 (512 envs over 8 GPUs)")
-    ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane: 0 auto, 1, 2 (tuning knob)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single-env", action="store_true")
-    args = ap.parse_args()
-    if args.config == "C3":
-        args.envs, args.rollouts, args.horizon = 64, 4096, 100
-    elif args.config == "C4":
-        args.envs, args.rollouts, args.horizon = 64, 2048, 50
+    args = parse_args()
+    in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # started by torch.distributed.run
+    if args.gpus > 1 and not in_rank:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
+    import numpy as np
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # launched by torch.distributed.run
-    if distributed:
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_rank else 1
+    rank = int(os.environ.get("RANK", "0")) if in_rank else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_rank else 0
+    if in_rank and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but torch.distributed.run started {world} ranks")
+    distributed = world > 1
+    if in_rank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # (development aid: CPMPPI_BENCH_BACKEND=gloo CPMPPI_BENCH_ONE_DEVICE=1 runs the N>1 code path on a 1-GPU box)
     backend = os.environ.get("CPMPPI_BENCH_BACKEND", "nccl")
     if os.environ.get("CPMPPI_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+
+    if args.dry_run:
+        # launcher + rendezvous + the all-gather of the control sequences on CPU tensors; nothing is computed or timed
+        if in_rank:
+            dist.init_process_group("gloo")
+            mine = torch.full((4,), float(rank))
+            out = torch.empty(world * 4)
+            dist.all_gather_into_tensor(out, mine)
+            assert torch.equal(out.view(world, 4)[:, 0], torch.arange(world, dtype=torch.float32))
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": f"MPPI rollouts/sec ({args.rollouts} samples x {args.horizon}-step horizon)",
+                              "value": None, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "dry_run": True,
+                              "note": "launcher / collective plumbing check on CPU (gloo); no kernel ran"}), flush=True)
+        if in_rank:
+            dist.destroy_process_group()
+        return
+
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if distributed:
+    if in_rank:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -141,92 +335,42 @@ def main():
         if rank == 0:
             import __graft_entry__
             __graft_entry__.build()
-        if distributed:
+        if in_rank:
             dist.barrier()
-    from cartpolesimulation_amd.engine import MPPIEngine
-    from cartpolesimulation_amd.configs import MPPIConfig
 
+    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "device": device}
     E, N, H = args.envs, args.rollouts, args.horizon
-    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=args.math, rollouts_per_lane=args.rpl)
-    eng = MPPIEngine(E, cfg, device=local_rank)
-    s0, tp, te, L = synthetic_inputs(E, H, seed=2 + rank, device=device)
-    u_nom = eng.zeros(E, H)
-    Q_out = eng.empty(E)
-    du = eng.empty(E, N, H) if args.noise == "buffer" else None
-    # the one collective of the path: all-gather of the updated nominal sequences.  Envs are independent,
-    # so step i+1 does not need step i's gathered result: the gather of a snapshot runs asynchronously on RCCL's stream
-    # while the next step's kernel computes (two snapshot/result buffers, each waited on before it is reused).
-    gathered = [torch.empty(world * E * H, dtype=torch.float32, device=device) for _ in range(2)] if distributed else None
-    snapshot = [torch.empty(E * H, dtype=torch.float32, device=device) for _ in range(2)] if distributed else None
-    pending = [None, None]
-    seed = 1234
-    pred_kw = {}
-    if args.predictor == "gru":
-        rng = np.random.Generator(np.random.SFC64(5))
-        u = lambda *s: rng.uniform(-1, 1, s).astype(np.float32) / np.sqrt(32.0, dtype=np.float32)
-        eng.set_gru(dict(w_ih0=u(96, 6), w_hh0=u(96, 32), b_ih0=u(96), b_hh0=u(96), w_ih1=u(96, 32), w_hh1=u(96, 32),
-                         b_ih1=u(96), b_hh1=u(96), w_out=u(5, 32), b_out=u(5)))
-        pred_kw = dict(predictor="GRU")
+    main_wl = Workload(ctx, E, N, H, noise=args.noise, math=args.math, predictor=args.predictor, rpl=args.rpl)
+    r = main_wl.run(args.steps, args.warmup)
+    cfg = main_wl.cfg
 
-    def step(i):
-        if args.noise == "buffer":
-            eng._check(eng.lib.cpmppi_sample(eng._h, E, seed, i, rank * E, None, du.data_ptr(), eng._stream()))
-            eng.step(s0, u_nom, tp, te, L=L, delta_u=du, Q_out=Q_out, **pred_kw)
-        else:
-            eng.step(s0, u_nom, tp, te, L=L, seed=seed, offset=i, env_offset=rank * E, Q_out=Q_out, **pred_kw)
-        if distributed:
-            b = i & 1
-            if pending[b] is not None:
-                pending[b].wait()                                   # stream-level wait: the buffers are free again
-            snapshot[b].copy_(u_nom.view(-1))
-            pending[b] = dist.all_gather_into_tensor(gathered[b], snapshot[b], async_op=True)
-
-    def barrier():
-        if distributed:
-            for b in range(2):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
-            torch.cuda.synchronize()
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    eng.set_profiling(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    rollout_ms, finalize_ms = eng.get_profile()
-    eng.set_profiling(False)
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(u_nom).all(), "non-finite nominal controls"
-    if distributed:      # the last gather delivered this rank's block (and finite blocks from every other rank)
-        last = gathered[(args.warmup + args.steps - 1) & 1].view(world, E * H)
-        assert torch.equal(last[rank], u_nom.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
+    # BASELINE's other configurations, measured by EVERY rank (the collective is part of them), reported by rank 0
+    extras = {}
+    if not args.no_extra_configs and args.config is None and args.predictor == "ode" and args.noise == "philox" and args.math == "fast":
+        side = [("C4", PRESETS["C4"], "ode", 200, 20)]
+        if world == 1:
+            side = [("C3", PRESETS["C3"], "ode", 100, 10)] + side + [("C5_gru", (256, 1024, 50), "gru", 20, 3)]
+        for name, (e_, n_, h_), pred, steps_, warm_ in side:
+            w = Workload(ctx, e_, n_, h_, predictor=pred)
+            rr = w.run(steps_, warm_)
+            w.close()
+            obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}",
+                   "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
+                   "kernel_ms": rr["kernel_ms"], "kernel_ms_min": rr["kernel_ms_min"]}
+            if pred == "ode":
+                obj["roofline_valu"] = roofline_valu(rr, e_, n_, h_)
+            else:
+                gru_flops = 2.0 * (3 * 32 * 38 + 3 * 32 * 64 + 5 * 32) * h_ * e_ * n_
+                obj["roofline"] = {"bound": "mfma", "achieved": gru_flops / (rr["kernel_ms"] * 1e-3) / 1e12,
+                                   "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": gru_flops / (rr["kernel_ms"] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                                   "note": "useful GRU flops against the dense f16 MFMA peak (split-f16 products issue 3.6x these)"}
+            extras[name] = obj
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * E * N * args.steps / elapsed
-        k_ms = float(np.mean(rollout_ms))
-        bytes_launch = algorithmic_bytes_per_rollout(N, H) * E * N
-        flops_launch = algorithmic_flops_per_rollout(H) * E * N
-        achieved_gbs = bytes_launch / (k_ms * 1e-3) / 1e9
-        traffic = None          # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/summarize_profile.py
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc)).get(args.noise, {})
-                if (rec.get("E"), rec.get("N"), rec.get("H")) == (E, N, H):
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        k_ms = r["kernel_ms"]
+        traffic, traffic_src, traffic_date = profiled_traffic(args.noise, E, N, H)
+        roof = None
         if args.predictor == "gru":
             # useful flops of the GRU-6IN-32H1-32H2-5OUT forward per rollout-step: 2 x (3*32*(6+32) + 3*32*(32+32) + 5*32)
             gru_flops = 2.0 * (3 * 32 * 38 + 3 * 32 * 64 + 5 * 32) * H * E * N
@@ -234,7 +378,7 @@ def main():
                 # FAST: float32-equivalent products as 3 f16 MFMAs (hi*hi + hi*lo + lo*hi), dense f16 peak ~2.5 PFLOP/s
                 peak, issued = F16_MFMA_PEAK_TFLOPS, 69 * 2.0 * 32 * 32 * 16 / 32.0 * H * E * N
                 note = ("split-f16 products on v_mfma_f32_32x32x16_f16 (69 MFMAs per 32-rollout tile step, 3.6x the algorithmic "
-                        "flops); the matrix pipe is ~40 % busy and overlaps with the gate math (exp, rcp), which bounds the "
+                        "flops); the matrix pipe overlaps with the gate math (exp, rcp), which bounds the "
                         "kernel; --math precise runs the exact-f32 MFMA kernel")
             else:
                 peak, issued = FP32_VALU_PEAK_TFLOPS, 156 * 2.0 * 32 * 32 * 2 / 32.0 * H * E * N
@@ -243,12 +387,10 @@ def main():
             roof = {"bound": "mfma", "kernel": "gru_rollout_cost_kernel", "achieved": gru_flops / (k_ms * 1e-3) / 1e12,
                     "peak": peak, "unit": "TFLOP/s", "frac": gru_flops / (k_ms * 1e-3) / 1e12 / peak, "traffic": traffic,
                     "issued_mfma_tflops": issued / (k_ms * 1e-3) / 1e12,
-                    "kernel_ms": k_ms, "finalize_kernel_ms": float(np.mean(finalize_ms)), "note": note}
-        else:
-            roof = None
+                    "kernel_ms": k_ms, "finalize_kernel_ms": r["finalize_kernel_ms"], "note": note}
         out = {
-            "metric": f"MPPI rollouts/sec ({N} samples x {H}-step horizon)", "value": value, "unit": "rollouts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "metric": f"MPPI rollouts/sec ({N} samples x {H}-step horizon)", "value": r["value"], "unit": "rollouts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config or 'C2'}-shape MPPI problems: {N} samples x {H}-step horizon x 10 Euler "
                                    f"substeps, {E} independent envs per GPU batched in one launch"
@@ -258,52 +400,57 @@ def main():
                        "predictor": "predictor_ODE_v0" if args.predictor == "ode" else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",
                        "parallelism": f"env-sharded x{world}, one RCCL all-gather of u_nom per step" if world > 1
                        else "single GPU"},
-            "roofline": roof or {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": achieved_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": k_ms, "finalize_kernel_ms": float(np.mean(finalize_ms)),
-                         "algorithmic_bytes_per_rollout": algorithmic_bytes_per_rollout(N, H),
-                         "note": "the path is fp32-VALU bound, not HBM bound (SURVEY.md F8): see roofline_valu"},
-            "roofline_valu": {"bound": "fp32-valu", "achieved": flops_launch / (k_ms * 1e-3) / 1e12,
-                              "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": flops_launch / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                              "algorithmic_flops_per_rollout": algorithmic_flops_per_rollout(H),
-                              # the same peak with every substep's sincos costed at ~30 flop-equivalents
-                              # (the algebraic count above leaves the 2 transcendental evaluations + fmod per substep out)
-                              "survey_ceiling_rollouts_per_s": FP32_VALU_PEAK_TFLOPS * 1e12 /
-                              (algorithmic_flops_per_rollout(H) + 2.0 * 10 * H * 30.0),
-                              "kernel_rollouts_per_s": E * N / (k_ms * 1e-3)},
+            "roofline": roof or {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": r["alg_gbs"],
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["alg_gbs"] / HBM_PEAK_GBS,
+                                 "traffic": traffic, "traffic_source": (f"profiled earlier, not in this run: {traffic_src}"
+                                                                        + (f" ({traffic_date})" if traffic_date else ""))
+                                 if traffic_src else None,
+                                 "kernel_ms": k_ms, "finalize_kernel_ms": r["finalize_kernel_ms"],
+                                 "algorithmic_bytes_per_rollout": algorithmic_bytes_per_rollout(N, H),
+                                 "note": "achieved = ALGORITHMIC bytes (SURVEY.md 8d) / kernel time, as the contract defines it; the "
+                                         "path is fp32-VALU bound, not HBM bound (SURVEY.md F8: ~100 flop/B vs a machine balance of "
+                                         "~20), so the binding roof is `roofline_valu`"
+                                         + ("; with in-kernel Philox noise no perturbation buffer moves at all" if args.noise == "philox" else "")},
         }
+        if args.predictor == "ode":
+            rv = roofline_valu(r, E, N, H)
+            # the same peak with every substep's sincos costed at ~30 flop-equivalents
+            rv["survey_ceiling_rollouts_per_s"] = FP32_VALU_PEAK_TFLOPS * 1e12 / (algorithmic_flops_per_rollout(H) + 2.0 * 10 * H * 30.0)
+            out["roofline_valu"] = rv
+        if extras:
+            out["configs"] = extras
         if not args.no_single_env and world == 1:
             # latency of ONE problem instance (BASELINE configs[1] literally: single env), same kernels
-            e1 = MPPIEngine(1, cfg, device=local_rank)
-            if args.predictor == "gru":
-                e1.lib.cpmppi_set_gru  # same synthetic model
-                e1.set_gru({k: v for k, v in zip(("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1",
-                                                  "w_out", "b_out"),
-                                                 (u(96, 6), u(96, 32), u(96), u(96), u(96, 32), u(96, 32), u(96), u(96),
-                                                  u(5, 32), u(5)))})
-            u1 = e1.zeros(1, H)
+            w1 = Workload(ctx, 1, N, H, noise="philox", math=args.math, predictor=args.predictor)
+            e1 = w1.eng
             for i in range(5):
-                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=i, **pred_kw)
+                w1.step(i)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            reps = 50
+            reps = 200
             for i in range(reps):
-                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=100 + i, **pred_kw)
+                w1.step(100 + i)
             torch.cuda.synchronize()
             dt1 = (time.perf_counter() - t1) / reps
             e1.set_profiling(True)
-            for i in range(20):
-                e1.step(s0[:1], u1, tp[:1], te[:1], L=L[:1], seed=seed, offset=200 + i, **pred_kw)
+            for i in range(50):
+                w1.step(400 + i)
             r1, f1 = e1.get_profile()
+            k1 = float(np.median(r1))
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
-                                 "rollout_kernel_us": float(np.median(r1)) * 1e3,
-                                 "finalize_kernel_us": float(np.median(f1)) * 1e3,
+                                 "rollout_kernel_us": k1 * 1e3, "finalize_kernel_us": float(np.median(f1)) * 1e3,
                                  "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time from HIP events"}
+            if args.predictor == "ode":
+                out["single_env"]["roofline_valu"] = {
+                    "bound": "fp32-valu", "achieved": algorithmic_flops_per_rollout(H) * N / (k1 * 1e-3) / 1e12,
+                    "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": algorithmic_flops_per_rollout(H) * N / (k1 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                    "note": f"{N} rollouts = {N // 64} waves on 1024 SIMDs: latency of one wave's dependency chain, not throughput"}
+            w1.close()
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             out["cpu_baseline"] = cpu_baseline(N, H)
         print(json.dumps(out), flush=True)
-    if distributed:
+    if in_rank:
         dist.barrier()
         dist.destroy_process_group()
 

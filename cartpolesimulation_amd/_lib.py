@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpmppi.so")
+LIB_PATH = os.environ.get("CPMPPI_LIB") or os.path.join(_HERE, "libcpmppi.so")   # CPMPPI_LIB: development builds (tools/)
 
 ABI_VERSION = 1
 COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG = 0, 1, 2, 3

@@ -21,6 +21,22 @@
 
 namespace cpmppi {
 
+// Diagnostic build only (-DCPMPPI_DEBUG_COUNTERS, tools/dev/cold_counts.py): per-translation-unit event counters and
+// per-wave lifetimes of the rollout kernel.  No counter exists in the product build.
+#ifdef CPMPPI_DEBUG_COUNTERS
+static __device__ unsigned long long g_dbg[8];        // unused slots kept for ad-hoc counters
+static __device__ unsigned long long g_wave_cycles[16384];
+static __device__ unsigned int g_wave_cold[16384];    // cold-branch entries of each wave (all substep flavours)
+#define CPMPPI_DBG(i, n)                                                                             \
+  do {                                                                                               \
+    const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                        \
+    if ((i) != 1 && (i) != 2 && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) && wv_ < 16384u) \
+      atomicAdd(&cpmppi::g_wave_cold[wv_], 1u);                                                      \
+  } while (0)
+#else
+#define CPMPPI_DBG(i, n) ((void)0)
+#endif
+
 constexpr float PI_F = 3.14159274101257324f;       // float32(np.pi)
 constexpr float TWO_PI_F = 6.28318548202514648f;   // float32(2*np.pi)
 
@@ -308,9 +324,8 @@ __device__ __forceinline__ void ode_euler_fast(const State<F>& st, F uK, float t
   v1 = fma_(xDD, tt, v);
 }
 
-// Edge bounce of one lane (cartpole_equations.py:341-347), rare.
-__device__ __forceinline__ void bounce_lane(float& thi, float& wi, float& xi, float& vi, float t, float inv_halfL) {
-  const float cb = cosf(thi);
+// Edge bounce of one lane (cartpole_equations.py:341-347), rare.  `cb` = cos of the integrated (un-wrapped) angle.
+__device__ __forceinline__ void bounce_lane(float& thi, float& wi, float& xi, float& vi, float cb, float t, float inv_halfL) {
   wi = __builtin_fmaf(-(2.0f * (vi * cb)), inv_halfL, wi);
   thi = __builtin_fmaf(wi, t, thi);
   vi = -vi;
@@ -325,7 +340,100 @@ __device__ __forceinline__ F wrap_rint(F th) {
   return fma_(-rint_(th * splat<F>(0.159154943091895336f)), splat<F>(TWO_PI_F), th);
 }
 
-// One Euler substep, FAST, with the reference's per-substep wrap and sin/cos evaluation.
+// ------------------------------------------------------------------------------------------------------------------
+// Rotation by a small angle d: (cos d, sin d) from their Taylor polynomials.
+//   rot_pair_lo: degree 5 / 4, |d| <= 0.125 (truncation < 1e-9): evaluated every substep by the one-rollout-per-lane path
+//   rot_pair   : degree 7 / 6, |d| <= ROT_LIMIT = 0.25 (truncation 1e-11 / 4e-10): seeds the carried pair of the packed
+//                path once per control step and serves every rare event (bounce, fast-spinning lane) of both paths
+// |d| = |w t| > 0.25 means an angular velocity beyond 125 rad/s at t = 2 ms; such a lane is evaluated with the exact
+// wrap + sincos on every substep (it practically never happens: a pole released from rest tops out near 20 rad/s).
+constexpr float ROT_LIMIT_LO = 0.125f;
+constexpr float ROT_LIMIT = 0.25f;
+
+template <class F>
+__device__ __forceinline__ void rot_pair_lo(F d, F& cd, F& sd) {
+  const F d2 = d * d;
+  sd = fma_(d * d2, fma_(d2, splat<F>(8.3333333e-3f), splat<F>(-1.6666667e-1f)), d);
+  cd = fma_(d2, fma_(d2, splat<F>(4.1666667e-2f), splat<F>(-0.5f)), splat<F>(1.0f));
+}
+
+template <class F>
+__device__ __forceinline__ void rot_pair(F d, F& cd, F& sd) {
+  const F d2 = d * d;
+  F ps = fma_(d2, splat<F>(-1.9841270e-4f), splat<F>(8.3333333e-3f));
+  ps = fma_(ps, d2, splat<F>(-1.6666667e-1f));
+  sd = fma_(d * d2, ps, d);
+  F pc = fma_(d2, splat<F>(-1.3888889e-3f), splat<F>(4.1666667e-2f));
+  pc = fma_(pc, d2, splat<F>(-0.5f));
+  cd = fma_(d2, pc, splat<F>(1.0f));
+}
+
+// (cos, sin)(a + d) from (cos, sin)(a) and |d| <= ROT_LIMIT.
+__device__ __forceinline__ void rotate_lane(float& c, float& s, float d) {
+  float cd, sd;
+  rot_pair<float>(d, cd, sd);
+  const float c1 = __builtin_fmaf(c, cd, -(s * sd)), s1 = __builtin_fmaf(s, cd, c * sd);
+  c = c1; s = s1;
+}
+
+// Rare event of ONE lane, shared by every FAST substep flavour.  On entry (thi, wi, xi, vi) is the Euler-advanced state
+// (angle un-wrapped) and (ci, si) = (cos, sin) of thi if `have_cs`, else they are evaluated here: by rotating the
+// previous substep's pair (c0, s0) through d0 = w_old t when |d0| <= ROT_LIMIT, exactly (wrap + polynomial sincos,
+// the angle is stored wrapped) otherwise.  A lane beyond the track edge bounces (cartpole_equations.py:341-347: cos of
+// the integrated angle, then the angle advances by the NEW angular velocity); (ci, si) follow by one more rotation.
+// Returns false if the lane's angular velocity is beyond the rotation range (its caller then treats it exactly on
+// every substep).  No libm call on this path: a wave that hits it pays ~40 instructions, about one substep.
+__device__ __forceinline__ bool rare_lane(float& thi, float& wi, float& xi, float& vi, float& ci, float& si, bool have_cs,
+                                          float c0, float s0, float d0, float t, float THL, float inv_halfL) {
+  bool in_range = true;
+  if (!have_cs) {
+    if (__builtin_fabsf(d0) <= ROT_LIMIT) {
+      ci = c0; si = s0;
+      rotate_lane(ci, si, d0);
+    } else {
+      thi = fma_(-rint_(thi * 0.159154943091895336f), TWO_PI_F, thi);
+      sincos_pi_half<float>(thi, si, ci);
+      in_range = false;
+    }
+  }
+  if (__builtin_fabsf(xi) >= THL) {
+    bounce_lane(thi, wi, xi, vi, ci, t, inv_halfL);
+    const float dl = wi * t;
+    if (__builtin_fabsf(dl) <= ROT_LIMIT) {
+      rotate_lane(ci, si, dl);
+    } else {
+      thi = fma_(-rint_(thi * 0.159154943091895336f), TWO_PI_F, thi);
+      sincos_pi_half<float>(thi, si, ci);
+      in_range = false;
+    }
+  }
+  return in_range;
+}
+
+// The bounce of cartpole_equations.py:341-347 applied to ALL lanes of the wave under a 0/1 mask `m` (packed where F is
+// float2): with one wave per SIMD the slowest wave sets a small launch's time, and a rollout that is caught beyond the
+// edge bounces on EVERY substep (v flips sign whichever way it points; the oracle shows rollouts with > 100 consecutive
+// bounces), so this event has to cost about as much as a substep, not the ~1000 cycles of per-lane divergent code.
+// `c1` = cos of the integrated (un-wrapped) angle.  Returns dl = m * w_new * t, the extra angle a bounced lane advances by.
+template <class F>
+__device__ __forceinline__ F bounce_masked(F m, F c1, F& th1, F& w1, F& x1, F& v1, float t, float inv_halfL) {
+  w1 = fma_(-(v1 * c1), m * splat<F>(2.0f * inv_halfL), w1);
+  const F mt = m * splat<F>(t);
+  th1 = fma_(mt, w1, th1);
+  v1 = v1 * fma_(m, splat<F>(-2.0f), splat<F>(1.0f));
+  x1 = fma_(mt, v1, x1);
+  return mt * w1;
+}
+
+template <class F>
+__device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
+  const F cn = fma_(c, cd, -(s * sd));
+  s = fma_(s, cd, c * sd);
+  c = cn;
+}
+
+// One Euler substep, FAST, with the reference's per-substep wrap and sin/cos evaluation (the control step's LAST
+// substep of the rotating flavours, every substep of the plain one).
 template <class F>
 __device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
   constexpr int W = Width<F>::value;
@@ -335,11 +443,31 @@ __device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const 
 #pragma unroll
   for (int i = 0; i < W; ++i) rare |= (__builtin_fabsf(get(x1, i)) >= p.THL);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
+    CPMPPI_DBG(3, 1);
+    // cos of the integrated angle by rotating the previous pair through d = w t; lanes beyond the rotation range (deep)
+    const F d = st.w * splat<F>(t);
+    F m;
+    bool deep = false;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-      float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
-      if (__builtin_fabsf(xi) >= p.THL) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
-      put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+      const bool hit = __builtin_fabsf(get(x1, i)) >= p.THL, far = __builtin_fabsf(get(d, i)) > ROT_LIMIT;
+      put(m, i, (hit && !far) ? 1.0f : 0.0f);
+      deep |= hit && far;
+    }
+    const F th0 = th1, w0 = w1, x0 = x1, v0 = v1;
+    F cd, sd;
+    rot_pair<F>(d, cd, sd);
+    const F cb = fma_(st.c, cd, -(st.s * sd));
+    bounce_masked<F>(m, cb, th1, w1, x1, v1, t, e.inv_halfL);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(deep) != 0, 0)) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        if (__builtin_fabsf(get(x0, i)) >= p.THL && __builtin_fabsf(get(d, i)) > ROT_LIMIT) {
+          float thi = get(th0, i), wi = get(w0, i), xi = get(x0, i), vi = get(v0, i), ci, si;
+          rare_lane(thi, wi, xi, vi, ci, si, false, get(st.c, i), get(st.s, i), get(d, i), t, p.THL, e.inv_halfL);
+          put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+        }
+      }
     }
   }
   th1 = wrap_rint<F>(th1);
@@ -351,37 +479,54 @@ __device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const 
 // through d = w*t, the exact increment of the angle, with sin d, cos d from their Taylor polynomials (|d| <= 0.125:
 // truncation < 1e-9).  Rounding adds ~1 ulp per rotation; the control step's LAST substep re-synchronises with the full
 // wrap + sincos (substep_fast), so the states observed at control-step granularity carry at most S-1 rotations of drift
-// (~2e-7).  Lanes that bounce, or spin faster than 0.125 rad per substep, are re-evaluated exactly in the cold branch.
+// (~2e-7).  Lanes that bounce, or spin faster than 0.125 rad per substep, are re-evaluated in the cold branch
+// (rare_lane: a higher-degree rotation up to 0.25 rad per substep, the exact wrap + sincos beyond).
 template <class F, bool CHECK_SPIN = true>
 __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   const F d = st.w * splat<F>(t);
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
-  const F d2 = d * d;
-  const F sd = fma_(d * d2, fma_(d2, splat<F>(8.3333333e-3f), splat<F>(-1.6666667e-1f)), d);
-  const F cd = fma_(d2, fma_(d2, splat<F>(4.1666667e-2f), splat<F>(-0.5f)), splat<F>(1.0f));
+  F cd, sd;
+  rot_pair_lo<F>(d, cd, sd);
   F c1 = fma_(st.c, cd, -(st.s * sd));
   F s1 = fma_(st.s, cd, st.c * sd);
   bool rare = false;
 #pragma unroll
   for (int i = 0; i < W; ++i) {
     rare |= (__builtin_fabsf(get(x1, i)) >= p.THL);
-    if constexpr (CHECK_SPIN) rare |= (__builtin_fabsf(get(d, i)) > 0.125f);
+    if constexpr (CHECK_SPIN) rare |= (__builtin_fabsf(get(d, i)) > ROT_LIMIT_LO);
   }
   const bool fired = __builtin_amdgcn_ballot_w64(rare) != 0;
   if (__builtin_expect(fired, 0)) {
+    CPMPPI_DBG(4, 1);
+    // plain bounces of lanes inside the rotation range: masked, all lanes at once; everything else per lane (deep)
+    F m;
+    bool deep = false;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-      float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
-      const bool hit = __builtin_fabsf(xi) >= p.THL;
-      if (hit || (CHECK_SPIN && __builtin_fabsf(get(d, i)) > 0.125f)) {
-        if (hit) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
-        thi = wrap_rint<float>(thi);
-        float sn, cs;
-        sincos_pi_half<float>(thi, sn, cs);
-        put(s1, i, sn); put(c1, i, cs);
-        put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+      const bool hit = __builtin_fabsf(get(x1, i)) >= p.THL;
+      const bool spin = CHECK_SPIN && __builtin_fabsf(get(d, i)) > ROT_LIMIT_LO;
+      put(m, i, (hit && !spin) ? 1.0f : 0.0f);
+      deep |= spin;
+    }
+    const F th0 = th1, w0 = w1, x0 = x1, v0 = v1, c0 = c1, s0 = s1;
+    const F dl = bounce_masked<F>(m, c1, th1, w1, x1, v1, t, e.inv_halfL);
+    F cdn, sdn;
+    rot_pair<F>(dl, cdn, sdn);
+    rotate_pair<F>(c1, s1, cdn, sdn);
+#pragma unroll
+    for (int i = 0; i < W; ++i) deep |= __builtin_fabsf(get(dl, i)) > ROT_LIMIT;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(deep) != 0, 0)) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        const bool spin = CHECK_SPIN && __builtin_fabsf(get(d, i)) > ROT_LIMIT_LO;
+        if (spin || __builtin_fabsf(get(dl, i)) > ROT_LIMIT) {
+          float thi = get(th0, i), wi = get(w0, i), xi = get(x0, i), vi = get(v0, i), ci = get(c0, i), si = get(s0, i);
+          rare_lane(thi, wi, xi, vi, ci, si, !spin, get(st.c, i), get(st.s, i), get(d, i), t, p.THL, e.inv_halfL);
+          put(s1, i, si); put(c1, i, ci);
+          put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+        }
       }
     }
   }
@@ -396,24 +541,19 @@ __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, co
 // Intermediate substep of the packed path with the rotation's (cos d, sin d) carried along: d = w t changes by
 // eps = angleDD t^2 (up to ~1e-3 for a fast-spinning pole) per substep, so
 //     (cd, sd) <- (cd - eps sd - eps^2/2, sd + eps cd)
-// replaces the two Taylor polynomials (4 instead of 7 instructions; truncation O(eps^3) in cd, eps^2 sd / 2 <= 7e-8 in
-// sd).  The pair is seeded from the polynomials at every control step, and the control step's last substep
-// re-synchronises (cos, sin) exactly as before.  Rare lanes are handled PER LANE in the wave-uniform cold branch — a
-// lane that hits the track edge bounces, gets the exact wrap + sincos and re-seeds its pair from its new angular
-// velocity; a lane whose |w t| exceeded 0.1 at the start of the control step (`spin`: its edge limit `xlim` is set to
-// -1, so the one comparison per lane covers both events) gets the exact sincos on every substep — so a rollout's
-// arithmetic never depends on what its wave partners do.  Measured (tools/cost_deviation.py,
-// all golden rollouts): relative cost deviation median 1.9e-7 / p99 7.5e-6 / max 2.8e-5 with it, 1.9e-7 / 6.9e-6 /
-// 2.3e-5 without.  The one-rollout-per-lane path keeps the per-substep polynomials: it is bound by the LATENCY of a
-// single wave's dependency chain, and carrying the pair makes the next rotation wait for this substep's angleDD (measured:
-// 79 us instead of 67 us per single-env step).
-template <class F>
-__device__ __forceinline__ void rot_seed(F d, F& cd, F& sd) {
-  const F d2 = d * d;
-  sd = fma_(d * d2, fma_(d2, splat<F>(8.3333333e-3f), splat<F>(-1.6666667e-1f)), d);
-  cd = fma_(d2, fma_(d2, splat<F>(4.1666667e-2f), splat<F>(-0.5f)), splat<F>(1.0f));
-}
-
+// replaces the two Taylor polynomials (4 instead of 7 instructions; truncation O(eps^3) in cd, eps^2 sd / 2 in sd:
+// <= 2e-7 at the range limit |sd| = 0.25, <= 1e-8 for ordinary angular velocities).  The pair is seeded from the
+// degree-7/6 polynomials at every control step, and the control step's last substep re-synchronises (cos, sin) exactly
+// as before.  Rare lanes are handled PER LANE in the wave-uniform cold branch (rare_lane) — a lane that hits the track
+// edge bounces with the cosine it already carries, is rotated on by its new angular velocity and re-seeds its pair; a
+// lane whose |w t| exceeded ROT_LIMIT at the start of the control step or after a bounce (`beyond`: its edge limit
+// `xlim` is set to -1, so the one comparison per lane covers both events) gets the exact sincos on every substep — so a
+// rollout's arithmetic never depends on what its wave partners do, and a wave that meets a rare lane pays about one
+// extra substep for it (no libm call anywhere on the FAST path: with ONE wave per SIMD the slowest wave sets the
+// kernel's time, and the first version's libm cosf + exact sincos per event made launches of the C3 / C4 size take
+// between 80 and 180 us depending on the noise drawn).  The one-rollout-per-lane path keeps the per-substep
+// polynomials: it is bound by the LATENCY of a single wave's dependency chain, and carrying the pair makes the next
+// rotation wait for this substep's angleDD (measured: 79 us instead of 67 us per single-env step).
 template <class F>
 __device__ __forceinline__ void substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
                                                          F& cd, F& sd, F& xlim) {
@@ -427,24 +567,39 @@ __device__ __forceinline__ void substep_fast_rot_carried(State<F>& st, F uK, flo
   F sd1 = fma_(cd, eps, sd);                                         // sd + eps cd
   bool rare = false;
 #pragma unroll
-  for (int i = 0; i < W; ++i) rare |= __builtin_fabsf(get(x1, i)) >= get(xlim, i);      // edge, or a lane flagged `spin`
+  for (int i = 0; i < W; ++i) rare |= __builtin_fabsf(get(x1, i)) >= get(xlim, i);      // edge, or a lane flagged `beyond`
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+    CPMPPI_DBG(0, 1);
+    // plain bounces (lanes inside the rotation range): masked, both rollouts of all lanes at once — about one substep's
+    // worth of packed instructions; lanes flagged `beyond`, or thrown beyond the range by this bounce, per lane (deep)
+    F m;
+    bool deep = false;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-      float thi = get(th1, i), wi = get(w1, i), xi = get(x1, i), vi = get(v1, i);
-      const bool hit = __builtin_fabsf(xi) >= p.THL, spin = get(xlim, i) < 0.0f;
-      if (hit || spin) {
-        if (hit) bounce_lane(thi, wi, xi, vi, t, e.inv_halfL);
-        thi = wrap_rint<float>(thi);
-        float sn, cs;
-        sincos_pi_half<float>(thi, sn, cs);
-        put(s1, i, sn); put(c1, i, cs);
-        put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
-        if (hit) {                                                  // the angular velocity jumped: new pair, new range test
-          float cdn, sdn;
-          rot_seed<float>(wi * t, cdn, sdn);
-          put(cd1, i, cdn); put(sd1, i, sdn);
-          if (__builtin_fabsf(wi) * t > 0.1f) put(xlim, i, -1.0f);
+      const bool hit = __builtin_fabsf(get(x1, i)) >= p.THL, beyond = get(xlim, i) < 0.0f;
+      put(m, i, (hit && !beyond) ? 1.0f : 0.0f);
+      deep |= beyond;
+    }
+    const F th0 = th1, w0 = w1, x0 = x1, v0 = v1, c0 = c1, s0 = s1;
+    const F dl = bounce_masked<F>(m, c1, th1, w1, x1, v1, t, e.inv_halfL);
+    F cdn, sdn;
+    rot_pair<F>(dl, cdn, sdn);                       // lanes that did not bounce: dl = 0, the identity
+    rotate_pair<F>(c1, s1, cdn, sdn);
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      if (get(m, i) != 0.0f) { put(cd1, i, get(cdn, i)); put(sd1, i, get(sdn, i)); }   // the pair of the new angular velocity
+      deep |= __builtin_fabsf(get(dl, i)) > ROT_LIMIT;
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(deep) != 0, 0)) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        const bool beyond = get(xlim, i) < 0.0f;
+        if (beyond || __builtin_fabsf(get(dl, i)) > ROT_LIMIT) {
+          float thi = get(th0, i), wi = get(w0, i), xi = get(x0, i), vi = get(v0, i), ci = get(c0, i), si = get(s0, i);
+          rare_lane(thi, wi, xi, vi, ci, si, !beyond, get(st.c, i), get(st.s, i), ROT_LIMIT + 1.0f, t, p.THL, e.inv_halfL);
+          put(s1, i, si); put(c1, i, ci);
+          put(th1, i, thi); put(w1, i, wi); put(x1, i, xi); put(v1, i, vi);
+          put(xlim, i, -1.0f);                        // exact on every substep until the next control step re-tests
         }
       }
     }
@@ -465,16 +620,16 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
     substep_fast<F>(st, uK, t, p, e);
     return;
   }
-  // The Taylor seed needs |w t| <= 0.125 (its cos error reaches half an ulp only at ~0.18).  Tested once per control
-  // step with the margin 0.1: without a bounce w cannot gain 12 rad/s within one control step, and a lane that bounces
-  // is re-tested.  Lanes beyond the range are flagged and take the exact sincos on every substep.
+  // The seed needs |w t| <= ROT_LIMIT.  Tested once per control step: without a bounce w cannot leave the range within
+  // one control step by more than the polynomials' margin, and a lane that bounces is re-tested.  Lanes beyond the
+  // range are flagged and take the exact sincos on every substep.
 #if CPMPPI_INCR_ROT
   F xlim;
-  const float wlim = 0.1f / t;                  // |w t| > 0.1 as one compare with a free abs modifier per lane
+  const float wlim = ROT_LIMIT / t;             // |w t| > ROT_LIMIT as one compare with a free abs modifier per lane
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
   F cd, sd;
-  rot_seed<F>(st.w * splat<F>(t), cd, sd);
+  rot_pair<F>(st.w * splat<F>(t), cd, sd);
   for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F>(st, uK, t, p, e, cd, sd, xlim);
   substep_fast<F>(st, uK, t, p, e);
 #else
@@ -498,7 +653,6 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
   for (uint32_t sub = 0; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);
 #endif
 }
-
 // ------------------------------------------------------------------------------------------------------------------
 // Stage / terminal costs (generic over float / float2).  `x_t` target position, `te` target equilibrium, `u` the
 // control applied at this stage.

@@ -121,6 +121,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 
   const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef CPMPPI_DEBUG_COUNTERS
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
   const uint32_t row0 = blk * (BLOCK * R) + wave * (64 * R);     // first rollout of this wave
   uint32_t n[R];
   bool valid[R];
@@ -260,6 +263,10 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     }
   }
 
+#ifdef CPMPPI_DEBUG_COUNTERS
+  if (lane == 0 && blockIdx.x * WAVES + wave < 16384u)
+    cpmppi::g_wave_cycles[blockIdx.x * WAVES + wave] = __builtin_amdgcn_s_memtime() - dbg_t0;
+#endif
   // ---- per-rollout total cost ------------------------------------------------------------------------------------
   F S_total;
   if constexpr (COST == COST_LEGACY) {

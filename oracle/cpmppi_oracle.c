@@ -48,8 +48,13 @@ typedef struct {
 #define PI_F 3.14159274101257324f
 #define TWO_PI_F 6.28318548202514648f
 
+#ifdef ORACLE_F32_TRIG      /* cpu_baseline timing builds only (oracle/Makefile: *_native*): libm's float kernels, as numba */
+static inline float cos32(float x) { return cosf(x); }
+static inline float sin32(float x) { return sinf(x); }
+#else                       /* the checker */
 static inline float cos32(float x) { return (float)cos((double)x); }
 static inline float sin32(float x) { return (float)sin((double)x); }
+#endif
 
 /* ---- mode A: strict float32 ------------------------------------------------------------------------------------ */
 static inline void ode_f32(const oracle_config* p, float L, float ca, float sa, float w, float v, float u, float* aDD,

@@ -78,7 +78,20 @@ def predict(cfg_c, s0, Q, L=None, L_default=0.395, n_threads=0):
     return traj
 
 
-def step(cfg_c, s0, u_nom, delta_u, x_t, te, L=None, u_prev=None, L_default=0.395, n_threads=0, want_S=True):
+def build_bench_variants():
+    """cpu_baseline timing builds (oracle/Makefile `bench`), always recompiled for the host this runs on (-march=native).
+    Returns {name: (ctypes lib, compiler flags)}.  Timing only — never used as a checker."""
+    subprocess.check_call(["make", "-s", "-B", "-C", HERE, "bench"])
+    out = {}
+    for name, flags in (("native", "-O3 -march=native -ffp-contract=off, libm float trig"),
+                        ("native_fastmath", "-O3 -march=native -ffast-math, libm float trig")):
+        v = C.CDLL(os.path.join(HERE, "_bench", f"liboracle_{name}.so"))
+        v.oracle_max_threads.restype = C.c_int
+        out[name] = (v, flags)
+    return out
+
+
+def step(cfg_c, s0, u_nom, delta_u, x_t, te, L=None, u_prev=None, L_default=0.395, n_threads=0, want_S=True, use_lib=None):
     """E envs.  Returns (u_new[E,H], Q[E], S[E,N] or None); u_nom is not modified."""
     delta_u = np.ascontiguousarray(delta_u, dtype=f32)
     E, N, H = delta_u.shape
@@ -91,7 +104,7 @@ def step(cfg_c, s0, u_nom, delta_u, x_t, te, L=None, u_prev=None, L_default=0.39
     u_prev = None if u_prev is None else np.ascontiguousarray(u_prev, dtype=f32).reshape(E, H)
     Q = np.empty(E, dtype=f32)
     S = np.empty((E, N), dtype=f32) if want_S else None
-    lib().oracle_step(C.byref(cfg_c), C.c_uint32(E), _p(s0), _p(u), _p(delta_u), _p(u_prev), _p(x_t), _p(te), _p(L),
+    (use_lib or lib()).oracle_step(C.byref(cfg_c), C.c_uint32(E), _p(s0), _p(u), _p(delta_u), _p(u_prev), _p(x_t), _p(te), _p(L),
                       C.c_float(L_default), _p(Q), _p(S), C.c_int(n_threads))
     return u, Q, S
 
