@@ -93,15 +93,22 @@ class controller_mpc(template_controller):
                                              environment_name=self.environment_name,
                                              cost_function_specification=cost_name,
                                              weights=cfg.get("cost_weights"), phys=self.phys, device=self.device)
-        self.predictor = PredictorWrapper(self.phys, device=self.device)
-        self.predictor.configure(batch_size=opt_probe.num_rollouts, horizon=opt_probe.mpc_horizon,
-                                 dt=opt_probe.mpc_timestep, predictor_specification=predictor_specification or "ODE_v0",
-                                 variable_parameters=self.variable_parameters)
+        spec = predictor_specification or cfg.pop("predictor_specification", None)
+        neural = spec is not None and str(spec).startswith("GRU-6IN-32H1-32H2-5OUT")
+        if cfg.get("gru_model") is not None and spec is not None and not neural:
+            raise ValueError(f"gru_model was given but predictor_specification={spec!r} selects the ODE predictor")
+        if neural or (spec is None and cfg.get("gru_model") is not None):
+            self.predictor = None            # the network runs inside the fused kernel (optimizer_mppi.gru_model); no ODE seam object
+        else:
+            self.predictor = PredictorWrapper(self.phys, device=self.device)
+            self.predictor.configure(batch_size=opt_probe.num_rollouts, horizon=opt_probe.mpc_horizon,
+                                     dt=opt_probe.mpc_timestep, predictor_specification=spec or "ODE_v0",
+                                     variable_parameters=self.variable_parameters)
         self.optimizer = optimizer_mppi(predictor=self.predictor, cost_function=self.cost_function_wrapper.cost_function,
                                         control_limits=self.control_limits, optimizer_logging=controller_logging,
                                         phys=self.phys, device=self.device, num_envs=self.num_envs,
                                         variable_parameters=self.variable_parameters, **cfg)
-        self.optimizer.configure(dt=opt_probe.mpc_timestep, predictor_specification="ODE_v0")
+        self.optimizer.configure(dt=opt_probe.mpc_timestep, predictor_specification=spec)
 
     def _configure_other(self, cls, predictor_specification, cost_function_specification, controller_logging, **kwargs):
         cfg = dict(self.config_optimizer)

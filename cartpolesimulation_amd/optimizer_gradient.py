@@ -75,7 +75,7 @@ class _GradientBase:
             self.cfg.SQRTRHOINV = s * math.sqrt(float(dt))
         if num_envs is not None:
             self.num_envs = int(num_envs)
-        if predictor_specification not in (None, "ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
+        if predictor_specification not in (None, "ODE_v0", "ODE_v0_default"):     # "ODE" is a different integrator
             raise NotImplementedError("the adjoint kernel differentiates the ODE_v0 predictor only")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         self.optimizer_reset()

@@ -91,8 +91,16 @@ class optimizer_mppi:
         if neural and self.gru_model is None:
             raise ValueError("a GRU predictor_specification needs gru_model=dict(weights) or a model folder path "
                              "(no GRU model files ship in-tree)")
-        if not neural and predictor_specification not in (None, "ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
+        if predictor_specification in ("ODE", "ODE_default"):
+            # predictors_customization.py:25-69 is a DIFFERENT integrator (Euler-Cromer, atan2 angle, no edge bounce): one
+            # control step already lies 1.6e-3 from ODE_v0, so it must not be served by the ODE_v0 kernel
+            raise NotImplementedError(f"predictor {predictor_specification!r} (next_state_predictor_ODE: Euler-Cromer, no "
+                                      "bounce) is not built; the HIP path implements 'ODE_v0' and 'GRU-6IN-32H1-32H2-5OUT-*'")
+        if not neural and predictor_specification not in (None, "ODE_v0", "ODE_v0_default"):
             raise NotImplementedError("built predictors: ODE_v0 and GRU-6IN-32H1-32H2-5OUT-*")
+        if self.gru_model is not None and not (neural or predictor_specification is None):
+            raise ValueError(f"gru_model was given but predictor_specification={predictor_specification!r} selects the ODE "
+                             "predictor: the model would be ignored")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         E, N, H = self.num_envs, self.num_rollouts, self.mpc_horizon
         if self.gru_model is not None and (neural or predictor_specification is None):

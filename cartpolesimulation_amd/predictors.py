@@ -118,9 +118,13 @@ class PredictorWrapper:
 
     def update_predictor_config_from_specification(self, predictor_specification=None, **kwargs):
         spec = predictor_specification or "ODE_v0"
-        if str(spec).split(":")[0] not in ("ODE_v0", "ODE_v0_default", "ODE", "ODE_default"):
-            raise NotImplementedError(f"predictor_specification {spec!r}: only the ODE_v0 path is built on this tier "
-                                      "(neural predictors are SURVEY.md §8f N3)")
+        if str(spec).split(":")[0] in ("ODE", "ODE_default"):
+            # predictors_customization.py:25-69: Euler-Cromer, atan2 angle, no edge bounce — not the ODE_v0 integrator
+            raise NotImplementedError(f"predictor_specification {spec!r} is next_state_predictor_ODE, a different integrator "
+                                      "from ODE_v0 (1.6e-3 apart after one control step); only ODE_v0 is built")
+        if str(spec).split(":")[0] not in ("ODE_v0", "ODE_v0_default"):
+            raise NotImplementedError(f"predictor_specification {spec!r}: the predictor seam serves ODE_v0; the GRU predictor "
+                                      "runs inside the fused kernel (optimizer_mppi(gru_model=...))")
         self.predictor_config = {"predictor_type": "ODE_v0", "model_name": None,
                                  "intermediate_steps": self.predictor_config["intermediate_steps"]}
         self.predictor_type = "ODE_v0"

@@ -475,15 +475,17 @@ def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
-def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
-    """torch.nn.GRU cell: r,z,n = chunks of 3*hidden rows.  x[B,I], h[B,Hd] -> h'[B,Hd] (float32)."""
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh, dtype=f32):
+    """torch.nn.GRU cell: r,z,n = chunks of 3*hidden rows.  x[B,I], h[B,Hd] -> h'[B,Hd] (float32; `dtype=np.float64`
+    carries the whole evaluation in double — used by the tests to measure how rounding-sensitive a rollout is)."""
     Hd = h.shape[1]
+    w_ih, w_hh, b_ih, b_hh = (np.asarray(a, dtype=dtype) for a in (w_ih, w_hh, b_ih, b_hh))
     gi = x @ w_ih.T + b_ih
     gh = h @ w_hh.T + b_hh
     r = _sigmoid(gi[:, :Hd] + gh[:, :Hd])
     z = _sigmoid(gi[:, Hd:2 * Hd] + gh[:, Hd:2 * Hd])
     n = np.tanh(gi[:, 2 * Hd:] + r * gh[:, 2 * Hd:])
-    return ((1.0 - z) * n + z * h).astype(f32)
+    return ((1.0 - z) * n + z * h).astype(dtype)
 
 
 def gru_features_from_state(s):
@@ -492,37 +494,40 @@ def gru_features_from_state(s):
                      s[..., POSITIOND_IDX]], axis=-1).astype(f32)
 
 
-def gru_predict(model, s0, Q, h0=None):
+def gru_predict(model, s0, Q, h0=None, dtype=f32):
     """Autoregressive rollout.  model: dict of float32 arrays (w_ih0[96,6], w_hh0[96,32], b_ih0, b_hh0, w_ih1[96,32],
     w_hh1, b_ih1, b_hh1, w_out[5,32], b_out[5], in_scale[6], in_shift[6], out_scale[5], out_shift[5]).
     s0[B,6], Q[B,H] -> traj[B,H+1,6] (traj[:,0]=s0), final hidden [2,B,32].  The network runs on normalised features
     (x*scale+shift), its normalised outputs are fed back unchanged; outputs are de-normalised and augmented with
-    angle = atan2(sin, cos)."""
+    angle = atan2(sin, cos).  `dtype`: float32 (the pinned restatement) or float64 (sensitivity probe, see gru_cell)."""
     s0 = np.asarray(s0, dtype=f32)
     Q = np.asarray(Q, dtype=f32)
     B, H = Q.shape
     if s0.ndim == 1:
         s0 = np.tile(s0, (B, 1))
     Hd = model["w_hh0"].shape[1]
-    h = np.zeros((2, B, Hd), dtype=f32) if h0 is None else np.array(h0, dtype=f32)
-    feat = (gru_features_from_state(s0) * model["in_scale"][1:] + model["in_shift"][1:]).astype(f32)
-    traj = np.zeros((B, H + 1, 6), dtype=f32)
+    h = np.zeros((2, B, Hd), dtype=dtype) if h0 is None else np.array(h0, dtype=dtype)
+    m = {k: np.asarray(v, dtype=dtype) for k, v in model.items()}
+    feat = (gru_features_from_state(s0).astype(dtype) * m["in_scale"][1:] + m["in_shift"][1:]).astype(dtype)
+    traj = np.zeros((B, H + 1, 6), dtype=dtype)
     traj[:, 0] = s0
     for k in range(H):
-        qn = (Q[:, k] * model["in_scale"][0] + model["in_shift"][0]).astype(f32)
-        x = np.concatenate([qn[:, None], feat], axis=1).astype(f32)
-        h[0] = gru_cell(x, h[0], model["w_ih0"], model["w_hh0"], model["b_ih0"], model["b_hh0"])
-        h[1] = gru_cell(h[0], h[1], model["w_ih1"], model["w_hh1"], model["b_ih1"], model["b_hh1"])
-        feat = (h[1] @ model["w_out"].T + model["b_out"]).astype(f32)
-        y = (feat * model["out_scale"] + model["out_shift"]).astype(f32)
+        qn = (Q[:, k].astype(dtype) * m["in_scale"][0] + m["in_shift"][0]).astype(dtype)
+        x = np.concatenate([qn[:, None], feat], axis=1).astype(dtype)
+        h[0] = gru_cell(x, h[0], m["w_ih0"], m["w_hh0"], m["b_ih0"], m["b_hh0"], dtype)
+        h[1] = gru_cell(h[0], h[1], m["w_ih1"], m["w_hh1"], m["b_ih1"], m["b_hh1"], dtype)
+        feat = (h[1] @ m["w_out"].T + m["b_out"]).astype(dtype)
+        y = (feat * m["out_scale"] + m["out_shift"]).astype(dtype)
         traj[:, k + 1, ANGLED_IDX], traj[:, k + 1, ANGLE_COS_IDX], traj[:, k + 1, ANGLE_SIN_IDX] = y[:, 0], y[:, 1], y[:, 2]
         traj[:, k + 1, POSITION_IDX], traj[:, k + 1, POSITIOND_IDX] = y[:, 3], y[:, 4]
         traj[:, k + 1, ANGLE_IDX] = np.arctan2(y[:, 2], y[:, 1])
     return traj, h
 
 
-def gru_mppi_step(model, s, u_nom, delta_u, target_position, target_equilibrium, cfg, h0=None, low=-1.0, high=1.0):
-    """optimizer step with the GRU predictor inside the same MPPI loop (BASELINE configs[4]); plugin costs only."""
+def gru_mppi_step(model, s, u_nom, delta_u, target_position, target_equilibrium, cfg, h0=None, low=-1.0, high=1.0,
+                  dtype=f32):
+    """optimizer step with the GRU predictor inside the same MPPI loop (BASELINE configs[4]); plugin costs only.
+    `dtype=np.float64` evaluates the network in double (costs are then formed from the float32-rounded trajectory)."""
     u_nom = np.asarray(u_nom, dtype=f32)
     if cfg.shift_mode == "repeat_last":
         u_nom = np.concatenate([u_nom[1:], u_nom[-1:]])
@@ -532,7 +537,8 @@ def gru_mppi_step(model, s, u_nom, delta_u, target_position, target_equilibrium,
     if cfg.control_mode == "clip":
         u_run = np.clip(u_run, f32(low), f32(high))
     h0b = None if h0 is None else np.repeat(np.asarray(h0, dtype=f32)[:, None, :], delta_u.shape[0], axis=1)
-    traj, _ = gru_predict(model, s, u_run, h0b)
+    traj, _ = gru_predict(model, s, u_run, h0b, dtype)
+    traj = traj.astype(f32)
     S_cost = trajectory_cost(cfg.cost_id, traj, u_run, target_position, target_equilibrium, cfg.horizon_reduce)
     u_corr = u_run if cfg.correction_u == "u_run" else u_nom[None, :]
     S_cost = (S_cost + mppi_correction_cost(u_corr, delta_u, cfg.cc_weight, cfg.R, cfg.NU)).astype(f32)

@@ -1,0 +1,118 @@
+"""Shared parity assertions of the GPU tests (BASELINE.json north_star: "within 1e-4").
+
+Every bound here is FIXED or derived from the ORACLE — never from the kernel's own error:
+
+  * the 1e-4 band itself: |d| <= 1e-4 + 1e-4 |ref| for states, 1e-4 relative for costs, 1e-4 absolute for controls;
+  * the reference's own arithmetic ambiguity (H1): numpy >= 2 keeps the substeps in float32 (mode A), numba carries them
+    in float64 (mode B).  A result inside the band around the interval [A, B] is a reference-conformant result, so the
+    per-element allowance is band + |A - B|, both computed by the oracle;
+  * H2 buckets: rollouts that the ORACLE's trajectory shows near a discontinuity (edge bounce, +-pi wrap, a cost
+    indicator threshold) are `flagged`; every unflagged rollout must be inside its allowance (100 %), flagged rollouts
+    are counted and at most `FLAGGED_CAP` of them (never more than 0.5 % of all rollouts) may sit outside — a bounce or an
+    indicator that fires one substep apart in two float32 evaluations is a legitimate, rare outcome of either one.
+
+Measured on MI355X (tools/dev/parity_buckets.py, all 8 x 1024 golden rollouts, both math modes and lane mappings): no
+rollout outside band + gap at all, flagged or not; worst clear rollout 0.32 bands; worst cost 2.9e-5 relative.
+"""
+import numpy as np
+
+from oracle import oracle_np as O
+
+f32 = np.float32
+THL = float(O.DEFAULT_PARAMS.TrackHalfLength)
+FLAGGED_CAP = 0.02            # fraction of the FLAGGED rollouts that may sit outside their allowance
+TOTAL_CAP = 0.005             # ... and never more than this fraction of all rollouts
+
+
+def band(ref, scale=1.0):
+    return scale * (1e-4 + 1e-4 * np.abs(ref))
+
+
+def flag_discontinuities(traj, dt=0.02, x_margin=2e-3, th_margin=2e-3):
+    """traj[N, H+1, 6] from the ORACLE (control-step granularity).  A rollout is flagged if between two samples its cart
+    can have reached the track edge (|x| + |v| dt within x_margin of THL) or its angle sits within th_margin of +-pi."""
+    x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
+    near_edge = (np.abs(x) + np.abs(v) * dt > THL - x_margin).any(axis=1)
+    near_wrap = (np.abs(np.abs(th) - np.pi) < th_margin).any(axis=1)
+    return near_edge | near_wrap
+
+
+def flag_indicators(traj, cost, target_position, margin=2e-4):
+    """Rollouts whose oracle trajectory passes within `margin` of a cost INDICATOR threshold (default.py:41-88: 1e7 at
+    |x| > 0.9 THL, terminal 1e4 at |angle| > 0.2 or |x - x*| > 0.1 THL; legacy q/phi: 1e6 at 0.95 THL, same terminal)."""
+    x = traj[:, :, O.POSITION_IDX]
+    flagged = np.zeros(traj.shape[0], dtype=bool)
+    if cost in ("default", "legacy"):
+        thr = (0.90 if cost == "default" else 0.95) * THL
+        flagged |= (np.abs(np.abs(x[:, :-1]) - thr) < margin).any(axis=1)
+        flagged |= np.abs(np.abs(traj[:, -1, O.ANGLE_IDX]) - 0.2) < margin
+        flagged |= np.abs(np.abs(x[:, -1] - target_position) - 0.1 * THL) < margin
+    return flagged
+
+
+def _check(off, flagged, what):
+    n = off.size
+    clear_off = int((off & ~flagged).sum())
+    assert clear_off == 0, f"{what}: {clear_off} of {int((~flagged).sum())} rollouts clear of every discontinuity are outside the band"
+    fl_off, fl = int((off & flagged).sum()), int(flagged.sum())
+    cap = min(int(np.ceil(FLAGGED_CAP * fl)), int(np.ceil(TOTAL_CAP * n)))
+    assert fl_off <= cap, f"{what}: {fl_off} of {fl} flagged rollouts outside the band (cap {cap})"
+
+
+def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0):
+    """out, ref_a, ref_b [N, 6] (or [N, k, 6]): inside band(ref_a) + |ref_a - ref_b| element-wise."""
+    off = np.abs(out - ref_a) > band(ref_a, scale) + np.abs(ref_a - ref_b)
+    off = off.reshape(off.shape[0], -1).any(axis=1)
+    _check(off, flagged, what)
+
+
+def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4):
+    """Per-rollout costs: |S - S_a| <= rtol |S_a| + |S_a - S_b| for every unflagged rollout."""
+    S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
+    gap = np.abs(S_a - np.asarray(S_b, np.float64)) if S_b is not None else 0.0
+    off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap
+    _check(off, np.zeros(S.shape, bool) if flagged is None else flagged, what)
+
+
+def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None):
+    """Updated control sequence / Q: 1e-4 absolute (north_star) around the reference's own [A, B] interval.  The soft-min
+    update amplifies cost differences by |S| / LBD (costs of ~5e4 at LBD = 100 turn a 1e-5 relative cost difference into
+    a 0.5 % weight change), so where the reference's two arithmetic modes themselves disagree on u by more than the
+    band, the allowance widens by exactly that disagreement (max over the horizon) — an oracle quantity.  `allowance`
+    (optional, per control): softmin_allowance(...) of the oracle's costs, for ill-conditioned updates."""
+    u, u_a = np.asarray(u, np.float64), np.asarray(u_a, np.float64)
+    gap = float(np.abs(u_a - np.asarray(u_b, np.float64)).max()) if u_b is not None else 0.0
+    extra = 0.0 if allowance is None else np.asarray(allowance, np.float64)
+    d = np.abs(u - u_a)
+    assert np.all(d <= atol + np.maximum(gap, extra)), (f"{what}: max |u - u_ref| = {d.max():.3e} > {atol:g} + oracle allowance "
+                                                      f"(A/B gap {gap:.3e}, soft-min conditioning {np.max(extra):.3e})")
+
+
+def softmin_allowance(S_a, S_b, du, LBD=100.0, cost_rtol=1e-5):
+    """How far a cost perturbation |dS_n| <= cost_rtol |S_n| + |S_a,n - S_b,n| can move the soft-min update, by its
+    Jacobian on the ORACLE's values:  u_k = sum_n w_n du[n,k],  w_n ~ exp(-S_n / LBD)  =>
+        |d u_k| <= (1 / LBD) sum_n w_n |du[n,k] - u_k| |dS_n|.
+    cost_rtol is FIXED at a tenth of the cost band: for costs of O(100) the term vanishes (the plain 1e-4 applies), for the
+    boundary-penalty regimes with costs of ~5e4 at LBD = 100 it is the honest conditioning of the reference's own update
+    (its float32 and float64-substep evaluations already differ by more than 1e-4 in u there)."""
+    S_a = np.asarray(S_a, np.float64)
+    eps = cost_rtol * np.abs(S_a) + (np.abs(S_a - np.asarray(S_b, np.float64)) if S_b is not None else 0.0)
+    w = np.exp(-(S_a - S_a.min()) / LBD)
+    w /= w.sum()
+    du = np.asarray(du, np.float64)
+    ubar = w @ du
+    return (w * eps) @ np.abs(du - ubar[None, :]) / LBD
+
+
+def flag_rounding_sensitive(S_f32, S_f64, thresh=0.25e-4):
+    """Rollouts whose cost the ORACLE itself cannot pin to a quarter of the band in float32 (its float32 and float64
+    evaluations differ by more than `thresh` relative): ill-conditioned, e.g. saturating random GRU weights."""
+    S_f32, S_f64 = np.asarray(S_f32, np.float64), np.asarray(S_f64, np.float64)
+    return np.abs(S_f32 - S_f64) > thresh * np.abs(S_f64)
+
+
+def oracle_step_both_modes(s0, u_nom, du, target_position, target_equilibrium, cfg, **kw):
+    """The oracle's MPPI step in both reference arithmetic modes (A: float32 substeps, B: float64 substeps)."""
+    a = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f32", **kw)
+    b = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f64sub", **kw)
+    return a, b

@@ -5,7 +5,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from oracle import oracle_np as O  # noqa: E402
+from oracle import oracle_np as O
+import parity_util as PU  # noqa: E402
 
 f32 = np.float32
 
@@ -41,8 +42,8 @@ def test_cem_sample_cost_update_vs_oracle():
     for e in range(E):
         traj = O.predict_core(s0[e], Qh[e], L=Lv[e])
         ref = O.trajectory_cost(O.COST_QBGM, traj, Qh[e], tp[e], f32(1.0))
-        rel = np.abs(Sh[e] - ref) / np.abs(ref)
-        assert np.median(rel) < 1e-4 and (rel < 2e-3).mean() >= 0.97
+        ref_b = O.trajectory_cost(O.COST_QBGM, O.predict_core(s0[e], Qh[e], L=Lv[e], mode="f64sub"), Qh[e], tp[e], f32(1.0))
+        PU.assert_costs(Sh[e], ref, ref_b, PU.flag_discontinuities(traj), f"env {e} costs")
     # top-k refit on the device's own costs: exact elite set, mean/std to rounding
     m2, s2, el = eng.cem_update(S, Q, K, 0.01, return_elites=True)
     for e in range(E):

@@ -222,3 +222,18 @@ def test_controller_mpc_and_optimizer_mppi_host_logic(fake_engine, monkeypatch):
     assert float(opt.u_nom.abs().max()) == 0.0 and opt.step_counter == 0
     with pytest.raises(ValueError):
         opt.step(np.zeros((3, 6), np.float32))                        # configured for one env
+
+
+def test_ode_is_not_served_as_ode_v0():
+    """`ODE` / `ODE_default` name next_state_predictor_ODE (predictors_customization.py:25-69: Euler-Cromer, atan2, no
+    bounce), 1.6e-3 from ODE_v0 after ONE control step: every seam must refuse it, not alias it."""
+    from cartpolesimulation_amd.optimizer_mppi import optimizer_mppi
+    from cartpolesimulation_amd.predictors import PredictorWrapper
+    for spec in ("ODE", "ODE_default"):
+        with pytest.raises(NotImplementedError):
+            optimizer_mppi(num_rollouts=8, mpc_horizon=4).configure(predictor_specification=spec)
+        with pytest.raises(NotImplementedError):
+            PredictorWrapper().update_predictor_config_from_specification(spec)
+    # a model that the chosen specification would silently ignore is an error too
+    with pytest.raises(ValueError):
+        optimizer_mppi(num_rollouts=8, mpc_horizon=4, gru_model={"w_ih0": None}).configure(predictor_specification="ODE_v0")
