@@ -727,12 +727,20 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
   return hipGetLastError();
 }
 
-// latency build for launches of at most one wave per SIMD (1024 SIMDs x 64 lanes), throughput build above
+// Which build of the kernel a launch gets (measured on MI355X, tools/kbench.py / tools/dev/step_series.py):
+//   one rollout per lane : latency build up to one wave per SIMD (1024 SIMDs x 64 lanes), throughput build above
+//   two rollouts per lane: mid-size build (loop constants in VGPRs) up to 2 M rollouts, throughput build above
+constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = 2ull << 20;
+constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                                const Params& p, const StepPtrs& a) {
   if (math == CPMPPI_MATH_FAST) {
-    if (rpl == 2) return launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
+    if (rpl == 2) {
+      const bool mid = (uint64_t)grid.x * BLOCK * 2 <= MID_SIZE_MAX_ROLLOUTS;
+      return mid ? launch_rollout_noise<COST, true, 2, 2>(noise, grid, lds, s, p, a)
+                 : launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
+    }
     const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
     return small ? launch_rollout_noise<COST, true, 1, 0>(noise, grid, lds, s, p, a)
                  : launch_rollout_noise<COST, true, 1, 1>(noise, grid, lds, s, p, a);
@@ -929,11 +937,12 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
   p.L = a->L; p.noise = a->noise; p.prev_in = a->previous_input; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
   p.offset_dev = (a->noise_kind == CPMPPI_NOISE_PHILOX) ? (const unsigned long long*)a->offset_dev : nullptr;
-  // lane mapping: two rollouts per lane (packed float2) once the launch is big enough to keep >= 2 such waves on
-  // every SIMD; one rollout per lane (shortest critical path) for small launches
+  // lane mapping: two rollouts per lane (packed float2) once the launch fills every SIMD with at least one such wave
+  // (1024 SIMDs x 128 rollouts); one rollout per lane (shortest critical path) below.  Measured at 128 envs x 1024 x 50:
+  // 76 us packed vs 90 us one per lane; at 64 envs the packed mapping would leave half the SIMDs empty.
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
-  else if (rpl == 0) rpl = ((uint64_t)a->E * h->cfg.N > 262144ull) ? 2 : 1;
+  else if (rpl == 0) rpl = ((uint64_t)a->E * h->cfg.N >= PACKED_MIN_ROLLOUTS) ? 2 : 1;
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = (a->noise_kind == CPMPPI_NOISE_DELTA_U) ? h->cfg.H : h->prm.P;
   p.S_out = a->S_out; p.partial = h->workspace;
@@ -1179,7 +1188,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   p.noise = inputs; p.prev_in = nullptr; p.seed = 0; p.offset = 0; p.offset_dev = nullptr; p.env_offset = 0; p.stash = 0;
   uint32_t rpl = h->cfg.rollouts_per_lane;
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
-  else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N > 262144ull) ? 2 : 1;
+  else if (rpl == 0) rpl = ((uint64_t)E * h->cfg.N >= PACKED_MIN_ROLLOUTS) ? 2 : 1;
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = h->cfg.H;
   p.S_out = S_out; p.partial = h->workspace; p.counter = nullptr; p.u_nom_out = nullptr; p.Q_out = nullptr;

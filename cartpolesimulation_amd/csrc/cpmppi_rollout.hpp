@@ -109,8 +109,9 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
 // The hot path.  R = rollouts per lane (1: latency mapping, 2: packed float2 throughput mapping, FAST only).
 // A block of 256 threads owns 256*R consecutive rollouts of one env; wave w owns rows [w*64*R, (w+1)*64*R) and lane l
 // integrates rows l (component 0) and l+64 (component 1).
-// VARIANT only selects the translation unit (hence the scheduling strategy) an instantiation is compiled in:
-// 0 = latency build (launches of at most one wave per SIMD), 1 = throughput build.  The code is the same.
+// VARIANT selects the translation unit (hence the scheduling strategy) an instantiation is compiled in:
+// 0 = latency build (one rollout per lane, launches of at most one wave per SIMD), 1 = throughput build, 2 = packed
+// mapping for mid-sized launches (same code except where the loop constants live, see below).
 template <int COST, bool FAST, int NOISE, int R, int VARIANT>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
   using F = typename Lanes<R>::F;
@@ -135,6 +136,19 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
   const float L = a.L ? a.L[env] : p.L_default;
   const EnvConst ec = make_env_const_uniform(p, L);
+  // VARIANT 2 (packed mapping, launches of up to ~16 waves per SIMD): the constants of the substep loop are held in
+  // vector registers instead of scalar ones.  The packed mapping wants every wave-uniform operand as a register PAIR and
+  // runs out of the 102 SGPRs; with them in VGPRs a lone wave's instruction stream is 4-7 % shorter in time (C3, C4, up
+  // to 2048 envs x 1024), while at 64 waves per SIMD the scalar-operand form is 5 % faster (A/B in one process,
+  // tools/kbench.py: 2.44 vs 2.56 ms at 8192 envs).
+  Params ph = p;
+  EnvConst eh = ec;
+  if constexpr (VARIANT == 2 && R == 2) {
+#define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
+    CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
+    CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.g_i); CPMPPI_TO_VGPR(eh.inv_kLh); CPMPPI_TO_VGPR(eh.cT_i);
+#undef CPMPPI_TO_VGPR
+  }
   const float x_t = a.x_t[env], te = a.te[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      control_step_fast<F>(st, uK, p.S, p.t_step, p, ec);
+      control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh);
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }

@@ -71,7 +71,7 @@ def test_config_full_size(name, E, N, H):
     assert np.array_equal(un2.cpu().numpy(), un_h)
     # stepped alone with the SAME lane mapping: bit-identical; with the other mapping (its intermediate substeps carry
     # the rotation differently): the same update to within the parity tolerance
-    rpl_batch = 2 if E * N > 262144 else 1
+    rpl_batch = 2 if E * N >= 131072 else 1                  # the library's lane-mapping rule (cpmppi.hip PACKED_MIN_ROLLOUTS)
     for rpl, exact in ((rpl_batch, True), (3 - rpl_batch, False)):
         small = make(1, N, H, rollouts_per_lane=rpl)
         for e in (1, E - 2):

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--noise", nargs="+", default=["philox", "buffer"])
     ap.add_argument("--math", nargs="+", default=["fast"])
+    ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane: 0 auto, 1, 2")
     args = ap.parse_args()
     E, N, H = args.envs, args.rollouts, args.horizon
     dev = torch.device("cuda", 0)
@@ -53,7 +54,7 @@ def main():
         lib.cpmppi_last_error.restype = C.c_char_p
         lib.cpmppi_last_error.argtypes = [vp]
         for math in args.math:
-            cfg = build_c_config(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math))
+            cfg = build_c_config(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=args.rpl))
             h = vp()
             rc = lib.cpmppi_create(C.byref(cfg), 0, C.byref(h))
             assert rc == 0, lib.cpmppi_last_error(None)
