@@ -51,10 +51,12 @@ def parse_args(argv=None):
     ap.add_argument("--envs", type=int, default=8192, help="independent MPPI problem instances per GPU")
     ap.add_argument("--rollouts", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=50)
-    ap.add_argument("--noise", choices=["buffer", "philox"], default="philox",
+    ap.add_argument("--noise", choices=["buffer", "buffer-ref", "philox"], default="philox",
                     help="philox: perturbation knots generated in-kernel from a counter-based RNG (no buffer); "
-                         "buffer: device sampler writes delta_u[E,N,H] to HBM, rollout kernel reads it back "
-                         "(the reference's tensor layout at the optimizer/predictor seam)")
+                         "buffer: the device sampler writes delta_u to HBM in the library's tiled layout and the rollout "
+                         "kernel reads it back with fully used, coalesced accesses; buffer-ref: the sampler writes the "
+                         "reference's rollout-major delta_u[E,N,H] (the tensor at the optimizer/predictor seam), read in "
+                         "32-byte row segments")
     ap.add_argument("--math", choices=["fast", "precise"], default="fast")
     ap.add_argument("--predictor", choices=["ode", "gru"], default="ode",
                     help="ode: predictor_ODE_v0 (the headline path); gru: GRU-6IN-32H1-32H2-5OUT on the matrix "
@@ -181,7 +183,7 @@ class Workload:
         self.s0, self.tp, self.te, self.L = synthetic_inputs(E, H, seed=2 + ctx["rank"], device=dev)
         self.u_nom = self.eng.zeros(E, H)
         self.Q_out = self.eng.empty(E)
-        self.du = self.eng.empty(E, N, H) if noise == "buffer" else None
+        self.du = self.eng.empty(E, N, H) if noise == "buffer-ref" else (self.eng.tiled_empty(E) if noise == "buffer" else None)
         self.seed = 1234
         self.pred_kw = {}
         if predictor == "gru":
@@ -201,9 +203,12 @@ class Workload:
     def step(self, i):
         import torch.distributed as dist
         e, rank = self.eng, self.ctx["rank"]
-        if self.noise == "buffer":
+        if self.noise == "buffer-ref":
             e._check(e.lib.cpmppi_sample(e._h, self.E, self.seed, i, rank * self.E, None, self.du.data_ptr(), e._stream()))
             e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=self.Q_out, **self.pred_kw)
+        elif self.noise == "buffer":
+            e.sample_tiled(self.seed, i, rank * self.E, E=self.E, out=self.du)
+            e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, delta_u_tiled=self.du, Q_out=self.Q_out)
         else:
             e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, seed=self.seed, offset=i, env_offset=rank * self.E,
                    Q_out=self.Q_out, **self.pred_kw)

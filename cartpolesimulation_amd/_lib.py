@@ -12,13 +12,14 @@ CONTROL_CLIP, CONTROL_PENALISE = 0, 1
 SHIFT_REPEAT_LAST, SHIFT_APPEND_ZERO, SHIFT_NONE = 0, 1, 2
 CORRECTION_U_RUN, CORRECTION_U_NOM = 0, 1
 MATH_PRECISE, MATH_FAST = 0, 1
-NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX = 0, 1, 2
+NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX, NOISE_DELTA_U_TILED = 0, 1, 2, 3
 
 EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
            "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_set_profiling", "cpmppi_get_profile",
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
-           "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version")
+           "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
+           "cpmppi_sample_tiled", "cpmppi_tile_delta_u")
 
 
 class cpmppi_config(C.Structure):
@@ -100,6 +101,10 @@ def load():
     lib.cpmppi_sgd_step.argtypes = [vp, u32, vp, vp, f, f, vp]
     lib.cpmppi_cem_sample.argtypes = [vp, u32, vp, vp, u64, u64, u32, vp, vp]
     lib.cpmppi_cem_update.argtypes = [vp, u32, vp, vp, u32, f, vp, vp, vp, vp]
+    lib.cpmppi_tiled_floats.argtypes = [vp, u32]
+    lib.cpmppi_tiled_floats.restype = C.c_size_t
+    lib.cpmppi_sample_tiled.argtypes = [vp, u32, u64, u64, u32, vp, vp, vp]
+    lib.cpmppi_tile_delta_u.argtypes = [vp, u32, vp, vp, vp]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

@@ -457,6 +457,85 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
 // CEM (hyper-parameters Control_Toolkit_ASF/config_optimizers.yml:1-11 "cem-tf"): the same rollout +
 // cost kernel, a different sampler and a top-k reduction instead of the soft-min.
 // Q[e,n,k] = clip(mean[e,k] + stdev[e,k] * z), z ~ N(0,1) from Philox (rollout, env, step pair, offset).
+// ---- the TILED perturbation layout --------------------------------------------------------------------------------
+// delta_u_tiled[E][G = ceil(N/64)][Hq = ceil(H/4)][64 rows][4 steps]: element (env, n, k) lives at
+//   ((((env * G + n / 64) * Hq + k / 4) * 64 + n % 64) * 4 + k % 4;   rows >= N and steps >= H are zero.
+// A wave of the rollout kernel reads it with one 16-byte load per lane per four control steps: 1 KB of contiguous memory
+// per wave-instruction, every byte used once per pass (the rollout-major reference layout delta_u[E,N,H] gives 200-byte
+// rows, of which a time tile touches 32 bytes: 5.9x the algorithmic traffic).
+
+// a17 straight into the tiled layout: one wave per (env, row group); lane = row; knots staged per lane in LDS.
+__global__ __launch_bounds__(BLOCK) void sample_tiled_kernel(const Params p, uint32_t E, uint64_t seed, uint64_t offset,
+                                                             uint32_t env_offset, const float* __restrict__ knots_in,
+                                                             float* __restrict__ tiled_out) {
+  extern __shared__ float kn_lds[];                               // [WAVES][64][P+1]
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t G = (p.N + 63u) >> 6, Hq = (p.H + 3u) >> 2;
+  const size_t grp = (size_t)blockIdx.x * WAVES + wave;           // flat (env, group)
+  if (grp >= (size_t)E * G) return;
+  const uint32_t env = (uint32_t)(grp / G), n = (uint32_t)(grp % G) * 64u + lane;
+  const uint32_t stride = p.P + 1;
+  float* __restrict__ mine = kn_lds + (wave * 64 + lane) * stride;
+  const bool valid = n < p.N;
+  for (uint32_t j0 = 0; j0 < p.P; j0 += 4) {
+    float zq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (valid && !knots_in) philox_normal_quad(seed, offset, env_offset + env, n, j0 >> 2, zq);
+#pragma unroll
+    for (uint32_t s = 0; s < 4; ++s) {
+      const uint32_t j = j0 + s;
+      if (j < p.P) mine[j] = !valid ? 0.0f : (knots_in ? knots_in[((size_t)env * p.N + n) * p.P + j] : p.sigma * zq[s]);
+    }
+  }
+  float4* __restrict__ out = reinterpret_cast<float4*>(tiled_out) + grp * Hq * 64u + lane;
+  const float inv_period = 1.0f / (float)p.period;
+  for (uint32_t q = 0; q < Hq; ++q) {
+    float v[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+      const uint32_t k = 4u * q + c;
+      if (k < p.H && valid) {
+        const uint32_t j = k / p.period, i = k % p.period;
+        const float zl = mine[j], zh = mine[j + 1];
+        v[c] = (p.interp_f32 && !knots_in) ? interp_from_slope32(knot_slope32(zl, zh, inv_period), zl, i)
+                                           : interp_knots(zl, zh, i, p.period);
+      } else {
+        v[c] = 0.0f;
+      }
+    }
+    out[(size_t)q * 64u] = float4{v[0], v[1], v[2], v[3]};
+  }
+}
+
+// delta_u[E,N,H] (reference layout) -> tiled: one wave per (env, row group); 64 x 64 sub-blocks through LDS (rows of the
+// sub-block are 256 contiguous bytes of the source; the destination quads are written 1 KB per wave-instruction).
+__global__ __launch_bounds__(BLOCK) void tile_kernel(const Params p, uint32_t E, const float* __restrict__ du,
+                                                     float* __restrict__ tiled_out) {
+  __shared__ float blk[WAVES][64][65];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t G = (p.N + 63u) >> 6, Hq = (p.H + 3u) >> 2;
+  const size_t grp = (size_t)blockIdx.x * WAVES + wave;
+  if (grp >= (size_t)E * G) return;
+  const uint32_t env = (uint32_t)(grp / G), n0 = (uint32_t)(grp % G) * 64u;
+  const float* __restrict__ src = du + ((size_t)env * p.N + n0) * p.H;
+  float4* __restrict__ out = reinterpret_cast<float4*>(tiled_out) + grp * Hq * 64u + lane;
+  for (uint32_t k0 = 0; k0 < p.H; k0 += 64) {
+    for (uint32_t r0 = 0; r0 < 64; r0 += 16) {                             // row r: steps k0 .. k0+63, lane = step
+      float v[16];                                                         // sixteen row segments in flight
+#pragma unroll
+      for (uint32_t u = 0; u < 16; ++u)
+        v[u] = (n0 + r0 + u < p.N && k0 + lane < p.H) ? src[(size_t)(r0 + u) * p.H + k0 + lane] : 0.0f;
+#pragma unroll
+      for (uint32_t u = 0; u < 16; ++u) blk[wave][r0 + u][lane] = v[u];
+    }
+    // (one wave owns blk[wave]: no block barrier; the wave's own LDS writes are ordered before its reads)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (uint32_t c = 0; c < 16 && k0 + 4u * c < p.H; ++c)
+      out[(size_t)((k0 >> 2) + c) * 64u] = float4{blk[wave][lane][4 * c], blk[wave][lane][4 * c + 1],
+                                                 blk[wave][lane][4 * c + 2], blk[wave][lane][4 * c + 3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void cem_sample_kernel(const Params p, uint32_t E, const float* __restrict__ mean,
                                                            const float* __restrict__ stdev, uint64_t seed, uint64_t offset,
                                                            uint32_t env_offset, float* __restrict__ Q) {
@@ -721,6 +800,8 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
       hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_KNOTS:
       hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
+    case CPMPPI_NOISE_DELTA_U_TILED:
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_TILED, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
     default:
       hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
   }
@@ -884,6 +965,41 @@ int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* 
   return CPMPPI_OK;
 }
 
+size_t cpmppi_tiled_floats(const cpmppi_handle* h, uint32_t E) {
+  if (!h) return 0;
+  return (size_t)E * ((h->cfg.N + 63u) / 64u) * ((h->cfg.H + 3u) / 4u) * 256u;
+}
+
+int cpmppi_sample_tiled(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, uint32_t env_offset,
+                        const float* knots_in, float* tiled_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !tiled_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample_tiled: bad argument");
+  if ((reinterpret_cast<uintptr_t>(tiled_out) & 15u) != 0 || misaligned(knots_in))
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_sample_tiled: tiled_out must be 16-byte aligned");
+  if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > SAMPLER_LDS_MAX)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample_tiled: more than 154 knots per rollout are not supported");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t groups = (size_t)E * ((h->cfg.N + 63u) / 64u);
+  hipLaunchKernelGGL(sample_tiled_kernel, dim3((unsigned)((groups + WAVES - 1) / WAVES)), dim3(BLOCK),
+                     (size_t)BLOCK * (h->prm.P + 1) * sizeof(float), (hipStream_t)stream, h->prm, E, seed, offset,
+                     env_offset, knots_in, tiled_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_tile_delta_u(cpmppi_handle* h, uint32_t E, const float* delta_u, float* tiled_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !delta_u || !tiled_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_tile_delta_u: bad argument");
+  if ((reinterpret_cast<uintptr_t>(tiled_out) & 15u) != 0 || misaligned(delta_u))
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_tile_delta_u: tiled_out must be 16-byte aligned");
+  if (int rc = ensure_device(h)) return rc;
+  const size_t groups = (size_t)E * ((h->cfg.N + 63u) / 64u);
+  hipLaunchKernelGGL(tile_kernel, dim3((unsigned)((groups + WAVES - 1) / WAVES)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     h->prm, E, delta_u, tiled_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
 int cpmppi_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* L,
                    float* traj_out, void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
@@ -926,7 +1042,11 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   if (a->E == 0 || a->E > h->cfg.E) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: E out of range");
   if (!a->s0 || !a->u_nom || !a->target_position || !a->target_equilibrium)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: s0, u_nom, target_position, target_equilibrium are required");
-  if (a->noise_kind > CPMPPI_NOISE_PHILOX) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: unknown noise_kind");
+  if (a->noise_kind > CPMPPI_NOISE_DELTA_U_TILED) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: unknown noise_kind");
+  if (a->noise_kind == CPMPPI_NOISE_DELTA_U_TILED && (reinterpret_cast<uintptr_t>(a->noise) & 15u) != 0)
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_step: the tiled perturbation buffer must be 16-byte aligned");
+  if (a->noise_kind == CPMPPI_NOISE_DELTA_U_TILED && a->predictor == CPMPPI_PREDICTOR_GRU)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor takes delta_u, knots or Philox noise");
   if (a->noise_kind != CPMPPI_NOISE_PHILOX && !a->noise)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: noise buffer required for this noise_kind");
   if (misaligned(a->s0) || misaligned(a->u_nom) || misaligned(a->noise) || misaligned(a->S_out) ||
@@ -944,10 +1064,12 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   if (h->cfg.math_mode != CPMPPI_MATH_FAST) rpl = 1;
   else if (rpl == 0) rpl = ((uint64_t)a->E * h->cfg.N >= PACKED_MIN_ROLLOUTS) ? 2 : 1;
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
-  p.W = (a->noise_kind == CPMPPI_NOISE_DELTA_U) ? h->cfg.H : h->prm.P;
+  uint32_t noise_kind = a->noise_kind;
+  const hipStream_t s = (hipStream_t)stream;
+  const bool du_space = (noise_kind == CPMPPI_NOISE_DELTA_U || noise_kind == CPMPPI_NOISE_DELTA_U_TILED);
+  p.W = du_space ? h->cfg.H : h->prm.P;
   p.S_out = a->S_out; p.partial = h->workspace;
   p.counter = nullptr; p.u_nom_out = a->u_nom; p.Q_out = a->Q_out;
-  const hipStream_t s = (hipStream_t)stream;
   hipEvent_t* ev = nullptr;
   if (h->profiling) {
     if (h->ev_used + 3 > h->ev.size()) {
@@ -997,12 +1119,12 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
       const size_t park = (size_t)p.W * rpl * BLOCK * sizeof(float);
       if (lds + park <= 32 * 1024) { p.stash = 1; lds += park; }
     }
-    CPMPPI_HIP(h, launch_rollout(h, rpl, a->noise_kind, dim3(a->E * p.nb), lds, s, p));
+    CPMPPI_HIP(h, launch_rollout(h, rpl, noise_kind, dim3(a->E * p.nb), lds, s, p));
   }
   const bool separate_finalize = (p.counter == nullptr);
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
   if (separate_finalize) {
-    if (a->noise_kind == CPMPPI_NOISE_DELTA_U)
+    if (du_space)
       hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
                          p.nb, p.W, a->u_nom, a->Q_out);
     else

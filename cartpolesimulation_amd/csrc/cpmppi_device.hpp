@@ -41,7 +41,7 @@ constexpr float PI_F = 3.14159274101257324f;       // float32(np.pi)
 constexpr float TWO_PI_F = 6.28318548202514648f;   // float32(2*np.pi)
 
 enum : int { COST_QBGM = 0, COST_DEFAULT = 1, COST_LEGACY = 2, COST_QBG = 3 };
-enum : int { NOISE_DELTA_U = 0, NOISE_KNOTS = 1, NOISE_PHILOX = 2 };
+enum : int { NOISE_DELTA_U = 0, NOISE_KNOTS = 1, NOISE_PHILOX = 2, NOISE_TILED = 3 };
 
 // Kernel-argument block (passed by value -> kernarg segment -> SGPRs).
 struct Params {
@@ -671,6 +671,7 @@ __device__ __forceinline__ F div_uniform(F x, float c) {
 
 template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang, F u, float x_t, float te) {
+#pragma clang fp contract(off)     // every product and sum rounds once, wherever the function is inlined
   const float THL = p.THL;
   const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   const F dd = (d * d) * splat<F>(p.w[0]);
@@ -694,6 +695,7 @@ __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang,
 // (previous_input at stage 0); terminal cost zero.
 template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_qbg(const Params& p, F x, F cosang, F w_ang, F u, F u_before, float x_t, float te) {
+#pragma clang fp contract(off)     // every product and sum rounds once, wherever the function is inlined
   const bool up = (te == 1.0f);
   const float* w = p.w + (up ? 0 : 7);
   const float corr = up ? p.w[14] : p.w[15];
@@ -726,6 +728,7 @@ __device__ __forceinline__ F stage_qbg(const Params& p, F x, F cosang, F w_ang, 
 // default.py:23-88; w = {dd, ep, cc, R}
 template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_default(const Params& p, F x, F cosang, F u, float x_t, float te) {
+#pragma clang fp contract(off)     // every product and sum rounds once, wherever the function is inlined
   const float THL = p.THL;
   const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   F ind;
@@ -762,6 +765,7 @@ __device__ __forceinline__ F mppi_correction(const Params& p, F u, F du) {
 template <class F, bool FAST = false>
 __device__ __forceinline__ F stage_legacy(const Params& p, F x, F cosang, F w_ang, F v, float u, F du, float u_prev,
                                           float x_t) {
+#pragma clang fp contract(off)     // every product and sum rounds once, wherever the function is inlined
   const float THL = p.THL;
   const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   F ind;

@@ -221,6 +221,38 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         control_step(k0 + kk, du);
       }
     }
+  } else if constexpr (NOISE == NOISE_TILED) {
+    // delta_u in the library's TILED layout [E][G = ceil(N/64)][Hq = ceil(H/4)][64 rows][4 steps] (cpmppi_sample_tiled /
+    // cpmppi_tile_delta_u): lane l of row-group g reads ONE float4 per four control steps, and a wave-instruction reads
+    // 1 KB of contiguous memory — every fetched byte is used, no LDS transpose.  The next quad is in flight while the
+    // current one is integrated (four control steps = thousands of cycles of cover).
+    const uint32_t G = (p.N + 63u) >> 6, Hq = (H + 3u) >> 2;
+    const float4* __restrict__ src[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      uint32_t g = (row0 >> 6) + (uint32_t)i;
+      g = g < G ? g : G - 1u;                                 // (rows of a group past the end are invalid anyway)
+      src[i] = reinterpret_cast<const float4*>(a.noise) + ((size_t)env * G + g) * Hq * 64u + lane;
+    }
+    float4 cur[R], nxt[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { cur[i] = src[i][0]; nxt[i] = cur[i]; }
+    for (uint32_t q = 0; q < Hq; ++q) {
+      if (q + 1 < Hq) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) nxt[i] = src[i][(size_t)(q + 1) * 64u];
+      }
+      const uint32_t kend = (H - 4u * q < 4u) ? (H - 4u * q) : 4u;
+      for (uint32_t j = 0; j < kend; ++j) {
+        F du;
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+          put(du, i, j == 0u ? cur[i].x : (j == 1u ? cur[i].y : (j == 2u ? cur[i].z : cur[i].w)));
+        control_step(4u * q + j, du);
+      }
+#pragma unroll
+      for (int i = 0; i < R; ++i) cur[i] = nxt[i];
+    }
   } else {
     // Philox: one block yields FOUR consecutive knots (4q .. 4q+3); the other three are kept until needed.  Every knot is
     // also parked in LDS (when it fits) so that the soft-min reduction below does not generate the sequence again.
@@ -326,6 +358,28 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       v = wave_sum(v);
       if (lane == 0) my_bsum[j] = v;
     }
+  } else if constexpr (NOISE == NOISE_TILED) {
+    // second, coalesced sweep over the wave's quads: lane = row, the sum over the 64 rows of a group by wave reduction
+    const uint32_t G = (p.N + 63u) >> 6, Hq = (H + 3u) >> 2;
+    for (uint32_t q = 0; q < Hq; ++q) {
+      float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        uint32_t g = (row0 >> 6) + (uint32_t)i;
+        g = g < G ? g : G - 1u;
+        const float4 v = reinterpret_cast<const float4*>(a.noise)[(((size_t)env * G + g) * Hq + q) * 64u + lane];
+        acc.x = __builtin_fmaf(e[i], v.x, acc.x); acc.y = __builtin_fmaf(e[i], v.y, acc.y);
+        acc.z = __builtin_fmaf(e[i], v.z, acc.z); acc.w = __builtin_fmaf(e[i], v.w, acc.w);
+      }
+      acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+      if (lane == 0) {
+        const uint32_t k = 4u * q;
+        my_bsum[k] = acc.x;
+        if (k + 1 < W) my_bsum[k + 1] = acc.y;
+        if (k + 2 < W) my_bsum[k + 2] = acc.z;
+        if (k + 3 < W) my_bsum[k + 3] = acc.w;
+      }
+    }
   } else {
     // transposed pass: lane = column (time-step or knot), loop over the wave's rows, rows read coalesced (cache-hot)
     const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * W;
@@ -389,7 +443,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         __hip_atomic_store(a.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       }
       __syncthreads();
-      finalize_env<NOISE != NOISE_DELTA_U, true>(p, a.partial, a.nb, W, a.u_nom_out, a.Q_out, env);
+      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom_out, a.Q_out, env);
     }
   }
 }

@@ -15,4 +15,8 @@ template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1,
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_TILED, 1, 0>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_TILED, 1, 0>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_TILED, 1, 0>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_TILED, 1, 0>(const Params, const StepPtrs);
 }  // namespace cpmppi_k

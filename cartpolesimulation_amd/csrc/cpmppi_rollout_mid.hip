@@ -16,4 +16,8 @@ template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 2,
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 2, 2>(const Params, const StepPtrs);
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 2, 2>(const Params, const StepPtrs);
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 2, 2>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_TILED, 2, 2>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_TILED, 2, 2>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_TILED, 2, 2>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_TILED, 2, 2>(const Params, const StepPtrs);
 }  // namespace cpmppi_k

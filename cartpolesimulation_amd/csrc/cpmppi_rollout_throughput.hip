@@ -39,6 +39,18 @@ template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 2, 1>(
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
 template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
 template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_TILED, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_TILED, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_TILED, 2, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_TILED, 1, 1>(const Params, const StepPtrs);
+template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_TILED, 2, 1>(const Params, const StepPtrs);
 }  // namespace cpmppi_k
 
 #ifdef CPMPPI_DEBUG_COUNTERS

@@ -120,6 +120,41 @@ class MPPIEngine:
                                            self._stream()))
         return kn, du
 
+    def tiled_empty(self, E=None):
+        """An uninitialised perturbation buffer in the library's tiled layout (include/cpmppi.h) for E envs."""
+        E = self.E if E is None else int(E)
+        return torch.empty(int(self.lib.cpmppi_tiled_floats(self._h, E)), dtype=torch.float32, device=self.device)
+
+    def sample_tiled(self, seed=0, offset=0, env_offset=0, E=None, knots=None, out=None):
+        """a17 straight into the tiled layout: Philox knots, or caller ``knots`` [E,N,P] interpolated."""
+        kn = None if knots is None else self.tensor(knots)
+        if kn is not None and kn.dim() == 2:
+            kn = kn.unsqueeze(0)
+        E = (self.E if E is None else int(E)) if kn is None else kn.shape[0]
+        out = self.tiled_empty(E) if out is None else out
+        self._check(self.lib.cpmppi_sample_tiled(self._h, E, int(seed), int(offset), int(env_offset), _ptr(kn), _ptr(out),
+                                                 self._stream()))
+        return out
+
+    def tile_delta_u(self, delta_u, out=None):
+        """delta_u [E,N,H] (reference layout) -> the tiled layout."""
+        du = self.tensor(delta_u)
+        if du.dim() == 2:
+            du = du.unsqueeze(0)
+        E = du.shape[0]
+        if du.shape != (E, self.N, self.H):
+            raise ValueError(f"delta_u must be [E,{self.N},{self.H}], got {tuple(du.shape)}")
+        out = self.tiled_empty(E) if out is None else out
+        self._check(self.lib.cpmppi_tile_delta_u(self._h, E, _ptr(du), _ptr(out), self._stream()))
+        return out
+
+    def untile(self, tiled, E=None):
+        """The tiled buffer viewed back as delta_u [E,N,H] (host-side index arithmetic; tests and debugging)."""
+        E = self.E if E is None else int(E)
+        G, Hq = (self.N + 63) // 64, (self.H + 3) // 4
+        t = tiled.reshape(E, G, Hq, 64, 4).permute(0, 1, 3, 2, 4).reshape(E, G * 64, Hq * 4)
+        return t[:, :self.N, :self.H].contiguous()
+
     def interpolate(self, knots):
         knots = self.tensor(knots)
         if knots.dim() == 2:
@@ -285,10 +320,11 @@ class MPPIEngine:
     # ------------------------------------------------------------------ the fused hot path
     def step(self, s0, u_nom, target_position, target_equilibrium, L=None, delta_u=None, knots=None, seed=None,
              offset=0, env_offset=0, u_prev=None, Q_out=None, S_out=None, predictor="ODE_v0", h0=None,
-             previous_input=None, offset_dev=None):
+             previous_input=None, offset_dev=None, delta_u_tiled=None):
         """One MPPI optimizer step for E envs.  ``u_nom`` [E,H] is updated IN PLACE.
 
-        Exactly one noise source: ``delta_u`` [E,N,H], ``knots`` [E,N,P], or ``seed`` (in-kernel Philox).
+        Exactly one noise source: ``delta_u`` [E,N,H], ``knots`` [E,N,P], ``seed`` (in-kernel Philox) or
+        ``delta_u_tiled`` (a buffer from sample_tiled / tile_delta_u).
         Returns (Q_out[E], S_out or None).
         """
         if not (torch.is_tensor(u_nom) and u_nom.is_cuda and u_nom.dtype == torch.float32 and u_nom.is_contiguous()):
@@ -296,9 +332,9 @@ class MPPIEngine:
         E = u_nom.shape[0]
         if u_nom.shape != (E, self.H) or E > self.E:
             raise ValueError(f"u_nom must be [E<={self.E},{self.H}], got {tuple(u_nom.shape)}")
-        given = [x is not None for x in (delta_u, knots, seed)]
+        given = [x is not None for x in (delta_u, knots, seed, delta_u_tiled)]
         if sum(given) != 1:
-            raise ValueError("give exactly one of delta_u, knots, seed")
+            raise ValueError("give exactly one of delta_u, knots, seed, delta_u_tiled")
         a = _L.cpmppi_step_args()
         s0 = self.tensor(s0, (E, 6))
         tp = self.tensor(target_position).reshape(-1)
@@ -310,7 +346,13 @@ class MPPIEngine:
             Lt = self.tensor(L).reshape(-1)
             Lt = Lt.expand(E).contiguous() if Lt.numel() == 1 else Lt
         noise = None
-        if delta_u is not None:
+        if delta_u_tiled is not None:
+            noise = delta_u_tiled
+            if not (torch.is_tensor(noise) and noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+                    and noise.numel() >= int(self.lib.cpmppi_tiled_floats(self._h, E))):
+                raise ValueError("delta_u_tiled must be a contiguous float32 ROCm tensor of cpmppi_tiled_floats(E) elements")
+            a.noise_kind = _L.NOISE_DELTA_U_TILED
+        elif delta_u is not None:
             noise = self.tensor(delta_u, (E, self.N, self.H))
             a.noise_kind = L_NOISE[0]
         elif knots is not None:

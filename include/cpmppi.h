@@ -78,7 +78,9 @@ enum { CPMPPI_MATH_PRECISE = 0,  /* IEEE divide, libm-grade sincos, no FMA contr
                                     only (tools/deviation.py: median 1e-6, p99 1e-5 of the reference's own mode A) */
 enum { CPMPPI_NOISE_DELTA_U = 0, /* noise = delta_u[E,N,H]  (reference layout, rollout-major)              */
        CPMPPI_NOISE_KNOTS = 1,   /* noise = knots[E,N,P], P = ceil(H/period)+1; interpolated in-kernel       */
-       CPMPPI_NOISE_PHILOX = 2 };/* knots generated in-kernel from (seed, offset): no perturbation buffer   */
+       CPMPPI_NOISE_PHILOX = 2,  /* knots generated in-kernel from (seed, offset): no perturbation buffer   */
+       CPMPPI_NOISE_DELTA_U_TILED = 3 }; /* noise = delta_u in the library's tiled layout (cpmppi_sample_tiled /
+                                    cpmppi_tile_delta_u): [E][ceil(N/64)][ceil(H/4)][64][4], 16-byte aligned          */
 
 typedef struct {
   uint32_t abi_version;          /* CPMPPI_ABI_VERSION */
@@ -140,7 +142,7 @@ typedef struct {
   const float* target_equilibrium;  /* [E] */
   const float* L;                   /* [E] pole length per env, or NULL = config.L_default */
   uint32_t noise_kind;              /* CPMPPI_NOISE_* */
-  const float* noise;               /* delta_u[E,N,H] or knots[E,N,P]; ignored for CPMPPI_NOISE_PHILOX */
+  const float* noise;               /* delta_u[E,N,H], knots[E,N,P] or the tiled delta_u; ignored for CPMPPI_NOISE_PHILOX */
   uint64_t seed;                    /* CPMPPI_NOISE_PHILOX: key */
   uint64_t offset;                  /* CPMPPI_NOISE_PHILOX: step counter (fresh noise per step) */
   uint32_t env_offset;              /* CPMPPI_NOISE_PHILOX: global index of env 0 (rank * E_local when sharded) */
@@ -173,6 +175,20 @@ int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, 
 /* Interpolate caller-provided knots[E,N,P] (e.g. drawn with numpy SFC64 for bit-identical parity runs) to
  * delta_u[E,N,H]. */
 int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* delta_u_out, void* stream);
+
+/* The TILED perturbation layout — delta_u[E,N,H] (controller_mppi_cartpole.py:434-446 produces it rollout-major) stored as
+ * [E][G = ceil(N/64)][Hq = ceil(H/4)][64 rows][4 steps]: element (env, n, k) at
+ * ((((env*G + n/64)*Hq + k/4)*64 + n%64)*4 + k%4, padding zero.  The rollout kernel reads it with fully used, contiguous
+ * 1 KB wave accesses (the rollout-major layout costs 5.9x the algorithmic traffic at H = 50).
+ *   cpmppi_tiled_floats   number of floats of the tiled buffer for E envs (allocate 16-byte aligned)
+ *   cpmppi_sample_tiled   a17 straight into it: Philox knots (knots_in NULL) or caller knots[E,N,P], interpolated
+ *   cpmppi_tile_delta_u   re-tile a reference-layout delta_u[E,N,H] (one coalesced pass: worth it when the buffer is
+ *                         reused over several steps — for a single step the extra pass costs more than the rollout-major
+ *                         kernel's over-fetch: 0.7 ms vs 0.36 ms at 8192 envs x 1024 x 50) */
+size_t cpmppi_tiled_floats(const cpmppi_handle* h, uint32_t E);
+int cpmppi_sample_tiled(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, uint32_t env_offset,
+                        const float* knots_in, float* tiled_out, void* stream);
+int cpmppi_tile_delta_u(cpmppi_handle* h, uint32_t E, const float* delta_u, float* tiled_out, void* stream);
 
 /* Predictor seam (a9-a11): B independent rollouts.  s0[B,6], Q[B,H] (dimensionless control in [-1,1]),
  * L[B] or NULL -> traj[B,H+1,6] with traj[:,0]=s0.  horizon may be < config.H (0 = config.H). */

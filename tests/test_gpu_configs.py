@@ -82,6 +82,18 @@ def test_config_full_size(name, E, N, H):
             else:
                 np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=1e-4)
 
+    # ---- the same perturbations through the reference-layout buffer and through its re-tiled form: identical costs
+    du_full = eng.interpolate(kn)
+    S4, u4 = eng.empty(E, N), eng.tensor(u0.copy())
+    eng.step(s0, u4, tp, te, L=Lv, delta_u=du_full, S_out=S4)
+    S5, u5 = eng.empty(E, N), eng.tensor(u0.copy())
+    eng.step(s0, u5, tp, te, L=Lv, delta_u_tiled=eng.tile_delta_u(du_full), S_out=S5)
+    assert np.array_equal(S4.cpu().numpy(), S5.cpu().numpy())
+    np.testing.assert_allclose(u4.cpu().numpy(), u5.cpu().numpy(), atol=5e-6)     # row-major vs quad-major summation order
+    np.testing.assert_allclose(S4.cpu().numpy(), S_h, rtol=2e-5)                  # caller knots: float64 interpolation either way
+    np.testing.assert_allclose(u4.cpu().numpy(), un_h, atol=2e-5)
+    del du_full
+
     # ---- permutation invariance: shuffling an env's rollouts leaves its update unchanged (to summation order)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).to(kn.device)
     u3 = eng.tensor(u0.copy())

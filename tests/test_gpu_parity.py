@@ -138,7 +138,8 @@ LANE_MODES = [("precise", 1), ("fast", 1), ("fast", 2)]      # (math_mode, rollo
 
 @pytest.mark.parametrize("math_mode,rpl", LANE_MODES)
 def test_noise_sources_agree(math_mode, rpl):
-    """delta_u buffer == in-kernel interpolation of the same knots == in-kernel Philox of the same (seed, offset)."""
+    """delta_u buffer == in-kernel interpolation of the same knots == in-kernel Philox of the same (seed, offset) == the
+    tiled delta_u buffer (N = 700 and H = 35 are multiples of neither the 64-row group nor the 4-step quad)."""
     E, N, H = 3, 700, 35
     eng = engine(E, N, H, math_mode=math_mode, rollouts_per_lane=rpl)
     rng = Generator(SFC64(7))
@@ -157,8 +158,13 @@ def test_noise_sources_agree(math_mode, rpl):
         assert np.array_equal(du64.cpu().numpy(), du.cpu().numpy())
     else:
         np.testing.assert_allclose(du.cpu().numpy(), du64.cpu().numpy(), rtol=0, atol=1.2e-7)
+    # the tiled layout holds the same values: device sampler straight into it == re-tiled reference-layout buffer
+    tiled = eng.sample_tiled(seed=1234, offset=5, env_offset=11)
+    assert np.array_equal(eng.untile(tiled).cpu().numpy(), du.cpu().numpy())
+    assert np.array_equal(eng.tile_delta_u(du).cpu().numpy(), tiled.cpu().numpy())            # padding included (zeros)
+    assert np.array_equal(eng.untile(eng.sample_tiled(knots=kn)).cpu().numpy(), du64.cpu().numpy())
     outs = []
-    for kw in (dict(delta_u=du), dict(knots=kn), dict(seed=1234, offset=5, env_offset=11)):
+    for kw in (dict(delta_u=du), dict(knots=kn), dict(seed=1234, offset=5, env_offset=11), dict(delta_u_tiled=tiled)):
         un = eng.tensor(u0.copy())
         S = eng.empty(E, N)
         Q, _ = eng.step(s0, un, tp, te, L=Lv, S_out=S, **kw)
@@ -170,6 +176,7 @@ def test_noise_sources_agree(math_mode, rpl):
         assert np.array_equal(outs[1][1], outs[0][1])
     else:
         np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5)
+    assert np.array_equal(outs[3][1], outs[0][1])                  # tiled buffer: the very same perturbations
     for o in outs[1:]:
         np.testing.assert_allclose(o[0], outs[0][0], atol=5e-6)    # knot-space vs delta_u-space reduction order
         np.testing.assert_allclose(o[2], outs[0][2], atol=5e-6)

@@ -62,6 +62,14 @@ def main():
     # one shared perturbation buffer (sampled by the first variant)
     lib0, h0 = variants[0][2], variants[0][3]
     lib0.cpmppi_sample(h0, E, 1234, 0, 0, kn.data_ptr(), du.data_ptr(), stream)
+    tiled = None
+    if "tiled" in args.noise:            # (needs a build with the tiled layout: the newest library goes last on the command line)
+        libT, hT = variants[-1][2], variants[-1][3]
+        libT.cpmppi_tiled_floats.argtypes = [vp, u32]
+        libT.cpmppi_tiled_floats.restype = C.c_size_t
+        libT.cpmppi_sample_tiled.argtypes = [vp, u32, u64, u64, u32, vp, vp, vp]
+        tiled = torch.empty(int(libT.cpmppi_tiled_floats(hT, E)), device=dev)
+        assert libT.cpmppi_sample_tiled(hT, E, 1234, 0, 0, None, tiled.data_ptr(), stream) == 0
     torch.cuda.synchronize()
     res = {}
     for rnd in range(args.rounds):
@@ -71,8 +79,11 @@ def main():
                 a.E = E
                 a.s0, a.u_nom, a.target_position, a.target_equilibrium = s0.data_ptr(), u_nom.data_ptr(), tp.data_ptr(), te.data_ptr()
                 a.L, a.Q_out = Lt.data_ptr(), Q.data_ptr()
-                a.noise_kind = {"buffer": 0, "knots": 1, "philox": 2}[noise]
-                a.noise = {"buffer": du.data_ptr(), "knots": kn.data_ptr(), "philox": None}[noise]
+                if noise == "tiled" and not hasattr(lib, "cpmppi_sample_tiled"):
+                    continue
+                a.noise_kind = {"buffer": 0, "knots": 1, "philox": 2, "tiled": 3}[noise]
+                a.noise = {"buffer": du.data_ptr(), "knots": kn.data_ptr(), "philox": None,
+                           "tiled": tiled.data_ptr() if tiled is not None else None}[noise]
                 a.seed, a.offset = 1234, 0
                 u_nom.zero_()
                 lib.cpmppi_set_profiling(h, 1)
