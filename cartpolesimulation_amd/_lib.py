@@ -19,7 +19,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_set_profiling", "cpmppi_get_profile",
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
-           "cpmppi_sample_tiled", "cpmppi_tile_delta_u")
+           "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample")
 
 
 class cpmppi_config(C.Structure):
@@ -105,6 +105,7 @@ def load():
     lib.cpmppi_tiled_floats.restype = C.c_size_t
     lib.cpmppi_sample_tiled.argtypes = [vp, u32, u64, u64, u32, vp, vp, vp]
     lib.cpmppi_tile_delta_u.argtypes = [vp, u32, vp, vp, vp]
+    lib.cpmppi_cem_gmm_sample.argtypes = [vp, u32, vp, u32, vp, u64, u64, u32, vp, vp, vp]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

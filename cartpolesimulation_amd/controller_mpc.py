@@ -11,7 +11,8 @@ import numpy as np
 
 from .configs import MPPIConfig, PhysicalParameters
 from .cost_functions import CostFunctionWrapper
-from .optimizer_cem import optimizer_cem, optimizer_cem_grad_bharadhwaj, optimizer_cem_naive_grad, optimizer_random_action
+from .optimizer_cem import (optimizer_cem, optimizer_cem_gmm, optimizer_cem_grad_bharadhwaj, optimizer_cem_naive_grad,
+                            optimizer_random_action)
 from .optimizer_gradient import optimizer_gradient, optimizer_rpgd
 from .optimizer_mppi import optimizer_mppi
 from .predictors import PredictorWrapper
@@ -70,7 +71,8 @@ class controller_mpc(template_controller):
     def configure(self, optimizer_name=None, predictor_specification=None, cost_function_specification=None,
                   controller_logging=False, **kwargs):
         optimizer_name = optimizer_name or "mppi"
-        others = {"cem": optimizer_cem, "cem-tf": optimizer_cem, "gradient": optimizer_gradient,
+        others = {"cem": optimizer_cem, "cem-tf": optimizer_cem, "cem-gmm": optimizer_cem_gmm, "cem-gmm-tf": optimizer_cem_gmm,
+                  "gradient": optimizer_gradient,
                   "gradient-tf": optimizer_gradient, "rpgd": optimizer_rpgd, "rpgd-tf": optimizer_rpgd,
                   "cem-naive-grad": optimizer_cem_naive_grad, "cem-naive-grad-tf": optimizer_cem_naive_grad,
                   "cem-grad-bharadhwaj": optimizer_cem_grad_bharadhwaj, "cem-grad-bharadhwaj-tf": optimizer_cem_grad_bharadhwaj,

@@ -553,6 +553,31 @@ __global__ __launch_bounds__(BLOCK) void cem_sample_kernel(const Params p, uint3
   }
 }
 
+// cem-gmm: samples from a mixture of K Gaussians with equal weights — component c of env e is centred on the elite
+// sequence centres[e, c, :] and shares the per-time-step stdev[e, :] — clipped to the control limits.  The component of
+// a rollout comes from the same Philox stream as its normals (counter word `pair` = 0x80000000: never a real pair index).
+__global__ __launch_bounds__(BLOCK) void cem_gmm_sample_kernel(const Params p, uint32_t E, const float* __restrict__ centres,
+                                                               uint32_t K, const float* __restrict__ stdev, uint64_t seed,
+                                                               uint64_t offset, uint32_t env_offset, float* __restrict__ Q,
+                                                               uint32_t* __restrict__ comp_out) {
+  const size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= (size_t)E * p.N) return;
+  const uint32_t env = (uint32_t)(r / p.N), n = (uint32_t)(r % p.N);
+  uint32_t c0 = n, c1 = env_offset + env, c2 = 0x80000000u, c3 = (uint32_t)offset;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32));
+  const uint32_t comp = (uint32_t)(((uint64_t)c0 * K) >> 32);              // uniform over 0 .. K-1
+  if (comp_out) comp_out[r] = comp;
+  const float* m = centres + ((size_t)env * K + comp) * p.H;
+  const float* sd = stdev + (size_t)env * p.H;
+  float* q = Q + r * p.H;
+  for (uint32_t k = 0; k < p.H; k += 2) {
+    float z0, z1;
+    philox_normal_pair(seed, offset, env_offset + env, n, k >> 1, z0, z1);
+    q[k] = fminf(fmaxf(__builtin_fmaf(sd[k], z0, m[k]), p.lo), p.hi);
+    if (k + 1 < p.H) q[k + 1] = fminf(fmaxf(__builtin_fmaf(sd[k + 1], z1, m[k + 1]), p.lo), p.hi);
+  }
+}
+
 // One block per env: sort (S, index) ascending with a bitonic network in LDS (ties by index = stable argsort), then
 // mean and population standard deviation of the best_k input sequences per time-step, stdev floored at stdev_min.
 __global__ __launch_bounds__(BLOCK) void cem_update_kernel(const Params p, const float* __restrict__ S,
@@ -783,12 +808,27 @@ void fill_params(const cpmppi_config& c, Params& p) {
   p.interp_f32 = (c.math_mode == CPMPPI_MATH_FAST) ? 1u : 0u;
 }
 
-int ensure_device(cpmppi_handle* h) {
-  int cur = -1;
-  CPMPPI_HIP(h, hipGetDevice(&cur));
-  if (cur != h->device) CPMPPI_HIP(h, hipSetDevice(h->device));
-  return 0;
-}
+// Every entry point runs on the handle's device and leaves the CALLER's current device as it found it (a process that
+// shares the HIP runtime with torch must not have its later raw HIP calls retargeted).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define CPMPPI_ON_DEVICE(h)                                                                        \
+  DeviceGuard device_guard_((h)->device);                                                          \
+  if (device_guard_.err != hipSuccess)                                                             \
+    return fail((h), CPMPPI_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_guard_.err))
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
@@ -829,13 +869,14 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3
   return launch_rollout_noise<COST, false, 1, 1>(noise, grid, lds, s, p, a);
 }
 
-hipError_t launch_rollout(const cpmppi_handle* h, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
-                          const StepPtrs& a) {
-  switch (h->prm.cost_id) {
-    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
-    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
-    case CPMPPI_COST_QBG: return launch_rollout_math<COST_QBG>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
-    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, rpl, noise, grid, lds, s, h->prm, a);
+// `prm`: the kernel-argument block of THIS launch (the handle's, or a modified copy: cost-only launches)
+hipError_t launch_rollout(const cpmppi_handle* h, const Params& prm, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds,
+                          hipStream_t s, const StepPtrs& a) {
+  switch (prm.cost_id) {
+    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
+    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
+    case CPMPPI_COST_QBG: return launch_rollout_math<COST_QBG>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
+    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
   }
 }
 
@@ -874,7 +915,11 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   fill_params(*cfg, h->prm);
   h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
   if (const char* ev = getenv("CPMPPI_FUSE_FINALIZE")) h->fuse_finalize = ev[0] != '0';
-  (void)hipSetDevice(device);
+  DeviceGuard guard(device);                     // the caller's current device is restored on every exit path
+  if (guard.err != hipSuccess) {
+    delete h;
+    return fail(nullptr, CPMPPI_ERR_HIP, std::string("cpmppi_create: hipSetDevice: ") + hipGetErrorString(guard.err));
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)SAMPLER_LDS_MAX);
   // the adjoint kernel parks S x 6 x 256 sub-states in LDS (61 KB at S = 10; more substeps need the opt-in as well)
@@ -884,18 +929,19 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_QBG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
+  // the CEM top-k sorts N (padded to a power of two) 8-byte records in LDS: 128 KB at N = 16384
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cem_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)SAMPLER_LDS_MAX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)SAMPLER_LDS_MAX);
   const uint32_t Wmax = cfg->H > h->prm.P ? cfg->H : h->prm.P;
   h->workspace_floats = (size_t)cfg->E * h->nb * (2 + Wmax);
   h->workspace = nullptr;
-  int cur = 0;
-  hipError_t e = hipGetDevice(&cur);
-  if (e == hipSuccess) e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipMalloc(&h->workspace, h->workspace_floats * sizeof(float));
+  hipError_t e = hipMalloc(&h->workspace, h->workspace_floats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->counters, (size_t)cfg->E * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(h->counters, 0, (size_t)cfg->E * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&h->zeros_H, (size_t)cfg->E * cfg->H * sizeof(float));
   if (e == hipSuccess) e = hipMemset(h->zeros_H, 0, (size_t)cfg->E * cfg->H * sizeof(float));
-  if (e == hipSuccess) e = hipSetDevice(cur);
   if (e != hipSuccess) {
     std::string msg = std::string("cpmppi_create: hipMalloc workspace: ") + hipGetErrorString(e);
     delete h;
@@ -940,7 +986,7 @@ int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, 
   if (misaligned(knots_out) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_sample: misaligned");
   if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > SAMPLER_LDS_MAX)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample: more than 154 knots per rollout are not supported");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t rows = (size_t)E * h->cfg.N;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK),
                      (size_t)BLOCK * (h->prm.P + 1) * sizeof(float), (hipStream_t)stream, h->prm, E, seed, offset,
@@ -956,7 +1002,7 @@ int cpmppi_interpolate(cpmppi_handle* h, uint32_t E, const float* knots, float* 
   if (misaligned(knots) || misaligned(delta_u_out)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_interpolate: misaligned");
   if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > SAMPLER_LDS_MAX)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_interpolate: more than 154 knots per rollout are not supported");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t rows = (size_t)E * h->cfg.N;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK),
                      (size_t)BLOCK * (h->prm.P + 1) * sizeof(float), (hipStream_t)stream, h->prm, E, (uint64_t)0,
@@ -978,7 +1024,7 @@ int cpmppi_sample_tiled(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t of
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_sample_tiled: tiled_out must be 16-byte aligned");
   if ((size_t)BLOCK * (h->prm.P + 1) * sizeof(float) > SAMPLER_LDS_MAX)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sample_tiled: more than 154 knots per rollout are not supported");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t groups = (size_t)E * ((h->cfg.N + 63u) / 64u);
   hipLaunchKernelGGL(sample_tiled_kernel, dim3((unsigned)((groups + WAVES - 1) / WAVES)), dim3(BLOCK),
                      (size_t)BLOCK * (h->prm.P + 1) * sizeof(float), (hipStream_t)stream, h->prm, E, seed, offset,
@@ -992,7 +1038,7 @@ int cpmppi_tile_delta_u(cpmppi_handle* h, uint32_t E, const float* delta_u, floa
   if (E == 0 || E > h->cfg.E || !delta_u || !tiled_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_tile_delta_u: bad argument");
   if ((reinterpret_cast<uintptr_t>(tiled_out) & 15u) != 0 || misaligned(delta_u))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_tile_delta_u: tiled_out must be 16-byte aligned");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t groups = (size_t)E * ((h->cfg.N + 63u) / 64u);
   hipLaunchKernelGGL(tile_kernel, dim3((unsigned)((groups + WAVES - 1) / WAVES)), dim3(BLOCK), 0, (hipStream_t)stream,
                      h->prm, E, delta_u, tiled_out);
@@ -1007,7 +1053,7 @@ int cpmppi_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* 
   if (B == 0 || !s0 || !Q || !traj_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_predict: bad argument");
   if (misaligned(s0) || misaligned(Q) || misaligned(L) || misaligned(traj_out))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_predict: misaligned pointer");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const dim3 grid((B + BLOCK - 1) / BLOCK);
   if (h->cfg.math_mode == CPMPPI_MATH_FAST)
     hipLaunchKernelGGL(predict_kernel<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, h->prm, B, horizon, s0, Q, L,
@@ -1028,7 +1074,7 @@ int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_trajectory_cost: bad argument");
   if (h->prm.cost_id == CPMPPI_COST_LEGACY && !u_nom)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_trajectory_cost: legacy cost needs u_nom");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(trajectory_cost_kernel, dim3((B + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm,
                      B, horizon, traj, inputs, target_position, target_equilibrium, u_nom, u_prev, stage_out,
                      terminal_out, total_out);
@@ -1052,7 +1098,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   if (misaligned(a->s0) || misaligned(a->u_nom) || misaligned(a->noise) || misaligned(a->S_out) ||
       misaligned(a->Q_out))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_step: misaligned pointer");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   StepPtrs p{};
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
   p.L = a->L; p.noise = a->noise; p.prev_in = a->previous_input; p.seed = a->seed; p.offset = a->offset; p.env_offset = a->env_offset;
@@ -1119,7 +1165,7 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
       const size_t park = (size_t)p.W * rpl * BLOCK * sizeof(float);
       if (lds + park <= 32 * 1024) { p.stash = 1; lds += park; }
     }
-    CPMPPI_HIP(h, launch_rollout(h, rpl, noise_kind, dim3(a->E * p.nb), lds, s, p));
+    CPMPPI_HIP(h, launch_rollout(h, h->prm, rpl, noise_kind, dim3(a->E * p.nb), lds, s, p));
   }
   const bool separate_finalize = (p.counter == nullptr);
   if (ev) CPMPPI_HIP(h, hipEventRecord(ev[1], s));
@@ -1272,7 +1318,7 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
         bv[8 * 32 + hf * 16 + v] = r < 5 ? m->b_out[r] : 0.0f;
       }
   }
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   if (!h->gru_image) CPMPPI_HIP(h, hipMalloc(&h->gru_image, img.size() * sizeof(float)));
   CPMPPI_HIP(h, hipMemcpy(h->gru_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
   if (!h->gru16_image) CPMPPI_HIP(h, hipMalloc(&h->gru16_image, img16.size()));
@@ -1286,7 +1332,7 @@ int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const flo
   if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_gru_predict: no model set (cpmppi_set_gru)");
   if (horizon == 0) horizon = h->cfg.H;
   if (B == 0 || !s0 || !Q || !traj_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_gru_predict: bad argument");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(gru_predict_kernel, dim3((B + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK), dim3(BLOCK),
                      (size_t)GRU_IMAGE_FLOATS * sizeof(float), (hipStream_t)stream, h->gru_norm,
                      (const float*)h->gru_image, B, horizon, s0, Q, h0, traj_out, h_out);
@@ -1301,7 +1347,7 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost: bad argument");
   if (h->prm.cost_id == CPMPPI_COST_LEGACY)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost: plugin costs only");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   Params prm = h->prm;
   prm.shift_mode = CPMPPI_SHIFT_NONE;
   prm.cc_weight = 0.0f;
@@ -1314,12 +1360,8 @@ int cpmppi_rollout_cost(cpmppi_handle* h, uint32_t E, const float* s0, const flo
   p.nb = (h->cfg.N + BLOCK * rpl - 1) / (BLOCK * rpl);
   p.W = h->cfg.H;
   p.S_out = S_out; p.partial = h->workspace; p.counter = nullptr; p.u_nom_out = nullptr; p.Q_out = nullptr;
-  cpmppi_handle* hh = h;
-  const Params saved = hh->prm;
-  hh->prm = prm;
-  hipError_t e = launch_rollout(hh, rpl, CPMPPI_NOISE_DELTA_U, dim3(E * p.nb), (size_t)WAVES * p.W * sizeof(float),
+  hipError_t e = launch_rollout(h, prm, rpl, CPMPPI_NOISE_DELTA_U, dim3(E * p.nb), (size_t)WAVES * p.W * sizeof(float),
                                 (hipStream_t)stream, p);
-  hh->prm = saved;
   CPMPPI_HIP(h, e);
   return CPMPPI_OK;
 }
@@ -1347,7 +1389,7 @@ int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, cons
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for the FAST arithmetic");
   const size_t lds = (size_t)h->cfg.S * 6 * BLOCK * sizeof(float);
   if (lds > 150 * 1024) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: S too large for the LDS sub-state buffer (<= 25)");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t B = (size_t)E * h->cfg.N;
   const size_t need = (size_t)h->cfg.H * 6 * (size_t)h->cfg.E * h->cfg.N;
   if (h->grad_ckpt_floats < need) {
@@ -1373,7 +1415,7 @@ int cpmppi_adam_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, 
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || E > h->cfg.E || !Q || !grad || !m || !v || iteration == 0)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_adam_step: bad argument (iteration counts from 1)");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t rows = (size_t)E * h->cfg.N;
   // Keras Adam: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), epsilon outside the square root
   const double lr_t = (double)learning_rate * sqrt(1.0 - pow((double)beta2, (double)iteration)) /
@@ -1388,7 +1430,7 @@ int cpmppi_sgd_step(cpmppi_handle* h, uint32_t E, float* Q, const float* grad, f
                     void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || E > h->cfg.E || !Q || !grad) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_sgd_step: bad argument");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t rows = (size_t)E * h->cfg.N;
   hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      rows, h->cfg.H, Q, grad, learning_rate, gradmax_clip, h->prm.lo, h->prm.hi);
@@ -1400,10 +1442,23 @@ int cpmppi_cem_sample(cpmppi_handle* h, uint32_t E, const float* mean, const flo
                       uint32_t env_offset, float* Q_out, void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || E > h->cfg.E || !mean || !stdev || !Q_out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_cem_sample: bad argument");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   const size_t rows = (size_t)E * h->cfg.N;
   hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      h->prm, E, mean, stdev, seed, offset, env_offset, Q_out);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_cem_gmm_sample(cpmppi_handle* h, uint32_t E, const float* centres, uint32_t K, const float* stdev, uint64_t seed,
+                          uint64_t offset, uint32_t env_offset, float* Q_out, uint32_t* component_out, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !centres || K == 0 || !stdev || !Q_out)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_cem_gmm_sample: bad argument");
+  CPMPPI_ON_DEVICE(h);
+  const size_t rows = (size_t)E * h->cfg.N;
+  hipLaunchKernelGGL(cem_gmm_sample_kernel, dim3((unsigned)((rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     h->prm, E, centres, K, stdev, seed, offset, env_offset, Q_out, component_out);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
@@ -1416,7 +1471,7 @@ int cpmppi_cem_update(cpmppi_handle* h, uint32_t E, const float* S, const float*
   uint32_t Np = 1;
   while (Np < h->cfg.N) Np <<= 1;
   if ((size_t)Np * 8 > 160 * 1024 - 1024) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_cem_update: N too large for the LDS sort (<= 16384)");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(cem_update_kernel, dim3(E), dim3(BLOCK), (size_t)Np * 8, (hipStream_t)stream, h->prm, S, Q, best_k,
                      stdev_min, Np, mean_out, stdev_out, elite_idx_out);
   CPMPPI_HIP(h, hipGetLastError());
@@ -1427,7 +1482,7 @@ int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S,
                                    void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || !S || !delta_u || !out) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_reward_weighted_average: bad argument");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(rwa_kernel, dim3(E), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, S, delta_u, out);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
@@ -1438,7 +1493,7 @@ int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q,
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance: bad argument");
   if (misaligned(s) || misaligned(Q) || misaligned(L)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance: misaligned");
-  if (int rc = ensure_device(h)) return rc;
+  CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
                      L, n_substeps, dt_sim);
   CPMPPI_HIP(h, hipGetLastError());

@@ -296,6 +296,18 @@ class MPPIEngine:
                                                _ptr(Q), self._stream()))
         return Q
 
+    def cem_gmm_sample(self, centres, stdev, seed, offset=0, env_offset=0, return_components=False):
+        """centres [E,K,H], stdev [E,H] -> Q [E,N,H]: each rollout drawn around one (uniformly chosen) centre."""
+        centres, stdev = self.tensor(centres), self.tensor(stdev)
+        E, K = centres.shape[0], centres.shape[1]
+        if centres.shape != (E, K, self.H) or stdev.shape != (E, self.H):
+            raise ValueError(f"centres must be [E,K,{self.H}] and stdev [E,{self.H}]")
+        Q = self.empty(E, self.N, self.H)
+        comp = torch.empty(E, self.N, dtype=torch.int32, device=self.device) if return_components else None
+        self._check(self.lib.cpmppi_cem_gmm_sample(self._h, E, _ptr(centres), K, _ptr(stdev), int(seed), int(offset),
+                                                   int(env_offset), _ptr(Q), _ptr(comp), self._stream()))
+        return (Q, comp) if return_components else Q
+
     def cem_update(self, S, Q, best_k, stdev_min, return_elites=False):
         S, Q = self.tensor(S), self.tensor(Q)
         E = S.shape[0]

@@ -6,10 +6,12 @@ NORMALIZE ...), ``normalization_vec_a.csv`` / ``normalization_vec_b.csv`` (one r
 a*x + b) and ``denormalization_vec_A.csv`` / ``denormalization_vec_B.csv`` (one value per OUTPUT: y = A*y_norm + B).
 Model names of the neural predictor: ``SI_Toolkit_ASF/config_predictors.yml:8-13`` (``GRU-6IN-32H1-32H2-5OUT-*``).
 
-Weights: the reference's folders carry TensorFlow checkpoints / ``.keras`` archives, which need TensorFlow or h5py —
-neither exists on this image, and no GRU folder is in the tree.  What can be read here: a ``torch`` state_dict
-(``ckpt.pt``, the layout of ``torch.nn.GRU`` + a ``Linear`` head) or ``weights.npz`` with the keys of
-``MPPIEngine.set_gru``.  Anything else raises with the reason; there is no silent fallback.
+Weights: the reference's folders carry TensorFlow checkpoints / ``.keras`` archives (a zip around ``model.weights.h5``),
+which need TensorFlow or h5py — neither exists on this image, and no GRU folder is in the tree.  What can be read here:
+``weights_keras.npz`` = ``np.savez(path, *model.get_weights())`` written once in the reference's environment (Keras
+layout, converted by ``keras_gru_weights_to_model``), a ``torch`` state_dict (``ckpt.pt``, the layout of
+``torch.nn.GRU`` + a ``Linear`` head) or ``weights.npz`` with the keys of ``MPPIEngine.set_gru``.  Anything else raises
+with the reason; there is no silent fallback.
 """
 import os
 import re
@@ -73,10 +75,52 @@ def read_normalization(folder, info=None):
     return out
 
 
+def keras_gru_weights_to_model(arrays, units=32):
+    """``model.get_weights()`` of the Keras network GRU(units) -> GRU(units) -> Dense(5) — the layout SI_Toolkit's
+    TensorFlow nets are saved in (``config_predictors.yml:8-13`` model folders hold ``.keras`` / ``ckpt`` files) —
+    into the ``torch.nn.GRU``-layout dict of ``MPPIEngine.set_gru``.
+
+    Keras GRU layer (``reset_after=True``, the TF2 default): kernel [in, 3u], recurrent_kernel [u, 3u], bias [2, 3u]
+    (row 0 input bias, row 1 recurrent bias), gate blocks ordered **z, r, h**, applied as ``x @ kernel``.
+    torch: weight_ih [3u, in], weight_hh [3u, u], bias_ih, bias_hh [3u], gate blocks ordered **r, z, n**, applied as
+    ``W @ x``; with reset_after the candidate is tanh(W_in x + b_in + r * (W_hn h + b_hn)) in both.  So: transpose and swap
+    the first two gate blocks.  ``reset_after=False`` (bias of shape [3u]: the reset gate multiplies h BEFORE the
+    recurrent product) is a different cell and is refused."""
+    arrays = [np.asarray(a, dtype=np.float32) for a in arrays]
+    if len(arrays) != 8:
+        raise ValueError(f"expected 8 arrays (2 x [kernel, recurrent_kernel, bias] + dense kernel, bias), got {len(arrays)}")
+    u = int(units)
+
+    def zrh_to_rzn(m):                       # m [..., 3u] with blocks z, r, h  ->  blocks r, z, n
+        z, r, h = m[..., :u], m[..., u:2 * u], m[..., 2 * u:]
+        return np.concatenate([r, z, h], axis=-1)
+
+    model = {}
+    for l in range(2):
+        k, rk, b = arrays[3 * l:3 * l + 3]
+        if b.ndim != 2 or b.shape != (2, 3 * u):
+            raise NotImplementedError(f"GRU layer {l}: bias shape {b.shape}; only reset_after=True layers ([2, {3 * u}]) "
+                                      "have the cell torch.nn.GRU and the HIP kernel implement")
+        if k.shape[1] != 3 * u or rk.shape != (u, 3 * u):
+            raise ValueError(f"GRU layer {l}: kernel {k.shape}, recurrent_kernel {rk.shape} for {u} units")
+        model[f"w_ih{l}"] = np.ascontiguousarray(zrh_to_rzn(k).T)
+        model[f"w_hh{l}"] = np.ascontiguousarray(zrh_to_rzn(rk).T)
+        model[f"b_ih{l}"], model[f"b_hh{l}"] = zrh_to_rzn(b[0]), zrh_to_rzn(b[1])
+    dk, db = arrays[6], arrays[7]
+    if dk.shape[0] != u or db.shape != (dk.shape[1],):
+        raise ValueError(f"dense head: kernel {dk.shape}, bias {db.shape}")
+    model["w_out"], model["b_out"] = np.ascontiguousarray(dk.T), db
+    return model
+
+
 def _weights(folder):
     npz, pt = os.path.join(folder, "weights.npz"), os.path.join(folder, "ckpt.pt")
+    knpz = os.path.join(folder, "weights_keras.npz")        # np.savez(path, *model.get_weights()) — INTEGRATION.md
     if os.path.exists(npz):
         return dict(np.load(npz))
+    if os.path.exists(knpz):
+        z = np.load(knpz)
+        return keras_gru_weights_to_model([z[f"arr_{i}"] for i in range(len(z.files))])
     if os.path.exists(pt):
         import torch
         sd = torch.load(pt, map_location="cpu", weights_only=True)
@@ -93,7 +137,8 @@ def _weights(folder):
     tf_like = [f for f in os.listdir(folder) if f.endswith((".keras", ".h5", ".index")) or ".ckpt" in f]
     if tf_like:
         raise NotImplementedError(f"{folder}: only TensorFlow/Keras weights found ({', '.join(sorted(tf_like)[:3])}); reading them "
-                                  "needs TensorFlow or h5py, which this image does not have - export weights.npz")
+                                  "needs TensorFlow or h5py, which this image does not have - export them once in the "
+                                  "reference's environment (INTEGRATION.md: np.savez('weights_keras.npz', *model.get_weights()))")
     raise FileNotFoundError(f"{folder}: no weights.npz or ckpt.pt")
 
 

@@ -110,6 +110,54 @@ class optimizer_cem:
         return q[:1].copy() if single else q.reshape(E, 1).copy()
 
 
+class optimizer_cem_gmm(optimizer_cem):
+    """``cem-gmm-tf`` (config_optimizers.yml:12-20): CEM whose sampling distribution is a Gaussian MIXTURE — one
+    component per elite of the previous iteration, centred on that elite sequence, equal weights, all sharing the
+    per-time-step standard deviation refitted to the elites (floored at ``cem_stdev_min``).  The first iteration after a
+    reset samples around the mid-point sequence with ``cem_initial_action_stdev`` (a single component).  Applied control:
+    the first input of the best sequence found; the elites are shifted by one step for the next control step.
+    [recalled semantics: the class lives in the absent Control_Toolkit submodule; unpinned, stated in DESIGN.md]"""
+    optimizer_name = "cem-gmm"
+
+    def optimizer_reset(self):
+        super().optimizer_reset()
+        self.centres = self.dist_mue[:, None, :].contiguous()           # [E, 1, H]: one component until elites exist
+
+    def step(self, s, time=None, as_tensor=False):
+        if self.engine is None:
+            self.configure()
+        eng = self.engine
+        s_t = eng.tensor(s)
+        single = s_t.dim() == 1
+        s_t = s_t.reshape(-1, 6)
+        E = s_t.shape[0]
+        if E != self.num_envs:
+            raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
+        vp = self.variable_parameters
+        tp = _vec(getattr(vp, "target_position", None), E, 0.0)
+        te = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
+        L = _vec(getattr(vp, "L", None), E, self.phys.L)
+        ar = torch.arange(E, device=self.dist_mue.device)[:, None]
+        for _ in range(self.cem_outer_it):
+            Q = eng.cem_gmm_sample(self.centres, self.stdev, self.seed, offset=self.step_counter)
+            S = eng.rollout_cost(s_t, Q, tp, te, L=L)
+            self.dist_mue, self.stdev, el = eng.cem_update(S, Q, self.cem_best_k, self.cem_stdev_min, return_elites=True)
+            self.centres = Q[ar, el.long()].contiguous()                # [E, K, H], cheapest first (stable order)
+            self.step_counter += 1
+        u = self.centres[:, 0, 0].clone()                               # first input of the best sequence
+        if self.optimizer_logging:
+            self.logging_values = {"Q_logged": u.cpu().numpy(), "J_logged": S.cpu().numpy(),
+                                   "u_logged": self.centres[:, 0].cpu().numpy()}
+        mid = 0.5 * (self.action_low + self.action_high)
+        self.centres = torch.cat([self.centres[:, :, 1:], torch.full_like(self.centres[:, :, :1], mid)], dim=2).contiguous()
+        self.dist_mue = torch.cat([self.dist_mue[:, 1:], torch.full_like(self.dist_mue[:, :1], mid)], dim=1).contiguous()
+        self.stdev = torch.cat([self.stdev[:, 1:], torch.full_like(self.stdev[:, :1], float(np.sqrt(0.5)))], dim=1).contiguous()
+        if as_tensor:
+            return u
+        q = u.cpu().numpy()
+        return q[:1].copy() if single else q.reshape(E, 1).copy()
+
+
 class optimizer_cem_naive_grad(optimizer_cem):
     """``cem-naive-grad-tf`` (config_optimizers.yml:21-31): CEM whose samples take ONE plain gradient step
     ``Q <- clip(Q - learning_rate * clip_by_norm(dJ/dQ, gradmax_clip))`` (cpmppi_rollout_cost_grad + cpmppi_sgd_step)

@@ -34,7 +34,7 @@ class optimizer_mppi:
                  mpc_timestep=0.02, num_envs=1, noise="philox", cost_function_specification=None, cost_weights=None,
                  horizon_reduce="sum", control_mode="clip", shift_mode="repeat_last", correction_u="u_run",
                  math_mode="fast", intermediate_steps=10, phys=None, device=0, variable_parameters=None, gru_model=None,
-                 **kwargs):
+                 SAMPLING_TYPE="interpolated", **kwargs):
         self.predictor, self.cost_function = predictor, cost_function
         low, high = (-1.0, 1.0) if control_limits is None else (float(np.asarray(control_limits[0]).reshape(-1)[0]),
                                                                   float(np.asarray(control_limits[1]).reshape(-1)[0]))
@@ -48,6 +48,14 @@ class optimizer_mppi:
         if noise not in ("philox", "sfc64"):
             raise ValueError("noise must be 'philox' (device RNG) or 'sfc64' (numpy stream, reference-identical knots)")
         self.noise = noise
+        # config_controllers.yml:28 (mppi-cartpole SAMPLING_TYPE).  The device sampler implements "interpolated"; the other
+        # modes exist on numpy's SFC64 stream (sampling.sample_delta_u_sfc64), i.e. with noise="sfc64"
+        from .sampling import SAMPLING_TYPES
+        if SAMPLING_TYPE not in SAMPLING_TYPES:
+            raise ValueError(f"SAMPLING_TYPE must be one of {SAMPLING_TYPES}")
+        if SAMPLING_TYPE != "interpolated" and noise != "sfc64":
+            raise ValueError(f"SAMPLING_TYPE={SAMPLING_TYPE!r} is built on the numpy SFC64 stream only: pass noise='sfc64'")
+        self.sampling_type = SAMPLING_TYPE
         if cost_function is not None and cost_function_specification is None:
             cost_function_specification = getattr(cost_function, "cost_name", None) or \
                 getattr(cost_function, "cost_function_name", None)
@@ -144,7 +152,11 @@ class optimizer_mppi:
             raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
         tp, te, L = self._attributes(E)
         kw = {}
-        if self.noise == "sfc64":
+        if self.noise == "sfc64" and self.sampling_type != "interpolated":
+            from .sampling import sample_delta_u_sfc64
+            kw["delta_u"] = sample_delta_u_sfc64(self._rng, E, self.num_rollouts, self.mpc_horizon, self.cfg.sigma,
+                                                 self.sampling_type)
+        elif self.noise == "sfc64":
             from .sampling import sample_knots_sfc64
             kw["knots"] = sample_knots_sfc64(self._rng, E, self.num_rollouts, self.cfg)
         else:

@@ -151,3 +151,59 @@ class PredictorWrapper:
 
     def update(self, Q0=None, s=None):
         return self.predictor.update(Q0, s)
+
+
+class predictor_output_augmentation:
+    """``SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:72-139``: the features a neural predictor's
+    output lacks and the state vector needs.  All three legs of the reference:
+      * outputs hold ``angle_sin`` and ``angle_cos`` but no ``angle``  -> append ``angle = atan2(angle_sin, angle_cos)``
+      * outputs hold ``angle`` but no ``angle_sin``                    -> append ``angle_sin = sin(angle)``
+      * outputs hold ``angle`` but no ``angle_cos``                    -> append ``angle_cos = cos(angle)``
+    in that order (:88-96, :121-137).  ``net_info`` needs ``.outputs`` (list of names; a differential network's ``D_*``
+    names are stripped as in :79-83).  ``augment`` takes ``[batch, time, features]`` as a torch tensor (any device) or a
+    numpy array and returns the same kind with the new features concatenated last.  (The fused GRU kernel applies the
+    first leg in registers; this class is the seam for networks evaluated outside it.)"""
+
+    def __init__(self, net_info, lib=None, disable_individual_compilation=False, differential_network=False):
+        from .state_utilities import ANGLE_COS_IDX, ANGLE_IDX, ANGLE_SIN_IDX
+        self.lib = lib
+        self.differential_network = differential_network
+        outputs = [x[2:] for x in net_info.outputs] if differential_network else list(net_info.outputs)
+        self.net_output_indices = {key: value for value, key in enumerate(outputs)}
+        self.indices_augmentation, self.features_augmentation = [], []
+        if "angle" not in outputs and "angle_sin" in outputs and "angle_cos" in outputs:
+            self.indices_augmentation.append(ANGLE_IDX)
+            self.features_augmentation.append("angle")
+        if "angle_sin" not in outputs and "angle" in outputs:
+            self.indices_augmentation.append(ANGLE_SIN_IDX)
+            self.features_augmentation.append("angle_sin")
+        if "angle_cos" not in outputs and "angle" in outputs:
+            self.indices_augmentation.append(ANGLE_COS_IDX)
+            self.features_augmentation.append("angle_cos")
+        self.augmentation_len = len(self.indices_augmentation)
+        self.index_angle = self.net_output_indices.get("angle")
+        self.index_angle_sin = self.net_output_indices.get("angle_sin")
+        self.index_angle_cos = self.net_output_indices.get("angle_cos")
+        self.augment = self._augment
+
+    def get_indices_augmentation(self):
+        return self.indices_augmentation
+
+    def get_features_augmentation(self):
+        return self.features_augmentation
+
+    def _augment(self, net_output):
+        import torch
+        is_t = torch.is_tensor(net_output)
+        xp_atan2 = torch.atan2 if is_t else np.arctan2
+        xp_sin, xp_cos = (torch.sin, torch.cos) if is_t else (np.sin, np.cos)
+        cat = (lambda xs: torch.cat(xs, dim=-1)) if is_t else (lambda xs: np.concatenate(xs, axis=-1))
+        output = net_output
+        if "angle" in self.features_augmentation:
+            angle = xp_atan2(net_output[..., self.index_angle_sin], net_output[..., self.index_angle_cos])[:, :, None]
+            output = cat([output, angle])
+        if "angle_sin" in self.features_augmentation:
+            output = cat([output, xp_sin(net_output[..., self.index_angle])[:, :, None]])
+        if "angle_cos" in self.features_augmentation:
+            output = cat([output, xp_cos(net_output[..., self.index_angle])[:, :, None]])
+        return output

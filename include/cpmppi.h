@@ -258,6 +258,10 @@ int cpmppi_cem_sample(cpmppi_handle* h, uint32_t E, const float* mean, const flo
                       uint32_t env_offset, float* Q_out, void* stream);
 int cpmppi_cem_update(cpmppi_handle* h, uint32_t E, const float* S, const float* Q, uint32_t best_k, float stdev_min,
                       float* mean_out, float* stdev_out, uint32_t* elite_idx_out, void* stream);
+/* cem-gmm (config_optimizers.yml:12-20): Q[E,N,H] = clip(centres[E, c, :] + stdev[E,H] * z) with the component c of every
+ * rollout uniform over the K centres (the elite sequences of the previous iteration); component_out[E,N] may be NULL. */
+int cpmppi_cem_gmm_sample(cpmppi_handle* h, uint32_t E, const float* centres, uint32_t K, const float* stdev, uint64_t seed,
+                          uint64_t offset, uint32_t env_offset, float* Q_out, uint32_t* component_out, void* stream);
 
 /* a16 alone: S[E,N], delta_u[E,N,H] -> weighted average [E,H] (controller_mppi_cartpole.py:306-321). */
 int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S, const float* delta_u, float* out,

@@ -318,6 +318,29 @@ def sample_delta_u(rng, N, H, stdev, period=10):
 
 # --------------------------------------------------------------------------------------------------------------------
 # One full MPPI optimizer step.
+# a17, the sampler's other modes — controller_mppi_cartpole.py:414-433,447-450 (`initialize_perturbations`); stdev is a
+# numpy float64 there (:91), so `stdev * standard_normal(float32)` is a float64 product: rounded to float32 where the
+# reference stores it into its float32 array (random_walk), left float64 where it returns the product (repeated, iid).
+def sample_delta_u_mode(rng, N, H, stdev, sampling_type, period=10):
+    stdev = np.float64(stdev)
+    if sampling_type == "random_walk":                                                  # :414-422
+        du = np.empty((N, H), dtype=f32)
+        du[:, 0] = stdev * rng.standard_normal(size=(N,), dtype=f32)
+        for i in range(1, H):
+            du[:, i] = du[:, i - 1] + stdev * rng.standard_normal(size=(N,), dtype=f32)
+        return du
+    if sampling_type == "uniform":                                                      # :423-428
+        du = np.empty((N, H), dtype=f32)
+        for i in range(H):
+            du[:, i] = rng.uniform(low=-1.0, high=1.0, size=(N,)).astype(f32)
+        return du
+    if sampling_type == "repeated":                                                     # :429-433
+        return np.tile(stdev * rng.standard_normal(size=(N, 1), dtype=f32), (1, H))
+    if sampling_type == "interpolated":                                                 # :434-446
+        return sample_delta_u(rng, N, H, stdev, period)
+    return stdev * rng.standard_normal(size=(N, H), dtype=f32)                          # :447-450 (iid)
+
+
 @dataclass
 class MPPIConfig:
     """config_optimizers.yml:87-97 (mppi) / config_controllers.yml:9-30 (mppi-cartpole)."""

@@ -44,7 +44,7 @@ def test_controller_mpc_reference_usage():
     ctrl.controller_reset()
     assert float(ctrl.optimizer.u_nom.abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
-        ctrl.configure(optimizer_name="cem-gmm-tf")
+        ctrl.configure(optimizer_name="mppi-var-tf")          # an optimizer section the reference does not ship
     assert s0[ANGLE_IDX] == f32(0.2)
 
 
@@ -228,3 +228,33 @@ def test_previous_input_reaches_the_cost_through_updated_attributes():
     np.testing.assert_allclose(0.5 * (d_pos + d_neg), 50.0 * 0.81, rtol=2e-3)          # w prev^2
     u0 = (d_neg - d_pos) / (4.0 * 50.0 * 0.9)                                            # the rollouts' first controls
     assert np.abs(u0).max() <= 1.0 + 1e-3 and u0.std() > 0.05
+
+
+@pytest.mark.parametrize("mode", ["random_walk", "uniform", "repeated", "iid"])
+def test_sampling_types_of_the_legacy_sampler(mode):
+    """config_controllers.yml:28 SAMPLING_TYPE: the optimizer seam with each of the sampler's other modes on the SFC64
+    stream against the oracle stepping on the oracle's restatement of the same mode (itself pinned to the reference's
+    outputs, tests/test_oracle_golden.py)."""
+    from types import SimpleNamespace
+    from cartpolesimulation_amd.optimizer_mppi import optimizer_mppi
+    N, H = 512, 20
+    vp = SimpleNamespace(target_position=f32(0.02), target_equilibrium=f32(1.0))
+    opt = optimizer_mppi(control_limits=(np.array([-1.0]), np.array([1.0])), seed=9, num_rollouts=N, mpc_horizon=H,
+                         noise="sfc64", SAMPLING_TYPE=mode, variable_parameters=vp, optimizer_logging=True)
+    opt.configure(dt=0.02, predictor_specification="ODE_v0")
+    rng = Generator(SFC64(9))
+    cfg = O.MPPIConfig(N=N, H=H)
+    u_ref = np.zeros(H, f32)
+    s = O.create_cartpole_state(0.2, -0.3, 0.01, 0.05)
+    for it in range(2):
+        u = opt.step(s)
+        du = O.sample_delta_u_mode(rng, N, H, np.float64(cfg.stdev), mode).astype(f32)
+        ref, ref_b = PU.oracle_step_both_modes(s, u_ref, du, vp.target_position, vp.target_equilibrium, cfg)
+        PU.assert_costs(opt.logging_values["J_logged"][0], ref["S"], ref_b["S"], PU.flag_discontinuities(ref["traj"]), f"{mode} step {it}")
+        PU.assert_controls(opt.u_nom.cpu().numpy()[0], ref["u_new"], ref_b["u_new"], f"{mode} step {it} u_nom",
+                           allowance=PU.softmin_allowance(ref["S"], ref_b["S"], du))
+        np.testing.assert_allclose(u, [ref["Q"]], atol=1e-4)
+        u_ref = ref["u_new"]
+        s = O.ode_v0_step(s[None], np.array([ref["Q"]], f32))[0]
+    with pytest.raises(ValueError):
+        optimizer_mppi(num_rollouts=8, mpc_horizon=4, SAMPLING_TYPE="uniform")           # device RNG: interpolated only

@@ -57,6 +57,26 @@ def test_cem_sample_cost_update_vs_oracle():
     assert np.array_equal(el2.cpu().numpy(), np.tile(np.arange(7), (E, 1)))
 
 
+def test_cem_update_at_the_largest_population():
+    """N = 16384 needs 128 KB of dynamic LDS for the top-k sort (the opt-in above the default 64 KB): exact elite set
+    and refit against the oracle; N one above that is refused cleanly."""
+    from cartpolesimulation_amd._lib import CpmppiError
+    E, N, H, K = 2, 16384, 6, 300
+    eng = make(E, N, H)
+    rng = np.random.Generator(np.random.SFC64(12))
+    S = rng.uniform(0.0, 1e4, (E, N)).astype(f32)
+    Q = rng.uniform(-1, 1, (E, N, H)).astype(f32)
+    m, sd, el = eng.cem_update(S, Q, K, 0.01, return_elites=True)
+    for e in range(E):
+        mr, sr, idx = O.cem_update(S[e], Q[e], K, 0.01)
+        assert np.array_equal(el.cpu().numpy()[e], idx)
+        np.testing.assert_allclose(m.cpu().numpy()[e], mr, atol=2e-6)
+        np.testing.assert_allclose(sd.cpu().numpy()[e], sr, atol=5e-6)
+    big = make(1, 16385, 4)
+    with pytest.raises(CpmppiError):
+        big.cem_update(np.zeros((1, 16385), f32), np.zeros((1, 16385, 4), f32), 5, 0.01)
+
+
 def test_optimizer_cem_improves_and_controls():
     from types import SimpleNamespace
     from cartpolesimulation_amd.optimizer_cem import optimizer_cem
@@ -120,4 +140,42 @@ def test_cem_hybrids_and_random_action_through_the_controller_seam(name, N):
     if name != "random-action-tf":          # (640 random plans per step do not balance a pole reliably; the CEM hybrids do)
         assert (np.abs(sh[:, O.ANGLE_IDX]) < 0.35).mean() >= 0.8
     with pytest.raises(NotImplementedError):
-        ctrl.configure("cem-gmm-tf")
+        ctrl.configure("no-such-optimizer")
+
+
+def test_cem_gmm_sampler_and_optimizer():
+    """cem-gmm-tf (config_optimizers.yml:12-20): the mixture sampler — uniform components, samples = centre + stdev z
+    with the same z stream as the plain CEM sampler — and the optimizer over it through the controller seam."""
+    from types import SimpleNamespace
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    E, N, H, K = 2, 4096, 10, 8
+    eng = make(E, N, H)
+    rng = np.random.Generator(np.random.SFC64(6))
+    centres = rng.uniform(-0.5, 0.5, (E, K, H)).astype(f32)
+    sd = rng.uniform(0.01, 0.05, (E, H)).astype(f32)
+    Q, comp = eng.cem_gmm_sample(centres, sd, seed=3, offset=7, return_components=True)
+    Qh, ch = Q.cpu().numpy(), comp.cpu().numpy()
+    assert ch.min() == 0 and ch.max() == K - 1
+    counts = np.stack([np.bincount(ch[e], minlength=K) for e in range(E)])
+    assert np.abs(counts - N / K).max() < 5 * np.sqrt(N / K)                      # uniform over the components
+    z = (Qh - centres[np.arange(E)[:, None], ch]) / sd[:, None, :]                # nothing clipped at these magnitudes
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    # the normals are the plain CEM sampler's for the same (seed, offset): Q - centre == stdev * z of cem_sample around 0
+    plain = eng.cem_sample(np.zeros((E, H), f32), sd, seed=3, offset=7).cpu().numpy()
+    np.testing.assert_allclose(Qh - centres[np.arange(E)[:, None], ch], plain, atol=2e-7)
+    assert np.array_equal(eng.cem_gmm_sample(centres, sd, seed=3, offset=7).cpu().numpy(), Qh)
+    # one component == the plain sampler
+    one = eng.cem_gmm_sample(centres[:, :1].copy(), sd, seed=3, offset=7).cpu().numpy()
+    np.testing.assert_array_equal(one, eng.cem_sample(centres[:, 0].copy(), sd, seed=3, offset=7).cpu().numpy())
+    # the optimizer: stabilises the pole near upright and its sampling distribution contracts
+    ctrl = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0}, control_limits=([-1.0], [1.0]),
+                          config=dict(seed=4, mpc_horizon=35, num_rollouts=200, cem_outer_it=3, cem_best_k=40,
+                                      cem_stdev_min=0.01, cem_initial_action_stdev=0.5))
+    ctrl.configure("cem-gmm-tf")
+    assert ctrl.optimizer.optimizer_name == "cem-gmm"
+    s = O.create_cartpole_state(0.15, 0.0, 0.0, 0.0)
+    for it in range(60):
+        u = ctrl.step(s, 0.02 * it)
+        s = O.ode_v0_step(s[None], np.asarray(u, f32))[0]
+    assert abs(s[O.ANGLE_IDX]) < 0.1 and abs(s[O.POSITION_IDX]) < 0.15
+    assert ctrl.optimizer.centres.shape == (1, 40, 35) and torch.isfinite(ctrl.optimizer.stdev).all()

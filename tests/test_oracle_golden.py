@@ -216,3 +216,25 @@ def test_qbg_cost_oracle_matches_reference(golden_dir, case):
                              g[f"{case}/target_position"], g[f"{case}/target_equilibrium"], w)
     np.testing.assert_allclose(stage, g[f"{case}/stage"], rtol=2e-6)
     np.testing.assert_allclose(stage.sum(1), g[f"{case}/total"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["random_walk", "uniform", "repeated", "iid", "interpolated"])
+def test_sampler_modes_match_the_reference(golden_dir, mode):
+    """controller_mppi_cartpole.py:414-450: every sampling_type of `initialize_perturbations`, bit for bit on the same
+    SFC64 stream (fixture: the reference's own outputs, oracle/gen_golden_sampler_modes.py) — the oracle restatement and
+    the product's host sampler."""
+    from cartpolesimulation_amd.sampling import sample_delta_u_sfc64
+    g = load(golden_dir, "sampler_modes.npz")
+    N, H, stdev = int(g["N"]), int(g["H"]), float(g["stdev"])
+
+    def stream():
+        rng = np.random.Generator(np.random.SFC64(int(g["seed"])))
+        for _ in range(5):
+            rng.uniform(-1.0, 1.0)                      # configure()'s cost-weight noise draws (:355-359)
+        return rng
+    ref = g[mode]
+    du = O.sample_delta_u_mode(stream(), N, H, stdev, mode)
+    assert du.dtype == ref.dtype and np.array_equal(du, ref)
+    if mode != "interpolated":
+        prod = sample_delta_u_sfc64(stream(), 1, N, H, stdev, mode)
+        assert prod.dtype == np.float32 and np.array_equal(prod[0], ref.astype(np.float32))
