@@ -850,8 +850,10 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 
 // Which build of the kernel a launch gets (measured on MI355X, tools/kbench.py / tools/dev/step_series.py):
 //   one rollout per lane : latency build up to one wave per SIMD (1024 SIMDs x 64 lanes), throughput build above
-//   two rollouts per lane: mid-size build (loop constants in VGPRs) up to 2 M rollouts, throughput build above
-constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = 2ull << 20;
+//   two rollouts per lane: mid-size build (loop constants in VGPRs, separate loop after a rare event) up to 4 packed
+//                          waves per SIMD = 524288 rollouts, throughput build above.  64..2048 envs x 1024 x 50, mid-size
+//                          vs throughput build: 128 envs 76 vs 82 us, 256 envs 145 vs 162 us, 1024 envs 406 vs 400 us
+constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = 524288ull;
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,

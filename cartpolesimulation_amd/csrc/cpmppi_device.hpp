@@ -558,9 +558,14 @@ __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, co
 // between 80 and 180 us depending on the noise drawn).  The one-rollout-per-lane path keeps the per-substep
 // polynomials: it is bound by the LATENCY of a single wave's dependency chain, and carrying the pair makes the next
 // rotation wait for this substep's angleDD (measured: 79 us instead of 67 us per single-env step).
-template <class F>
-__device__ __forceinline__ void substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
-                                                         F& cd, F& sd, F& xlim) {
+// BOUNCY = false: the event block sits behind a wave-uniform branch (cold).  BOUNCY = true: the same arithmetic inline,
+// evaluated every substep under its mask — the loop a wave switches to for the rest of a control step once one of its
+// lanes has bounced: a rollout caught beyond the edge bounces on EVERY substep, and behind the branch each of those
+// costs ~500 cycles (exec-mask and SGPR shuffling around 45 instructions) against ~300 for the whole substep; inline
+// and scheduled with the rest it costs ~100.  Returns whether an event occurred (wave-uniform).
+template <class F, bool BOUNCY>
+__device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
+                                                             F& cd, F& sd, F& xlim) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1, aDD;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1, &aDD);
@@ -569,11 +574,12 @@ __device__ __forceinline__ void substep_fast_rot_carried(State<F>& st, F uK, flo
   const F eps = aDD * splat<F>(t * t);
   F cd1 = fma_(-eps, fma_(eps, splat<F>(0.5f), sd), cd);            // cd - eps sd - eps^2/2  (cd ~ 1: the eps^2 term matters)
   F sd1 = fma_(cd, eps, sd);                                         // sd + eps cd
-  bool rare = false;
+  uint64_t fired = 0;                                               // wave mask (a scalar register pair; the loops' exit tests read it)
 #pragma unroll
-  for (int i = 0; i < W; ++i) rare |= __builtin_fabsf(get(x1, i)) >= get(xlim, i);      // edge, or a lane flagged `beyond`
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
-    CPMPPI_DBG(0, 1);
+  for (int i = 0; i < W; ++i)                                       // edge, or a lane flagged `beyond`  (3 = ordered >=)
+    fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), get(xlim, i), 3);
+  if (BOUNCY || __builtin_expect(fired != 0, 0)) {
+    if (!BOUNCY) CPMPPI_DBG(0, 1);
     // plain bounces (lanes inside the rotation range): masked, both rollouts of all lanes at once — about one substep's
     // worth of packed instructions; lanes flagged `beyond`, or thrown beyond the range by this bounce, per lane (deep)
     F m;
@@ -610,10 +616,11 @@ __device__ __forceinline__ void substep_fast_rot_carried(State<F>& st, F uK, flo
   }
   cd = cd1; sd = sd1;
   st.th = th1; st.w = w1; st.x = x1; st.v = v1; st.c = c1; st.s = s1;
+  return fired;
 }
 
 // One control step of S substeps under a held control (FAST).
-template <class F>
+template <class F, bool TWO_LOOPS = false>
 __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e) {
 #if CPMPPI_ROTATE && CPMPPI_HOIST_SPIN
@@ -634,7 +641,24 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
   for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
-  for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F>(st, uK, t, p, e, cd, sd, xlim);
+  if constexpr (TWO_LOOPS) {
+    // two loops with ONE exit each: the plain one runs until the end of this control step or an event (handled inside,
+    // behind the cold branch), the bouncy one — the event arithmetic inline — takes the remaining substeps after an event.
+    // The second exit test costs ~7 scalar instructions per substep: 13 % of a lone wave's substep, nothing measurable at
+    // full occupancy — but the slowest wave sets a small launch's time (C3: mean 301 -> 265 us, C4: 106 -> 101 us)
+    uint32_t left = S - 1u;
+    uint64_t fired = 0;
+    while (left != 0u && fired == 0) {
+      fired = substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim);
+      --left;
+    }
+    while (left != 0u) {
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      --left;
+    }
+  } else {
+    for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim);
+  }
   substep_fast<F>(st, uK, t, p, e);
 #else
   bool spin = false;

@@ -136,11 +136,11 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
   const float L = a.L ? a.L[env] : p.L_default;
   const EnvConst ec = make_env_const_uniform(p, L);
-  // VARIANT 2 (packed mapping, launches of up to ~16 waves per SIMD): the constants of the substep loop are held in
-  // vector registers instead of scalar ones.  The packed mapping wants every wave-uniform operand as a register PAIR and
-  // runs out of the 102 SGPRs; with them in VGPRs a lone wave's instruction stream is 4-7 % shorter in time (C3, C4, up
-  // to 2048 envs x 1024), while at 64 waves per SIMD the scalar-operand form is 5 % faster (A/B in one process,
-  // tools/kbench.py: 2.44 vs 2.56 ms at 8192 envs).
+  // VARIANT 2 (packed mapping, launches of up to 4 waves per SIMD): the constants of the substep loop are held in vector
+  // registers instead of scalar ones.  The packed mapping wants every wave-uniform operand as a register PAIR and runs
+  // out of the 102 SGPRs; with them in VGPRs a lone wave's instruction stream is 4-7 % shorter in time (C3, C4), while
+  // at 64 waves per SIMD the scalar-operand form is 5 % faster (A/B in one process, tools/kbench.py: 2.44 vs 2.56 ms at
+  // 8192 envs).  The same variant runs the substeps that follow a rare event in their own loop (control_step_fast).
   Params ph = p;
   EnvConst eh = ec;
   if constexpr (VARIANT == 2 && R == 2) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh);
+      control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh);
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
