@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into profiles/<tag>/ and profiles/pmc_traffic.json."""
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into profiles/<tag>/ (kernel stats, PMC summary, pmc_traffic.json)."""
 import collections
 import csv
 import glob
@@ -28,7 +28,7 @@ def short(name):
 
 
 summary = {}
-for noise in ("philox", "buffer"):
+for noise in ("philox", "buffer", "buffer-ref"):
     ks = glob.glob(os.path.join(src, f"stats_{noise}", "**", "*_kernel_stats.csv"), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(dst, f"kernel_stats_{noise}.csv"))
@@ -74,5 +74,8 @@ for noise in rec:
     if os.path.exists(p):
         cfg = json.load(open(p))["config"]
         rec[noise].update(E=cfg["envs_per_gpu"], N=cfg["rollouts"], H=cfg["horizon"], noise=noise)
-json.dump(rec, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+import datetime
+for r in rec.values():
+    r["collected"] = datetime.date.today().isoformat() + " (tools/profile.sh " + tag + ", separate --pmc passes)"
+json.dump(rec, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
