@@ -116,3 +116,22 @@ def oracle_step_both_modes(s0, u_nom, du, target_position, target_equilibrium, c
     a = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f32", **kw)
     b = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f64sub", **kw)
     return a, b
+
+
+def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None):
+    """The plain-C oracle's MPPI step for E envs in BOTH reference arithmetic modes, plus the H2 flags of every rollout
+    from the oracle's own trajectories (default glue: shift repeat-last, clip).  -> dict(S_a, S_b, u_a, u_b, Q_a, flags)."""
+    from oracle import oracle_c as OC
+    E, N, H = du.shape
+    ca, cb = OC.make_config(ocfg, params), OC.make_config(ocfg, params, mode="f64sub")
+    u_a, Q_a, S_a = OC.step(ca, s0, u0, du, tp, te, L=L)
+    u_b, _, S_b = OC.step(cb, s0, u0, du, tp, te, L=L)
+    u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1) if ocfg.shift_mode == "repeat_last" else u0
+    u_run = np.clip(u_shift[:, None, :] + du, -1, 1).astype(f32).reshape(E * N, H)
+    Lr = None if L is None else np.repeat(np.asarray(L, f32), N)
+    traj = OC.predict(ca, np.repeat(np.asarray(s0, f32), N, axis=0), u_run, L=Lr)
+    thl = float((params or O.DEFAULT_PARAMS).TrackHalfLength)
+    x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
+    step = float(ocfg.dt if dt is None else dt)
+    flags = ((np.abs(x) + np.abs(v) * step > thl - 2e-3).any(axis=1) | (np.abs(np.abs(th) - np.pi) < 2e-3).any(axis=1))
+    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags.reshape(E, N))
