@@ -563,7 +563,7 @@ __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, co
 // lanes has bounced: a rollout caught beyond the edge bounces on EVERY substep, and behind the branch each of those
 // costs ~500 cycles (exec-mask and SGPR shuffling around 45 instructions) against ~300 for the whole substep; inline
 // and scheduled with the rest it costs ~100.  Returns whether an event occurred (wave-uniform).
-template <class F, bool BOUNCY>
+template <class F, bool BOUNCY, bool MASK_ONLY = false>
 __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
                                                              F& cd, F& sd, F& xlim) {
   constexpr int W = Width<F>::value;
@@ -578,7 +578,7 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
 #pragma unroll
   for (int i = 0; i < W; ++i)                                       // edge, or a lane flagged `beyond`  (3 = ordered >=)
     fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), get(xlim, i), 3);
-  if (BOUNCY || __builtin_expect(fired != 0, 0)) {
+  if (!MASK_ONLY && (BOUNCY || __builtin_expect(fired != 0, 0))) {
     if (!BOUNCY) CPMPPI_DBG(0, 1);
     // plain bounces (lanes inside the rotation range): masked, both rollouts of all lanes at once — about one substep's
     // worth of packed instructions; lanes flagged `beyond`, or thrown beyond the range by this bounce, per lane (deep)
@@ -642,15 +642,24 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
   if constexpr (TWO_LOOPS) {
-    // two loops with ONE exit each: the plain one runs until the end of this control step or an event (handled inside,
-    // behind the cold branch), the bouncy one — the event arithmetic inline — takes the remaining substeps after an event.
-    // The second exit test costs ~7 scalar instructions per substep: 13 % of a lone wave's substep, nothing measurable at
-    // full occupancy — but the slowest wave sets a small launch's time (C3: mean 301 -> 265 us, C4: 106 -> 101 us)
+    // Three substeps at a time WITHOUT event handling — one exit test, one loop latch and one VALU -> scalar hand-over
+    // per triple, and a basic block three substeps long for the scheduler — under a rollback: the edge masks of the
+    // three are or-ed, and if any lane fired the triple is discarded and the rest of the control step is integrated
+    // substep by substep with the event arithmetic inline (BOUNCY).  S - 1 = 9 intermediate substeps = 3 triples.
     uint32_t left = S - 1u;
     uint64_t fired = 0;
-    while (left != 0u && fired == 0) {
-      fired = substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim);
-      --left;
+    while (left >= 3u && fired == 0) {
+      const State<F> st0 = st;
+      const F cd0 = cd, sd0 = sd;
+      fired = substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim);
+      fired |= substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim);
+      fired |= substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim);
+      if (__builtin_expect(fired != 0, 0)) {
+        asm volatile("" ::: "memory");            // (keeps this a branch: as selects the rollback costs 16 v_cndmask per triple)
+        st = st0; cd = cd0; sd = sd0;
+      } else {
+        left -= 3u;
+      }
     }
     while (left != 0u) {
       substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);

@@ -24,6 +24,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_GRU_MIN_WAVES
 #define CPMPPI_GRU_MIN_WAVES 2      // waves per SIMD the GRU kernels are compiled for (register budget 512 / this)
 #endif
+#ifndef CPMPPI_TRIPLES_EVERYWHERE
+#define CPMPPI_TRIPLES_EVERYWHERE 0
+#endif
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
 #endif
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh);
+      control_step_fast<F, (VARIANT == 2 || CPMPPI_TRIPLES_EVERYWHERE)>(st, uK, p.S, p.t_step, ph, eh);
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
