@@ -277,7 +277,9 @@ void oracle_step(const oracle_config* p, uint32_t E, const float* s0, float* u_n
 
 int oracle_max_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
+  static int cached = 0;             /* the value at first call (the binding calls it when it loads the library): a later */
+  if (!cached) cached = omp_get_max_threads();   /* n_threads = 1 run must not stick, and affinity limits are respected */
+  return cached;
 #else
   return 1;
 #endif

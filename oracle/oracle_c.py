@@ -33,6 +33,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.oracle_max_threads.restype = C.c_int
+        _lib.oracle_max_threads()            # (caches the thread count the process started with)
     return _lib
 
 
@@ -87,6 +88,7 @@ def build_bench_variants():
                         ("native_fastmath", "-O3 -march=native -ffast-math, libm float trig")):
         v = C.CDLL(os.path.join(HERE, "_bench", f"liboracle_{name}.so"))
         v.oracle_max_threads.restype = C.c_int
+        v.oracle_max_threads()
         out[name] = (v, flags)
     return out
 
