@@ -215,11 +215,25 @@ __global__ __launch_bounds__(BLOCK) void rwa_kernel(const Params p, const float*
   if (tid == 0) { float v = red[0]; for (int w = 1; w < WAVES; ++w) v += red[w]; sh_a = v; }
   __syncthreads();
   a = sh_a;
-  for (uint32_t k = tid; k < p.H; k += BLOCK) {
+  // lane = column, one wave = every WAVES-th row: rows are read coalesced and a row's weight is formed once per wave (the
+  // first version evaluated expf N x H times from H threads); the waves' sums meet in LDS
+  __shared__ float part[WAVES][64];
+  for (uint32_t k0 = 0; k0 < p.H; k0 += 64) {
+    const uint32_t k = k0 + lane;
     float acc = 0.0f;
-    for (uint32_t n = 0; n < p.N; ++n)
-      acc += expf((-1.0f / p.LBD) * (Se[n] - m)) * de[(size_t)n * p.H + k] / a;
-    out[(size_t)env * p.H + k] = acc;
+    for (uint32_t n = wave; n < p.N; n += WAVES) {
+      const float e = expf((-1.0f / p.LBD) * (Se[n] - m));
+      if (k < p.H) acc = __builtin_fmaf(e, de[(size_t)n * p.H + k], acc);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && k < p.H) {
+      float v = part[0][lane];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) v += part[w][lane];
+      out[(size_t)env * p.H + k] = v / a;
+    }
+    __syncthreads();
   }
 }
 
