@@ -485,8 +485,10 @@ __device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const 
 // wrap + sincos (substep_fast), so the states observed at control-step granularity carry at most S-1 rotations of drift
 // (~2e-7).  Lanes that bounce, or spin faster than 0.125 rad per substep, are re-evaluated in the cold branch
 // (rare_lane: a higher-degree rotation up to 0.25 rad per substep, the exact wrap + sincos beyond).
-template <class F, bool CHECK_SPIN = true>
-__device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
+// EVENTS: 1 = rare events behind a wave-uniform branch, 0 = none handled — only the wave mask of lanes that WOULD need it
+// is returned (the caller rolls the substeps back), 2 = the event arithmetic inline on every call.
+template <class F, bool CHECK_SPIN = true, int EVENTS = 1>
+__device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   const F d = st.w * splat<F>(t);
@@ -495,14 +497,13 @@ __device__ __forceinline__ bool substep_fast_rot(State<F>& st, F uK, float t, co
   rot_pair_lo<F>(d, cd, sd);
   F c1 = fma_(st.c, cd, -(st.s * sd));
   F s1 = fma_(st.s, cd, st.c * sd);
-  bool rare = false;
+  uint64_t fired = 0;
 #pragma unroll
   for (int i = 0; i < W; ++i) {
-    rare |= (__builtin_fabsf(get(x1, i)) >= p.THL);
-    if constexpr (CHECK_SPIN) rare |= (__builtin_fabsf(get(d, i)) > ROT_LIMIT_LO);
+    fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), p.THL, 3);                        // 3 = ordered >=
+    if constexpr (CHECK_SPIN) fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(d, i)), ROT_LIMIT_LO, 2);   // 2 = ordered >
   }
-  const bool fired = __builtin_amdgcn_ballot_w64(rare) != 0;
-  if (__builtin_expect(fired, 0)) {
+  if (EVENTS == 2 || (EVENTS == 1 && __builtin_expect(fired != 0, 0))) {
     CPMPPI_DBG(4, 1);
     // plain bounces of lanes inside the rotation range: masked, all lanes at once; everything else per lane (deep)
     F m;
@@ -627,6 +628,8 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
   if constexpr (Width<F>::value == 1) {
     // one rollout per lane is the small-launch (latency-bound) mapping: there the per-substep test, which overlaps with
     // the arithmetic, is faster than the shorter loop with its test at the head (single env: 70 us vs 80 us)
+    // (three substeps per iteration under a rollback, as in the packed mid-size build, was measured here too: single env
+    // 63 -> 72 us — the lone wave of this mapping gains nothing from longer basic blocks and pays for the bookkeeping)
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
     substep_fast<F>(st, uK, t, p, e);
     return;
