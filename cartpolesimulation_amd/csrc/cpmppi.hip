@@ -159,7 +159,10 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
 }
 
 // cost seam on materialised trajectories
-__global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, uint32_t B, uint32_t H,
+// Cost seam.  traj[B,H+1,6] and inputs[B,H] are the reference's tensors (row-major per rollout): lane = time-step, a
+// wave walks its rows — a row's 24(H+1) bytes are read by consecutive lanes (coalesced) instead of 64 rows 1224 bytes
+// apart per load as in the first version (0.59 TB/s at 262144 rows) — and sums a row's stage costs by wave reduction.
+__global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, uint32_t B, uint32_t H, uint32_t rows_per_wave,
                                                                 const float* __restrict__ traj,
                                                                 const float* __restrict__ inputs, float x_t, float te,
                                                                 const float* __restrict__ u_nom,
@@ -167,27 +170,37 @@ __global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, 
                                                                 float* __restrict__ stage_out,
                                                                 float* __restrict__ terminal_out,
                                                                 float* __restrict__ total_out) {
-  const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (b >= B) return;
-  const float* t = traj + b * (size_t)(H + 1) * 6;
-  float sum = 0.0f;
-  for (uint32_t k = 0; k < H; ++k, t += 6) {
-    const float in = inputs[b * H + k];
-    const float cosang = cosf(t[0]);
-    float c;
-    if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm<float>(p, t[4], cosang, t[1], in, x_t, te);
-    else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default<float>(p, t[4], cosang, in, x_t, te);
-    else if (p.cost_id == CPMPPI_COST_QBG)
-      c = stage_qbg<float>(p, t[4], cosang, t[1], in, k == 0 ? (u_prev ? u_prev[0] : 0.0f) : inputs[b * H + k - 1], x_t, te);
-    else c = stage_legacy<float>(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
-    if (stage_out) stage_out[b * H + k] = c;
-    sum += c;
+  const uint32_t lane = threadIdx.x & 63u;
+  const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const size_t b0 = wave * rows_per_wave;
+  for (size_t b = b0; b < b0 + rows_per_wave && b < B; ++b) {
+    const float* __restrict__ row = traj + b * (size_t)(H + 1) * 6;
+    float sum = 0.0f;
+    for (uint32_t k0 = 0; k0 < H; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      float c = 0.0f;
+      if (k < H) {
+        const float* __restrict__ t = row + (size_t)k * 6;
+        const float in = inputs[b * H + k];
+        const float cosang = cosf(t[0]);
+        if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm<float>(p, t[4], cosang, t[1], in, x_t, te);
+        else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default<float>(p, t[4], cosang, in, x_t, te);
+        else if (p.cost_id == CPMPPI_COST_QBG)
+          c = stage_qbg<float>(p, t[4], cosang, t[1], in, k == 0 ? (u_prev ? u_prev[0] : 0.0f) : inputs[b * H + k - 1], x_t, te);
+        else c = stage_legacy<float>(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
+        if (stage_out) stage_out[b * H + k] = c;
+      }
+      sum += wave_sum(c);
+    }
+    if (lane == 0) {
+      const float* __restrict__ tl = row + (size_t)H * 6;
+      const float term = (p.cost_id == CPMPPI_COST_QBGM || p.cost_id == CPMPPI_COST_QBG) ? 0.0f : terminal_indicator<float>(p, tl[0], tl[4], x_t);
+      if (terminal_out) terminal_out[b] = term;
+      if (total_out)
+        total_out[b] = (p.cost_id == CPMPPI_COST_LEGACY || p.horizon_reduce == CPMPPI_REDUCE_SUM)
+                           ? (sum + term) : (sum + term) / (float)(H + 1);
+    }
   }
-  const float term = (p.cost_id == CPMPPI_COST_QBGM || p.cost_id == CPMPPI_COST_QBG) ? 0.0f : terminal_indicator<float>(p, t[0], t[4], x_t);
-  if (terminal_out) terminal_out[b] = term;
-  if (total_out)
-    total_out[b] = (p.cost_id == CPMPPI_COST_LEGACY || p.horizon_reduce == CPMPPI_REDUCE_SUM)
-                       ? (sum + term) : (sum + term) / (float)(H + 1);
 }
 
 // a16 on given (S, delta_u): one block per env
@@ -221,10 +234,16 @@ __global__ __launch_bounds__(BLOCK) void rwa_kernel(const Params p, const float*
   for (uint32_t k0 = 0; k0 < p.H; k0 += 64) {
     const uint32_t k = k0 + lane;
     float acc = 0.0f;
-    for (uint32_t n = wave; n < p.N; n += WAVES) {
-      const float e = expf((-1.0f / p.LBD) * (Se[n] - m));
-      if (k < p.H) acc = __builtin_fmaf(e, de[(size_t)n * p.H + k], acc);
+    const uint32_t kk = k < p.H ? k : 0u;
+    uint32_t n = wave;
+    for (; n + 7 * WAVES < p.N; n += 8 * WAVES) {           // eight rows in flight: the pass is bound by load latency
+      float x[8], e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { x[u] = de[(size_t)(n + u * WAVES) * p.H + kk]; e[u] = Se[n + u * WAVES]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(expf((-1.0f / p.LBD) * (e[u] - m)), x[u], acc);
     }
+    for (; n < p.N; n += WAVES) acc = __builtin_fmaf(expf((-1.0f / p.LBD) * (Se[n] - m)), de[(size_t)n * p.H + kk], acc);
     part[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && k < p.H) {
@@ -1091,8 +1110,13 @@ int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const
   if (h->prm.cost_id == CPMPPI_COST_LEGACY && !u_nom)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_trajectory_cost: legacy cost needs u_nom");
   CPMPPI_ON_DEVICE(h);
-  hipLaunchKernelGGL(trajectory_cost_kernel, dim3((B + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm,
-                     B, horizon, traj, inputs, target_position, target_equilibrium, u_nom, u_prev, stage_out,
+  // rows per wave: one for the reference's call shape (a few thousand rollouts: spread them over the chip), up to 64
+  // once there are more rows than ~8 waves per SIMD can take one each
+  uint32_t rpw = (uint32_t)(((uint64_t)B + 8191) / 8192);
+  rpw = rpw < 1 ? 1 : (rpw > 64 ? 64 : rpw);
+  const uint32_t waves = (B + rpw - 1) / rpw;
+  hipLaunchKernelGGL(trajectory_cost_kernel, dim3((waves + WAVES - 1) / WAVES), dim3(BLOCK), 0, (hipStream_t)stream, h->prm,
+                     B, horizon, rpw, traj, inputs, target_position, target_equilibrium, u_nom, u_prev, stage_out,
                      terminal_out, total_out);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
