@@ -31,56 +31,12 @@ using namespace cpmppi;
 
 using namespace cpmppi_k;
 
-// rollout_cost_kernel is instantiated in cpmppi_rollout_latency.hip (VARIANT 0) and cpmppi_rollout_throughput.hip (1)
+// rollout_cost_kernel is instantiated in cpmppi_rollout_latency.hip (VARIANT 0), cpmppi_rollout_throughput.hip (1) and
+// cpmppi_rollout_mid.hip (2), each with its own compiler flags; nothing of it may be instantiated here
 namespace cpmppi_k {
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBGM, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_DEFAULT, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_LEGACY, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_DELTA_U, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_DELTA_U, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_KNOTS, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_KNOTS, 2, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 0>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, false, NOISE_PHILOX, 1, 1>(const Params, const StepPtrs);
-extern template __global__ void rollout_cost_kernel<COST_QBG, true, NOISE_PHILOX, 2, 1>(const Params, const StepPtrs);
+CPMPPI_LATENCY_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
+CPMPPI_MID_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
+CPMPPI_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 }  // namespace cpmppi_k
 
 namespace {
@@ -898,6 +854,9 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3
                  : launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
     }
     const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
+#if CPMPPI_R1_MID
+    if (!small && (uint64_t)grid.x * BLOCK <= MID_SIZE_MAX_ROLLOUTS) return launch_rollout_noise<COST, true, 1, 2>(noise, grid, lds, s, p, a);
+#endif
     return small ? launch_rollout_noise<COST, true, 1, 0>(noise, grid, lds, s, p, a)
                  : launch_rollout_noise<COST, true, 1, 1>(noise, grid, lds, s, p, a);
   }

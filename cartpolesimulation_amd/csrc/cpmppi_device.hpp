@@ -27,6 +27,25 @@ namespace cpmppi {
 static __device__ unsigned long long g_dbg[8];        // unused slots kept for ad-hoc counters
 static __device__ unsigned long long g_wave_cycles[16384];
 static __device__ unsigned int g_wave_cold[16384];    // cold-branch entries of each wave (all substep flavours)
+static __device__ unsigned long long g_wave_t[16384][4];   // s_memrealtime (100 MHz, chip-wide): entry, loop end, partials written, exit
+#define CPMPPI_DBG_STAMP(slot)                                                                       \
+  do {                                                                                               \
+    const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                        \
+    if ((threadIdx.x & 63u) == 0u && wv_ < 16384u) cpmppi::g_wave_t[wv_][slot] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+// one reader per translation unit (the arrays are per unit): extern "C" int NAME(cold, cycles, stamps, n_waves, reset)
+#define CPMPPI_DEBUG_READER(NAME)                                                                                      \
+  extern "C" int NAME(unsigned int* wave_cold, unsigned long long* wave_cycles, unsigned long long* stamps,            \
+                      unsigned n_waves, int reset) {                                                                   \
+    if (wave_cold && hipMemcpyFromSymbol(wave_cold, HIP_SYMBOL(cpmppi::g_wave_cold), (size_t)n_waves * 4) != hipSuccess) return -1; \
+    if (wave_cycles && hipMemcpyFromSymbol(wave_cycles, HIP_SYMBOL(cpmppi::g_wave_cycles), (size_t)n_waves * 8) != hipSuccess) return -1; \
+    if (stamps && hipMemcpyFromSymbol(stamps, HIP_SYMBOL(cpmppi::g_wave_t), (size_t)n_waves * 32) != hipSuccess) return -1; \
+    if (reset) {                                                                                                       \
+      static unsigned int z[16384];                                                                                    \
+      if (hipMemcpyToSymbol(HIP_SYMBOL(cpmppi::g_wave_cold), z, sizeof(z)) != hipSuccess) return -1;                   \
+    }                                                                                                                  \
+    return 0;                                                                                                          \
+  }
 #define CPMPPI_DBG(i, n)                                                                             \
   do {                                                                                               \
     const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                        \
@@ -35,6 +54,7 @@ static __device__ unsigned int g_wave_cold[16384];    // cold-branch entries of 
   } while (0)
 #else
 #define CPMPPI_DBG(i, n) ((void)0)
+#define CPMPPI_DBG_STAMP(slot) ((void)0)
 #endif
 
 constexpr float PI_F = 3.14159274101257324f;       // float32(np.pi)

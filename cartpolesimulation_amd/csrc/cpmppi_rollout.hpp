@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #ifdef CPMPPI_DEBUG_COUNTERS
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+  CPMPPI_DBG_STAMP(0);
 #endif
   const uint32_t row0 = blk * (BLOCK * R) + wave * (64 * R);     // first rollout of this wave
   uint32_t n[R];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // 8192 envs).  The same variant runs the substeps that follow a rare event in their own loop (control_step_fast).
   Params ph = p;
   EnvConst eh = ec;
-  if constexpr (VARIANT == 2 && R == 2) {
+  if constexpr (VARIANT == 2) {
 #define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
     CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
     CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.g_i); CPMPPI_TO_VGPR(eh.inv_kLh); CPMPPI_TO_VGPR(eh.cT_i);
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #ifdef CPMPPI_DEBUG_COUNTERS
   if (lane == 0 && blockIdx.x * WAVES + wave < 16384u)
     cpmppi::g_wave_cycles[blockIdx.x * WAVES + wave] = __builtin_amdgcn_s_memtime() - dbg_t0;
+  CPMPPI_DBG_STAMP(1);
 #endif
   // ---- per-rollout total cost ------------------------------------------------------------------------------------
   F S_total;
@@ -425,6 +427,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     for (int w = 1; w < WAVES; ++w) v += bsum[w * W + c];
     out[2 + c] = v;
   }
+  CPMPPI_DBG_STAMP(2);
   // ---- fused finalize: the env's last-arriving block merges the partials (no second launch) -----------------------
   // Placement-independent hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, the
   // block's barrier, one lane's agent-scope release, then the ticket; the consumer block does one agent-scope acquire
@@ -449,8 +452,32 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom_out, a.Q_out, env);
     }
   }
+  CPMPPI_DBG_STAMP(3);
 }
 
-// Stand-alone form: one block per env (used after the GRU rollout kernel).
-
 }  // namespace cpmppi_k
+
+// Every instantiation of rollout_cost_kernel, by the translation unit that compiles it.  X(COST, FAST, NOISE, R, VARIANT).
+// The units define them with CPMPPI_DEFINE_ROLLOUT, cpmppi.hip declares ALL of them extern with CPMPPI_DECLARE_ROLLOUT —
+// an instantiation missing there would be compiled a second time in cpmppi.hip with that unit's flags, and the runtime
+// would launch whichever copy registered last.
+#define CPMPPI_FOR_COSTS(X, FAST, NOISE, R, V) \
+  X(COST_QBGM, FAST, NOISE, R, V) X(COST_DEFAULT, FAST, NOISE, R, V) X(COST_LEGACY, FAST, NOISE, R, V) X(COST_QBG, FAST, NOISE, R, V)
+#define CPMPPI_FOR_NOISES(X, FAST, R, V)                                                        \
+  CPMPPI_FOR_COSTS(X, FAST, NOISE_DELTA_U, R, V) CPMPPI_FOR_COSTS(X, FAST, NOISE_KNOTS, R, V)   \
+  CPMPPI_FOR_COSTS(X, FAST, NOISE_PHILOX, R, V) CPMPPI_FOR_COSTS(X, FAST, NOISE_TILED, R, V)
+#define CPMPPI_LATENCY_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 1, 0)
+#ifndef CPMPPI_R1_MID
+#define CPMPPI_R1_MID 0
+#endif
+#if CPMPPI_R1_MID
+#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 2) CPMPPI_FOR_NOISES(X, true, 1, 2)
+#else
+#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 2)
+#endif
+#define CPMPPI_THROUGHPUT_INSTANCES(X) \
+  CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
+#define CPMPPI_DEFINE_ROLLOUT(COST, FAST, NOISE, R, V) \
+  template __global__ void rollout_cost_kernel<COST, FAST, NOISE, R, V>(const Params, const StepPtrs);
+#define CPMPPI_DECLARE_ROLLOUT(COST, FAST, NOISE, R, V) \
+  extern template __global__ void rollout_cost_kernel<COST, FAST, NOISE, R, V>(const Params, const StepPtrs);

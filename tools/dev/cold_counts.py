@@ -31,14 +31,14 @@ E, N, H = {"C2": (8192, 1024, 50), "C3": (64, 4096, 100), "C4": (64, 2048, 50)}[
 dev = torch.device("cuda", 0)
 eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=args.rpl), device=0)
 lib = L.load()
-lib.cpmppi_debug_read.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_uint, C.c_int]
+lib.cpmppi_debug_read.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_void_p, C.c_uint, C.c_int]
 s0, tp, te, Lt = synthetic_inputs(E, H, 2, dev)
 u_nom = eng.zeros(E, H)
 rpl = args.rpl or 2
 n_waves = min(16384, E * ((N + 256 * rpl - 1) // (256 * rpl)) * 4)
 cnt = (C.c_uint * n_waves)()
 wc = (C.c_ulonglong * n_waves)()
-lib.cpmppi_debug_read(cnt, wc, n_waves, 1)
+lib.cpmppi_debug_read(cnt, wc, None, n_waves, 1)
 rows = []
 for i in range(args.steps):
     if args.frozen:
@@ -48,7 +48,7 @@ for i in range(args.steps):
     torch.cuda.synchronize()
     r, _ = eng.get_profile()
     eng.set_profiling(False)
-    assert lib.cpmppi_debug_read(cnt, wc, n_waves, 1) == 0
+    assert lib.cpmppi_debug_read(cnt, wc, None, n_waves, 1) == 0
     w = np.frombuffer(wc, dtype=np.uint64).astype(np.float64)
     c = np.frombuffer(cnt, dtype=np.uint32).astype(np.float64)
     ok = w > 0
