@@ -250,8 +250,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       for (uint32_t j = 0; j < kend; ++j) {
         F du;
 #pragma unroll
-        for (int i = 0; i < R; ++i)
-          put(du, i, j == 0u ? cur[i].x : (j == 1u ? cur[i].y : (j == 2u ? cur[i].z : cur[i].w)));
+        for (int i = 0; i < R; ++i) {
+          put(du, i, cur[i].x);
+          // the quad moves down one step (three register moves) instead of a select on the wave-uniform j, which the
+          // compiler turns into a tree of scalar branches per control step
+          cur[i].x = cur[i].y; cur[i].y = cur[i].z; cur[i].z = cur[i].w;
+        }
         control_step(4u * q + j, du);
       }
 #pragma unroll
@@ -364,25 +368,42 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       if (lane == 0) my_bsum[j] = v;
     }
   } else if constexpr (NOISE == NOISE_TILED) {
-    // second, coalesced sweep over the wave's quads: lane = row, the sum over the 64 rows of a group by wave reduction
+    // second, coalesced sweep over the wave's quads: lane = row, the sum over the 64 rows of a group by wave reduction.
+    // Four quads per batch with all their loads issued first: the sweep is a chain of load latencies otherwise (13 quads
+    // at ~1 us each are 13 us of a 60 us single-env launch).
     const uint32_t G = (p.N + 63u) >> 6, Hq = (H + 3u) >> 2;
-    for (uint32_t q = 0; q < Hq; ++q) {
-      float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float4* __restrict__ src2[R];
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        uint32_t g = (row0 >> 6) + (uint32_t)i;
-        g = g < G ? g : G - 1u;
-        const float4 v = reinterpret_cast<const float4*>(a.noise)[(((size_t)env * G + g) * Hq + q) * 64u + lane];
-        acc.x = __builtin_fmaf(e[i], v.x, acc.x); acc.y = __builtin_fmaf(e[i], v.y, acc.y);
-        acc.z = __builtin_fmaf(e[i], v.z, acc.z); acc.w = __builtin_fmaf(e[i], v.w, acc.w);
+    for (int i = 0; i < R; ++i) {
+      uint32_t g = (row0 >> 6) + (uint32_t)i;
+      g = g < G ? g : G - 1u;
+      src2[i] = reinterpret_cast<const float4*>(a.noise) + ((size_t)env * G + g) * Hq * 64u + lane;
+    }
+    constexpr int QB = 4;
+    for (uint32_t q0 = 0; q0 < Hq; q0 += QB) {
+      float4 v[QB][R];
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        const uint32_t q = (q0 + u < Hq) ? q0 + u : Hq - 1u;
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[u][i] = src2[i][(size_t)q * 64u];
       }
-      acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
-      if (lane == 0) {
-        const uint32_t k = 4u * q;
-        my_bsum[k] = acc.x;
-        if (k + 1 < W) my_bsum[k + 1] = acc.y;
-        if (k + 2 < W) my_bsum[k + 2] = acc.z;
-        if (k + 3 < W) my_bsum[k + 3] = acc.w;
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          acc.x = __builtin_fmaf(e[i], v[u][i].x, acc.x); acc.y = __builtin_fmaf(e[i], v[u][i].y, acc.y);
+          acc.z = __builtin_fmaf(e[i], v[u][i].z, acc.z); acc.w = __builtin_fmaf(e[i], v[u][i].w, acc.w);
+        }
+        acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+        const uint32_t k = 4u * (q0 + u);
+        if (lane == 0 && q0 + u < Hq) {
+          my_bsum[k] = acc.x;
+          if (k + 1 < W) my_bsum[k + 1] = acc.y;
+          if (k + 2 < W) my_bsum[k + 2] = acc.z;
+          if (k + 3 < W) my_bsum[k + 3] = acc.w;
+        }
       }
     }
   } else {
