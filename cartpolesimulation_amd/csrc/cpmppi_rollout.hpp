@@ -77,18 +77,49 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
     if constexpr (COHERENT) return __hip_atomic_load(pe + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return pe[i];
   };
-  float M = INFINITY;
-  for (uint32_t b = 0; b < nb; ++b) M = fminf(M, ld((size_t)b * (2 + W)));
+  // One memory round trip per batch of eight blocks: the minimum, the weight sum and this thread's column of every block are
+  // requested together (the loads do not depend on each other; issued one after the other as written they were three
+  // dependent L2 round trips at the tail of every launch), then merged with the running minimum (identical arithmetic
+  // to a min-first pass when nb <= 8).
+  constexpr int NBB = 8;
   float a = 0.0f;
-  for (uint32_t b = 0; b < nb; ++b) a += ld((size_t)b * (2 + W) + 1) * expf((-1.0f / p.LBD) * (ld((size_t)b * (2 + W)) - M));
   auto merged = [&](uint32_t c) {
-    float v = 0.0f;
-    for (uint32_t b = 0; b < nb; ++b)
-      v = __builtin_fmaf(ld((size_t)b * (2 + W) + 2 + c), expf((-1.0f / p.LBD) * (ld((size_t)b * (2 + W)) - M)), v);
+    float M = INFINITY, v = 0.0f;
+    a = 0.0f;
+    for (uint32_t b0 = 0; b0 < nb; b0 += NBB) {
+      float mb[NBB], ab[NBB], vb[NBB];
+#pragma unroll
+      for (int u = 0; u < NBB; ++u) {
+        const uint32_t b = (b0 + u < nb) ? b0 + u : nb - 1u;
+        mb[u] = ld((size_t)b * (2 + W));
+        ab[u] = ld((size_t)b * (2 + W) + 1);
+        vb[u] = ld((size_t)b * (2 + W) + 2 + c);
+      }
+      float Mn = M;
+#pragma unroll
+      for (int u = 0; u < NBB; ++u) Mn = fminf(Mn, mb[u]);
+      if (b0 != 0) {
+        const float sc = expf((-1.0f / p.LBD) * (M - Mn));
+        a *= sc;
+        v *= sc;
+      }
+      M = Mn;
+#pragma unroll
+      for (int u = 0; u < NBB; ++u) {
+        if (b0 + u < nb) {
+          const float w = expf((-1.0f / p.LBD) * (mb[u] - M));
+          a += ab[u] * w;
+          v = __builtin_fmaf(vb[u], w, v);
+        }
+      }
+    }
     return v;
   };
   if constexpr (KNOT_SPACE) {
-    for (uint32_t c = tid; c < W; c += BLOCK) bz[c] = merged(c);
+    // every thread merges one column (clamped), so that every thread also holds the weight sum `a`
+    const float v0 = merged(tid < W ? tid : W - 1u);
+    if (tid < W) bz[tid] = v0;
+    for (uint32_t c = tid + BLOCK; c < W; c += BLOCK) bz[c] = merged(c);
     __syncthreads();
   }
   float* __restrict__ un = u_nom + (size_t)env * H;
