@@ -39,15 +39,22 @@ constexpr int G16_IMAGE_BYTES = G16_BIAS_OFF + 9 * 32 * 4;
 
 struct HSplit { h8 hi, lo; };      // one k-block of a tile as B operand
 
-// registers [8b, 8b+8) of a float32 tile -> (hi, lo)
+// registers [8b, 8b+8) of a float32 tile -> (hi, lo).  lo = f16(x - hi) with the difference formed by v_fma_mix_f32, which
+// reads hi straight from its packed f16 register (one instruction per element instead of a conversion back to float32
+// and a subtraction; the compiler does not form it from `x - (float)hi`).
 __device__ __forceinline__ HSplit gru16_split(const f16v& t, int b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   HSplit s;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float x = t[8 * b + i];
-    const _Float16 hi = (_Float16)x;
-    s.hi[i] = hi;
-    s.lo[i] = (_Float16)(x - (float)hi);
+  for (int i = 0; i < 8; i += 2) {
+    const float x0 = t[8 * b + i], x1 = t[8 * b + i + 1];
+    const h2 hp = {(_Float16)x0, (_Float16)x1};
+    const uint32_t hbits = __builtin_bit_cast(uint32_t, hp);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hbits), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hbits), "v"(x1));
+    s.hi[i] = hp.x; s.hi[i + 1] = hp.y;
+    s.lo[i] = (_Float16)l0; s.lo[i + 1] = (_Float16)l1;
   }
   return s;
 }
