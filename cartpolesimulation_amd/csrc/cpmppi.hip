@@ -842,7 +842,10 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 //   two rollouts per lane: mid-size build (loop constants in VGPRs, separate loop after a rare event) up to 4 packed
 //                          waves per SIMD = 524288 rollouts, throughput build above.  64..2048 envs x 1024 x 50, mid-size
 //                          vs throughput build: 128 envs 76 vs 82 us, 256 envs 145 vs 162 us, 1024 envs 406 vs 400 us
-constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = 524288ull;
+#ifndef CPMPPI_MID_SIZE_MAX
+#define CPMPPI_MID_SIZE_MAX 524288ull
+#endif
+constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,

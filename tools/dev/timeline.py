@@ -69,4 +69,8 @@ for i in range(args.steps):
                       "life_p50": round(float(np.percentile(life, 50)), 1), "life_max": round(float(life.max()), 1),
                       "partials_max": round(float(us[:, 2].max()), 1), "exit_max": round(float(us[:, 3].max()), 1),
                       "cold_max": int(cold.max()),
+                      "us_per_cold_entry": round(float(np.polyfit(cold.astype(np.float64), life, 1)[0]), 3) if cold.max() > 0 else None,
+                      "slowest": [(round(float(life[j]), 1), int(cold[j])) for j in np.argsort(-life)[:6]],
+                      "life_p90": round(float(np.percentile(life, 90)), 1), "life_cold0_p50": round(float(np.median(life[cold == 0])), 1) if np.any(cold == 0) else None,
+                      "waves_cold0": int((cold == 0).sum()),
                       "shader_clock_ghz": round(float(np.median(cyc.astype(np.float64) / np.maximum(life, 1e-3))) / 1e3, 3)}))
