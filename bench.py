@@ -196,8 +196,9 @@ class Workload:
         # independent, so step i+1 does not need step i's gathered result: the gather of a snapshot runs asynchronously on
         # RCCL's stream while the next step's kernel computes (two snapshot/result buffers, each waited on before reuse).
         W = ctx["world"]
-        self.gathered = [torch.empty(W * E * H, dtype=torch.float32, device=dev) for _ in range(2)] if W > 1 else None
-        self.snapshot = [torch.empty(E * H, dtype=torch.float32, device=dev) for _ in range(2)] if W > 1 else None
+        coll = ctx["collective"]
+        self.gathered = [torch.empty(W * E * H, dtype=torch.float32, device=dev) for _ in range(2)] if coll else None
+        self.snapshot = [torch.empty(E * H, dtype=torch.float32, device=dev) for _ in range(2)] if coll else None
         self.pending = [None, None]
 
     def step(self, i):
@@ -212,7 +213,7 @@ class Workload:
         else:
             e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, seed=self.seed, offset=i, env_offset=rank * self.E,
                    Q_out=self.Q_out, **self.pred_kw)
-        if self.ctx["world"] > 1:
+        if self.ctx["collective"]:
             b = i & 1
             if self.pending[b] is not None:
                 self.pending[b].wait()                              # stream-level wait: the buffers are free again
@@ -222,7 +223,7 @@ class Workload:
     def barrier(self):
         import torch
         import torch.distributed as dist
-        if self.ctx["world"] > 1:
+        if self.ctx["collective"]:
             for b in range(2):
                 if self.pending[b] is not None:
                     self.pending[b].wait()
@@ -247,12 +248,12 @@ class Workload:
         rollout_ms, finalize_ms = self.eng.get_profile()
         self.eng.set_profiling(False)
         W, rank = self.ctx["world"], self.ctx["rank"]
-        if W > 1:
+        if self.ctx["collective"]:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.ctx["device"])
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         assert torch.isfinite(self.u_nom).all(), "non-finite nominal controls"
-        if W > 1:        # the last gather delivered this rank's block (and finite blocks from every other rank)
+        if self.ctx["collective"]:        # the last gather delivered this rank's block (and finite blocks from every other rank)
             last = self.gathered[(warmup + steps - 1) & 1].view(W, self.E * self.H)
             assert torch.equal(last[rank], self.u_nom.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
         k_ms = float(np.mean(rollout_ms))
@@ -301,7 +302,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_rank else 0
     if in_rank and world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but torch.distributed.run started {world} ranks")
-    distributed = world > 1
+    # the data-path collective runs whenever there is more than one rank; CPMPPI_BENCH_FORCE_COLLECTIVE=1 runs it with a
+    # single rank too (development aid: exercises RCCL init, the async all-gather and the max-reduce on a 1-GPU box)
+    collective = world > 1 or (in_rank and os.environ.get("CPMPPI_BENCH_FORCE_COLLECTIVE") == "1")
     if in_rank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -343,7 +346,7 @@ def main():
         if in_rank:
             dist.barrier()
 
-    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "device": device}
+    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "device": device, "collective": collective}
     E, N, H = args.envs, args.rollouts, args.horizon
     main_wl = Workload(ctx, E, N, H, noise=args.noise, math=args.math, predictor=args.predictor, rpl=args.rpl)
     r = main_wl.run(args.steps, args.warmup)
