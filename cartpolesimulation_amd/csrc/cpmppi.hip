@@ -287,9 +287,6 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_rollout_cost_
   constexpr int IMAGE_FLOATS = F16 ? G16_IMAGE_BYTES / 4 : GRU_IMAGE_FLOATS;
   for (int i = threadIdx.x; i < IMAGE_FLOATS; i += BLOCK) lds[i] = image[i];
   __syncthreads();
-#if CPMPPI_GRU_STAGGER
-  if ((blockIdx.x >> 8) & 1u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(CPMPPI_GRU_STAGGER); }
-#endif
   float* bsum = lds + IMAGE_FLOATS;
   const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, c = lane & 31u;
@@ -857,9 +854,6 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3
                  : launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
     }
     const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
-#if CPMPPI_R1_MID
-    if (!small && (uint64_t)grid.x * BLOCK <= MID_SIZE_MAX_ROLLOUTS) return launch_rollout_noise<COST, true, 1, 2>(noise, grid, lds, s, p, a);
-#endif
     return small ? launch_rollout_noise<COST, true, 1, 0>(noise, grid, lds, s, p, a)
                  : launch_rollout_noise<COST, true, 1, 1>(noise, grid, lds, s, p, a);
   }

@@ -18,14 +18,8 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_TK
 #define CPMPPI_TK 8
 #endif
-#ifndef CPMPPI_GRU_STAGGER
-#define CPMPPI_GRU_STAGGER 0
-#endif
 #ifndef CPMPPI_GRU_MIN_WAVES
 #define CPMPPI_GRU_MIN_WAVES 2      // waves per SIMD the GRU kernels are compiled for (register budget 512 / this)
-#endif
-#ifndef CPMPPI_TRIPLES_EVERYWHERE
-#define CPMPPI_TRIPLES_EVERYWHERE 0
 #endif
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
@@ -178,7 +172,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // 8192 envs).  The same variant runs the substeps that follow a rare event in their own loop (control_step_fast).
   Params ph = p;
   EnvConst eh = ec;
-  if constexpr (VARIANT == 2) {
+  if constexpr (VARIANT == 2 && R == 2) {
 #define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
     CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
     CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.g_i); CPMPPI_TO_VGPR(eh.inv_kLh); CPMPPI_TO_VGPR(eh.cT_i);
@@ -214,7 +208,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      control_step_fast<F, (VARIANT == 2 || CPMPPI_TRIPLES_EVERYWHERE)>(st, uK, p.S, p.t_step, ph, eh);
+      control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh);
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
@@ -519,14 +513,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   CPMPPI_FOR_COSTS(X, FAST, NOISE_DELTA_U, R, V) CPMPPI_FOR_COSTS(X, FAST, NOISE_KNOTS, R, V)   \
   CPMPPI_FOR_COSTS(X, FAST, NOISE_PHILOX, R, V) CPMPPI_FOR_COSTS(X, FAST, NOISE_TILED, R, V)
 #define CPMPPI_LATENCY_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 1, 0)
-#ifndef CPMPPI_R1_MID
-#define CPMPPI_R1_MID 0
-#endif
-#if CPMPPI_R1_MID
-#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 2) CPMPPI_FOR_NOISES(X, true, 1, 2)
-#else
 #define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 2)
-#endif
 #define CPMPPI_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
 #define CPMPPI_DEFINE_ROLLOUT(COST, FAST, NOISE, R, V) \
