@@ -213,11 +213,17 @@ __global__ __launch_bounds__(BLOCK) void rwa_kernel(const Params p, const float*
 }
 
 // Plant (caller side): advance E simulated cartpoles n_sub simulation steps under held controls.
+// With logs: Q_log[row][E] = Q, states_log[row + 1][E][6] = the advanced state (the closed loop's recording, in the same
+// launch instead of two copy kernels per control step); row = the caller's, or *row_dev - 1 (the device step counter
+// of cpmppi_step_args.offset_dev, which cpmppi_step has already advanced).
 __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E, float* __restrict__ s,
                                                       const float* __restrict__ Q, const float* __restrict__ Lp,
-                                                      uint32_t n_sub, float dt_sim) {
+                                                      uint32_t n_sub, float dt_sim, float* __restrict__ states_log,
+                                                      float* __restrict__ Q_log, uint64_t row,
+                                                      const unsigned long long* __restrict__ row_dev) {
   const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
   if (env >= E) return;
+  if (row_dev) row = (uint64_t)*row_dev - 1u;
   const EnvConst ec = make_env_const(p, Lp ? Lp[env] : p.L_default);
   float* se = s + (size_t)env * 6;
   State<float> st{se[0], se[1], se[2], se[3], se[4], se[5]};
@@ -229,6 +235,11 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E
     ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);
   }
   se[0] = st.th; se[1] = st.w; se[2] = st.c; se[3] = st.s; se[4] = st.x; se[5] = st.v;
+  if (Q_log) Q_log[row * E + env] = Q[env];
+  if (states_log) {
+    float* lg = states_log + ((row + 1u) * E + env) * 6u;
+    lg[0] = st.th; lg[1] = st.w; lg[2] = st.c; lg[3] = st.s; lg[4] = st.x; lg[5] = st.v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1491,7 +1502,22 @@ int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q,
   if (misaligned(s) || misaligned(Q) || misaligned(L)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance: misaligned");
   CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
-                     L, n_substeps, dt_sim);
+                     L, n_substeps, dt_sim, (float*)nullptr, (float*)nullptr, (uint64_t)0, (const unsigned long long*)nullptr);
+  CPMPPI_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
+int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
+                                float dt_sim, float* states_log, float* Q_log, uint64_t row, const void* row_dev,
+                                void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance_record: bad argument");
+  if (misaligned(s) || misaligned(Q) || misaligned(L) || misaligned(states_log) || misaligned(Q_log) ||
+      (row_dev && ((uintptr_t)row_dev & 7u)))
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance_record: misaligned");
+  CPMPPI_ON_DEVICE(h);
+  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
+                     L, n_substeps, dt_sim, states_log, Q_log, row, (const unsigned long long*)row_dev);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }

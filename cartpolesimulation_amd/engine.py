@@ -178,15 +178,31 @@ class MPPIEngine:
                                                             self._stream()))
         return out
 
-    def plant_advance(self, s, Q, L=None, n_substeps=10, dt_sim=0.002):
-        """In-place plant update of s[E,6] under held controls Q[E]."""
+    def plant_advance(self, s, Q, L=None, n_substeps=10, dt_sim=0.002, states_log=None, Q_log=None, row=0, row_dev=None):
+        """In-place plant update of s[E,6] under held controls Q[E].  With ``states_log`` [T+1,E,6] / ``Q_log`` [T,E] the
+        same launch records the control period: Q_log[row] = Q, states_log[row+1] = the advanced state; ``row_dev`` (an
+        int64 device tensor: the step counter of ``step(offset_dev=...)``, already advanced) replaces ``row`` by its
+        value - 1."""
         if not (torch.is_tensor(s) and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()):
             raise ValueError("s must be a contiguous float32 ROCm tensor (it is updated in place)")
         E = s.shape[0]
         Q = self.tensor(Q).reshape(E)
         L = self.tensor(L).reshape(E) if L is not None else None
-        self._check(self.lib.cpmppi_plant_advance(self._h, E, _ptr(s), _ptr(Q), _ptr(L), int(n_substeps),
-                                                  float(dt_sim), self._stream()))
+        if states_log is None and Q_log is None:
+            self._check(self.lib.cpmppi_plant_advance(self._h, E, _ptr(s), _ptr(Q), _ptr(L), int(n_substeps),
+                                                      float(dt_sim), self._stream()))
+            return s
+        for name, t, tail in (("states_log", states_log, (E, 6)), ("Q_log", Q_log, (E,))):
+            if t is not None and not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                                      and tuple(t.shape[1:]) == tail):
+                raise ValueError(f"{name} must be a contiguous float32 ROCm tensor [T, {', '.join(map(str, tail))}]")
+        if row_dev is None:
+            if (states_log is not None and not 0 <= row + 1 < states_log.shape[0]) or (Q_log is not None and not 0 <= row < Q_log.shape[0]):
+                raise IndexError(f"row {row} outside the logs")
+        elif not (torch.is_tensor(row_dev) and row_dev.is_cuda and row_dev.dtype == torch.int64):
+            raise ValueError("row_dev must be an int64 ROCm tensor")
+        self._check(self.lib.cpmppi_plant_advance_record(self._h, E, _ptr(s), _ptr(Q), _ptr(L), int(n_substeps), float(dt_sim),
+                                                         _ptr(states_log), _ptr(Q_log), int(row), _ptr(row_dev), self._stream()))
         return s
 
     # ------------------------------------------------------------------ GRU predictor (BASELINE configs[4])

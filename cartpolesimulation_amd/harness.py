@@ -54,28 +54,22 @@ class BatchedCartPoleExperiment:
             return self._run_graph(s, u_nom, Q, tp, te, Lt, states, Qs, n_control_steps, env_offset, int(steps_per_graph))
         for t in range(n_control_steps):
             eng.step(s, u_nom, tp, te, L=Lt, seed=self.seed, offset=t, env_offset=env_offset, Q_out=Q)
-            eng.plant_advance(s, Q, L=Lt, n_substeps=self.n_sub, dt_sim=self.dt_simulation)
-            if record:
-                Qs[t] = Q
-                states[t + 1] = s
+            # plant + this period's row of the recording in ONE launch (two kernels per control step in all)
+            eng.plant_advance(s, Q, L=Lt, n_substeps=self.n_sub, dt_sim=self.dt_simulation, states_log=states, Q_log=Qs, row=t)
         return dict(states=states, Q=Qs, final_state=s, u_nom=u_nom)
 
     def _run_graph(self, s, u_nom, Q, tp, te, Lt, states, Qs, n_control_steps, env_offset, per_graph):
         """The same loop as ONE captured HIP graph of `per_graph` control steps, replayed: controller step (Philox counter in device
-        memory, `offset_dev`), plant, recording by a device-side index — no launch argument changes between steps, the
+        memory, `offset_dev`), plant + recording at the row the same counter names — no launch argument changes between steps, the
         host only enqueues replays (the launch-bound case: few envs, ~70 us of GPU work per control step)."""
         eng = self.engine
         counter = torch.zeros(1, dtype=torch.int64, device=s.device)          # Philox step counter = control step index
-        slot = torch.zeros(1, dtype=torch.int64, device=s.device)             # recording row
-        record = states is not None
+                                                                              # = recording row (after the step: + 1)
 
         def one_step():
             eng.step(s, u_nom, tp, te, L=Lt, seed=self.seed, offset_dev=counter, env_offset=env_offset, Q_out=Q)
-            eng.plant_advance(s, Q, L=Lt, n_substeps=self.n_sub, dt_sim=self.dt_simulation)
-            if record:
-                Qs.index_copy_(0, slot, Q.unsqueeze(0))
-                slot.add_(1)
-                states.index_copy_(0, slot, s.unsqueeze(0))
+            eng.plant_advance(s, Q, L=Lt, n_substeps=self.n_sub, dt_sim=self.dt_simulation, states_log=states, Q_log=Qs,
+                              row_dev=counter)
 
         side = torch.cuda.Stream(device=s.device)
         side.wait_stream(torch.cuda.current_stream(s.device))

@@ -273,6 +273,15 @@ int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S,
 int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
                          float dt_sim, void* stream);
 
+/* The same advance with the closed loop's recording in the same launch (the experiment loop of
+ * CartPole/__init__.py:659-735 appends one row per control period): Q_log[row][E] = Q and states_log[row + 1][E][6] =
+ * the advanced state; either log may be NULL.  row = the control-step index, or, when row_dev is given, *row_dev - 1:
+ * the device step counter of cpmppi_step_args.offset_dev, which the preceding cpmppi_step has already advanced (a
+ * captured graph of control steps then replays without any changing launch argument). */
+int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
+                                float dt_sim, float* states_log, float* Q_log, uint64_t row, const void* row_dev,
+                                void* stream);
+
 /* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */
 const char* cpmppi_version(void);
 

@@ -112,3 +112,36 @@ def test_graph_replayed_loop_equals_the_launched_loop():
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
     assert np.abs(outs[0][1]).max() > 0.01
+
+
+def test_plant_advance_records_in_the_same_launch():
+    """cpmppi_plant_advance_record: the advanced state and the held control land in the logs at the caller's row (or at
+    the device counter's), and the state itself is what the plain advance gives, bit for bit."""
+    import torch
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, T = 5, 4
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=64, mpc_horizon=10))
+    rng = np.random.Generator(np.random.SFC64(11))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(-0.15, 0.15), rng.uniform(-0.3, 0.3))
+                   for _ in range(E)])
+    Qs = rng.uniform(-1, 1, (T, E)).astype(np.float32)
+    plain = eng.tensor(s0).clone()
+    logged = eng.tensor(s0).clone()
+    by_counter = eng.tensor(s0).clone()
+    states_log, Q_log = eng.zeros(T + 1, E, 6), eng.zeros(T, E)
+    states_log2, Q_log2 = eng.zeros(T + 1, E, 6), eng.zeros(T, E)
+    counter = torch.zeros(1, dtype=torch.int64, device=plain.device)
+    for t in range(T):
+        eng.plant_advance(plain, Qs[t])
+        eng.plant_advance(logged, Qs[t], states_log=states_log, Q_log=Q_log, row=t)
+        counter.add_(1)                                       # what cpmppi_step(offset_dev=counter) does after its step
+        eng.plant_advance(by_counter, Qs[t], states_log=states_log2, Q_log=Q_log2, row_dev=counter)
+        assert torch.equal(plain, logged) and torch.equal(plain, by_counter)
+        assert torch.equal(states_log[t + 1], plain) and torch.equal(states_log2[t + 1], plain)
+    assert np.array_equal(Q_log.cpu().numpy(), Qs) and np.array_equal(Q_log2.cpu().numpy(), Qs)
+    assert float(states_log[0].abs().max()) == 0.0            # row 0 is the caller's (the initial state)
+    with pytest.raises(IndexError):
+        eng.plant_advance(logged, Qs[0], states_log=states_log, Q_log=Q_log, row=T)
+    eng.plant_advance(logged, Qs[0], states_log=None, Q_log=Q_log, row=T - 1)          # either log alone
+    eng.close()
