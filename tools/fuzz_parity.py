@@ -19,19 +19,33 @@ from cartpolesimulation_amd.engine import MPPIEngine  # noqa: E402
 from cartpolesimulation_amd.configs import MPPIConfig  # noqa: E402
 from oracle import oracle_np as O  # noqa: E402
 from oracle import oracle_c as OC  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import parity_util as PU  # noqa: E402  (the tests' own allowance rules: 1e-4 + the oracle's A/B gap / soft-min conditioning)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", type=int, default=10)
 ap.add_argument("--envs", type=int, default=64)
+ap.add_argument("--costs", nargs="+", default=["qbgm"], choices=["qbgm", "default", "legacy"],
+                help="cost plugins to sweep (quadratic_boundary_grad_minimal, default, the legacy mppi-cartpole cost with its glue)")
 args = ap.parse_args()
 E, N, H = args.envs, 1024, 50
 THL = 0.198
-out = {"workload": f"{args.batches} batches x {E} random envs x {N} rollouts x {H} steps, default cost, perturbations from the device sampler",
+from cartpolesimulation_amd.configs import legacy_mppi_config  # noqa: E402
+
+out = {"workload": f"{args.batches} batches x {E} random envs x {N} rollouts x {H} steps per variant, perturbations from the device sampler",
        "variants": {}}
-for math, rpl in (("fast", 1), ("fast", 2), ("precise", 1)):
-    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=rpl))
-    cfg_c = OC.make_config(O.MPPIConfig(N=N, H=H))
-    rels, du_max, bounced = [], [], 0
+ENGINE_CFG = {"qbgm": lambda **kw: MPPIConfig(**kw),
+              "default": lambda **kw: MPPIConfig(cost_function_specification="default", **kw),
+              "legacy": lambda **kw: legacy_mppi_config(**kw)}
+ORACLE_CFG = {"qbgm": lambda: O.MPPIConfig(N=N, H=H),
+              "default": lambda: O.MPPIConfig(N=N, H=H, cost_id=O.COST_DEFAULT),
+              "legacy": lambda: O.MPPIConfig(N=N, H=H, cost_id=O.COST_LEGACY, SQRTRHOINV=0.02, control_mode="penalise",
+                                             shift_mode="append_zero", correction_u="u_nom")}
+for cost, math, rpl in [(c, m, r) for c in args.costs for m, r in (("fast", 1), ("fast", 2), ("precise", 1))]:
+    eng = MPPIEngine(E, ENGINE_CFG[cost](num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=rpl))
+    cfg_c = OC.make_config(ORACLE_CFG[cost]())
+    cfg_b = OC.make_config(ORACLE_CFG[cost](), mode="f64sub")
+    rels, du_max, excess = [], [], []
     rng = np.random.Generator(np.random.SFC64(77))
     for b in range(args.batches):
         ang = rng.uniform(-np.pi, np.pi, E)
@@ -51,12 +65,22 @@ for math, rpl in (("fast", 1), ("fast", 2), ("precise", 1)):
         rel = np.abs(S.cpu().numpy() - S_ref) / np.abs(S_ref)
         rels.append(rel.reshape(-1))
         du_max.append(np.abs(un.cpu().numpy() - u_ref).max(axis=1))
+        # the same deviation against what the tests allow: 1e-4 + max(oracle A/B gap, soft-min conditioning bound)
+        du_h = du.cpu().numpy()
+        u_b, _, S_b = OC.step(cfg_b, s0, u0, du_h, tp, te, L=Lv)
+        for e in range(E):
+            allow = 1e-4 + max(float(np.abs(u_ref[e] - u_b[e]).max()),
+                               float(np.max(PU.softmin_allowance(S_ref[e], S_b[e], du_h[e], LBD=100.0))))
+            excess.append(float(np.abs(un.cpu().numpy()[e] - u_ref[e]).max()) / allow)
     r, d = np.concatenate(rels), np.concatenate(du_max)
-    out["variants"][f"{math}/rollouts_per_lane={rpl}"] = {
+    eng.close()
+    out["variants"][f"{cost}/{math}/rollouts_per_lane={rpl}"] = {
         "rollouts": int(r.size), "envs": int(d.size),
         "cost_rel_dev": {"median": float(np.median(r)), "p90": float(np.percentile(r, 90)), "p99": float(np.percentile(r, 99)),
                          "p999": float(np.percentile(r, 99.9)), "max": float(r.max()), "frac_below_1e-4": float(np.mean(r < 1e-4)),
                          "frac_below_1e-3": float(np.mean(r < 1e-3))},
         "control_update_abs_dev_per_env": {"median": float(np.median(d)), "p90": float(np.percentile(d, 90)), "max": float(d.max()),
-                                           "frac_below_1e-4": float(np.mean(d < 1e-4))}}
+                                           "frac_below_1e-4": float(np.mean(d < 1e-4)),
+                                           "frac_within_test_allowance": float(np.mean(np.asarray(excess) <= 1.0)),
+                                           "max_over_test_allowance": float(np.max(excess))}}
 print(json.dumps(out))
