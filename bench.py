@@ -239,7 +239,13 @@ class Workload:
         for i in range(warmup):
             self.step(i)
         self.barrier()
-        self.eng.set_profiling(True)
+        # kernel duration from HIP events on the launch stream, live inside the timed region.  An event costs ~5 us on the
+        # stream (two per bracketed launch = 10 % of a 100 us launch, and the wall clock of these K steps is what `value`
+        # is made of), so launches shorter than ~1 ms are bracketed in GROUPS of 8: kernel_ms is then the average
+        # duration of a launch back to back, inter-launch gaps included (an upper bound of the kernel's own duration).
+        small = self.predictor == "ode" and self.E * self.N * self.H < 100_000_000      # (< ~0.5 ms per launch)
+        self.profile_group = 8 if (small and steps >= 16) else 1
+        self.eng.set_profiling(True, group=self.profile_group)
         t0 = time.perf_counter()
         for i in range(steps):
             self.step(warmup + i)
@@ -260,6 +266,7 @@ class Workload:
         E, N, H = self.E, self.N, self.H
         return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
                 "kernel_ms": k_ms, "kernel_ms_min": float(np.min(rollout_ms)), "finalize_kernel_ms": float(np.mean(finalize_ms)),
+                "kernel_launches_timed": int(len(rollout_ms)) * self.profile_group, "kernel_event_group": self.profile_group,
                 "valu_tflops": algorithmic_flops_per_rollout(H) * E * N / (k_ms * 1e-3) / 1e12,
                 "alg_gbs": algorithmic_bytes_per_rollout(N, H) * E * N / (k_ms * 1e-3) / 1e9}
 
@@ -364,7 +371,8 @@ def main():
             w.close()
             obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}",
                    "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
-                   "kernel_ms": rr["kernel_ms"], "kernel_ms_min": rr["kernel_ms_min"]}
+                   "kernel_ms": rr["kernel_ms"], "kernel_ms_min": rr["kernel_ms_min"],
+                   "kernel_launches_timed": rr["kernel_launches_timed"], "kernel_event_group": rr["kernel_event_group"]}
             if pred == "ode":
                 obj["roofline_valu"] = roofline_valu(rr, e_, n_, h_)
             else:
@@ -395,7 +403,8 @@ def main():
             roof = {"bound": "mfma", "kernel": "gru_rollout_cost_kernel", "achieved": gru_flops / (k_ms * 1e-3) / 1e12,
                     "peak": peak, "unit": "TFLOP/s", "frac": gru_flops / (k_ms * 1e-3) / 1e12 / peak, "traffic": traffic,
                     "issued_mfma_tflops": issued / (k_ms * 1e-3) / 1e12,
-                    "kernel_ms": k_ms, "finalize_kernel_ms": r["finalize_kernel_ms"], "note": note}
+                    "kernel_ms": k_ms, "finalize_kernel_ms": r["finalize_kernel_ms"],
+                    "kernel_launches_timed": r["kernel_launches_timed"], "note": note}
         out = {
             "metric": f"MPPI rollouts/sec ({N} samples x {H}-step horizon)", "value": r["value"], "unit": "rollouts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
@@ -414,6 +423,7 @@ def main():
                                                                         + (f" ({traffic_date})" if traffic_date else ""))
                                  if traffic_src else None,
                                  "kernel_ms": k_ms, "finalize_kernel_ms": r["finalize_kernel_ms"],
+                                 "kernel_launches_timed": r["kernel_launches_timed"],
                                  "algorithmic_bytes_per_rollout": algorithmic_bytes_per_rollout(N, H),
                                  "note": "achieved = ALGORITHMIC bytes (SURVEY.md 8d) / kernel time, as the contract defines it; the "
                                          "path is fp32-VALU bound, not HBM bound (SURVEY.md F8: ~100 flop/B vs a machine balance of "
@@ -440,14 +450,14 @@ def main():
                 w1.step(100 + i)
             torch.cuda.synchronize()
             dt1 = (time.perf_counter() - t1) / reps
-            e1.set_profiling(True)
+            e1.set_profiling(True, group=10)             # (an event pair per launch would add ~10 us to each 60 us step)
             for i in range(50):
                 w1.step(400 + i)
             r1, f1 = e1.get_profile()
             k1 = float(np.median(r1))
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": k1 * 1e3, "finalize_kernel_us": float(np.median(f1)) * 1e3,
-                                 "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time from HIP events"}
+                                 "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time = HIP events around groups of 10 launches / 10"}
             if args.predictor == "ode":
                 out["single_env"]["roofline_valu"] = {
                     "bound": "fp32-valu", "achieved": algorithmic_flops_per_rollout(H) * N / (k1 * 1e-3) / 1e12,

@@ -768,8 +768,11 @@ struct cpmppi_handle {
   size_t grad_ckpt_floats = 0;
   GruNorm gru_norm;
   bool fuse_finalize = true;           // ODE path: the env's last block finalizes in-kernel (CPMPPI_FUSE_FINALIZE=0 disables)
-  bool profiling = false;
-  std::vector<hipEvent_t> ev;          // triples per step: before rollout, between, after finalize
+  uint32_t profile_every = 0;          // 0 = off, 1 = every rollout kernel bracketed, n > 1 = one bracket around n steps
+  uint32_t profile_count = 0;
+  bool group_open = false;             // n > 1: the current group's closing event is still to come
+  std::vector<hipEvent_t> ev;          // triples per sampled step: before rollout, after it, after the trailing kernels
+  std::vector<uint8_t> ev_tail;        // per triple: was the third event recorded (a separate finalize / counter kernel ran)
   size_t ev_used = 0;
 };
 
@@ -1124,7 +1127,9 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   p.S_out = a->S_out; p.partial = h->workspace;
   p.counter = nullptr; p.u_nom_out = a->u_nom; p.Q_out = a->Q_out;
   hipEvent_t* ev = nullptr;
-  if (h->profiling) {
+  const uint32_t group_pos = h->profile_every ? h->profile_count++ % h->profile_every : 0;
+  const bool grouped = h->profile_every > 1;
+  if (h->profile_every && group_pos == 0) {
     if (h->ev_used + 3 > h->ev.size()) {
       for (int i = 0; i < 3; ++i) {
         hipEvent_t e;
@@ -1133,9 +1138,12 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
       }
     }
     ev = &h->ev[h->ev_used];
+    if (h->ev_tail.size() < h->ev.size() / 3) h->ev_tail.resize(h->ev.size() / 3, 0);
     h->ev_used += 3;
+    h->group_open = grouped;
     CPMPPI_HIP(h, hipEventRecord(ev[0], s));
   }
+  if (grouped) ev = nullptr;                       // (no events inside a group)
   if (a->predictor == CPMPPI_PREDICTOR_GRU) {
     if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: predictor GRU requested but no model set (cpmppi_set_gru)");
     if (h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT)
@@ -1189,31 +1197,48 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)a->offset_dev);
     CPMPPI_HIP(h, hipGetLastError());
   }
-  if (ev) CPMPPI_HIP(h, hipEventRecord(ev[2], s));
+  if (ev) {
+    // an event costs ~5 us on the stream: the third one only if something ran after the rollout kernel
+    const bool tail = separate_finalize || p.offset_dev;
+    h->ev_tail[(size_t)(ev - h->ev.data()) / 3] = tail ? 1 : 0;
+    if (tail) CPMPPI_HIP(h, hipEventRecord(ev[2], s));
+  }
+  if (grouped && h->group_open && group_pos == h->profile_every - 1) {     // the group's last step: close the bracket
+    hipEvent_t* g = &h->ev[h->ev_used - 3];
+    h->ev_tail[(h->ev_used - 3) / 3] = 0;
+    CPMPPI_HIP(h, hipEventRecord(g[1], s));
+    h->group_open = false;
+  }
   return CPMPPI_OK;
 }
 
 int cpmppi_set_profiling(cpmppi_handle* h, int enable) {
-  if (!h) return CPMPPI_ERR_BAD_ARG;
-  h->profiling = enable != 0;
+  if (!h || enable < 0) return CPMPPI_ERR_BAD_ARG;
+  h->profile_every = (uint32_t)enable;
+  h->profile_count = 0;
   h->ev_used = 0;
+  h->group_open = false;
   return CPMPPI_OK;
 }
 
 int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, uint32_t max_steps, uint32_t* n_steps) {
   if (!h || !n_steps) return CPMPPI_ERR_BAD_ARG;
+  if (h->group_open) { h->ev_used -= 3; h->group_open = false; }       // an unfinished group has no closing event
   const uint32_t n = (uint32_t)(h->ev_used / 3);
+  const float per = h->profile_every > 1 ? 1.0f / (float)h->profile_every : 1.0f;
   *n_steps = n;
   for (uint32_t i = 0; i < n && i < max_steps; ++i) {
     hipEvent_t* ev = &h->ev[(size_t)i * 3];
-    CPMPPI_HIP(h, hipEventSynchronize(ev[2]));
+    const bool tail = h->ev_tail[i] != 0;
+    CPMPPI_HIP(h, hipEventSynchronize(ev[tail ? 2 : 1]));
     float a = 0.f, b = 0.f;
     CPMPPI_HIP(h, hipEventElapsedTime(&a, ev[0], ev[1]));
-    CPMPPI_HIP(h, hipEventElapsedTime(&b, ev[1], ev[2]));
-    if (rollout_ms) rollout_ms[i] = a;
+    if (tail) CPMPPI_HIP(h, hipEventElapsedTime(&b, ev[1], ev[2]));
+    if (rollout_ms) rollout_ms[i] = a * per;
     if (finalize_ms) finalize_ms[i] = b;
   }
   h->ev_used = 0;
+  h->profile_count = 0;
   return CPMPPI_OK;
 }
 

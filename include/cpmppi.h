@@ -207,10 +207,15 @@ int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const
 /* Fused hot path: rollout (a3-a11) + cost (a12-a15) + importance-weighted update (a16) + shift/clip (a18). */
 int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* args, void* stream);
 
-/* Per-kernel timing with HIP events recorded on the launch stream (off by default).  While enabled, every
- * cpmppi_step records three events (before the rollout kernel, between the kernels, after the finalize kernel).
- * cpmppi_get_profile synchronises on them, returns the elapsed milliseconds of the steps recorded since the last
- * call (at most max_steps entries are written; *n_steps receives the number recorded) and resets the recorder. */
+/* Kernel timing with HIP events recorded on the launch stream (off by default; enable = 0 switches it off).
+ * enable = 1: every cpmppi_step is bracketed by an event before the rollout kernel, one after it and - only when a
+ *   separate finalize or counter kernel follows - a third after those; rollout_ms / finalize_ms are per step.
+ * enable = n > 1: ONE bracket around every n consecutive steps (an event costs ~5 us on the stream - two per launch
+ *   are 10 % of a 100 us launch and would show in any wall-clock figure taken at the same time); rollout_ms then holds,
+ *   per completed group, the bracket divided by n: the average duration of a step's kernels back to back, inter-launch
+ *   gaps included; finalize_ms is 0.
+ * cpmppi_get_profile synchronises on the events, returns the entries recorded since the last call (at most max_steps
+ * are written; *n_steps receives their number) and resets the recorder. */
 int cpmppi_set_profiling(cpmppi_handle* h, int enable);
 int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, uint32_t max_steps, uint32_t* n_steps);
 
