@@ -8,6 +8,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import oracle_np as O  # noqa: E402
 from oracle import oracle_torch as OT  # noqa: E402
+import parity_util as PU  # noqa: E402
 
 f32 = np.float32
 QBG_W = dict(ccrc_weight_up=3.0, ccrc_weight_down=3.0, dd_linear_weight_up=2.0, dd_linear_weight_down=2.0)
@@ -54,7 +55,7 @@ def test_gradient_vs_autograd(name, cost_id, te, reduce, edge):
     S2 = eng.rollout_cost(s0, Q, tp, np.full(E, te, f32), L=Lv).cpu().numpy() if cost_id != 3 else None
     if S2 is not None:
         np.testing.assert_allclose(S, S2, rtol=2e-4)
-    bounced = 0
+    bounced, n_flagged, n_flagged_off = 0, 0, 0
     for e in range(E):
         J, g = OT.cost_and_grad(cost_id, s0[e], Q[e], tp[e], te, L=Lv[e], horizon_reduce=reduce, previous_input=prev[e],
                                 qbg_weights=QBG_W)
@@ -62,13 +63,19 @@ def test_gradient_vs_autograd(name, cost_id, te, reduce, edge):
         bounced += int((np.abs(traj[:, :, O.POSITION_IDX]).max(axis=1) >= 0.197).sum())
         np.testing.assert_allclose(S[e], J, rtol=5e-4)
         assert np.all(G[e][np.abs(Q[e]) > 1.0] == 0.0) and np.all(g[np.abs(Q[e]) > 1.0] == 0.0)
-        # float32 adjoint through 350 substeps vs float64 autograd: relative to each rollout's gradient scale;
-        # rollouts within float32 reach of a branch boundary (bounce / indicator) may legitimately differ
+        # float32 adjoint through 350 substeps vs float64 autograd, relative to each rollout's gradient scale.  Buckets as
+        # in parity_util, from the ORACLE's trajectory: a rollout that comes within float32 reach of a branch
+        # (edge bounce, +-pi wrap, a cost indicator threshold, the control limit) may legitimately take the other branch
+        # in one of the two evaluations - those are flagged and capped; every other rollout must be inside the bound.
         scale = np.abs(g).max(axis=1, keepdims=True) + 1e-6
-        err = np.abs(G[e] - g) / scale
-        ok = err.max(axis=1) < 2e-3
-        assert ok.mean() >= (0.85 if edge else 0.97), f"env {e}: {ok.mean():.3f} rollouts within 2e-3, worst {err.max():.2e}"
+        err = (np.abs(G[e] - g) / scale).max(axis=1)
+        flagged = PU.flag_discontinuities(traj) | PU.flag_indicators(traj, {O.COST_QBGM: "qbgm", O.COST_DEFAULT: "default"}.get(cost_id, "qbg"), tp[e])
+        flagged |= (np.abs(np.abs(Q[e]) - 1.0) < 1e-3).any(axis=1)
+        clear_off = int(((err >= 2e-3) & ~flagged).sum())
+        assert clear_off == 0, f"env {e}: {clear_off} of {int((~flagged).sum())} rollouts clear of every branch differ by more than 2e-3 (worst {err[~flagged].max():.2e})"
         assert np.median(err) < 1e-4
+        n_flagged += int(flagged.sum()); n_flagged_off += int(((err >= 2e-3) & flagged).sum())
+    assert n_flagged_off <= int(np.ceil(0.05 * n_flagged)), f"{n_flagged_off} of {n_flagged} flagged rollouts outside 2e-3"
     if edge:
         assert bounced > 0                                       # the bounce branch of the adjoint was exercised
 
