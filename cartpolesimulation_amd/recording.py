@@ -85,26 +85,38 @@ def second_derivatives(states, Q, L, phys):
     return aDD, xDD, torch.as_tensor(u)
 
 
-def experiment_columns(result, env, dt_control, target_position, target_equilibrium, L, phys):
-    """One env of a harness.BatchedCartPoleExperiment.run(record=True) result -> the reference's column dict."""
+def _host_block(result, L, phys):
+    """The whole recording on the host in ONE pass: derived columns for all envs on the device, one copy each."""
     import torch
-    states = result["states"][:-1, env]                     # state at the time each control was computed
-    Q = result["Q"][:, env]
-    T = states.shape[0]
-    Lt = torch.full((T,), float(L), device=states.device)
+    states = result["states"][:-1]                          # [T,E,6]: the state at the time each control was computed
+    Q = result["Q"]                                         # [T,E]
+    Lt = torch.as_tensor(np.asarray(L, dtype=np.float32), device=states.device).reshape(1, -1).expand(Q.shape)
     aDD, xDD, u = second_derivatives(states, Q, Lt, phys)
-    c = lambda t: t.detach().cpu().numpy()
+    c = lambda t: t.detach().cpu().numpy()                  # noqa: E731
+    return dict(s=c(states), Q=c(Q), aDD=c(aDD), xDD=c(xDD), u=c(u))
+
+
+def _columns_of(block, env, dt_control, target_position, target_equilibrium, L, phys):
+    s, Q = block["s"][:, env], block["Q"][:, env]
+    T = s.shape[0]
     zeros, ones = np.zeros(T), np.ones(T)
-    s = c(states)
-    cols = {"time": np.arange(T) * dt_control, "angle": s[:, 0], "angleD": s[:, 1], "angleDD": c(aDD), "angle_cos": s[:, 2],
-            "angle_sin": s[:, 3], "position": s[:, 4], "positionD": s[:, 5], "positionDD": c(xDD), "Q_calculated": c(Q),
-            "Q_applied": c(Q), "Q_ccrc": np.concatenate([[0.0], c(Q)[:-1]]), "u": c(u),
+    cols = {"time": np.arange(T) * dt_control, "angle": s[:, 0], "angleD": s[:, 1], "angleDD": block["aDD"][:, env],
+            "angle_cos": s[:, 2], "angle_sin": s[:, 3], "position": s[:, 4], "positionD": s[:, 5],
+            "positionDD": block["xDD"][:, env], "Q_calculated": Q, "Q_applied": Q, "Q_ccrc": np.concatenate([[0.0], Q[:-1]]),
+            "u": block["u"][:, env],
             "target_position": ones * float(target_position), "target_equilibrium": ones * float(target_equilibrium),
             "L": ones * float(L), "L_for_controller": ones * float(L), "m_pole": ones * phys.m_pole,
             "m_pole_for_controller": ones * phys.m_pole, "vertical_angle_offset": zeros,
             "vertical_angle_offset_cos": ones, "vertical_angle_offset_sin": zeros, "Q_update_time": zeros}
     assert list(cols) == COLUMNS
     return cols
+
+
+def experiment_columns(result, env, dt_control, target_position, target_equilibrium, L, phys):
+    """One env of a harness.BatchedCartPoleExperiment.run(record=True) result -> the reference's column dict."""
+    E = result["Q"].shape[1]
+    block = _host_block(result, np.full(E, float(L), np.float32), phys)
+    return _columns_of(block, env, dt_control, target_position, target_equilibrium, L, phys)
 
 
 def generate_dataset(engine, num_envs, length_of_experiment, out_dir, seed=0, target_position=None, L=None,
@@ -122,8 +134,9 @@ def generate_dataset(engine, num_envs, length_of_experiment, out_dir, seed=0, ta
     res = exp.run(s0, steps, target_position=tp, target_equilibrium=1.0, L=Lv, record=True)
     header = create_csv_header(length_of_experiment, dt_simulation, dt_control, dt_control, "mpc", "mppi", phys)
     paths = []
+    block = _host_block(res, Lv, phys)                      # (one device pass and one copy for all envs)
     for e in range(num_envs):
-        cols = experiment_columns(res, e, dt_control, tp[e], 1.0, Lv[e], phys)
+        cols = _columns_of(block, e, dt_control, tp[e], 1.0, Lv[e], phys)
         name = create_csv_file_name("mpc", "mppi", prefix=prefix, with_date=False, title=f"env{e:05d}")
         paths.append(write_recording(_unique_path(out_dir, name), cols, header=header))
     return paths
