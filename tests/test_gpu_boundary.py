@@ -261,3 +261,36 @@ def test_sampling_types_of_the_legacy_sampler(mode):
         s = O.ode_v0_step(s[None], np.array([ref["Q"]], f32))[0]
     with pytest.raises(ValueError):
         optimizer_mppi(num_rollouts=8, mpc_horizon=4, SAMPLING_TYPE="uniform")           # device RNG: interpolated only
+
+
+def test_profiling_brackets_single_launches_or_groups():
+    """cpmppi_set_profiling: 1 = an event pair around every rollout kernel, n > 1 = one pair around every n consecutive
+    steps, reported per completed group as bracket / n (an unfinished group is dropped); get_profile resets."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, N, H = 4, 512, 20
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H))
+    s0 = np.stack([O.create_cartpole_state(0.1 * e, 0.0, 0.0, 0.0) for e in range(E)])
+    un = eng.zeros(E, H)
+    tp, te = np.zeros(E, f32), np.ones(E, f32)
+
+    def run(k):
+        for i in range(k):
+            eng.step(s0, un, tp, te, seed=1, offset=i)
+
+    run(3)
+    eng.set_profiling(True)
+    run(10)
+    single, fin = eng.get_profile()
+    assert len(single) == 10 and all(0.001 < t < 5.0 for t in single) and all(f == 0.0 for f in fin)   # fused finalize: no third event
+    assert len(eng.get_profile()[0]) == 0                     # the recorder was reset
+    eng.set_profiling(True, group=4)
+    run(10)                                                   # two complete groups, two steps of a third
+    grouped, _ = eng.get_profile()
+    assert len(grouped) == 2
+    # a group's per-step average is a launch cadence: positive, and not far from the singly bracketed durations
+    assert all(0.2 * min(single) < g < 3.0 * max(single) for g in grouped)
+    eng.set_profiling(False)
+    run(2)
+    assert len(eng.get_profile()[0]) == 0
+    eng.close()
