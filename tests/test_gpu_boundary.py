@@ -294,3 +294,28 @@ def test_profiling_brackets_single_launches_or_groups():
     run(2)
     assert len(eng.get_profile()[0]) == 0
     eng.close()
+
+
+@pytest.mark.parametrize("math_mode", ["fast", "precise"])
+def test_predict_large_launch_equals_small_launches(math_mode):
+    """cpmppi_predict stages its stores through LDS above 65536 rollouts (whole 192-byte row segments per store): the
+    trajectories are, bit for bit, what the direct-store kernel of smaller launches writes — ragged B (not a multiple of
+    the block), H not a multiple of the 8-step staging chunk, per-rollout pole lengths."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    B, H = 65536 + 4391, 13
+    eng = MPPIEngine(1, MPPIConfig(num_rollouts=64, mpc_horizon=H, math_mode=math_mode))
+    rng = Generator(SFC64(31))
+    ang = rng.uniform(-np.pi, np.pi, B)
+    s = np.zeros((B, 6), f32)
+    s[:, 0], s[:, 1], s[:, 2], s[:, 3] = ang, rng.uniform(-8, 8, B), np.cos(ang), np.sin(ang)
+    s[:, 4], s[:, 5] = rng.uniform(-0.19, 0.19, B), rng.uniform(-0.6, 0.6, B)
+    Q = rng.uniform(-1, 1, (B, H)).astype(f32)
+    Lv = rng.uniform(0.25, 0.45, B).astype(f32)
+    big = eng.predict(s, Q, L=Lv).cpu().numpy()
+    half = B // 2
+    small = np.concatenate([eng.predict(s[:half], Q[:half], L=Lv[:half]).cpu().numpy(),
+                            eng.predict(s[half:], Q[half:], L=Lv[half:]).cpu().numpy()])
+    assert big.shape == (B, H + 1, 6) and np.array_equal(big, small)
+    assert np.array_equal(big[:, 0], s)
+    eng.close()
