@@ -28,14 +28,16 @@ def timeit(fn, reps=30):
 
 
 for B, H in ((1024, 50), (262144, 50)):
-    eng = MPPIEngine(1, MPPIConfig(num_rollouts=B, mpc_horizon=H))
+    # the reward-weighted average is per env (one block each): the large case is 256 envs x 1024 rollouts, not one env
+    E_rwa, N_rwa = (1, B) if B <= 4096 else (B // 1024, 1024)
+    eng = MPPIEngine(E_rwa, MPPIConfig(num_rollouts=N_rwa, mpc_horizon=H))
     rng = np.random.Generator(np.random.SFC64(1))
     s0 = eng.tensor(np.tile(np.array([0.1, 0.0, np.cos(0.1), np.sin(0.1), 0.0, 0.0], np.float32), (B, 1)))
     Q = eng.tensor((0.3 * rng.standard_normal((B, H))).astype(np.float32))
     traj = eng.predict(s0, Q)
-    S = eng.tensor(rng.uniform(10, 1000, (1, B)).astype(np.float32))
-    du = Q.reshape(1, B, H)
-    rec = {"B": B, "H": H}
+    S = eng.tensor(rng.uniform(10, 1000, (E_rwa, N_rwa)).astype(np.float32))
+    du = Q.reshape(E_rwa, N_rwa, H)
+    rec = {"B": B, "H": H, "rwa_shape": [E_rwa, N_rwa]}
     t = timeit(lambda: eng.predict(s0, Q))
     rec["predict_us"] = t * 1e6
     rec["predict_GBs"] = (B * (H + 1) * 24 + B * H * 4 + B * 24) / t / 1e9
