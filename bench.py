@@ -425,6 +425,7 @@ def main():
                                  "kernel_ms": k_ms, "finalize_kernel_ms": r["finalize_kernel_ms"],
                                  "kernel_launches_timed": r["kernel_launches_timed"],
                                  "algorithmic_bytes_per_rollout": algorithmic_bytes_per_rollout(N, H),
+                                 "binding_roof": "roofline_valu",
                                  "note": "achieved = ALGORITHMIC bytes (SURVEY.md 8d) / kernel time, as the contract defines it; the "
                                          "path is fp32-VALU bound, not HBM bound (SURVEY.md F8: ~100 flop/B vs a machine balance of "
                                          "~20), so the binding roof is `roofline_valu`"
