@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Timing of one controller step per optimizer section of config_optimizers.yml at its shipped hyper-parameters, through
+the controller seam (controller_mpc.configure(name) / .step), for E problem instances at once (GPU box).
+
+  python tools/optim_bench.py [--envs 64] [--steps 30]
+Prints one JSON object per optimizer: ms per controller step (all envs), candidate plans evaluated per second.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cartpolesimulation_amd.controller_mpc import controller_mpc  # noqa: E402
+from oracle import oracle_np as O  # noqa: E402  (initial states only)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=64)
+ap.add_argument("--steps", type=int, default=30)
+args = ap.parse_args()
+E = args.envs
+rng = np.random.Generator(np.random.SFC64(3))
+s_host = np.stack([O.create_cartpole_state(rng.uniform(-0.3, 0.3), rng.uniform(-0.5, 0.5), rng.uniform(-0.05, 0.05), 0.0)
+                   for _ in range(E)])
+for name in ("mppi", "cem-tf", "cem-gmm-tf", "cem-naive-grad-tf", "cem-grad-bharadhwaj-tf", "gradient-tf", "rpgd", "random-action-tf"):
+    ctrl = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
+                          control_limits=([-1.0], [1.0]), num_envs=E, config=dict(seed=1))
+    ctrl.configure(name)
+    opt = ctrl.optimizer
+    s = opt.engine.tensor(s_host)
+    for _ in range(3):
+        ctrl.step(s, 0.0, {})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctrl.step(s, 0.0, {})
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    rec = {"optimizer": name, "envs": E, "num_rollouts": int(getattr(opt, "num_rollouts", 0)), "mpc_horizon": int(getattr(opt, "mpc_horizon", 0)),
+           "ms_per_controller_step": round(dt * 1e3, 3)}
+    for k in ("outer_its", "cem_outer_it", "gradient_steps", "opt_iters", "num_iterations"):
+        if hasattr(opt, k):
+            rec[k] = getattr(opt, k)
+    print(json.dumps(rec), flush=True)
