@@ -66,12 +66,18 @@ def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0):
     _check(off, flagged, what)
 
 
-def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4):
-    """Per-rollout costs: |S - S_a| <= rtol |S_a| + |S_a - S_b| for every unflagged rollout."""
+def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False):
+    """Per-rollout costs: |S - S_a| <= rtol |S_a| + |S_a - S_b| for every unflagged rollout.  flag_sensitive: a rollout on
+    which the reference's OWN two arithmetic modes disagree by more than the band (|S_a - S_b| > rtol |S_a|: a chaotic
+    trajectory that amplifies 1e-7 roundings beyond the tolerance) joins the flagged bucket - no evaluation in float32,
+    the reference's included, pins it to the band."""
     S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
     gap = np.abs(S_a - np.asarray(S_b, np.float64)) if S_b is not None else 0.0
     off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap
-    _check(off, np.zeros(S.shape, bool) if flagged is None else flagged, what)
+    flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
+    if flag_sensitive and S_b is not None:
+        flagged = flagged | (gap > rtol * np.abs(S_a))
+    _check(off, flagged, what)
 
 
 def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None):
@@ -118,20 +124,34 @@ def oracle_step_both_modes(s0, u_nom, du, target_position, target_equilibrium, c
     return a, b
 
 
-def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None):
+def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None, cost=None):
     """The plain-C oracle's MPPI step for E envs in BOTH reference arithmetic modes, plus the H2 flags of every rollout
-    from the oracle's own trajectories (default glue: shift repeat-last, clip).  -> dict(S_a, S_b, u_a, u_b, Q_a, flags)."""
+    from the oracle's own trajectories (default glue: shift repeat-last, clip); with ``cost`` ("default" / "legacy") also
+    the rollouts within reach of that plugin's indicator thresholds.  -> dict(S_a, S_b, u_a, u_b, Q_a, flags)."""
     from oracle import oracle_c as OC
     E, N, H = du.shape
     ca, cb = OC.make_config(ocfg, params), OC.make_config(ocfg, params, mode="f64sub")
     u_a, Q_a, S_a = OC.step(ca, s0, u0, du, tp, te, L=L)
     u_b, _, S_b = OC.step(cb, s0, u0, du, tp, te, L=L)
-    u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1) if ocfg.shift_mode == "repeat_last" else u0
-    u_run = np.clip(u_shift[:, None, :] + du, -1, 1).astype(f32).reshape(E * N, H)
+    if ocfg.shift_mode == "repeat_last":
+        u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1)
+    elif ocfg.shift_mode == "append_zero":
+        u_shift = np.concatenate([u0[:, 1:], np.zeros_like(u0[:, :1])], axis=1)
+    else:
+        u_shift = u0
+    u_run = u_shift[:, None, :] + du
+    if ocfg.control_mode == "clip":
+        u_run = np.clip(u_run, -1, 1)
+    u_run = u_run.astype(f32).reshape(E * N, H)
     Lr = None if L is None else np.repeat(np.asarray(L, f32), N)
     traj = OC.predict(ca, np.repeat(np.asarray(s0, f32), N, axis=0), u_run, L=Lr)
     thl = float((params or O.DEFAULT_PARAMS).TrackHalfLength)
     x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
     step = float(ocfg.dt if dt is None else dt)
     flags = ((np.abs(x) + np.abs(v) * step > thl - 2e-3).any(axis=1) | (np.abs(np.abs(th) - np.pi) < 2e-3).any(axis=1))
-    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags.reshape(E, N))
+    flags = flags.reshape(E, N)
+    if cost in ("default", "legacy"):
+        tr = traj.reshape(E, N, H + 1, 6)
+        for e in range(E):
+            flags[e] |= flag_indicators(tr[e], cost, float(np.asarray(tp).reshape(-1)[e]))
+    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags)
