@@ -134,3 +134,19 @@ def test_other_physical_parameters(rpl):
         PU.assert_costs(S.cpu().numpy()[e], ref["S_a"][e], ref["S_b"][e], ref["flags"][e], f"env {e} costs")
         PU.assert_controls(un.cpu().numpy()[e], ref["u_a"][e], ref["u_b"][e], f"env {e} u_nom",
                            allowance=PU.softmin_allowance(ref["S_a"][e], ref["S_b"][e], duh[e]))
+
+
+def test_random_configurations_regression():
+    """A fixed cut of tools/dev/shape_fuzz.py (60 random shape / substep / period / cost / glue / noise-source / lane-
+    mapping / math-mode configurations, seed 33) must stay inside the parity rules: ragged rollout counts around wave and
+    block sizes, horizons that are not multiples of the knot period or of the tile quads, every glue flag."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "shape_fuzz.py"), "--n", "60", "--seed", "33"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    summary = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert summary == {"configurations": 60, "passed": 60, "failed": 0, "seed": 33}, r.stdout[-3000:]
