@@ -80,6 +80,16 @@ for it in range(args.n):
             PU.assert_costs(Sh[e], ref["S_a"][e], ref["S_b"][e], ref["flags"][e], f"env {e} costs", flag_sensitive=True)
             PU.assert_controls(uh[e], ref["u_a"][e], ref["u_b"][e], f"env {e} u_nom",
                                allowance=PU.softmin_allowance(ref["S_a"][e], ref["S_b"][e], duh[e], LBD=cfg.LBD))
+            # and the update GIVEN the kernel's own costs (float64 soft-min of S_gpu over the same perturbations): exact to
+            # float32 rounding whatever the conditioning
+            Sg = Sh[e].astype(np.float64)
+            w = np.exp(-(Sg - Sg.min()) / cfg.LBD)
+            ush = (np.concatenate([u0[e, 1:], u0[e, -1:]]) if glue["shift_mode"] == "repeat_last" else
+                   (np.concatenate([u0[e, 1:], [0.0]]) if glue["shift_mode"] == "append_zero" else u0[e])).astype(np.float64)
+            u_exp = ush + (w @ duh[e].astype(np.float64)) / w.sum()
+            if glue["control_mode"] == "clip":
+                u_exp = np.clip(u_exp, -1.0, 1.0)
+            assert np.abs(uh[e] - u_exp).max() <= 2e-5, f"env {e}: update differs from the soft-min of the kernel's own costs by {np.abs(uh[e] - u_exp).max():.2e}"
         eng.close()
         done += 1
     except AssertionError as ex:
