@@ -46,8 +46,8 @@ def algorithmic_flops_per_rollout(H, S=10):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; --config C3: 100, C4: 200)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; C3: 10, C4: 20)")
     ap.add_argument("--envs", type=int, default=8192, help="independent MPPI problem instances per GPU")
     ap.add_argument("--rollouts", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=50)
@@ -74,6 +74,11 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.config:
         args.envs, args.rollouts, args.horizon = PRESETS[args.config]
+    # the small configurations take ~0.1-0.3 ms per step and start from u_nom = 0 (the first steps meet more rare events
+    # than the settled loop): their default run is as long as the side measurements of the default line
+    d_steps, d_warm = {"C3": (100, 10), "C4": (200, 20)}.get(args.config, (20, 3))
+    args.steps = d_steps if args.steps is None else args.steps
+    args.warmup = d_warm if args.warmup is None else args.warmup
     return args
 
 
