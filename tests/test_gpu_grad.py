@@ -71,8 +71,8 @@ def test_gradient_vs_autograd(name, cost_id, te, reduce, edge):
         err = (np.abs(G[e] - g) / scale).max(axis=1)
         flagged = PU.flag_discontinuities(traj) | PU.flag_indicators(traj, {O.COST_QBGM: "qbgm", O.COST_DEFAULT: "default"}.get(cost_id, "qbg"), tp[e])
         flagged |= (np.abs(np.abs(Q[e]) - 1.0) < 1e-3).any(axis=1)
-        clear_off = int(((err >= 2e-3) & ~flagged).sum())
-        assert clear_off == 0, f"env {e}: {clear_off} of {int((~flagged).sum())} rollouts clear of every branch differ by more than 2e-3 (worst {err[~flagged].max():.2e})"
+        clear_off = int(((err >= 5e-4) & ~flagged).sum())
+        assert clear_off == 0, f"env {e}: {clear_off} of {int((~flagged).sum())} rollouts clear of every branch differ by more than 5e-4 (worst {err[~flagged].max():.2e})"
         assert np.median(err) < 1e-4
         n_flagged += int(flagged.sum()); n_flagged_off += int(((err >= 2e-3) & flagged).sum())
     assert n_flagged_off <= int(np.ceil(0.05 * n_flagged)), f"{n_flagged_off} of {n_flagged} flagged rollouts outside 2e-3"
