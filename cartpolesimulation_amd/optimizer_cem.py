@@ -86,9 +86,10 @@ class optimizer_cem:
         if E != self.num_envs:
             raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
         vp = self.variable_parameters
-        tp = _vec(getattr(vp, "target_position", None), E, 0.0)
-        te = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
-        L = _vec(getattr(vp, "L", None), E, self.phys.L)
+        # (uploaded ONCE per control step: every sampler / cost / gradient launch of the iterations below reuses the tensors)
+        tp = eng.tensor(_vec(getattr(vp, "target_position", None), E, 0.0))
+        te = eng.tensor(_vec(getattr(vp, "target_equilibrium", None), E, 1.0))
+        L = eng.tensor(_vec(getattr(vp, "L", None), E, self.phys.L))
         iters = self.warmup_iterations if (self.warmup and self._first) else self.cem_outer_it
         self._first = False
         for _ in range(iters):
@@ -134,9 +135,10 @@ class optimizer_cem_gmm(optimizer_cem):
         if E != self.num_envs:
             raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
         vp = self.variable_parameters
-        tp = _vec(getattr(vp, "target_position", None), E, 0.0)
-        te = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
-        L = _vec(getattr(vp, "L", None), E, self.phys.L)
+        # (uploaded ONCE per control step: every sampler / cost / gradient launch of the iterations below reuses the tensors)
+        tp = eng.tensor(_vec(getattr(vp, "target_position", None), E, 0.0))
+        te = eng.tensor(_vec(getattr(vp, "target_equilibrium", None), E, 1.0))
+        L = eng.tensor(_vec(getattr(vp, "L", None), E, self.phys.L))
         ar = torch.arange(E, device=self.dist_mue.device)[:, None]
         for _ in range(self.cem_outer_it):
             Q = eng.cem_gmm_sample(self.centres, self.stdev, self.seed, offset=self.step_counter)
@@ -223,9 +225,10 @@ class optimizer_random_action(optimizer_cem):
         if E != self.num_envs:
             raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
         vp = self.variable_parameters
-        tp = _vec(getattr(vp, "target_position", None), E, 0.0)
-        te = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
-        L = _vec(getattr(vp, "L", None), E, self.phys.L)
+        # (uploaded ONCE per control step: every sampler / cost / gradient launch of the iterations below reuses the tensors)
+        tp = eng.tensor(_vec(getattr(vp, "target_position", None), E, 0.0))
+        te = eng.tensor(_vec(getattr(vp, "target_equilibrium", None), E, 1.0))
+        L = eng.tensor(_vec(getattr(vp, "L", None), E, self.phys.L))
         # N(0,1) from the device Philox sampler (clip limits far away), mapped to U(low, high) through the normal CDF
         wide = eng.zeros(E, self.mpc_horizon)
         z = self._normal(wide, self.step_counter)

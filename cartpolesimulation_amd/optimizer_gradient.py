@@ -100,8 +100,9 @@ class _GradientBase:
     # -- one control step ----------------------------------------------------------------------------------------
     def _targets(self, E):
         vp = self.variable_parameters
-        return (_vec(getattr(vp, "target_position", None), E, 0.0), _vec(getattr(vp, "target_equilibrium", None), E, 1.0),
-                _vec(getattr(vp, "L", None), E, self.phys.L))
+        t = self.engine.tensor      # (uploaded once per control step; every gradient / cost launch below reuses the tensors)
+        return (t(_vec(getattr(vp, "target_position", None), E, 0.0)), t(_vec(getattr(vp, "target_equilibrium", None), E, 1.0)),
+                t(_vec(getattr(vp, "L", None), E, self.phys.L)))
 
     def _descend(self, s_t, tp, te, L, iterations):
         eng = self.engine

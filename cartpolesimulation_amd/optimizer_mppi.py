@@ -14,6 +14,7 @@ in ONE launch (``step`` accepts ``s[6]`` or ``s[E,6]``), and perturbations come 
 import time as _time
 
 import numpy as np
+import torch
 
 from .configs import MPPIConfig, PhysicalParameters
 
@@ -84,6 +85,7 @@ class optimizer_mppi:
         self.step_counter = 0
         self.gru_model = gru_model           # dict of GRU-6IN-32H1-32H2-5OUT weights -> neural predictor in the loop
         self.h = None                        # its memory per env [E,2,32] (controller_mppi_cartpole.py:566-567 update)
+        self._hblock = self._hview = self._dblock = self._h2d_done = self._hq = self._q_done = None     # pinned staging of the host seam
 
     # ------------------------------------------------------------------
     def configure(self, dt=None, predictor_specification=None, num_envs=None, **kwargs):
@@ -132,6 +134,25 @@ class optimizer_mppi:
         self._rng = np.random.Generator(np.random.SFC64(self.seed))
 
     # ------------------------------------------------------------------
+    def _upload(self, s_np, E):
+        """[E,6] host state + per-env attributes -> device views of one block uploaded with one asynchronous copy."""
+        if self._hblock is None or self._hblock.numel() != 9 * E:
+            self._hblock = torch.empty(9 * E, dtype=torch.float32).pin_memory()
+            self._hview = self._hblock.numpy()
+            self._dblock = torch.empty(9 * E, dtype=torch.float32, device=self.u_nom.device)
+            self._h2d_done = torch.cuda.Event()
+        else:
+            self._h2d_done.synchronize()                      # (the previous upload has left the pinned block)
+        vp, hv = self.variable_parameters, self._hview
+        hv[:6 * E] = s_np.reshape(-1)
+        hv[6 * E:7 * E] = _vec(getattr(vp, "target_position", None), E, 0.0)
+        hv[7 * E:8 * E] = _vec(getattr(vp, "target_equilibrium", None), E, 1.0)
+        hv[8 * E:9 * E] = _vec(getattr(vp, "L", None), E, self.phys.L)
+        self._dblock.copy_(self._hblock, non_blocking=True)
+        self._h2d_done.record()
+        d = self._dblock
+        return d[:6 * E].view(E, 6), d[6 * E:7 * E], d[7 * E:8 * E], d[8 * E:9 * E]
+
     def _attributes(self, E):
         vp = self.variable_parameters
         tp = _vec(getattr(vp, "target_position", None), E, 0.0)
@@ -144,13 +165,26 @@ class optimizer_mppi:
         if self.engine is None:
             self.configure()
         eng = self.engine
-        s_t = eng.tensor(s)
-        single = s_t.dim() == 1
-        s_t = s_t.reshape(-1, 6)
-        E = s_t.shape[0]
-        if E != self.num_envs:
-            raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
-        tp, te, L = self._attributes(E)
+        host_state = not hasattr(s, "is_cuda")
+        if host_state and self.u_nom.is_cuda:                 # (a CPU test double of the engine takes the plain path below)
+            # the simulator's call (CartPole/__init__.py:509-520): state and attributes live on the host.  They go up as ONE
+            # pinned block in ONE asynchronous copy (state, target_position, target_equilibrium, L: four separate pageable
+            # uploads cost ~50 us per control step, more than the rollout kernel's share for small problems)
+            s_np = np.asarray(s, dtype=np.float32)
+            single = s_np.ndim == 1
+            s_np = s_np.reshape(-1, 6)
+            E = s_np.shape[0]
+            if E != self.num_envs:
+                raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
+            s_t, tp, te, L = self._upload(s_np, E)
+        else:
+            s_t = eng.tensor(s)
+            single = s_t.dim() == 1
+            s_t = s_t.reshape(-1, 6)
+            E = s_t.shape[0]
+            if E != self.num_envs:
+                raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
+            tp, te, L = self._attributes(E)
         kw = {}
         if self.noise == "sfc64" and self.sampling_type != "interpolated":
             from .sampling import sample_delta_u_sfc64
@@ -185,5 +219,15 @@ class optimizer_mppi:
             self.optimal_trajectory = eng.predict(s_t, self.u_nom, L=L).cpu().numpy()
         if as_tensor:
             return self.Q
-        q = self.Q.cpu().numpy()          # the single D2H copy float(controller.step(...)) forces (CartPole/__init__.py:509)
-        return q[:1].copy() if single else q.reshape(E, 1).copy()
+        # the single D2H copy float(controller.step(...)) forces (CartPole/__init__.py:509): into a pinned buffer, then wait
+        if not self.Q.is_cuda:
+            q = self.Q.numpy().copy()
+            return q[:1] if single else q.reshape(E, 1)
+        if self._hq is None or self._hq.numel() != E:
+            self._hq = torch.empty(E, dtype=torch.float32).pin_memory()
+            self._q_done = torch.cuda.Event()
+        self._hq.copy_(self.Q, non_blocking=True)
+        self._q_done.record()
+        self._q_done.synchronize()
+        q = self._hq.numpy().copy()
+        return q[:1] if single else q.reshape(E, 1)
