@@ -69,6 +69,7 @@ class controller_mppi_cartpole(template_controller):
         self.LOGS = {"cost_to_go": [], "states": [], "trajectory": [], "target_trajectory": [], "inputs": [],
                      "nominal_rollouts": []}
         self.engine = None
+        self._staging = {}
 
     # ------------------------------------------------------------------ :345-390
     def configure(self):
@@ -151,14 +152,24 @@ class controller_mppi_cartpole(template_controller):
         target = float(np.asarray(getattr(vp, "target_position", 0.0)).reshape(-1)[0])
         if self.iteration % self.update_every == 0:
             L = getattr(vp, "L", None)
-            kw = dict(L=None if L is None else np.asarray(L, np.float32).reshape(-1)[:1])
+            # host -> device through pinned staging buffers and asynchronous copies (state / target / pole length as one
+            # block, the perturbations as another): pageable uploads cost ~80 us of a 300 us control step
+            small = self._staged("small", (9,))
+            small[0][:6], small[0][6], small[0][7] = self.s, target, 1.0
+            small[0][8] = self.phys.L if L is None else float(np.asarray(L, np.float32).reshape(-1)[0])
+            d = self._upload("small")
+            kw = dict(L=d[8:9])
             if self.config["SAMPLING_TYPE"] == "interpolated":
-                kw["knots"] = self._knots(self.SQRTRHODTINV)                                # interpolated on the device
+                kn = self._staged("knots", (1, self.num_rollouts, self.engine.P))
+                kn[0][0] = self._knots(self.SQRTRHODTINV)[0]                                # interpolated on the device
+                kw["knots"] = self._upload("knots")
                 self.delta_u = None
             else:
                 self.delta_u = self.initialize_perturbations(self.SQRTRHODTINV, self.config["SAMPLING_TYPE"])
-                kw["delta_u"] = self.delta_u[None]
-            self.engine.step(self.s[None], self._u, target, 1.0, u_prev=self._u_prev, S_out=self._S, Q_out=self._Q, **kw)
+                du = self._staged("delta_u", (1, self.num_rollouts, self.mpc_horizon))
+                du[0][0] = self.delta_u
+                kw["delta_u"] = self._upload("delta_u")
+            self.engine.step(d[:6].view(1, 6), self._u, d[6:7], d[7:8], u_prev=self._u_prev, S_out=self._S, Q_out=self._Q, **kw)
             if self.config["controller_logging"]:
                 self.LOGS["cost_to_go"].append(self.S_tilde_k.copy())
                 self.LOGS["inputs"].append(self.u.copy())
@@ -174,6 +185,23 @@ class controller_mppi_cartpole(template_controller):
         self._u[:, :-1] = self._u[:, 1:].clone()                                             # :561-562
         self._u[:, -1] = 0.0
         return Q
+
+    def _staged(self, name, shape):
+        """-> (numpy view of a pinned host buffer, the buffer, its device twin) for `name`, (re)allocated on a shape change."""
+        ent = self._staging.get(name)
+        if ent is None or tuple(ent[1].shape) != tuple(shape):
+            host = torch.empty(*shape, dtype=torch.float32).pin_memory()
+            ent = (host.numpy(), host, torch.empty(*shape, dtype=torch.float32, device=self._u.device), torch.cuda.Event())
+            self._staging[name] = ent
+        else:
+            ent[3].synchronize()                              # the previous upload has left the pinned buffer
+        return ent
+
+    def _upload(self, name):
+        _, host, dev, ev = self._staging[name]
+        dev.copy_(host, non_blocking=True)
+        ev.record()
+        return dev
 
     def update_control_vector(self):
         """:574-583 — the horizon was changed: keep the leading part of the best-guess sequence, zero the rest."""
