@@ -188,8 +188,25 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
 
+  // Latency build: the nominal control (and the legacy cost's previous sequence) of step k + 1 is requested while step k
+  // integrates - a scalar load consumed a few instructions after its issue is ~100 ns of exposed latency per control step
+  // for a wave that has its SIMD to itself (single env 60.5 -> 57.2 us; measured neutral at C4 and 8192 envs, +2 % at C3,
+  // so the packed builds load it where it is used).
+  constexpr bool PREFETCH_NOMINAL = (VARIANT == 0);
+  float uk_next = PREFETCH_NOMINAL ? shifted_nominal(p, un, 0) : 0.0f;
+  float up_next = (PREFETCH_NOMINAL && COST == COST_LEGACY) ? up[0] : 0.0f;
   auto control_step = [&](uint32_t k, F du) __attribute__((always_inline)) {
-    const float uk = shifted_nominal(p, un, k);
+    float uk, upk = 0.0f;
+    if constexpr (PREFETCH_NOMINAL) {
+      uk = uk_next; upk = up_next;
+      if (k + 1 < H) {
+        uk_next = shifted_nominal(p, un, k + 1);
+        if constexpr (COST == COST_LEGACY) up_next = up[k + 1];
+      }
+    } else {
+      uk = shifted_nominal(p, un, k);
+      if constexpr (COST == COST_LEGACY) upk = up[k];
+    }
     F ur = splat<F>(uk) + du;
     if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
     if constexpr (COST == COST_QBGM) {
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
       u_before = ur;
     } else {
-      cost += stage_legacy<F, FAST>(p, st.x, cosang, st.w, st.v, uk, du, up[k], x_t);
+      cost += stage_legacy<F, FAST>(p, st.x, cosang, st.w, st.v, uk, du, upk, x_t);
     }
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
