@@ -331,9 +331,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const float inv_period = 1.0f / (float)p.period;
     float z_lo[R], z_hi[R], slope32[R];
     double slope[R];
+    // knots from memory (the reference's own noise stream): the one after next is requested a whole knot period before it
+    // is needed - a vector load consumed right after its issue is ~1 us of exposed latency per knot for a lone wave
+    constexpr bool KNOT_AHEAD = (NOISE == NOISE_KNOTS);
+    float z_ahead[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       z_lo[i] = knot(i, 0); z_hi[i] = knot(i, 1);
+      z_ahead[i] = (KNOT_AHEAD && 2 < p.P) ? knot(i, 2) : 0.0f;
       if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
       else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
     }
@@ -351,7 +356,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           z_lo[i] = z_hi[i];
-          if (j + 1 < p.P) z_hi[i] = knot(i, j + 1);
+          if constexpr (KNOT_AHEAD) {
+            if (j + 1 < p.P) z_hi[i] = z_ahead[i];
+            if (j + 2 < p.P) z_ahead[i] = knot(i, j + 2);
+          } else {
+            if (j + 1 < p.P) z_hi[i] = knot(i, j + 1);
+          }
           if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
           else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
         }
