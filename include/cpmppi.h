@@ -34,6 +34,7 @@
 #ifndef CPMPPI_H
 #define CPMPPI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -43,6 +43,33 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_lib.cpmppi_config) == 4 * (len(fields) - 1) + 96
 
 
+def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
+    """include/cpmppi.h compiles on its own as C99 and as C++ (what a cgo / ctypes / JNI binding generator would feed it to),
+    and sizeof / offsetof of the argument structs as a C compiler lays them out equal the ctypes mirrors'."""
+    import shutil
+    import subprocess
+    from cartpolesimulation_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    hdr = os.path.join(ROOT, "include", "cpmppi.h")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    gxx = shutil.which("g++")
+    if gxx:
+        subprocess.run([gxx, "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cpmppi.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(cpmppi_config), sizeof(cpmppi_step_args), '
+                   'sizeof(cpmppi_gru_model), offsetof(cpmppi_step_args, noise), offsetof(cpmppi_step_args, Q_out), '
+                   'offsetof(cpmppi_step_args, offset_dev)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    A = _lib.cpmppi_step_args
+    assert got == [C.sizeof(_lib.cpmppi_config), C.sizeof(A), C.sizeof(_lib.cpmppi_gru_model), A.noise.offset, A.Q_out.offset,
+                   A.offset_dev.offset]
+
+
 def test_no_cpu_fallback():
     """Without a GPU the library refuses to create a handle and the engine refuses to construct."""
     import torch
