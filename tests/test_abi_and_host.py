@@ -70,6 +70,26 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
                    A.offset_dev.offset]
 
 
+def test_integration_doc_binding_matches_the_library():
+    """The ctypes stub INTEGRATION.md shows a maintainer (section 2) lists the same fields, in the same order and with the
+    same ctypes types, as the package's own binding."""
+    from cartpolesimulation_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cls in (_lib.cpmppi_config, _lib.cpmppi_step_args):
+        block = text[text.index(f"class {cls.__name__}(C.Structure):"):]
+        block = block[block.index("_fields_ = ["):]
+        block = block[:block.index("]\n")]                      # (no field spec ends a line with ']': arrays are C.c_float * 24)
+        doc = re.findall(r'\("(\w+)",\s*C\.(\w+)(?:\s*\*\s*(\d+))?\)', block)
+        doc = [(n, getattr(C, t), k) for n, t, k in doc]         # (C.c_uint32 is an alias of c_uint: compare the types)
+        own = []
+        for name, typ in cls._fields_:
+            if hasattr(typ, "_length_"):
+                own.append((name, typ._type_, str(typ._length_)))
+            else:
+                own.append((name, typ, ""))
+        assert doc == own, cls.__name__
+
+
 def test_no_cpu_fallback():
     """Without a GPU the library refuses to create a handle and the engine refuses to construct."""
     import torch
