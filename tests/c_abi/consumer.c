@@ -1,0 +1,66 @@
+/* A C consumer of libcpmppi.so: no torch, no C++ - the HIP runtime's C API for the device buffers and include/cpmppi.h.
+ * tests/test_gpu_c_consumer.py builds it with gcc, runs it and compares its output with the Python binding's.
+ *   consumer <config.bin> <E> <seed> <steps>
+ * Reads a cpmppi_config blob (written by the test from the ctypes mirror), runs `steps` fused MPPI steps for E envs
+ * from fixed states with in-kernel Philox noise, prints Q of every env per step and the final nominal sequence of env 0. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include "cpmppi.h"
+
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: consumer config.bin E seed steps\n"); return 1; }
+  cpmppi_config cfg;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f || fread(&cfg, sizeof cfg, 1, f) != 1) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+  fclose(f);
+  const uint32_t E = (uint32_t)atoi(argv[2]);
+  const uint64_t seed = (uint64_t)atoll(argv[3]);
+  const int steps = atoi(argv[4]);
+  const uint32_t H = cfg.H;
+  cpmppi_handle* h = NULL;
+  if (cpmppi_create(&cfg, 0, &h) != CPMPPI_OK) { fprintf(stderr, "create: %s\n", cpmppi_last_error(NULL)); return 3; }
+  printf("%s\n", cpmppi_version());
+
+  float* hs = (float*)calloc((size_t)E * 6, sizeof(float));
+  float* ht = (float*)calloc((size_t)E * 3, sizeof(float));
+  for (uint32_t e = 0; e < E; ++e) {              /* angle, angleD, cos, sin, position, positionD */
+    const float th = 0.05f + 0.1f * (float)e;
+    hs[6 * e + 0] = th; hs[6 * e + 1] = -0.2f * (float)e; hs[6 * e + 2] = 1.0f - 0.5f * th * th; hs[6 * e + 3] = th - th * th * th / 6.0f;
+    hs[6 * e + 4] = 0.01f * (float)e; hs[6 * e + 5] = 0.0f;
+    ht[e] = 0.02f; ht[E + e] = 1.0f; ht[2 * E + e] = 0.395f;        /* target_position, target_equilibrium, L */
+  }
+  float *s0, *tgt, *u_nom, *Q;
+  HIPCHECK(hipMalloc((void**)&s0, (size_t)E * 6 * sizeof(float)));
+  HIPCHECK(hipMalloc((void**)&tgt, (size_t)E * 3 * sizeof(float)));
+  HIPCHECK(hipMalloc((void**)&u_nom, (size_t)E * H * sizeof(float)));
+  HIPCHECK(hipMalloc((void**)&Q, (size_t)E * sizeof(float)));
+  HIPCHECK(hipMemcpy(s0, hs, (size_t)E * 6 * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(tgt, ht, (size_t)E * 3 * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemset(u_nom, 0, (size_t)E * H * sizeof(float)));
+
+  float* hq = (float*)malloc((size_t)E * sizeof(float));
+  for (int it = 0; it < steps; ++it) {
+    cpmppi_step_args a;
+    memset(&a, 0, sizeof a);
+    a.E = E; a.s0 = s0; a.u_nom = u_nom; a.target_position = tgt; a.target_equilibrium = tgt + E; a.L = tgt + 2 * E;
+    a.noise_kind = CPMPPI_NOISE_PHILOX; a.seed = seed; a.offset = (uint64_t)it; a.Q_out = Q;
+    if (cpmppi_step(h, &a, NULL) != CPMPPI_OK) { fprintf(stderr, "step: %s\n", cpmppi_last_error(h)); return 4; }
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(hq, Q, (size_t)E * sizeof(float), hipMemcpyDeviceToHost));
+    printf("Q");
+    for (uint32_t e = 0; e < E; ++e) printf(" %.9g", hq[e]);
+    printf("\n");
+  }
+  float* hu = (float*)malloc((size_t)H * sizeof(float));
+  HIPCHECK(hipMemcpy(hu, u_nom, (size_t)H * sizeof(float), hipMemcpyDeviceToHost));
+  printf("u");
+  for (uint32_t k = 0; k < H; ++k) printf(" %.9g", hu[k]);
+  printf("\n");
+  cpmppi_destroy(h);
+  return 0;
+}
