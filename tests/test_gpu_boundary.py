@@ -347,3 +347,29 @@ def test_builds_of_the_kernel_agree_bit_for_bit(rpl, small_E, big_E):
         eng.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_host_seam_staging_equals_device_inputs():
+    """optimizer_mppi.step with the state and attributes on the HOST (one pinned block, one asynchronous copy, Q back
+    through a pinned buffer) gives exactly what the same call with a device-resident state gives, for one env (the
+    simulator's call) and for several, over consecutive steps with changing attributes."""
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    for E in (1, 5):
+        rng = Generator(SFC64(3 + E))
+        ctrls = []
+        for _ in range(2):
+            c = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
+                               control_limits=([-1.0], [1.0]), num_envs=E, config=dict(seed=11, num_rollouts=256, mpc_horizon=15))
+            c.configure("mppi")
+            ctrls.append(c)
+        for it in range(4):
+            s = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2))
+                          for _ in range(E)])
+            attrs = {"target_position": (0.02 * (it + 1) * np.ones(E)).astype(f32), "L": rng.uniform(0.3, 0.45, E).astype(f32)}
+            s_in = s[0] if E == 1 else s
+            q_host = ctrls[0].step(s_in, 0.02 * it, dict(attrs))
+            s_dev = ctrls[1].optimizer.engine.tensor(s_in)
+            q_dev = ctrls[1].step(s_dev, 0.02 * it, dict(attrs))
+            assert np.array_equal(np.asarray(q_host), np.asarray(q_dev))
+            assert q_host.shape == ((1,) if E == 1 else (E, 1))
+        assert torch.equal(ctrls[0].optimizer.u_nom, ctrls[1].optimizer.u_nom)
