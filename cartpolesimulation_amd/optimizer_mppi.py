@@ -85,7 +85,8 @@ class optimizer_mppi:
         self.step_counter = 0
         self.gru_model = gru_model           # dict of GRU-6IN-32H1-32H2-5OUT weights -> neural predictor in the loop
         self.h = None                        # its memory per env [E,2,32] (controller_mppi_cartpole.py:566-567 update)
-        self._hblock = self._hview = self._dblock = self._h2d_done = self._hq = self._q_done = None     # pinned staging of the host seam
+        self._hblock = self._hview = self._dblock = self._h2d_done = self._hq = self._q_done = None
+        self._prepared = self._prepared_key = None     # pinned staging of the host seam
 
     # ------------------------------------------------------------------
     def configure(self, dt=None, predictor_specification=None, num_envs=None, **kwargs):
@@ -205,7 +206,17 @@ class optimizer_mppi:
             prev = getattr(vp, "Q_ccrc", None)
         if prev is not None and self.cfg.cost_function_specification == "quadratic_boundary_grad":
             kw["previous_input"] = _vec(prev, E, 0.0)
-        eng.step(s_t, self.u_nom, tp, te, L=L, Q_out=self.Q, S_out=self.S, **kw)
+        if host_state and self.u_nom.is_cuda and set(kw) == {"seed", "offset"}:
+            # the simulator's call with in-kernel noise: every pointer is the same from call to call (staging block, u_nom,
+            # Q), so the argument block is built once and only the Philox step counter changes
+            key = (id(eng), s_t.data_ptr(), self.u_nom.data_ptr(), self.Q.data_ptr(), None if self.S is None else self.S.data_ptr(),
+                   E, self.seed)
+            if self._prepared is None or self._prepared_key != key:
+                self._prepared = eng.prepare_step(s_t, self.u_nom, tp, te, L=L, Q_out=self.Q, S_out=self.S, **kw)
+                self._prepared_key = key
+            self._prepared.run(offset=self.step_counter)
+        else:
+            eng.step(s_t, self.u_nom, tp, te, L=L, Q_out=self.Q, S_out=self.S, **kw)
         self.step_counter += 1
         if self.h is not None:
             # advance the network's memory with the state just seen and the control just chosen (update_internal_state)
