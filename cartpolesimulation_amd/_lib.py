@@ -16,7 +16,7 @@ NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX, NOISE_DELTA_U_TILED = 0, 1, 2, 3
 
 EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
            "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
-           "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_plant_advance_record", "cpmppi_set_profiling", "cpmppi_get_profile",
+           "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_plant_advance_record", "cpmppi_step_host", "cpmppi_set_profiling", "cpmppi_get_profile",
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample")
@@ -92,6 +92,7 @@ def load():
     lib.cpmppi_reward_weighted_average.argtypes = [vp, u32, vp, vp, vp, vp]
     lib.cpmppi_plant_advance.argtypes = [vp, u32, vp, vp, vp, u32, f, vp]
     lib.cpmppi_plant_advance_record.argtypes = [vp, u32, vp, vp, vp, u32, f, vp, vp, u64, vp, vp]
+    lib.cpmppi_step_host.argtypes = [vp, u32, vp, vp, vp, vp, vp, u64, u64, u32, vp, vp]
     lib.cpmppi_set_profiling.argtypes = [vp, C.c_int]
     lib.cpmppi_get_profile.argtypes = [vp, C.POINTER(f), C.POINTER(f), u32, C.POINTER(u32)]
     lib.cpmppi_set_gru.argtypes = [vp, C.POINTER(cpmppi_gru_model)]

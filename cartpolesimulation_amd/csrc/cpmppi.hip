@@ -807,6 +807,8 @@ struct cpmppi_handle {
   // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
   uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
   float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
+  float* host_stage = nullptr;         // pinned [cfg.E * 10]: staging of cpmppi_step_host (state 6, target, equilibrium, L | Q)
+  float* dev_stage = nullptr;          // device [cfg.E * 10], allocated on first use
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
   void* gru16_image = nullptr;         // device copy of the f16 split image (cpmppi_gru16.hpp)
   float* grad_ckpt = nullptr;          // [H][6][E*N] check-points of cpmppi_rollout_cost_grad (allocated on first use)
@@ -1009,6 +1011,8 @@ void cpmppi_destroy(cpmppi_handle* h) {
   if (h->grad_ckpt) (void)hipFree(h->grad_ckpt);
   if (h->counters) (void)hipFree(h->counters);
   if (h->zeros_H) (void)hipFree(h->zeros_H);
+  if (h->host_stage) (void)hipHostFree(h->host_stage);
+  if (h->dev_stage) (void)hipFree(h->dev_stage);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
 }
@@ -1259,6 +1263,35 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
     CPMPPI_HIP(h, hipEventRecord(g[1], s));
     h->group_open = false;
   }
+  return CPMPPI_OK;
+}
+
+int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float* target_position,
+                     const float* target_equilibrium, const float* L, float* u_nom, uint64_t seed, uint64_t offset,
+                     uint32_t env_offset, float* Q, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || E > h->cfg.E || !s0 || !target_position || !target_equilibrium || !u_nom || !Q)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_host: bad argument");
+  CPMPPI_ON_DEVICE(h);
+  const size_t cap = (size_t)h->cfg.E * 10;
+  if (!h->host_stage) CPMPPI_HIP(h, hipHostMalloc((void**)&h->host_stage, cap * sizeof(float), hipHostMallocDefault));
+  if (!h->dev_stage) CPMPPI_HIP(h, hipMalloc((void**)&h->dev_stage, cap * sizeof(float)));
+  const hipStream_t st = (hipStream_t)stream;
+  float* hs = h->host_stage;
+  memcpy(hs, s0, (size_t)E * 6 * sizeof(float));
+  memcpy(hs + 6 * E, target_position, (size_t)E * sizeof(float));
+  memcpy(hs + 7 * E, target_equilibrium, (size_t)E * sizeof(float));
+  for (uint32_t e = 0; e < E; ++e) hs[8 * E + e] = L ? L[e] : h->cfg.L_default;
+  float* d = h->dev_stage;
+  CPMPPI_HIP(h, hipMemcpyAsync(d, hs, (size_t)E * 9 * sizeof(float), hipMemcpyHostToDevice, st));
+  cpmppi_step_args a{};
+  a.E = E; a.s0 = d; a.u_nom = u_nom; a.target_position = d + 6 * E; a.target_equilibrium = d + 7 * E; a.L = d + 8 * E;
+  a.noise_kind = CPMPPI_NOISE_PHILOX; a.seed = seed; a.offset = offset; a.env_offset = env_offset; a.Q_out = d + 9 * E;
+  const int rc = cpmppi_step(h, &a, stream);
+  if (rc != CPMPPI_OK) return rc;
+  CPMPPI_HIP(h, hipMemcpyAsync(hs + 9 * E, d + 9 * E, (size_t)E * sizeof(float), hipMemcpyDeviceToHost, st));
+  CPMPPI_HIP(h, hipStreamSynchronize(st));
+  memcpy(Q, hs + 9 * E, (size_t)E * sizeof(float));
   return CPMPPI_OK;
 }
 

@@ -426,6 +426,21 @@ class MPPIEngine:
         # keep the temporaries alive until the launch is enqueued (stream-ordered frees are safe in torch's allocator)
         return Q_out, S_out
 
+    def step_host(self, s0, u_nom, target_position, target_equilibrium, L, seed, offset, Q_host, env_offset=0):
+        """cpmppi_step_host: float32 numpy arrays on the HOST for the state [E,6], the per-env vectors [E] and the result
+        ``Q_host`` [E] (written in place); ``u_nom`` [E,H] stays on the device.  One library call per control step:
+        staging, copy up, launch (in-kernel Philox noise), copy down, wait.  Synchronous."""
+        E = u_nom.shape[0]
+        for name, x, shape in (("s0", s0, (E, 6)), ("target_position", target_position, (E,)),
+                               ("target_equilibrium", target_equilibrium, (E,)), ("Q_host", Q_host, (E,))) + \
+                (() if L is None else (("L", L, (E,)),)):
+            if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags.c_contiguous and x.shape == shape):
+                raise ValueError(f"{name} must be a C-contiguous float32 numpy array of shape {shape}")
+        self._check(self.lib.cpmppi_step_host(self._h, E, s0.ctypes.data, target_position.ctypes.data, target_equilibrium.ctypes.data,
+                                              None if L is None else L.ctypes.data, u_nom.data_ptr(), int(seed), int(offset),
+                                              int(env_offset), Q_host.ctypes.data, self._stream()))
+        return Q_host
+
     def prepare_step(self, *args, **kwargs):
         """The argument block of ``step(...)`` built and validated ONCE, for callers whose buffers persist from step to step
         (the host seam's staging block, a closed loop): ``.run(offset=...)`` only updates the Philox step counter and

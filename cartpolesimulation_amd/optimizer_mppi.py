@@ -167,6 +167,22 @@ class optimizer_mppi:
             self.configure()
         eng = self.engine
         host_state = not hasattr(s, "is_cuda")
+        if (host_state and self.u_nom.is_cuda and self.noise == "philox" and self.h is None and not as_tensor
+                and not self.optimizer_logging and not self.calculate_optimal_trajectory
+                and self.cfg.cost_function_specification != "quadratic_boundary_grad"):
+            # the simulator's call (CartPole/__init__.py:509-520) in its plain form: host state in, host Q out, in-kernel
+            # noise - ONE library call (cpmppi_step_host: staging, copy up, launch, copy down, wait)
+            s_np = np.ascontiguousarray(np.asarray(s, dtype=np.float32))
+            single = s_np.ndim == 1
+            s_np = s_np.reshape(-1, 6)
+            E = s_np.shape[0]
+            if E != self.num_envs:
+                raise ValueError(f"optimizer configured for {self.num_envs} envs, got {E} states")
+            tp, te, L = self._attributes(E)
+            q = np.empty(E, dtype=np.float32)
+            eng.step_host(s_np, self.u_nom, tp, te, L, self.seed, self.step_counter, q)
+            self.step_counter += 1
+            return q[:1] if single else q.reshape(E, 1)
         if host_state and self.u_nom.is_cuda:                 # (a CPU test double of the engine takes the plain path below)
             # the simulator's call (CartPole/__init__.py:509-520): state and attributes live on the host.  They go up as ONE
             # pinned block in ONE asynchronous copy (state, target_position, target_equilibrium, L: four separate pageable

@@ -208,6 +208,15 @@ int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const
 /* Fused hot path: rollout (a3-a11) + cost (a12-a15) + importance-weighted update (a16) + shift/clip (a18). */
 int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* args, void* stream);
 
+/* The fused step for a caller whose state lives on the HOST - the simulator's own call, controller.step(s, time,
+ * updated_attributes) -> Q (CartPole/__init__.py:509-520): s0[E,6], target_position[E], target_equilibrium[E], L[E] (or
+ * NULL) and Q[E] are HOST pointers, u_nom[E,H] stays a device buffer (the plan persists between control steps).  One
+ * call = stage into the handle's pinned block, one asynchronous copy up, the launch with in-kernel Philox noise
+ * (seed, offset, env_offset as in cpmppi_step_args), one copy down, a wait on the stream.  Synchronous by nature. */
+int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float* target_position,
+                     const float* target_equilibrium, const float* L, float* u_nom, uint64_t seed, uint64_t offset,
+                     uint32_t env_offset, float* Q, void* stream);
+
 /* Kernel timing with HIP events recorded on the launch stream (off by default; enable = 0 switches it off).
  * enable = 1: every cpmppi_step is bracketed by an event before the rollout kernel, one after it and - only when a
  *   separate finalize or counter kernel follows - a third after those; rollout_ms / finalize_ms are per step.
