@@ -373,3 +373,27 @@ def test_host_seam_staging_equals_device_inputs():
             assert np.array_equal(np.asarray(q_host), np.asarray(q_dev))
             assert q_host.shape == ((1,) if E == 1 else (E, 1))
         assert torch.equal(ctrls[0].optimizer.u_nom, ctrls[1].optimizer.u_nom)
+
+
+def test_step_host_equals_step():
+    """cpmppi_step_host (host state / attributes in, host Q out, one call) == cpmppi_step on device copies of the same
+    inputs with the same Philox (seed, offset, env_offset), with and without per-env pole lengths; bad arrays raise."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, N, H = 3, 320, 12
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H))
+    rng = Generator(SFC64(23))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.1) for _ in range(E)])
+    tp, te = rng.uniform(-0.05, 0.05, E).astype(f32), np.ones(E, f32)
+    for Lv in (None, rng.uniform(0.3, 0.45, E).astype(f32)):
+        ua, ub = eng.zeros(E, H), eng.zeros(E, H)
+        for it in range(3):
+            q = np.empty(E, f32)
+            eng.step_host(s0, ua, tp, te, Lv, 9, it, q, env_offset=4)
+            Qd, _ = eng.step(s0, ub, tp, te, L=Lv, seed=9, offset=it, env_offset=4)
+            assert np.array_equal(q, Qd.cpu().numpy()) and torch.equal(ua, ub)
+    with pytest.raises(ValueError):
+        eng.step_host(s0.astype(np.float64), eng.zeros(E, H), tp, te, None, 1, 0, np.empty(E, f32))
+    with pytest.raises(ValueError):
+        eng.step_host(s0, eng.zeros(E, H), tp[:2], te, None, 1, 0, np.empty(E, f32))
+    eng.close()
