@@ -2,7 +2,8 @@
  * tests/test_gpu_c_consumer.py builds it with gcc, runs it and compares its output with the Python binding's.
  *   consumer <config.bin> <E> <seed> <steps>
  * Reads a cpmppi_config blob (written by the test from the ctypes mirror), runs `steps` fused MPPI steps for E envs
- * from fixed states with in-kernel Philox noise, prints Q of every env per step and the final nominal sequence of env 0. */
+ * from fixed states with in-kernel Philox noise through cpmppi_step (device pointers) and again through cpmppi_step_host
+ * (host pointers), prints Q of every env per step ("Q ..." / "Qh ...") and the final nominal sequence of env 0. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,6 +54,17 @@ int main(int argc, char** argv) {
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(hq, Q, (size_t)E * sizeof(float), hipMemcpyDeviceToHost));
     printf("Q");
+    for (uint32_t e = 0; e < E; ++e) printf(" %.9g", hq[e]);
+    printf("\n");
+  }
+  /* the same steps again through the host-pointer entry point: state, targets and Q never leave host memory on this side */
+  HIPCHECK(hipMemset(u_nom, 0, (size_t)E * H * sizeof(float)));
+  for (int it = 0; it < steps; ++it) {
+    if (cpmppi_step_host(h, E, hs, ht, ht + E, ht + 2 * E, u_nom, seed, (uint64_t)it, 0, hq, NULL) != CPMPPI_OK) {
+      fprintf(stderr, "step_host: %s\n", cpmppi_last_error(h));
+      return 5;
+    }
+    printf("Qh");
     for (uint32_t e = 0; e < E; ++e) printf(" %.9g", hq[e]);
     printf("\n");
   }

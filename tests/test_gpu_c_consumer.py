@@ -36,7 +36,9 @@ def test_c_consumer_matches_the_python_binding(tmp_path):
     lines = r.stdout.strip().splitlines()
     assert lines[0].startswith("cpmppi 1 gfx950")
     Q_c = np.array([[np.float32(x) for x in l.split()[1:]] for l in lines[1:1 + steps]], dtype=np.float32)
-    u_c = np.array([np.float32(x) for x in lines[1 + steps].split()[1:]], dtype=np.float32)
+    Qh_c = np.array([[np.float32(x) for x in l.split()[1:]] for l in lines[1 + steps:1 + 2 * steps]], dtype=np.float32)
+    assert all(l.startswith("Qh") for l in lines[1 + steps:1 + 2 * steps]) and np.array_equal(Qh_c, Q_c)   # host-pointer entry point
+    u_c = np.array([np.float32(x) for x in lines[1 + 2 * steps].split()[1:]], dtype=np.float32)
     # the same through the Python binding
     eng = MPPIEngine(E, mppi)
     f32 = np.float32
