@@ -72,6 +72,9 @@ def parse_args(argv=None):
                     help="launcher / collective plumbing only (CPU, gloo): no kernel runs and `value` is null; what the "
                          "CPU test of the N > 1 entry point uses")
     args = ap.parse_args(argv)
+    if args.predictor == "gru" and args.noise == "buffer":
+        ap.error("--predictor gru takes --noise philox or buffer-ref (the tiled buffer layout is read by the ODE rollout "
+                 "kernel only; cpmppi_step refuses the combination)")
     if args.config:
         args.envs, args.rollouts, args.horizon = PRESETS[args.config]
     # the small configurations take ~0.1-0.3 ms per step and start from u_nom = 0 (the first steps meet more rare events
@@ -198,17 +201,74 @@ class Workload:
                                   w_hh1=u(96, 32), b_ih1=u(96), b_hh1=u(96), w_out=u(5, 32), b_out=u(5)))
             self.pred_kw = dict(predictor="GRU")
         # the one collective of the path: all-gather of the updated nominal sequences.  Envs are
-        # independent, so step i+1 does not need step i's gathered result: the gather of a snapshot runs asynchronously on
-        # RCCL's stream while the next step's kernel computes (two snapshot/result buffers, each waited on before reuse).
+        # independent, so step i+1 does not need step i's gathered result: the gather of step i runs on a side stream under
+        # step i+1's rollout kernel.  Production path = the library's own RCCL communicator (shard.NativeGather:
+        # cpmppi_comm_gather, two alternating u_nom buffers, everything enqueued from C); if RCCL cannot be bound on ANY rank,
+        # every rank falls back to torch.distributed (snapshot copy + async all_gather_into_tensor) and the line says so.
         W = ctx["world"]
         coll = ctx["collective"]
-        self.gathered = [torch.empty(W * E * H, dtype=torch.float32, device=dev) for _ in range(2)] if coll else None
-        self.snapshot = [torch.empty(E * H, dtype=torch.float32, device=dev) for _ in range(2)] if coll else None
+        self.native, self.collective_impl = None, None
+        self.gathered = self.snapshot = None
         self.pending = [None, None]
+        self.prepared = None
+        if coll:
+            self._init_collective(W, dev)
+
+    _serial = 0
+
+    def _init_collective(self, W, dev):
+        import torch
+        import torch.distributed as dist
+        from cartpolesimulation_amd.shard import NativeGather, exchange_unique_id
+        E, H, rank = self.E, self.H, self.ctx["rank"]
+        Workload._serial += 1
+        ok, why = 1, ""
+        if os.environ.get("CPMPPI_BENCH_COLLECTIVE", "native") != "native" or self.ctx["backend"] != "nccl":
+            ok, why = 0, "torch.distributed requested (CPMPPI_BENCH_COLLECTIVE / non-RCCL backend)"
+        else:
+            try:
+                uid = exchange_unique_id(self.eng.lib, rank, key=f"cpmppi_comm_id_{Workload._serial}")
+                self.native = NativeGather(self.eng, uid, W, rank)
+            except Exception as e:                       # RCCL missing / init failed on this rank
+                ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if self.ctx["backend"] == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
+        if int(flag.item()) == 1:
+            self.collective_impl = "cpmppi_comm_gather: ncclAllGather on the library's side stream, one per step"
+            self.u_nom = None                            # (the two buffers live in self.native.u)
+            return
+        if self.native is not None:
+            self.native.close()
+            self.native = None
+        self.collective_impl = "torch.distributed all_gather_into_tensor (async_op) of a snapshot" + (f" [{why}]" if why else "")
+        self.gathered = [torch.empty(W * E * H, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.snapshot = [torch.empty(E * H, dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def final_u_nom(self, last_step):
+        """The nominal sequences as step `last_step` left them."""
+        return self.native.u_out(last_step) if self.native else self.u_nom
 
     def step(self, i):
         import torch.distributed as dist
         e, rank = self.eng, self.ctx["rank"]
+        if self.native is not None:
+            g = self.native
+            g.before_step(i)                             # (device-side: the gather that still reads the buffer written now)
+            uin, uout = g.u_in(i), g.u_out(i)
+            if self.noise == "buffer-ref":
+                e._check(e.lib.cpmppi_sample(e._h, self.E, self.seed, i, rank * self.E, None, self.du.data_ptr(), e._stream()))
+                e.step(self.s0, uin, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=self.Q_out, u_nom_out=uout, **self.pred_kw)
+            elif self.noise == "buffer":
+                e.sample_tiled(self.seed, i, rank * self.E, E=self.E, out=self.du)
+                e.step(self.s0, uin, self.tp, self.te, L=self.L, delta_u_tiled=self.du, Q_out=self.Q_out, u_nom_out=uout)
+            else:
+                if self.prepared is None:                # argument blocks built once: the pointers only alternate
+                    self.prepared = [e.prepare_step(self.s0, g.u[b], self.tp, self.te, L=self.L, seed=self.seed, offset=0,
+                                                    env_offset=rank * self.E, Q_out=self.Q_out, u_nom_out=g.u[1 - b],
+                                                    **self.pred_kw) for b in range(2)]
+                self.prepared[i & 1].run(offset=i)
+            g.after_step(i)
+            return
         if self.noise == "buffer-ref":
             e._check(e.lib.cpmppi_sample(e._h, self.E, self.seed, i, rank * self.E, None, self.du.data_ptr(), e._stream()))
             e.step(self.s0, self.u_nom, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=self.Q_out, **self.pred_kw)
@@ -229,6 +289,8 @@ class Workload:
         import torch
         import torch.distributed as dist
         if self.ctx["collective"]:
+            if self.native is not None:
+                self.native.sync()
             for b in range(2):
                 if self.pending[b] is not None:
                     self.pending[b].wait()
@@ -263,10 +325,12 @@ class Workload:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.ctx["device"])
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        assert torch.isfinite(self.u_nom).all(), "non-finite nominal controls"
+        i_last = warmup + steps - 1
+        u_final = self.final_u_nom(i_last)
+        assert torch.isfinite(u_final).all(), "non-finite nominal controls"
         if self.ctx["collective"]:        # the last gather delivered this rank's block (and finite blocks from every other rank)
-            last = self.gathered[(warmup + steps - 1) & 1].view(W, self.E * self.H)
-            assert torch.equal(last[rank], self.u_nom.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
+            last = (self.native.gathered[(i_last + 1) & 1] if self.native else self.gathered[i_last & 1]).view(W, self.E * self.H)
+            assert torch.equal(last[rank], u_final.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
         k_ms = float(np.mean(rollout_ms))
         E, N, H = self.E, self.N, self.H
         return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
@@ -276,6 +340,8 @@ class Workload:
                 "alg_gbs": algorithmic_bytes_per_rollout(N, H) * E * N / (k_ms * 1e-3) / 1e9}
 
     def close(self):
+        if self.native is not None:
+            self.native.close()
         self.eng.close()
 
 
@@ -290,7 +356,10 @@ def profiled_traffic(noise, E, N, H):
     WRITE_SIZE in separate passes, tools/profile.sh -> tools/summarize_profile.py -> profiles/<round>/pmc_traffic.json,
     committed).  PMC counters cannot be collected from inside the run; the figure is labelled with its source."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+    import re
+    rounds = glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))
+    key = lambda p: int((re.search(r"profiles[/\\]r(\d+)", p) or [0, -1])[1])      # newest ROUND first (r10 after r9)
+    for path in sorted(rounds, key=key, reverse=True):
         try:
             rec = json.load(open(path)).get(noise, {})
         except Exception:
@@ -358,7 +427,8 @@ def main():
         if in_rank:
             dist.barrier()
 
-    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "device": device, "collective": collective}
+    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "device": device, "collective": collective,
+           "backend": backend}
     E, N, H = args.envs, args.rollouts, args.horizon
     main_wl = Workload(ctx, E, N, H, noise=args.noise, math=args.math, predictor=args.predictor, rpl=args.rpl)
     r = main_wl.run(args.steps, args.warmup)
@@ -373,11 +443,14 @@ def main():
         for name, (e_, n_, h_), pred, steps_, warm_ in side:
             w = Workload(ctx, e_, n_, h_, predictor=pred)
             rr = w.run(steps_, warm_)
+            impl = w.collective_impl
             w.close()
             obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}",
                    "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
                    "kernel_ms": rr["kernel_ms"], "kernel_ms_min": rr["kernel_ms_min"],
                    "kernel_launches_timed": rr["kernel_launches_timed"], "kernel_event_group": rr["kernel_event_group"]}
+            if impl:
+                obj["collective"] = impl
             if pred == "ode":
                 obj["roofline_valu"] = roofline_valu(rr, e_, n_, h_)
             else:
@@ -421,7 +494,8 @@ def main():
                        "cost": cfg.cost_function_specification, "noise": args.noise, "math": args.math,
                        "predictor": "predictor_ODE_v0" if args.predictor == "ode" else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",
                        "parallelism": f"env-sharded x{world}, one RCCL all-gather of u_nom per step" if world > 1
-                       else "single GPU"},
+                       else "single GPU",
+                       **({"collective": main_wl.collective_impl} if main_wl.collective_impl else {})},
             "roofline": roof or {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": r["alg_gbs"],
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["alg_gbs"] / HBM_PEAK_GBS,
                                  "traffic": traffic, "traffic_source": (f"profiled earlier, not in this run: {traffic_src}"

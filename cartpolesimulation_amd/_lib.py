@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPMPPI_LIB") or os.path.join(_HERE, "libcpmppi.so")   # CPMPPI_LIB: development builds (tools/)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG = 0, 1, 2, 3
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 CONTROL_CLIP, CONTROL_PENALISE = 0, 1
@@ -19,7 +19,9 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_plant_advance_record", "cpmppi_step_host", "cpmppi_set_profiling", "cpmppi_get_profile",
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
-           "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample")
+           "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
+           "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy")
+COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
 class cpmppi_config(C.Structure):
@@ -40,7 +42,8 @@ class cpmppi_step_args(C.Structure):
                 ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p), ("L", C.c_void_p),
                 ("noise_kind", C.c_uint32), ("noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("env_offset", C.c_uint32), ("Q_out", C.c_void_p), ("S_out", C.c_void_p),
-                ("predictor", C.c_uint32), ("h0", C.c_void_p), ("previous_input", C.c_void_p), ("offset_dev", C.c_void_p)]
+                ("predictor", C.c_uint32), ("h0", C.c_void_p), ("previous_input", C.c_void_p), ("offset_dev", C.c_void_p),
+                ("u_nom_out", C.c_void_p)]
 
 
 class cpmppi_gru_model(C.Structure):
@@ -91,7 +94,7 @@ def load():
     lib.cpmppi_step.argtypes = [vp, C.POINTER(cpmppi_step_args), vp]
     lib.cpmppi_reward_weighted_average.argtypes = [vp, u32, vp, vp, vp, vp]
     lib.cpmppi_plant_advance.argtypes = [vp, u32, vp, vp, vp, u32, f, vp]
-    lib.cpmppi_plant_advance_record.argtypes = [vp, u32, vp, vp, vp, u32, f, vp, vp, u64, vp, vp]
+    lib.cpmppi_plant_advance_record.argtypes = [vp, u32, vp, vp, vp, u32, f, vp, vp, u64, u64, vp, vp]
     lib.cpmppi_step_host.argtypes = [vp, u32, vp, vp, vp, vp, vp, u64, u64, u32, vp, vp]
     lib.cpmppi_set_profiling.argtypes = [vp, C.c_int]
     lib.cpmppi_get_profile.argtypes = [vp, C.POINTER(f), C.POINTER(f), u32, C.POINTER(u32)]
@@ -108,6 +111,12 @@ def load():
     lib.cpmppi_sample_tiled.argtypes = [vp, u32, u64, u64, u32, vp, vp, vp]
     lib.cpmppi_tile_delta_u.argtypes = [vp, u32, vp, vp, vp]
     lib.cpmppi_cem_gmm_sample.argtypes = [vp, u32, vp, u32, vp, u64, u64, u32, vp, vp, vp]
+    lib.cpmppi_comm_unique_id.argtypes = [vp, C.c_char_p]
+    lib.cpmppi_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_char_p]
+    lib.cpmppi_comm_gather.argtypes = [vp, u32, vp, vp, C.c_size_t, vp]
+    lib.cpmppi_comm_wait.argtypes = [vp, u32, vp]
+    lib.cpmppi_comm_sync.argtypes = [vp]
+    lib.cpmppi_comm_destroy.argtypes = [vp]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "cpmppi.h"
+#include "cpmppi_internal.hpp"
 #include "cpmppi_device.hpp"
 #include "cpmppi_gru.hpp"
 #include "cpmppi_gru16.hpp"
@@ -43,9 +44,9 @@ namespace {
 
 template <bool KNOT_SPACE>
 __global__ __launch_bounds__(BLOCK) void finalize_kernel(const Params p, const float* __restrict__ partial,
-                                                         uint32_t nb, uint32_t W, float* __restrict__ u_nom,
+                                                         uint32_t nb, uint32_t W, const float* u_nom, float* u_nom_out,
                                                          float* __restrict__ Q_out) {
-  finalize_env<KNOT_SPACE, false>(p, partial, nb, W, u_nom, Q_out, blockIdx.x);
+  finalize_env<KNOT_SPACE, false>(p, partial, nb, W, u_nom, u_nom_out, Q_out, blockIdx.x);
 }
 
 // a17: knots[E,N,P] and/or delta_u[E,N,H].  One lane draws (or loads) the knots of one rollout into LDS; the wave then
@@ -265,10 +266,16 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E
                                                       const float* __restrict__ Q, const float* __restrict__ Lp,
                                                       uint32_t n_sub, float dt_sim, float* __restrict__ states_log,
                                                       float* __restrict__ Q_log, uint64_t row,
-                                                      const unsigned long long* __restrict__ row_dev) {
+                                                      const unsigned long long* __restrict__ row_dev, uint64_t log_rows) {
   const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
   if (env >= E) return;
-  if (row_dev) row = (uint64_t)*row_dev - 1u;
+  // a row outside the logs (a device counter that is still 0, a graph replayed past the recording's end) is not recorded
+  bool in_log = row < log_rows;
+  if (row_dev) {
+    const uint64_t c = (uint64_t)*row_dev;
+    row = c - 1u;
+    in_log = (c != 0u) && (row < log_rows);
+  }
   const EnvConst ec = make_env_const(p, Lp ? Lp[env] : p.L_default);
   float* se = s + (size_t)env * 6;
   State<float> st{se[0], se[1], se[2], se[3], se[4], se[5]};
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E
     ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);
   }
   se[0] = st.th; se[1] = st.w; se[2] = st.c; se[3] = st.s; se[4] = st.x; se[5] = st.v;
-  if (Q_log) Q_log[row * E + env] = Q[env];
-  if (states_log) {
+  if (Q_log && in_log) Q_log[row * E + env] = Q[env];
+  if (states_log && in_log) {
     float* lg = states_log + ((row + 1u) * E + env) * 6u;
     lg[0] = st.th; lg[1] = st.w; lg[2] = st.c; lg[3] = st.s; lg[4] = st.x; lg[5] = st.v;
   }
@@ -807,7 +814,9 @@ struct cpmppi_handle {
   // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
   uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
   float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
-  float* host_stage = nullptr;         // pinned [cfg.E * 10]: staging of cpmppi_step_host (state 6, target, equilibrium, L | Q)
+  float* host_stage = nullptr;         // pinned [cfg.E * 10 + 16]: staging of cpmppi_step_host (state 6, target, equilibrium, L | Q | ticket)
+  uint32_t host_ticket_value = 0;      // what the ticket in that block reads once every launch so far has delivered
+  uint32_t host_zero_copy_max = 64;    // up to this many envs cpmppi_step_host runs without copies and stream waits (CPMPPI_HOST_ZERO_COPY_MAX)
   float* dev_stage = nullptr;          // device [cfg.E * 10], allocated on first use
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
   void* gru16_image = nullptr;         // device copy of the f16 split image (cpmppi_gru16.hpp)
@@ -821,7 +830,11 @@ struct cpmppi_handle {
   std::vector<hipEvent_t> ev;          // triples per sampled step: before rollout, after it, after the trailing kernels
   std::vector<uint8_t> ev_tail;        // per triple: was the third event recorded (a separate finalize / counter kernel ran)
   size_t ev_used = 0;
+  cpmppi_comm::CommState* comm = nullptr;   // RCCL communicator + side stream of cpmppi_comm_* (cpmppi_comm.hip)
 };
+
+cpmppi_comm::CommState*& cpmppi_internal_comm(cpmppi_handle* h) { return h->comm; }
+int cpmppi_internal_device(const cpmppi_handle* h) { return h->device; }
 
 namespace {
 
@@ -829,6 +842,10 @@ int fail(cpmppi_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg; else g_create_error = msg;
   return code;
 }
+
+}  // namespace
+int cpmppi_internal_fail(cpmppi_handle* h, int code, const std::string& msg) { return fail(h, code, msg); }
+namespace {
 
 #define CPMPPI_HIP(h, call)                                                                        \
   do {                                                                                             \
@@ -967,6 +984,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   fill_params(*cfg, h->prm);
   h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
   if (const char* ev = getenv("CPMPPI_FUSE_FINALIZE")) h->fuse_finalize = ev[0] != '0';
+  if (const char* ev = getenv("CPMPPI_HOST_ZERO_COPY_MAX")) h->host_zero_copy_max = (uint32_t)strtoul(ev, nullptr, 10);
   DeviceGuard guard(device);                     // the caller's current device is restored on every exit path
   if (guard.err != hipSuccess) {
     delete h;
@@ -1005,6 +1023,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
 
 void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
+  if (h->comm) { cpmppi_comm::destroy(h->comm); h->comm = nullptr; }
   if (h->workspace) (void)hipFree(h->workspace);
   if (h->gru_image) (void)hipFree(h->gru_image);
   if (h->gru16_image) (void)hipFree(h->gru16_image);
@@ -1146,7 +1165,11 @@ int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const
   return CPMPPI_OK;
 }
 
-int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
+static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, uint32_t* host_ticket);
+
+int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) { return step_impl(h, a, stream, nullptr); }
+
+static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, uint32_t* host_ticket) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (!a) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: null args");
   if (a->E == 0 || a->E > h->cfg.E) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: E out of range");
@@ -1160,8 +1183,16 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   if (a->noise_kind != CPMPPI_NOISE_PHILOX && !a->noise)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: noise buffer required for this noise_kind");
   if (misaligned(a->s0) || misaligned(a->u_nom) || misaligned(a->noise) || misaligned(a->S_out) ||
-      misaligned(a->Q_out))
+      misaligned(a->Q_out) || misaligned(a->u_nom_out))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_step: misaligned pointer");
+  // (every check that can fail comes BEFORE the event recorder is touched: a failed step must not leave a half-recorded
+  // bracket behind for cpmppi_get_profile)
+  if (a->predictor > CPMPPI_PREDICTOR_GRU) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: unknown predictor");
+  if (a->predictor == CPMPPI_PREDICTOR_GRU) {
+    if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: predictor GRU requested but no model set (cpmppi_set_gru)");
+    if (h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT)
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports quadratic_boundary_grad_minimal and default");
+  }
   CPMPPI_ON_DEVICE(h);
   StepPtrs p{};
   p.s0 = a->s0; p.u_nom = a->u_nom; p.u_prev = a->u_prev; p.x_t = a->target_position; p.te = a->target_equilibrium;
@@ -1179,7 +1210,8 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   const bool du_space = (noise_kind == CPMPPI_NOISE_DELTA_U || noise_kind == CPMPPI_NOISE_DELTA_U_TILED);
   p.W = du_space ? h->cfg.H : h->prm.P;
   p.S_out = a->S_out; p.partial = h->workspace;
-  p.counter = nullptr; p.u_nom_out = a->u_nom; p.Q_out = a->Q_out;
+  p.counter = nullptr; p.u_nom_out = a->u_nom_out ? a->u_nom_out : a->u_nom; p.Q_out = a->Q_out;
+  p.host_ticket = host_ticket;
   hipEvent_t* ev = nullptr;
   const uint32_t group_pos = h->profile_every ? h->profile_count++ % h->profile_every : 0;
   const bool grouped = h->profile_every > 1;
@@ -1199,9 +1231,6 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   }
   if (grouped) ev = nullptr;                       // (no events inside a group)
   if (a->predictor == CPMPPI_PREDICTOR_GRU) {
-    if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: predictor GRU requested but no model set (cpmppi_set_gru)");
-    if (h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT)
-      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports quadratic_boundary_grad_minimal and default");
     p.nb = (h->cfg.N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;
     // FAST: float32-equivalent split products on the f16 matrix cores (cpmppi_gru16.hpp); PRECISE: exact f32 MFMA chains
     const bool f16 = h->cfg.math_mode == CPMPPI_MATH_FAST && h->gru16_image != nullptr;
@@ -1241,10 +1270,10 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) {
   if (separate_finalize) {
     if (du_space)
       hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
-                         p.nb, p.W, a->u_nom, a->Q_out);
+                         p.nb, p.W, (const float*)a->u_nom, p.u_nom_out, a->Q_out);
     else
       hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
-                         p.nb, p.W, a->u_nom, a->Q_out);
+                         p.nb, p.W, (const float*)a->u_nom, p.u_nom_out, a->Q_out);
   }
   CPMPPI_HIP(h, hipGetLastError());
   if (p.offset_dev) {
@@ -1273,20 +1302,51 @@ int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float*
   if (E == 0 || E > h->cfg.E || !s0 || !target_position || !target_equilibrium || !u_nom || !Q)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_host: bad argument");
   CPMPPI_ON_DEVICE(h);
+  // pinned, fine-grained, device-mapped block: [cfg.E * 10 floats: state 6, target, equilibrium, L | Q][ticket]
   const size_t cap = (size_t)h->cfg.E * 10;
-  if (!h->host_stage) CPMPPI_HIP(h, hipHostMalloc((void**)&h->host_stage, cap * sizeof(float), hipHostMallocDefault));
-  if (!h->dev_stage) CPMPPI_HIP(h, hipMalloc((void**)&h->dev_stage, cap * sizeof(float)));
+  if (!h->host_stage) {
+    CPMPPI_HIP(h, hipHostMalloc((void**)&h->host_stage, (cap + 16) * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h->host_stage, 0, (cap + 16) * sizeof(float));
+  }
   const hipStream_t st = (hipStream_t)stream;
   float* hs = h->host_stage;
   memcpy(hs, s0, (size_t)E * 6 * sizeof(float));
   memcpy(hs + 6 * E, target_position, (size_t)E * sizeof(float));
   memcpy(hs + 7 * E, target_equilibrium, (size_t)E * sizeof(float));
   for (uint32_t e = 0; e < E; ++e) hs[8 * E + e] = L ? L[e] : h->cfg.L_default;
+  cpmppi_step_args a{};
+  a.E = E; a.u_nom = u_nom;
+  a.noise_kind = CPMPPI_NOISE_PHILOX; a.seed = seed; a.offset = offset; a.env_offset = env_offset;
+  if (h->fuse_finalize && E <= h->host_zero_copy_max) {
+    // Few envs (the simulator's own call: one): no copy packets and no stream wait at all.  The kernel reads the 9 floats
+    // per env straight from the pinned block over the host link, the env's finalizing block stores Q into the same
+    // block and bumps a system-scope ticket; this thread spins on the ticket (a stream wait is an interrupt + a thread
+    // wake-up: ~15 us of an 80 us control step).  The stream is polled now and then so that a failed launch cannot hang the caller.
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(hs + cap);
+    a.s0 = hs; a.target_position = hs + 6 * E; a.target_equilibrium = hs + 7 * E; a.L = hs + 8 * E; a.Q_out = hs + 9 * E;
+    const uint32_t target = (h->host_ticket_value += E);
+    const int rc = step_impl(h, &a, stream, ticket);
+    if (rc != CPMPPI_OK) { h->host_ticket_value -= E; return rc; }
+    for (uint32_t spins = 1;; ++spins) {
+      if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == target) break;
+      __builtin_ia32_pause();
+      if ((spins & 0xFFFu) == 0u) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) return fail(h, CPMPPI_ERR_HIP, std::string("cpmppi_step_host: ") + hipGetErrorString(q));
+        if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == target) break;
+        // the stream drained without the ticket: resynchronise the counter and report
+        h->host_ticket_value = __atomic_load_n(ticket, __ATOMIC_ACQUIRE);
+        return fail(h, CPMPPI_ERR_HIP, "cpmppi_step_host: the launch completed without delivering its controls");
+      }
+    }
+    memcpy(Q, hs + 9 * E, (size_t)E * sizeof(float));
+    return CPMPPI_OK;
+  }
+  if (!h->dev_stage) CPMPPI_HIP(h, hipMalloc((void**)&h->dev_stage, cap * sizeof(float)));
   float* d = h->dev_stage;
   CPMPPI_HIP(h, hipMemcpyAsync(d, hs, (size_t)E * 9 * sizeof(float), hipMemcpyHostToDevice, st));
-  cpmppi_step_args a{};
-  a.E = E; a.s0 = d; a.u_nom = u_nom; a.target_position = d + 6 * E; a.target_equilibrium = d + 7 * E; a.L = d + 8 * E;
-  a.noise_kind = CPMPPI_NOISE_PHILOX; a.seed = seed; a.offset = offset; a.env_offset = env_offset; a.Q_out = d + 9 * E;
+  a.s0 = d; a.target_position = d + 6 * E; a.target_equilibrium = d + 7 * E; a.L = d + 8 * E; a.Q_out = d + 9 * E;
   const int rc = cpmppi_step(h, &a, stream);
   if (rc != CPMPPI_OK) return rc;
   CPMPPI_HIP(h, hipMemcpyAsync(hs + 9 * E, d + 9 * E, (size_t)E * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1610,22 +1670,25 @@ int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q,
   if (misaligned(s) || misaligned(Q) || misaligned(L)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance: misaligned");
   CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
-                     L, n_substeps, dt_sim, (float*)nullptr, (float*)nullptr, (uint64_t)0, (const unsigned long long*)nullptr);
+                     L, n_substeps, dt_sim, (float*)nullptr, (float*)nullptr, (uint64_t)0, (const unsigned long long*)nullptr,
+                     (uint64_t)0);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
 
 int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
-                                float dt_sim, float* states_log, float* Q_log, uint64_t row, const void* row_dev,
-                                void* stream) {
+                                float dt_sim, float* states_log, float* Q_log, uint64_t log_rows, uint64_t row,
+                                const void* row_dev, void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance_record: bad argument");
+  if ((states_log || Q_log) && !row_dev && row >= log_rows)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance_record: row outside the logs (row >= log_rows)");
   if (misaligned(s) || misaligned(Q) || misaligned(L) || misaligned(states_log) || misaligned(Q_log) ||
       (row_dev && ((uintptr_t)row_dev & 7u)))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance_record: misaligned");
   CPMPPI_ON_DEVICE(h);
   hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
-                     L, n_substeps, dt_sim, states_log, Q_log, row, (const unsigned long long*)row_dev);
+                     L, n_substeps, dt_sim, states_log, Q_log, row, (const unsigned long long*)row_dev, log_rows);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }

@@ -1,0 +1,218 @@
+// cpmppi_comm.hip — the one collective of the path: env-sharded ranks, one process per GPU, and ONE
+// all-gather of the chosen control sequences u_nom[E_local, H] per step over RCCL / xGMI.
+//
+// The reference has no counterpart: its only fan-out is share-nothing SLURM job arrays
+// (others/EulerClusterScripts/ParallelDataGeneration.sh:2-17), i.e. zero communication cost — which is the bar: the
+// gather must not show in the step time.  Envs are independent, so step i+1 never needs step i's gathered result; the
+// gather of step i therefore runs on a high-priority side stream UNDER step i+1's rollout kernel:
+//
+//   launch stream :  step i (reads B[i&1], writes B[(i+1)&1]) | step i+1 (reads B[(i+1)&1], writes B[i&1]) | ...
+//   side stream   :                         wait(ready i) -> ncclAllGather(B[(i+1)&1] -> G[slot]) -> record(done[slot])
+//
+// with the two nominal-sequence buffers of cpmppi_step_args.u_nom_out (no snapshot copy) and, per step, one event record
+// on the launch stream, one cross-stream wait, one RCCL call and one event record on the side stream — all issued from
+// C through this entry point (the per-step cost of torch.distributed's Work objects and stream guards driven from Python
+// was 33 us next to a 91 us kernel at BASELINE configs[3]).  The launch stream waits on done[slot] only before the
+// step that overwrites the gathered buffer again (two steps later).
+//
+// RCCL is bound at run time (dlopen) so that libcpmppi.so loads on hosts without it and, inside a PyTorch process,
+// binds to the RCCL torch itself has loaded.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include <rccl/rccl.h>      // types only (ncclComm_t, ncclUniqueId, ncclFloat); every function is looked up with dlsym
+
+#include "cpmppi.h"
+#include "cpmppi_internal.hpp"
+
+namespace cpmppi_comm {
+
+struct Rccl {
+  void* dl = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+Rccl g_rccl;
+
+bool load_rccl(const char* path) {
+  Rccl& r = g_rccl;
+  if (r.dl) return true;
+  // a caller-given path first; then whatever the process has already loaded under the names PyTorch-ROCm and ROCm use;
+  // then a fresh load by those names (libcpmppi.so's RUNPATH covers /opt/rocm/lib)
+  const char* names[] = {path, "librccl.so", "librccl.so.1"};
+  for (int pass = 0; pass < 2 && !r.dl; ++pass) {
+    for (const char* n : names) {
+      if (!n || !n[0]) continue;
+      r.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      if (r.dl) break;
+    }
+  }
+  if (!r.dl) {
+    const char* e = dlerror();
+    r.err = std::string("RCCL not found (librccl.so): ") + (e ? e : "");
+    return false;
+  }
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.dl, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.dl, "ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.dl, "ncclCommDestroy"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.dl, "ncclAllGather"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.dl, "ncclGetErrorString"));
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+    r.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
+    dlclose(r.dl);
+    r.dl = nullptr;
+    return false;
+  }
+  return true;
+}
+
+constexpr int SLOTS = CPMPPI_COMM_SLOTS;
+
+struct CommState {
+  ncclComm_t comm = nullptr;
+  int world = 0, rank = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ready = nullptr;           // launch stream -> side stream: the step whose result is gathered has been enqueued
+  hipEvent_t done[SLOTS] = {};          // side stream -> launch stream: the gather of this slot has completed
+  bool pending[SLOTS] = {};
+};
+
+void destroy(CommState* c) {
+  if (!c) return;
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->ready) (void)hipEventDestroy(c->ready);
+  for (hipEvent_t e : c->done)
+    if (e) (void)hipEventDestroy(e);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  delete c;
+}
+
+struct OnDevice {                       // (the handle's device for the duration of a call; the caller's restored after)
+  int prev = -1;
+  bool switched = false;
+  explicit OnDevice(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~OnDevice() { if (switched) (void)hipSetDevice(prev); }
+};
+
+}  // namespace cpmppi_comm
+
+using namespace cpmppi_comm;
+
+#define COMM_HIP(h, call)                                                                                  \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return cpmppi_internal_fail((h), CPMPPI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define COMM_NCCL(h, call)                                                                                      \
+  do {                                                                                                          \
+    ncclResult_t r_ = (call);                                                                                   \
+    if (r_ != ncclSuccess)                                                                                      \
+      return cpmppi_internal_fail((h), CPMPPI_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+extern "C" {
+
+int cpmppi_comm_unique_id(void* id_out, const char* rccl_path) {
+  if (!id_out) return cpmppi_internal_fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_unique_id: null argument");
+  if (!load_rccl(rccl_path)) return cpmppi_internal_fail(nullptr, CPMPPI_ERR_COMM, g_rccl.err);
+  static_assert(sizeof(ncclUniqueId) == CPMPPI_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  COMM_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return CPMPPI_OK;
+}
+
+int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, const char* rccl_path) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (!id || world < 1 || rank < 0 || rank >= world)
+    return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_init: bad argument");
+  if (cpmppi_internal_comm(h)) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_init: this handle has a communicator");
+  if (!load_rccl(rccl_path)) return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, g_rccl.err);
+  OnDevice guard(cpmppi_internal_device(h));
+  CommState* c = new CommState();
+  c->world = world; c->rank = rank;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    destroy(c);
+    return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+  }
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = the numerically lowest = greatest priority
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);
+  // launch -> side: both streams are on this device and the RCCL kernel reads the send buffer through the same L2, so the
+  // event needs no system-scope fence (the default fence is a cache write-back on the launch stream's critical path)
+  unsigned ready_flags = hipEventDisableTiming | hipEventDisableSystemFence;
+  if (const char* ev = getenv("CPMPPI_COMM_READY_FENCE")) if (ev[0] == '1') ready_flags = hipEventDisableTiming;
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, ready_flags);
+  for (int i = 0; i < SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    destroy(c);
+    return cpmppi_internal_fail(h, CPMPPI_ERR_HIP, std::string("cpmppi_comm_init: ") + hipGetErrorString(e));
+  }
+  cpmppi_internal_comm(h) = c;
+  return CPMPPI_OK;
+}
+
+int cpmppi_comm_gather(cpmppi_handle* h, uint32_t slot, const float* send, float* recv_all, size_t count, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_gather: no communicator (cpmppi_comm_init)");
+  if (slot >= (uint32_t)SLOTS || !send || !recv_all || count == 0)
+    return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_gather: bad argument");
+  OnDevice guard(cpmppi_internal_device(h));
+  COMM_HIP(h, hipEventRecord(c->ready, (hipStream_t)stream));
+  COMM_HIP(h, hipStreamWaitEvent(c->side, c->ready, 0));
+  COMM_NCCL(h, g_rccl.AllGather(send, recv_all, count, ncclFloat, c->comm, c->side));
+  COMM_HIP(h, hipEventRecord(c->done[slot], c->side));
+  c->pending[slot] = true;
+  return CPMPPI_OK;
+}
+
+int cpmppi_comm_wait(cpmppi_handle* h, uint32_t slot, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c || slot >= (uint32_t)SLOTS) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_wait: bad argument");
+  if (!c->pending[slot]) return CPMPPI_OK;
+  OnDevice guard(cpmppi_internal_device(h));
+  COMM_HIP(h, hipStreamWaitEvent((hipStream_t)stream, c->done[slot], 0));
+  c->pending[slot] = false;
+  return CPMPPI_OK;
+}
+
+int cpmppi_comm_sync(cpmppi_handle* h) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c) return CPMPPI_OK;
+  OnDevice guard(cpmppi_internal_device(h));
+  COMM_HIP(h, hipStreamSynchronize(c->side));
+  for (bool& p : c->pending) p = false;
+  return CPMPPI_OK;
+}
+
+int cpmppi_comm_destroy(cpmppi_handle* h) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  CommState*& c = cpmppi_internal_comm(h);
+  if (c) {
+    OnDevice guard(cpmppi_internal_device(h));
+    destroy(c);
+    c = nullptr;
+  }
+  return CPMPPI_OK;
+}
+
+}  // extern "C"

@@ -46,8 +46,9 @@ struct StepPtrs {
   float* S_out;
   float* partial;       // [E][nb][2 + W]
   uint32_t* counter;    // [E] arrival tickets of the env's blocks (0 between launches); NULL = separate finalize kernel
-  float* u_nom_out;     // fused finalize: where the updated nominal sequence goes (== u_nom)
+  float* u_nom_out;     // fused finalize: where the updated nominal sequence goes (u_nom itself, or the caller's second buffer)
   float* Q_out;
+  uint32_t* host_ticket; // cpmppi_step_host: counter in pinned host memory, +1 (system scope) per finalized env; NULL otherwise
 };
 
 // Nominal control for stage k after the configured shift (a18).
@@ -62,7 +63,8 @@ __device__ __forceinline__ float shifted_nominal(const Params& p, const float* _
 // them with agent-scope (sc1) loads that bypass this CU's L1.
 template <bool KNOT_SPACE, bool COHERENT>
 __device__ __forceinline__ void finalize_env(const Params& p, const float* partial, uint32_t nb, uint32_t W,
-                                             float* __restrict__ u_nom, float* __restrict__ Q_out, uint32_t env) {
+                                             const float* u_nom_in, float* u_nom_out, float* __restrict__ Q_out,
+                                             uint32_t env, uint32_t* host_ticket = nullptr) {
   __shared__ float u_new[CPMPPI_MAX_HORIZON];
   __shared__ float bz[KNOT_SPACE ? (CPMPPI_MAX_HORIZON + 2) : 1];
   const uint32_t tid = threadIdx.x, H = p.H;
@@ -116,7 +118,8 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
     for (uint32_t c = tid + BLOCK; c < W; c += BLOCK) bz[c] = merged(c);
     __syncthreads();
   }
-  float* __restrict__ un = u_nom + (size_t)env * H;
+  const float* un = u_nom_in + (size_t)env * H;       // (may alias the output: every read precedes the barrier below)
+  float* uo = u_nom_out + (size_t)env * H;
   for (uint32_t k = tid; k < H; k += BLOCK) {
     float bk;
     if constexpr (KNOT_SPACE) {
@@ -130,8 +133,14 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
     u_new[k] = v;
   }
   __syncthreads();                          // every read of the old nominal sequence is done
-  for (uint32_t k = tid; k < H; k += BLOCK) un[k] = u_new[k];
+  for (uint32_t k = tid; k < H; k += BLOCK) uo[k] = u_new[k];
   if (tid == 0 && Q_out) Q_out[env] = u_new[0];
+  if (tid == 0 && host_ticket) {
+    // the simulator's host thread spins on this counter instead of waiting on the stream (cpmppi_step_host): Q_out lives
+    // in the same pinned, fine-grained block; system-scope release so that the control is visible before the ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_fetch_add(host_ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // The hot path.  R = rollouts per lane (1: latency mapping, 2: packed float2 throughput mapping, FAST only).
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         __hip_atomic_store(a.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       }
       __syncthreads();
-      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom_out, a.Q_out, env);
+      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom, a.u_nom_out, a.Q_out, env, a.host_ticket);
     }
   }
   CPMPPI_DBG_STAMP(3);

@@ -201,13 +201,16 @@ class MPPIEngine:
             if t is not None and not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                                       and tuple(t.shape[1:]) == tail):
                 raise ValueError(f"{name} must be a contiguous float32 ROCm tensor [T, {', '.join(map(str, tail))}]")
+        # control periods the logs can take; the kernel itself refuses to write outside them (device counter case)
+        log_rows = min([states_log.shape[0] - 1] * (states_log is not None) + [Q_log.shape[0]] * (Q_log is not None))
         if row_dev is None:
-            if (states_log is not None and not 0 <= row + 1 < states_log.shape[0]) or (Q_log is not None and not 0 <= row < Q_log.shape[0]):
+            if not 0 <= row < log_rows:
                 raise IndexError(f"row {row} outside the logs")
         elif not (torch.is_tensor(row_dev) and row_dev.is_cuda and row_dev.dtype == torch.int64):
             raise ValueError("row_dev must be an int64 ROCm tensor")
         self._check(self.lib.cpmppi_plant_advance_record(self._h, E, _ptr(s), _ptr(Q), _ptr(L), int(n_substeps), float(dt_sim),
-                                                         _ptr(states_log), _ptr(Q_log), int(row), _ptr(row_dev), self._stream()))
+                                                         _ptr(states_log), _ptr(Q_log), int(max(log_rows, 0)), int(row),
+                                                         _ptr(row_dev), self._stream()))
         return s
 
     # ------------------------------------------------------------------ GRU predictor (BASELINE configs[4])
@@ -356,8 +359,9 @@ class MPPIEngine:
     # ------------------------------------------------------------------ the fused hot path
     def step(self, s0, u_nom, target_position, target_equilibrium, L=None, delta_u=None, knots=None, seed=None,
              offset=0, env_offset=0, u_prev=None, Q_out=None, S_out=None, predictor="ODE_v0", h0=None,
-             previous_input=None, offset_dev=None, delta_u_tiled=None, _prepare=False):
-        """One MPPI optimizer step for E envs.  ``u_nom`` [E,H] is updated IN PLACE.
+             previous_input=None, offset_dev=None, delta_u_tiled=None, u_nom_out=None, _prepare=False):
+        """One MPPI optimizer step for E envs.  ``u_nom`` [E,H] is updated IN PLACE, or — with ``u_nom_out`` [E,H] — only
+        read, the updated sequence going to ``u_nom_out`` (two buffers used alternately: shard.NativeGather).
 
         Exactly one noise source: ``delta_u`` [E,N,H], ``knots`` [E,N,P], ``seed`` (in-kernel Philox) or
         ``delta_u_tiled`` (a buffer from sample_tiled / tile_delta_u).
@@ -414,13 +418,18 @@ class MPPIEngine:
         a.h0 = h0.data_ptr() if h0 is not None else None
         previous_input = self._per_env(previous_input, E) if previous_input is not None else None
         a.previous_input = previous_input.data_ptr() if previous_input is not None else None
+        if u_nom_out is not None:
+            if not (torch.is_tensor(u_nom_out) and u_nom_out.is_cuda and u_nom_out.dtype == torch.float32
+                    and u_nom_out.is_contiguous() and u_nom_out.shape == u_nom.shape):
+                raise ValueError("u_nom_out must be a contiguous float32 ROCm tensor of u_nom's shape")
+            a.u_nom_out = u_nom_out.data_ptr()
         if offset_dev is not None:           # int64 device scalar: Philox step counter kept on the device (graph replay)
             if not (torch.is_tensor(offset_dev) and offset_dev.is_cuda and offset_dev.dtype == torch.int64 and offset_dev.numel() == 1):
                 raise ValueError("offset_dev must be a one-element int64 ROCm tensor")
             a.offset_dev = offset_dev.data_ptr()
         if _prepare:
             # every tensor the argument block points into is kept alive by the returned object
-            return PreparedStep(self, a, (s0, u_nom, tp, te, Lt, noise, u_prev, Q_out, S_out, h0, previous_input, offset_dev),
+            return PreparedStep(self, a, (s0, u_nom, tp, te, Lt, noise, u_prev, Q_out, S_out, h0, previous_input, offset_dev, u_nom_out),
                                 Q_out, S_out)
         self._check(self.lib.cpmppi_step(self._h, C.byref(a), self._stream()))
         # keep the temporaries alive until the launch is enqueued (stream-ordered frees are safe in torch's allocator)

@@ -120,10 +120,24 @@ class optimizer_mppi:
         else:
             self.h = None
         self.u_nom = self.engine.zeros(E, H)
-        self.Q = self.engine.empty(E)
+        self._Q = self.engine.zeros(E)
+        self._Q_host = None
         self.S = self.engine.empty(E, N) if self.optimizer_logging else None
         self._rng = np.random.Generator(np.random.SFC64(self.seed))
         self.optimizer_reset()
+
+    @property
+    def Q(self):
+        """Device tensor [E]: the controls chosen by the last step.  After a host-state step (cpmppi_step_host delivers
+        them to the host only) it is refreshed from that host copy on first use."""
+        if self._Q_host is not None:
+            self._Q.copy_(torch.from_numpy(self._Q_host))
+            self._Q_host = None
+        return self._Q
+
+    @Q.setter
+    def Q(self, value):
+        self._Q, self._Q_host = value, None
 
     def optimizer_reset(self):
         """u_nom = midpoint of the control limits; restart the noise stream."""
@@ -181,6 +195,7 @@ class optimizer_mppi:
             tp, te, L = self._attributes(E)
             q = np.empty(E, dtype=np.float32)
             eng.step_host(s_np, self.u_nom, tp, te, L, self.seed, self.step_counter, q)
+            self._Q_host = q
             self.step_counter += 1
             return q[:1] if single else q.reshape(E, 1)
         if host_state and self.u_nom.is_cuda:                 # (a CPU test double of the engine takes the plain path below)

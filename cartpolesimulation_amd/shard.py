@@ -5,7 +5,16 @@ ParallelDataGeneration.sh:2-17).  Envs are fully independent, so the data path n
 process per GPU, torch.distributed backend "nccl" = RCCL over xGMI) owns a contiguous block of envs, and the updated
 nominal control sequences u_nom[E_local,H] (C4: 64 x 50 floats = 12.8 KB per rank) are all-gathered once per step.
 The per-env Philox streams are keyed by the GLOBAL env index, so results do not depend on the number of ranks.
+
+Two implementations of that one collective:
+  * :class:`NativeGather` — the production path: ``cpmppi_comm_gather`` (csrc/cpmppi_comm.hip) enqueues ``ncclAllGather``
+    from C on a high-priority side stream under the NEXT step's rollout kernel, straight from one of the two nominal-
+    sequence buffers of ``cpmppi_step_args.u_nom_out`` (no snapshot copy, no torch ``Work`` object per step);
+  * :func:`gather_controls` — ``torch.distributed`` (gloo on CPU: what the world_size-2 tests run; also the fallback
+    when RCCL cannot be bound).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -63,8 +72,11 @@ class ShardedMPPI:
         return x[self.start:self.start + self.count]
 
     def step(self, s_local):
-        u_local, q_local = self.step_fn(s_local, self.start)
-        return gather_controls(u_local, self.E_total, self.group), gather_controls(q_local, self.E_total, self.group)
+        """-> (u_nom[E_total,H], Q[E_total]) on every rank.  ONE collective: the control to apply is the first element of
+        the gathered nominal sequence (Q = u_nom[:,0], controller_mppi_cartpole.py:563), so only u_nom travels."""
+        u_local, _ = self.step_fn(s_local, self.start)
+        u_all = gather_controls(u_local, self.E_total, self.group)
+        return u_all, u_all[:, 0].clone()
 
 
 def hip_step_fn(engine, u_nom, target_position, target_equilibrium, L, seed):
@@ -78,3 +90,63 @@ def hip_step_fn(engine, u_nom, target_position, target_equilibrium, L, seed):
         return u_nom, Q
 
     return fn
+
+
+def exchange_unique_id(lib, rank, key="cpmppi_comm_id", rccl_path=None):
+    """Rank 0 draws the RCCL unique id (cpmppi_comm_unique_id), every rank receives it through the process group's
+    key-value store (no collective, no device tensors: works under any torch.distributed backend)."""
+    from . import _lib as _L
+    store = dist.distributed_c10d._get_default_store()
+    if rank == 0:
+        buf = C.create_string_buffer(_L.COMM_ID_BYTES)
+        rc = lib.cpmppi_comm_unique_id(buf, rccl_path)
+        if rc != 0:
+            store.set(key, b"!" + lib.cpmppi_last_error(None))
+            raise _L.CpmppiError(rc, lib.cpmppi_last_error(None).decode())
+        store.set(key, b"+" + buf.raw)
+        return buf.raw
+    got = store.get(key)
+    if got[:1] != b"+":
+        raise RuntimeError("rank 0 could not create the RCCL id: " + got[1:].decode(errors="replace"))
+    return got[1:]
+
+
+class NativeGather:
+    """The per-step all-gather of u_nom[E_local,H] through libcpmppi's own RCCL communicator.
+
+    ``u[0]``, ``u[1]``: the two nominal-sequence buffers (step i reads ``u[i & 1]`` and writes ``u[(i + 1) & 1]`` via
+    ``u_nom_out``); ``gathered[b]`` [world, E_local*H] receives the gather of ``u[b]``.  Per step:
+    ``before_step(i)`` (device-side wait for the gather that still reads the buffer this step overwrites), the step,
+    ``after_step(i)`` (enqueue the gather of the buffer just written).  Nothing here blocks the host."""
+
+    def __init__(self, engine, unique_id, world, rank, rccl_path=None):
+        self.engine, self.world, self.rank = engine, int(world), int(rank)
+        e = engine
+        e._check(e.lib.cpmppi_comm_init(e._h, unique_id, self.world, self.rank, rccl_path))
+        n = e.E * e.H
+        self.u = [e.zeros(e.E, e.H), e.zeros(e.E, e.H)]
+        self.gathered = [torch.empty(self.world, n, dtype=torch.float32, device=e.device) for _ in range(2)]
+
+    def before_step(self, i):
+        e = self.engine
+        e._check(e.lib.cpmppi_comm_wait(e._h, (i + 1) & 1, e._stream()))       # gather i-2 read the buffer step i writes
+
+    def after_step(self, i):
+        e = self.engine
+        b = (i + 1) & 1
+        e._check(e.lib.cpmppi_comm_gather(e._h, b, self.u[b].data_ptr(), self.gathered[b].data_ptr(), e.E * e.H, e._stream()))
+
+    def u_in(self, i):
+        return self.u[i & 1]
+
+    def u_out(self, i):
+        return self.u[(i + 1) & 1]
+
+    def sync(self):
+        e = self.engine
+        e._check(e.lib.cpmppi_comm_sync(e._h))
+
+    def close(self):
+        e = self.engine
+        if getattr(e, "_h", None) and e._h.value:
+            e.lib.cpmppi_comm_destroy(e._h)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CPMPPI_ABI_VERSION 1u
+#define CPMPPI_ABI_VERSION 2u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_* */
 #define CPMPPI_STATE_DIM 6u
 #define CPMPPI_MAX_HORIZON 1024u
 
@@ -51,7 +51,8 @@ typedef enum {
   CPMPPI_ERR_ABI = -2,          /* abi_version mismatch */
   CPMPPI_ERR_NO_DEVICE = -3,    /* no HIP device / not a gfx950 part */
   CPMPPI_ERR_HIP = -4,          /* a HIP runtime call failed (text in cpmppi_last_error) */
-  CPMPPI_ERR_ALIGN = -5         /* pointer not 4-byte aligned */
+  CPMPPI_ERR_ALIGN = -5,        /* pointer not 4-byte aligned */
+  CPMPPI_ERR_COMM = -6          /* RCCL missing or an RCCL call failed (text in cpmppi_last_error) */
 } cpmppi_status;
 
 /* cost_id: which in-tree cost formulation the rollout kernel evaluates. */
@@ -107,8 +108,9 @@ typedef struct {
   uint32_t correction_u;         /* CPMPPI_CORRECTION_*  */
   uint32_t math_mode;            /* CPMPPI_MATH_* */
   uint32_t rollouts_per_lane;    /* lane mapping of the FAST rollout kernel: 0 = automatic (2 for launches of
-                                    >= 393216 rollouts, else 1; measured crossover), 1 = one rollout per lane (lowest latency),
-                                    2 = two rollouts per lane as packed float2 (highest throughput) */
+                                    >= 131072 rollouts = one packed wave on every SIMD, else 1; measured crossover),
+                                    1 = one rollout per lane (lowest latency), 2 = two rollouts per lane as packed
+                                    float2 (highest throughput) */
 } cpmppi_config;
 
 typedef struct cpmppi_handle cpmppi_handle;
@@ -157,6 +159,10 @@ typedef struct {
                                        instead of `offset` and incremented by one after the step, stream-ordered.  With it a
                                        captured HIP graph of (step, plant, ...) can be replayed: no launch argument changes
                                        between control steps.  NULL = use `offset`. */
+  float* u_nom_out;                 /* [E,H] optional (ODE predictor): where the updated nominal sequence is written; `u_nom`
+                                       is then only read.  Two buffers used alternately let a consumer of step i's result
+                                       (the all-gather of cpmppi_comm_gather) overlap step i+1 without a snapshot copy.
+                                       NULL = in place (u_nom). */
 } cpmppi_step_args;
 
 int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out);
@@ -210,9 +216,13 @@ int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* args, void* stream);
 
 /* The fused step for a caller whose state lives on the HOST - the simulator's own call, controller.step(s, time,
  * updated_attributes) -> Q (CartPole/__init__.py:509-520): s0[E,6], target_position[E], target_equilibrium[E], L[E] (or
- * NULL) and Q[E] are HOST pointers, u_nom[E,H] stays a device buffer (the plan persists between control steps).  One
- * call = stage into the handle's pinned block, one asynchronous copy up, the launch with in-kernel Philox noise
- * (seed, offset, env_offset as in cpmppi_step_args), one copy down, a wait on the stream.  Synchronous by nature. */
+ * NULL) and Q[E] are HOST pointers, u_nom[E,H] stays a device buffer (the plan persists between control steps); in-kernel
+ * Philox noise (seed, offset, env_offset as in cpmppi_step_args).  Synchronous by nature.
+ *   up to 64 envs (CPMPPI_HOST_ZERO_COPY_MAX; the simulator's call is one): NO copy and NO stream wait - the inputs are
+ *     staged into the handle's pinned, device-mapped block, which the kernel reads directly; the env's finalizing block
+ *     stores Q into the same block and bumps a system-scope ticket the calling thread spins on (the stream is polled
+ *     every few thousand spins, so a failed launch returns CPMPPI_ERR_HIP instead of hanging);
+ *   more envs: one asynchronous copy up, the launch, one copy down, a wait on the stream. */
 int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float* target_position,
                      const float* target_equilibrium, const float* L, float* u_nom, uint64_t seed, uint64_t offset,
                      uint32_t env_offset, float* Q, void* stream);
@@ -292,10 +302,38 @@ int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q,
  * CartPole/__init__.py:659-735 appends one row per control period): Q_log[row][E] = Q and states_log[row + 1][E][6] =
  * the advanced state; either log may be NULL.  row = the control-step index, or, when row_dev is given, *row_dev - 1:
  * the device step counter of cpmppi_step_args.offset_dev, which the preceding cpmppi_step has already advanced (a
- * captured graph of control steps then replays without any changing launch argument). */
+ * captured graph of control steps then replays without any changing launch argument).  log_rows = the number of
+ * control periods the logs hold (Q_log[log_rows][E], states_log[log_rows + 1][E][6]): a host `row` >= log_rows is
+ * CPMPPI_ERR_BAD_ARG; a device counter that is still 0 or points past the logs advances the plant WITHOUT recording
+ * (a graph replayed beyond the recording's end never writes outside the buffers). */
 int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
-                                float dt_sim, float* states_log, float* Q_log, uint64_t row, const void* row_dev,
-                                void* stream);
+                                float dt_sim, float* states_log, float* Q_log, uint64_t log_rows, uint64_t row,
+                                const void* row_dev, void* stream);
+
+/* Multi-GPU (no reference counterpart - its only fan-out is share-nothing SLURM job arrays,
+ * others/EulerClusterScripts/ParallelDataGeneration.sh:2-17): one process per GPU, each owning a contiguous block of
+ * envs, and ONE all-gather of the chosen control sequences per step over RCCL / xGMI, enqueued from C on a high-priority
+ * side stream so that it runs under the NEXT step's rollout kernel:
+ *   cpmppi_comm_unique_id  rank 0: the 128-byte RCCL id every rank needs (distribute it by any means - a
+ *                          torch.distributed store, MPI, a file); rccl_path may be NULL (the RCCL already in the process,
+ *                          else librccl.so by name)
+ *   cpmppi_comm_init       collective over all ranks: creates the handle's communicator, side stream and events
+ *   cpmppi_comm_gather     after step i on `stream`: recv_all[world][count] <- all-gather of send[count] on the side stream,
+ *                          ordered after everything enqueued on `stream` so far; `stream` itself does not wait.  slot <
+ *                          CPMPPI_COMM_SLOTS names the completion event of this gather
+ *   cpmppi_comm_wait       `stream` waits (on the device) for the gather of `slot` - call it before the step that overwrites
+ *                          that gather's send buffer (with the two u_nom buffers of cpmppi_step_args.u_nom_out: two steps later)
+ *                          or before reading recv_all on `stream`
+ *   cpmppi_comm_sync       host wait for every gather enqueued so far
+ * Errors: CPMPPI_ERR_COMM.  RCCL is bound at run time: the library loads without it. */
+#define CPMPPI_COMM_ID_BYTES 128
+#define CPMPPI_COMM_SLOTS 4
+int cpmppi_comm_unique_id(void* id_out, const char* rccl_path);
+int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, const char* rccl_path);
+int cpmppi_comm_gather(cpmppi_handle* h, uint32_t slot, const float* send, float* recv_all, size_t count, void* stream);
+int cpmppi_comm_wait(cpmppi_handle* h, uint32_t slot, void* stream);
+int cpmppi_comm_sync(cpmppi_handle* h);
+int cpmppi_comm_destroy(cpmppi_handle* h);
 
 /* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */
 const char* cpmppi_version(void);

@@ -10,6 +10,8 @@ Every bound here is FIXED or derived from the ORACLE — never from the kernel's
     indicator threshold) are `flagged`; every unflagged rollout must be inside its allowance (100 %), flagged rollouts
     are counted and at most `FLAGGED_CAP` of them (never more than 0.5 % of all rollouts) may sit outside — a bounce or an
     indicator that fires one substep apart in two float32 evaluations is a legitimate, rare outcome of either one.
+    That allowance is for the RANDOM-instance tests only: on the reference-generated golden fixtures and step traces the
+    assertions run `strict` (cap 0: no rollout outside band + gap, flagged or not).
 
 Measured on MI355X (tools/dev/parity_buckets.py, all 8 x 1024 golden rollouts, both math modes and lane mappings): no
 rollout outside band + gap at all, flagged or not; worst clear rollout 0.32 bands; worst cost 2.9e-5 relative.
@@ -50,23 +52,25 @@ def flag_indicators(traj, cost, target_position, margin=2e-4):
     return flagged
 
 
-def _check(off, flagged, what):
+def _check(off, flagged, what, strict=False):
+    """strict: the flagged bucket gets NO allowance either (the golden fixtures and the reference's own step traces:
+    measured on MI355X, no rollout of theirs is outside band + gap, flagged or not — so none may be)."""
     n = off.size
     clear_off = int((off & ~flagged).sum())
     assert clear_off == 0, f"{what}: {clear_off} of {int((~flagged).sum())} rollouts clear of every discontinuity are outside the band"
     fl_off, fl = int((off & flagged).sum()), int(flagged.sum())
-    cap = min(int(np.ceil(FLAGGED_CAP * fl)), int(np.ceil(TOTAL_CAP * n)))
+    cap = 0 if strict else min(int(np.ceil(FLAGGED_CAP * fl)), int(np.ceil(TOTAL_CAP * n)))
     assert fl_off <= cap, f"{what}: {fl_off} of {fl} flagged rollouts outside the band (cap {cap})"
 
 
-def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0):
+def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0, strict=False):
     """out, ref_a, ref_b [N, 6] (or [N, k, 6]): inside band(ref_a) + |ref_a - ref_b| element-wise."""
     off = np.abs(out - ref_a) > band(ref_a, scale) + np.abs(ref_a - ref_b)
     off = off.reshape(off.shape[0], -1).any(axis=1)
-    _check(off, flagged, what)
+    _check(off, flagged, what, strict)
 
 
-def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False):
+def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False):
     """Per-rollout costs: |S - S_a| <= rtol |S_a| + |S_a - S_b| for every unflagged rollout.  flag_sensitive: a rollout on
     which the reference's OWN two arithmetic modes disagree by more than the band (|S_a - S_b| > rtol |S_a|: a chaotic
     trajectory that amplifies 1e-7 roundings beyond the tolerance) joins the flagged bucket - no evaluation in float32,
@@ -77,7 +81,7 @@ def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_s
     flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
     if flag_sensitive and S_b is not None:
         flagged = flagged | (gap > rtol * np.abs(S_a))
-    _check(off, flagged, what)
+    _check(off, flagged, what, strict)
 
 
 def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None):

@@ -1,5 +1,6 @@
 """CPU-only: the C-ABI library loads and exports every symbol include/cpmppi.h declares; host-side config logic."""
 import ctypes as C
+import sys
 import os
 import re
 
@@ -59,15 +60,15 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
         subprocess.run([gxx, "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cpmppi.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(cpmppi_config), sizeof(cpmppi_step_args), '
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cpmppi_config), sizeof(cpmppi_step_args), '
                    'sizeof(cpmppi_gru_model), offsetof(cpmppi_step_args, noise), offsetof(cpmppi_step_args, Q_out), '
-                   'offsetof(cpmppi_step_args, offset_dev)); return 0; }\n')
+                   'offsetof(cpmppi_step_args, offset_dev), offsetof(cpmppi_step_args, u_nom_out)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     A = _lib.cpmppi_step_args
     assert got == [C.sizeof(_lib.cpmppi_config), C.sizeof(A), C.sizeof(_lib.cpmppi_gru_model), A.noise.offset, A.Q_out.offset,
-                   A.offset_dev.offset]
+                   A.offset_dev.offset, A.u_nom_out.offset]
 
 
 def test_integration_doc_binding_matches_the_library():
@@ -184,3 +185,27 @@ def test_controller_reads_a_checkout():
     assert c.config_optimizer["cost_weights"]["db_weight_up"] == 10000 and c.has_optimizer
     with pytest.raises(ValueError):
         controller_mpc("Pendulum")
+
+
+def test_rollout_kernels_have_no_scratch_and_no_vgpr_spills():
+    """Round 1 lost 4 % (Philox) / 15 % (buffer mode) of the hot kernel to a 28-byte private slot per lane that a compiler
+    pass had introduced silently.  The bench line cannot see that (its traffic figure comes from a committed profile), so
+    the BUILT library is inspected: every instantiation of rollout_cost_kernel — and the GRU rollout kernels — must have
+    .private_segment_fixed_size == 0 and no VGPR spills in the code object's metadata."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import code_objects
+    if not os.path.exists(os.path.join(code_objects.LLVM_BIN, "llvm-readelf")):
+        pytest.skip("no llvm-readelf")
+    from cartpolesimulation_amd import _lib
+    ks = [k for k in code_objects.kernels(_lib.LIB_PATH) if "rollout_cost_kernel" in k["name"]]
+    hot = [k for k in ks if "19rollout_cost_kernel" in k["name"]]
+    # 4 costs x 4 noise sources x (latency R1, throughput R1 fast + precise, throughput R2, mid R2)
+    assert len(hot) == 4 * 4 * 5, len(hot)
+    bad = [(k["name"], k["private_segment_fixed_size"], k["vgpr_spill_count"]) for k in ks
+           if k["private_segment_fixed_size"] != 0 or k["vgpr_spill_count"] != 0]
+    assert not bad, bad
+    # the headline kernel (quadratic_boundary_grad_minimal, FAST, Philox, two rollouts per lane, throughput build) must
+    # keep four waves per SIMD (512 registers / 128)
+    for k in hot:
+        if "kernelILi0ELb1ELi2ELi2ELi1E" in k["name"]:
+            assert k["vgpr_count"] + k["agpr_count"] <= 128, (k["name"], k["vgpr_count"])

@@ -397,3 +397,106 @@ def test_step_host_equals_step():
     with pytest.raises(ValueError):
         eng.step_host(s0, eng.zeros(E, H), tp[:2], te, None, 1, 0, np.empty(E, f32))
     eng.close()
+
+
+def test_step_host_zero_copy_and_copy_paths_agree():
+    """cpmppi_step_host has two routes: up to 64 envs the kernel reads the pinned block directly and the caller spins on
+    a system-scope ticket (no copies, no stream wait); above, one copy each way and a stream wait.  Same controls, bit
+    for bit, and the same as the device-pointer entry point; many calls in a row (the ticket is a running counter)."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    N, H = 256, 10
+    rng = Generator(SFC64(31))
+    for E in (1, 64, 65, 130):
+        eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H))
+        s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.1) for _ in range(E)])
+        tp, te = rng.uniform(-0.05, 0.05, E).astype(f32), np.ones(E, f32)
+        Lv = rng.uniform(0.3, 0.45, E).astype(f32)
+        ua, ub = eng.zeros(E, H), eng.zeros(E, H)
+        for it in range(40):
+            q = np.full(E, np.nan, f32)
+            eng.step_host(s0, ua, tp, te, Lv, 5, it, q)
+            Qd, _ = eng.step(s0, ub, tp, te, L=Lv, seed=5, offset=it)
+            assert np.array_equal(q, Qd.cpu().numpy()), (E, it)
+            s0[:, 4] += 0.001 * q                                   # the next call sees a different host state
+        assert torch.equal(ua, ub)
+        eng.close()
+
+
+def test_u_nom_out_leaves_the_input_untouched():
+    """cpmppi_step_args.u_nom_out: the updated sequence goes to the second buffer, u_nom is only read; same values as the
+    in-place step, for every noise source and for the GRU path's separate finalize kernel."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, N, H = 3, 512, 20
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H))
+    rng = Generator(SFC64(41))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.1) for _ in range(E)])
+    tp, te = rng.uniform(-0.05, 0.05, E).astype(f32), np.ones(E, f32)
+    u0 = (0.2 * rng.standard_normal((E, H))).astype(f32)
+    kn, du = eng.sample(seed=3, offset=1, delta_u=True)
+    for kw in (dict(seed=3, offset=1), dict(knots=kn), dict(delta_u=du), dict(delta_u_tiled=eng.tile_delta_u(du))):
+        a, b_in, b_out = eng.tensor(u0.copy()), eng.tensor(u0.copy()), eng.zeros(E, H)
+        Qa, _ = eng.step(s0, a, tp, te, **kw)
+        Qb, _ = eng.step(s0, b_in, tp, te, u_nom_out=b_out, **kw)
+        assert torch.equal(a, b_out) and torch.equal(Qa, Qb) and np.array_equal(b_in.cpu().numpy(), u0), list(kw)
+    with pytest.raises(ValueError):
+        eng.step(s0, eng.tensor(u0.copy()), tp, te, seed=1, u_nom_out=eng.zeros(E, H + 1))
+    eng.close()
+
+
+def test_native_gather_one_rank():
+    """cpmppi_comm_*: the library's own RCCL communicator with world = 1 (what a 1-GPU box can run): unique id,
+    communicator, the per-step all-gather from the two alternating u_nom buffers on the side stream — same controls as
+    the in-place loop, bit for bit, and every gathered block equals the buffer it was taken from."""
+    import ctypes as C
+    from cartpolesimulation_amd import _lib as L
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.shard import NativeGather
+    E, N, H = 6, 512, 16
+    eng, ref = (MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H)) for _ in range(2))
+    uid = C.create_string_buffer(L.COMM_ID_BYTES)
+    assert eng.lib.cpmppi_comm_unique_id(uid, None) == 0, eng.lib.cpmppi_last_error(None)
+    g = NativeGather(eng, uid.raw, 1, 0)
+    assert eng.lib.cpmppi_comm_init(eng._h, uid.raw, 1, 0, None) == -1          # one communicator per handle
+    rng = Generator(SFC64(51))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.1) for _ in range(E)])
+    tp, te = rng.uniform(-0.05, 0.05, E).astype(f32), np.ones(E, f32)
+    u_ref = ref.zeros(E, H)
+    for i in range(9):
+        g.before_step(i)
+        eng.step(s0, g.u_in(i), tp, te, seed=2, offset=i, u_nom_out=g.u_out(i))
+        g.after_step(i)
+        ref.step(s0, u_ref, tp, te, seed=2, offset=i)
+        g.sync()
+        torch.cuda.synchronize()
+        assert torch.equal(g.u_out(i), u_ref), i
+        assert torch.equal(g.gathered[(i + 1) & 1].view(E, H), u_ref), i
+    assert eng.lib.cpmppi_comm_gather(eng._h, 9, g.u[0].data_ptr(), g.gathered[0].data_ptr(), E * H, None) == -1   # slot out of range
+    g.close()
+    assert eng.lib.cpmppi_comm_gather(eng._h, 0, g.u[0].data_ptr(), g.gathered[0].data_ptr(), E * H, None) == -1   # no communicator
+    eng.close(); ref.close()
+
+
+def test_failed_step_leaves_the_event_recorder_intact():
+    """A step that fails validation while profiling is on (GRU requested without a model) must not leave a half-recorded
+    bracket: the steps before and after it are still reported."""
+    from cartpolesimulation_amd import _lib as L
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, N, H = 2, 256, 10
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H))
+    s0 = np.stack([O.create_cartpole_state(0.1, 0.0, 0.0, 0.0)] * E)
+    u = eng.zeros(E, H)
+    for group in (1, 2):
+        eng.set_profiling(True, group=group)
+        eng.step(s0, u, 0.0, 1.0, seed=1, offset=0)
+        eng.step(s0, u, 0.0, 1.0, seed=1, offset=1)
+        with pytest.raises(L.CpmppiError):
+            eng.step(s0, u, 0.0, 1.0, seed=1, offset=2, predictor="GRU")
+        eng.step(s0, u, 0.0, 1.0, seed=1, offset=3)
+        eng.step(s0, u, 0.0, 1.0, seed=1, offset=4)
+        r, _ = eng.get_profile()
+        assert len(r) == 4 // group and (r > 0).all(), (group, r)
+    eng.close()

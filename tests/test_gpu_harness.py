@@ -144,4 +144,22 @@ def test_plant_advance_records_in_the_same_launch():
     with pytest.raises(IndexError):
         eng.plant_advance(logged, Qs[0], states_log=states_log, Q_log=Q_log, row=T)
     eng.plant_advance(logged, Qs[0], states_log=None, Q_log=Q_log, row=T - 1)          # either log alone
+    # a device counter outside the recording (one replay too many, a counter still at 0) advances the plant but writes
+    # NOTHING: the logs sit in the middle of a guarded allocation whose borders must stay untouched
+    guard = torch.full((3 * (T + 1) * E * 6,), 7.0, device=plain.device)
+    mid = guard[(T + 1) * E * 6:2 * (T + 1) * E * 6].view(T + 1, E, 6)
+    qguard = torch.full((3 * T * E,), 7.0, device=plain.device)
+    qmid = qguard[T * E:2 * T * E].view(T, E)
+    for c in (0, T + 1, T + 5, 2 ** 40):
+        counter.fill_(c)
+        before = by_counter.clone()
+        eng.plant_advance(by_counter, Qs[0], states_log=mid, Q_log=qmid, row_dev=counter)
+        assert not torch.equal(before, by_counter)            # the plant itself advanced
+        assert float((guard - 7.0).abs().max()) == 0.0 and float((qguard - 7.0).abs().max()) == 0.0, c
+    counter.fill_(T)                                          # the last valid row is still recorded
+    eng.plant_advance(by_counter, Qs[0], states_log=mid, Q_log=qmid, row_dev=counter)
+    assert torch.equal(mid[T], by_counter) and np.array_equal(qmid[T - 1].cpu().numpy(), Qs[0])
+    lib_rc = eng.lib.cpmppi_plant_advance_record(eng._h, E, by_counter.data_ptr(), eng.tensor(Qs[0]).data_ptr(), None, 10, 0.002,
+                                                 mid.data_ptr(), qmid.data_ptr(), T, T, None, eng._stream())
+    assert lib_rc == -1                                       # a host row outside the logs is refused by the C entry point too
     eng.close()

@@ -61,7 +61,7 @@ def test_step_traces_of_the_reference_class(golden_dir, shape, math_mode):
         S_b, _ = O.legacy_rollout_costs(g["s_seq"][it], u_before, du, u_prev_before, f32(g["target"]), cfg, mode="f64sub")
         _, traj = O.legacy_rollout_costs(g["s_seq"][it], u_before, du, u_prev_before, f32(g["target"]), cfg)
         fl = PU.flag_discontinuities(traj) | PU.flag_indicators(traj, "legacy", float(g["target"]))
-        PU.assert_costs(ctrl.S_tilde_k, g["S"][it], S_b, fl, f"{shape} step {it} S_tilde_k")
+        PU.assert_costs(ctrl.S_tilde_k, g["S"][it], S_b, fl, f"{shape} step {it} S_tilde_k", strict=True)
 
 
 @pytest.mark.parametrize("math_mode", ["precise", "fast"])

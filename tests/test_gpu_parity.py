@@ -55,10 +55,10 @@ def test_predict_single_step_kats(golden_dir, math_mode):
     # rows the reference itself takes through a bounce or to the +-pi seam within these two control steps are flagged
     both = np.stack([s, g["step1_A"], g["step2_A"]], axis=1)
     flagged = PU.flag_discontinuities(both)
-    PU.assert_states(out1, g["step1_A"], g["step1_B"], flagged, "one control step", scale=0.1)     # a tenth of the band
+    PU.assert_states(out1, g["step1_A"], g["step1_B"], flagged, "one control step", scale=0.1, strict=True)     # a tenth of the band
     eng2 = engine(1, 256, 2, math_mode=math_mode)
     out2 = eng2.predict(s, np.stack([Q, Q], 1), L=L)[:, 2].cpu().numpy()
-    PU.assert_states(out2, g["step2_A"], g["step2_B"], flagged, "two control steps", scale=0.2)
+    PU.assert_states(out2, g["step2_A"], g["step2_B"], flagged, "two control steps", scale=0.2, strict=True)
     # one substep: run with dt = 0.002, S = 1 through a dedicated engine
     eng3 = engine(1, 256, 1, math_mode=math_mode, mpc_timestep=0.002, intermediate_steps=1)
     sub = eng3.predict(s, Q[:, None], L=L)[:, 1].cpu().numpy()
@@ -84,10 +84,10 @@ def test_c2_rollouts_costs_update(golden_dir, name, math_mode):
     assert np.array_equal(ref_traj[:, -1], final) or np.abs(ref_traj[:, -1] - final).max() < 2e-6
     flagged = PU.flag_discontinuities(ref_traj)
     # final states after 50 control steps: every clear rollout inside the band around the reference's [A, B] interval
-    PU.assert_states(traj[:, -1], final, final_B, flagged, f"{name} final states")
+    PU.assert_states(traj[:, -1], final, final_B, flagged, f"{name} final states", strict=True)
     # ... and the whole first half of the horizon for the rollouts the golden holds in full
     nh = head.shape[0]
-    PU.assert_states(traj[:nh, :H // 2], head[:, :H // 2], ref_traj_B[:nh, :H // 2], flagged[:nh], f"{name} trajectory heads")
+    PU.assert_states(traj[:nh, :H // 2], head[:, :H // 2], ref_traj_B[:nh, :H // 2], flagged[:nh], f"{name} trajectory heads", strict=True)
 
     # ---- cost seam on the ORACLE's trajectories (isolates the cost arithmetic from integration differences)
     for cost_name, key in (("quadratic_boundary_grad_minimal", "S_qbgm"), ("default", "S_default")):
@@ -110,7 +110,7 @@ def test_c2_rollouts_costs_update(golden_dir, name, math_mode):
         uc = np.clip(u_run, -1, 1).astype(f32) if control_mode == "clip" else u_run
         tr_a, tr_b = O.predict_core(s0, uc), O.predict_core(s0, uc, mode="f64sub")
         S_b = O.trajectory_cost(O.COST_QBGM, tr_b, uc, f32(target), f32(1.0))
-        PU.assert_costs(S, S_ref, S_b, PU.flag_discontinuities(tr_a), f"{name}/{tag} S_qbgm")
+        PU.assert_costs(S, S_ref, S_b, PU.flag_discontinuities(tr_a), f"{name}/{tag} S_qbgm", strict=True)
         u_new_ref = u_nom + O.reward_weighted_average(S_ref, du)
         if control_mode == "clip":
             u_new_ref = np.clip(u_new_ref, -1, 1)
@@ -129,7 +129,7 @@ def test_c2_rollouts_costs_update(golden_dir, name, math_mode):
     S_b = O.legacy_rollout_costs(s0, u_nom, du, u_prev, f32(target), cfg_l, mode="f64sub")
     S_b = S_b[0] if isinstance(S_b, tuple) else S_b
     fl = PU.flag_discontinuities(ref_traj) | PU.flag_indicators(ref_traj, "legacy", target)
-    PU.assert_costs(S, S_ref, S_b, fl, f"{name} S_legacy")
+    PU.assert_costs(S, S_ref, S_b, fl, f"{name} S_legacy", strict=True)
     np.testing.assert_allclose(un.cpu().numpy()[0], g[f"{name}/u_new_legacy"], atol=1e-4)
 
 
@@ -343,7 +343,7 @@ def test_legacy_controller_step_traces(golden_dir, shape, math_mode, rpl):
         S_b, _ = O.legacy_rollout_costs(s, u_host, du, u_prev.cpu().numpy()[0], f32(target), cfg, mode="f64sub")
         _, traj = O.legacy_rollout_costs(s, u_host, du, u_prev.cpu().numpy()[0], f32(target), cfg)
         fl = PU.flag_discontinuities(traj) | PU.flag_indicators(traj, "legacy", target)
-        PU.assert_costs(S.cpu().numpy()[0], g["S"][it], S_b, fl, f"{shape} step {it} S")
+        PU.assert_costs(S.cpu().numpy()[0], g["S"][it], S_b, fl, f"{shape} step {it} S", strict=True)
         np.testing.assert_allclose(un.cpu().numpy()[0], g["u_updated"][it], atol=1e-4)
         Q = f32(Qd.cpu().numpy()[0] * (1 + float(g["p_Q"]) * rng.uniform(-1.0, 1.0)))      # :553
         np.testing.assert_allclose(np.clip(Q, f32(-1), f32(1)), g["Q"][it], atol=1e-4)
