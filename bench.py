@@ -208,6 +208,7 @@ class Workload:
         W = ctx["world"]
         coll = ctx["collective"]
         self.native, self.collective_impl = None, None
+        self.collective_events = os.environ.get("CPMPPI_BENCH_COLLECTIVE") == "native-events"
         self.gathered = self.snapshot = None
         self.pending = [None, None]
         self.prepared = None
@@ -223,7 +224,7 @@ class Workload:
         E, H, rank = self.E, self.H, self.ctx["rank"]
         Workload._serial += 1
         ok, why = 1, ""
-        if os.environ.get("CPMPPI_BENCH_COLLECTIVE", "native") != "native" or self.ctx["backend"] != "nccl":
+        if os.environ.get("CPMPPI_BENCH_COLLECTIVE", "native") not in ("native", "native-events") or self.ctx["backend"] != "nccl":
             ok, why = 0, "torch.distributed requested (CPMPPI_BENCH_COLLECTIVE / non-RCCL backend)"
         else:
             try:
@@ -234,7 +235,10 @@ class Workload:
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if self.ctx["backend"] == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
         if int(flag.item()) == 1:
-            self.collective_impl = "cpmppi_comm_gather: ncclAllGather on the library's side stream, one per step"
+            self.collective_impl = ("cpmppi_comm_gather: ncclAllGather on the library's side stream, ordered with HIP events"
+                                    if self.collective_events else
+                                    "cpmppi_step_gather: one ncclAllGather per step on the library's side stream, ordered with "
+                                    "the rollout kernel through device memory")
             self.u_nom = None                            # (the two buffers live in self.native.u)
             return
         if self.native is not None:
@@ -253,21 +257,27 @@ class Workload:
         e, rank = self.eng, self.ctx["rank"]
         if self.native is not None:
             g = self.native
-            g.before_step(i)                             # (device-side: the gather that still reads the buffer written now)
-            uin, uout = g.u_in(i), g.u_out(i)
+            uin, uout, recv = g.u_in(i), g.u_out(i), g.recv(i)
+            ev = self.collective_events                  # development aid: the HIP-event form of the same ordering
+            if ev:
+                g.before_step(i)
+                recv = None
             if self.noise == "buffer-ref":
                 e._check(e.lib.cpmppi_sample(e._h, self.E, self.seed, i, rank * self.E, None, self.du.data_ptr(), e._stream()))
-                e.step(self.s0, uin, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=self.Q_out, u_nom_out=uout, **self.pred_kw)
+                e.step(self.s0, uin, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=self.Q_out, u_nom_out=uout,
+                       gather_into=recv, **self.pred_kw)
             elif self.noise == "buffer":
                 e.sample_tiled(self.seed, i, rank * self.E, E=self.E, out=self.du)
-                e.step(self.s0, uin, self.tp, self.te, L=self.L, delta_u_tiled=self.du, Q_out=self.Q_out, u_nom_out=uout)
+                e.step(self.s0, uin, self.tp, self.te, L=self.L, delta_u_tiled=self.du, Q_out=self.Q_out, u_nom_out=uout,
+                       gather_into=recv)
             else:
                 if self.prepared is None:                # argument blocks built once: the pointers only alternate
                     self.prepared = [e.prepare_step(self.s0, g.u[b], self.tp, self.te, L=self.L, seed=self.seed, offset=0,
                                                     env_offset=rank * self.E, Q_out=self.Q_out, u_nom_out=g.u[1 - b],
                                                     **self.pred_kw) for b in range(2)]
-                self.prepared[i & 1].run(offset=i)
-            g.after_step(i)
+                self.prepared[i & 1].run(offset=i, gather_into=recv)
+            if ev:
+                g.after_step(i)
             return
         if self.noise == "buffer-ref":
             e._check(e.lib.cpmppi_sample(e._h, self.E, self.seed, i, rank * self.E, None, self.du.data_ptr(), e._stream()))

@@ -20,7 +20,8 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
-           "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy")
+           "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
+           "cpmppi_step_gather")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -117,6 +118,7 @@ def load():
     lib.cpmppi_comm_wait.argtypes = [vp, u32, vp]
     lib.cpmppi_comm_sync.argtypes = [vp]
     lib.cpmppi_comm_destroy.argtypes = [vp]
+    lib.cpmppi_step_gather.argtypes = [vp, C.POINTER(cpmppi_step_args), vp, vp]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

@@ -12,6 +12,7 @@
 //   trajectory_cost_kernel                cost seam on materialised trajectories.
 //   rwa_kernel                            a16 on given (S, delta_u).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,8 +46,8 @@ namespace {
 template <bool KNOT_SPACE>
 __global__ __launch_bounds__(BLOCK) void finalize_kernel(const Params p, const float* __restrict__ partial,
                                                          uint32_t nb, uint32_t W, const float* u_nom, float* u_nom_out,
-                                                         float* __restrict__ Q_out) {
-  finalize_env<KNOT_SPACE, false>(p, partial, nb, W, u_nom, u_nom_out, Q_out, blockIdx.x);
+                                                         float* __restrict__ Q_out, const GatherSync gs) {
+  finalize_env<KNOT_SPACE, false>(p, partial, nb, W, u_nom, u_nom_out, Q_out, blockIdx.x, nullptr, gs);
 }
 
 // a17: knots[E,N,P] and/or delta_u[E,N,H].  One lane draws (or loads) the knots of one rollout into LDS; the wave then
@@ -816,6 +817,7 @@ struct cpmppi_handle {
   float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
   float* host_stage = nullptr;         // pinned [cfg.E * 10 + 16]: staging of cpmppi_step_host (state 6, target, equilibrium, L | Q | ticket)
   uint32_t host_ticket_value = 0;      // what the ticket in that block reads once every launch so far has delivered
+  double host_t[4] = {0, 0, 0, 0};     // development aid (cpmppi_debug_host_times): sums of staging / launch / wait seconds, calls
   uint32_t host_zero_copy_max = 64;    // up to this many envs cpmppi_step_host runs without copies and stream waits (CPMPPI_HOST_ZERO_COPY_MAX)
   float* dev_stage = nullptr;          // device [cfg.E * 10], allocated on first use
   float* gru_image = nullptr;          // device copy of the LDS fragment image (cpmppi_set_gru)
@@ -1165,11 +1167,31 @@ int cpmppi_trajectory_cost(cpmppi_handle* h, uint32_t B, uint32_t horizon, const
   return CPMPPI_OK;
 }
 
-static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, uint32_t* host_ticket);
+static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, uint32_t* host_ticket,
+                     const cpmppi_comm::GatherTicket* gather = nullptr);
 
 int cpmppi_step(cpmppi_handle* h, const cpmppi_step_args* a, void* stream) { return step_impl(h, a, stream, nullptr); }
 
-static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, uint32_t* host_ticket) {
+// The step and the all-gather of its result in ONE call (contract in cpmppi.h; mechanism in cpmppi_comm.hip): the launch
+// stream gets the rollout kernel and nothing else; the side stream gets waiter -> ncclAllGather -> post.
+int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* a, float* recv_all, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (!a || !recv_all) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: null argument");
+  if (!h->comm) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: no communicator (cpmppi_comm_init)");
+  if (a->E == 0 || a->E > h->cfg.E || !a->u_nom) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: bad step arguments");
+  const bool in_place = !a->u_nom_out || a->u_nom_out == a->u_nom;
+  cpmppi_comm::GatherTicket t;
+  cpmppi_comm::begin_step_gather(h->comm, in_place ? a->u_nom : a->u_nom_out, &t);
+  const int rc = step_impl(h, a, stream, nullptr, &t);
+  if (rc != CPMPPI_OK) {
+    cpmppi_comm::abort_step_gather(h->comm);
+    return rc;
+  }
+  return cpmppi_comm::enqueue_gather(h, in_place ? a->u_nom : a->u_nom_out, recv_all, (size_t)a->E * h->cfg.H);
+}
+
+static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, uint32_t* host_ticket,
+                     const cpmppi_comm::GatherTicket* gather) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (!a) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: null args");
   if (a->E == 0 || a->E > h->cfg.E) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: E out of range");
@@ -1212,6 +1234,7 @@ static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, 
   p.S_out = a->S_out; p.partial = h->workspace;
   p.counter = nullptr; p.u_nom_out = a->u_nom_out ? a->u_nom_out : a->u_nom; p.Q_out = a->Q_out;
   p.host_ticket = host_ticket;
+  p.gs = gather ? GatherSync{gather->flags, gather->publish, gather->need, a->E} : GatherSync{nullptr, 0u, 0u, 0u};
   hipEvent_t* ev = nullptr;
   const uint32_t group_pos = h->profile_every ? h->profile_count++ % h->profile_every : 0;
   const bool grouped = h->profile_every > 1;
@@ -1270,10 +1293,10 @@ static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, 
   if (separate_finalize) {
     if (du_space)
       hipLaunchKernelGGL(finalize_kernel<false>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
-                         p.nb, p.W, (const float*)a->u_nom, p.u_nom_out, a->Q_out);
+                         p.nb, p.W, (const float*)a->u_nom, p.u_nom_out, a->Q_out, p.gs);
     else
       hipLaunchKernelGGL(finalize_kernel<true>, dim3(a->E), dim3(BLOCK), 0, s, h->prm, (const float*)h->workspace,
-                         p.nb, p.W, (const float*)a->u_nom, p.u_nom_out, a->Q_out);
+                         p.nb, p.W, (const float*)a->u_nom, p.u_nom_out, a->Q_out, p.gs);
   }
   CPMPPI_HIP(h, hipGetLastError());
   if (p.offset_dev) {
@@ -1301,6 +1324,7 @@ int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float*
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (E == 0 || E > h->cfg.E || !s0 || !target_position || !target_equilibrium || !u_nom || !Q)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_host: bad argument");
+  const auto tp0 = std::chrono::steady_clock::now();
   CPMPPI_ON_DEVICE(h);
   // pinned, fine-grained, device-mapped block: [cfg.E * 10 floats: state 6, target, equilibrium, L | Q][ticket]
   const size_t cap = (size_t)h->cfg.E * 10;
@@ -1323,10 +1347,12 @@ int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float*
     // block and bumps a system-scope ticket; this thread spins on the ticket (a stream wait is an interrupt + a thread
     // wake-up: ~15 us of an 80 us control step).  The stream is polled now and then so that a failed launch cannot hang the caller.
     uint32_t* ticket = reinterpret_cast<uint32_t*>(hs + cap);
+    const auto tp1 = std::chrono::steady_clock::now();
     a.s0 = hs; a.target_position = hs + 6 * E; a.target_equilibrium = hs + 7 * E; a.L = hs + 8 * E; a.Q_out = hs + 9 * E;
     const uint32_t target = (h->host_ticket_value += E);
     const int rc = step_impl(h, &a, stream, ticket);
     if (rc != CPMPPI_OK) { h->host_ticket_value -= E; return rc; }
+    const auto tp2 = std::chrono::steady_clock::now();
     for (uint32_t spins = 1;; ++spins) {
       if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == target) break;
       __builtin_ia32_pause();
@@ -1341,6 +1367,11 @@ int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float*
       }
     }
     memcpy(Q, hs + 9 * E, (size_t)E * sizeof(float));
+    const auto tp3 = std::chrono::steady_clock::now();
+    h->host_t[0] += std::chrono::duration<double>(tp1 - tp0).count();
+    h->host_t[1] += std::chrono::duration<double>(tp2 - tp1).count();
+    h->host_t[2] += std::chrono::duration<double>(tp3 - tp2).count();
+    h->host_t[3] += 1.0;
     return CPMPPI_OK;
   }
   if (!h->dev_stage) CPMPPI_HIP(h, hipMalloc((void**)&h->dev_stage, cap * sizeof(float)));
@@ -1352,6 +1383,17 @@ int cpmppi_step_host(cpmppi_handle* h, uint32_t E, const float* s0, const float*
   CPMPPI_HIP(h, hipMemcpyAsync(hs + 9 * E, d + 9 * E, (size_t)E * sizeof(float), hipMemcpyDeviceToHost, st));
   CPMPPI_HIP(h, hipStreamSynchronize(st));
   memcpy(Q, hs + 9 * E, (size_t)E * sizeof(float));
+  return CPMPPI_OK;
+}
+
+// development aid (tools/dev/seam_latency.py; not part of the contract): mean seconds per zero-copy cpmppi_step_host call
+// spent staging the inputs, inside the launch call, and spinning on the ticket; the number of calls; resets the sums
+int cpmppi_debug_host_times(cpmppi_handle* h, double out[4]) {
+  if (!h || !out) return CPMPPI_ERR_BAD_ARG;
+  const double n = h->host_t[3] > 0 ? h->host_t[3] : 1.0;
+  for (int i = 0; i < 3; ++i) out[i] = h->host_t[i] / n;
+  out[3] = h->host_t[3];
+  for (double& v : h->host_t) v = 0.0;
   return CPMPPI_OK;
 }
 

@@ -4,16 +4,22 @@
 // The reference has no counterpart: its only fan-out is share-nothing SLURM job arrays
 // (others/EulerClusterScripts/ParallelDataGeneration.sh:2-17), i.e. zero communication cost — which is the bar: the
 // gather must not show in the step time.  Envs are independent, so step i+1 never needs step i's gathered result; the
-// gather of step i therefore runs on a high-priority side stream UNDER step i+1's rollout kernel:
+// gather of step i therefore runs on a high-priority side stream UNDER step i+1's rollout kernel, straight from one of
+// the two nominal-sequence buffers of cpmppi_step_args.u_nom_out (no snapshot copy):
 //
 //   launch stream :  step i (reads B[i&1], writes B[(i+1)&1]) | step i+1 (reads B[(i+1)&1], writes B[i&1]) | ...
-//   side stream   :                         wait(ready i) -> ncclAllGather(B[(i+1)&1] -> G[slot]) -> record(done[slot])
+//   side stream   :            wait until step i is published -> ncclAllGather(B[(i+1)&1] -> G) -> post "gather i done"
 //
-// with the two nominal-sequence buffers of cpmppi_step_args.u_nom_out (no snapshot copy) and, per step, one event record
-// on the launch stream, one cross-stream wait, one RCCL call and one event record on the side stream — all issued from
-// C through this entry point (the per-step cost of torch.distributed's Work objects and stream guards driven from Python
-// was 33 us next to a 91 us kernel at BASELINE configs[3]).  The launch stream waits on done[slot] only before the
-// step that overwrites the gathered buffer again (two steps later).
+// Two ways to order the two streams:
+//   * cpmppi_step_gather (the production path): through DEVICE MEMORY.  The env-finalizing blocks of the rollout kernel
+//     count themselves; the last one publishes the step number (agent-scope release).  On the side stream a one-lane
+//     kernel waits for that number, the all-gather follows in stream order, a second one-lane kernel posts the number
+//     of completed gathers, which the finalize of the step that overwrites the gathered buffer (two steps later) checks
+//     before its stores.  The launch stream carries the rollout kernels and NOTHING else: an event record or a
+//     cross-stream wait is a barrier packet the next dispatch has to queue behind - measured 4-5 us each next to a 91 us
+//     kernel at BASELINE configs[3] (torch.distributed's snapshot copy + Work object + two waits per step: 33 us).
+//     Every device-side wait gives up after ~2 s and raises an error flag (cpmppi_comm_sync reports it).
+//   * cpmppi_comm_gather / cpmppi_comm_wait: HIP events, for buffers that are not produced by cpmppi_step.
 //
 // RCCL is bound at run time (dlopen) so that libcpmppi.so loads on hosts without it and, inside a PyTorch process,
 // binds to the RCCL torch itself has loaded.
@@ -83,7 +89,31 @@ struct CommState {
   hipEvent_t ready = nullptr;           // launch stream -> side stream: the step whose result is gathered has been enqueued
   hipEvent_t done[SLOTS] = {};          // side stream -> launch stream: the gather of this slot has completed
   bool pending[SLOTS] = {};
+  // cpmppi_step_gather: ordering through device memory instead of events (no packet on the launch stream)
+  unsigned* flags = nullptr;            // [0] envs finalized, [1] steps published, [2] gathers completed, [3] error
+  unsigned gather_index = 0;            // step_gathers enqueued so far
+  const float* last_send = nullptr;     // the buffer the previous step_gather's all-gather reads
 };
+
+// side stream, one lane: hold the stream until the rollout kernel's last finalizing block has published step `need`
+// (finalize_env, cpmppi_rollout.hpp).  Gives up after ~2 s and raises the error flag: a launch that never comes must not
+// wedge the queue.
+__global__ void wait_published_kernel(unsigned* flags, unsigned need) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while ((int)(__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+      __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+
+// side stream, after the all-gather: gathers completed = value (read by the finalize of the step that overwrites the
+// gathered buffer next)
+__global__ void post_gathered_kernel(unsigned* flags, unsigned value) {
+  __hip_atomic_store(flags + 2, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 void destroy(CommState* c) {
   if (!c) return;
@@ -92,9 +122,21 @@ void destroy(CommState* c) {
   if (c->ready) (void)hipEventDestroy(c->ready);
   for (hipEvent_t e : c->done)
     if (e) (void)hipEventDestroy(e);
+  if (c->flags) (void)hipFree(c->flags);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
+
+// Gather number g (0-based) publishes steps = g + 1.  The buffer this step writes was last read by the all-gather two
+// steps back when the caller alternates two buffers (completed once gathers >= g - 1); when the step writes the very
+// buffer the previous gather reads (in place, or the same output twice in a row) that one must be complete (>= g).
+void begin_step_gather(CommState* c, const float* out_buffer, GatherTicket* out) {
+  const unsigned g = c->gather_index;
+  out->flags = c->flags;
+  out->publish = g + 1u;
+  out->need = (out_buffer == c->last_send) ? g : (g >= 1u ? g - 1u : 0u);
+}
+void abort_step_gather(CommState*) {}
 
 struct OnDevice {                       // (the handle's device for the duration of a call; the caller's restored after)
   int prev = -1;
@@ -160,6 +202,9 @@ int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, cons
   if (const char* ev = getenv("CPMPPI_COMM_READY_FENCE")) if (ev[0] == '1') ready_flags = hipEventDisableTiming;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, ready_flags);
   for (int i = 0; i < SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->flags, 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(c->flags, 0, 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     destroy(c);
     return cpmppi_internal_fail(h, CPMPPI_ERR_HIP, std::string("cpmppi_comm_init: ") + hipGetErrorString(e));
@@ -201,6 +246,12 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
   OnDevice guard(cpmppi_internal_device(h));
   COMM_HIP(h, hipStreamSynchronize(c->side));
   for (bool& p : c->pending) p = false;
+  unsigned f[4] = {0, 0, 0, 0};
+  COMM_HIP(h, hipMemcpy(f, c->flags, sizeof(f), hipMemcpyDeviceToHost));
+  if (f[3] != 0u) {
+    (void)hipMemset(c->flags + 3, 0, sizeof(unsigned));
+    return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, "cpmppi_comm_sync: a device-side wait between a step and its all-gather timed out");
+  }
   return CPMPPI_OK;
 }
 
@@ -216,3 +267,21 @@ int cpmppi_comm_destroy(cpmppi_handle* h) {
 }
 
 }  // extern "C"
+
+namespace cpmppi_comm {
+
+int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t count) {
+  CommState* c = cpmppi_internal_comm(h);
+  OnDevice guard(cpmppi_internal_device(h));
+  const unsigned g = c->gather_index;
+  hipLaunchKernelGGL(wait_published_kernel, dim3(1), dim3(1), 0, c->side, c->flags, g + 1u);
+  COMM_HIP(h, hipGetLastError());
+  COMM_NCCL(h, g_rccl.AllGather(send, recv_all, count, ncclFloat, c->comm, c->side));
+  hipLaunchKernelGGL(post_gathered_kernel, dim3(1), dim3(1), 0, c->side, c->flags, g + 1u);
+  COMM_HIP(h, hipGetLastError());
+  c->gather_index = g + 1u;
+  c->last_send = send;
+  return CPMPPI_OK;
+}
+
+}  // namespace cpmppi_comm

@@ -28,6 +28,28 @@ constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per wo
 constexpr int TK = CPMPPI_TK;                // time-steps per LDS perturbation tile
 constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
 
+// Device-side ordering between a step and the all-gather of its result (cpmppi_step_gather, cpmppi_comm.hip) without any
+// packet on the launch stream: flags[0] envs finalized by this launch, flags[1] steps published, flags[2] gathers
+// completed (written by the side stream), flags[3] a spin gave up (error).
+struct GatherSync {
+  uint32_t* flags;      // NULL = no gather follows this step
+  uint32_t publish;     // value of flags[1] once every env of this launch has written its nominal sequence
+  uint32_t need;        // flags[2] must have reached this before the output buffer may be overwritten (0 = no wait)
+  uint32_t envs;        // envs in this launch
+};
+
+// flag >= need (wrap-safe), polling at agent scope; gives up after ~2 s (100 MHz counter) and raises the error flag
+__device__ __forceinline__ void spin_until_reached(uint32_t* flag, uint32_t need, uint32_t* err) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+    __builtin_amdgcn_s_sleep(4);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+
 struct StepPtrs {
   const float* s0;
   const float* u_nom;
@@ -49,6 +71,7 @@ struct StepPtrs {
   float* u_nom_out;     // fused finalize: where the updated nominal sequence goes (u_nom itself, or the caller's second buffer)
   float* Q_out;
   uint32_t* host_ticket; // cpmppi_step_host: counter in pinned host memory, +1 (system scope) per finalized env; NULL otherwise
+  GatherSync gs;
 };
 
 // Nominal control for stage k after the configured shift (a18).
@@ -64,7 +87,8 @@ __device__ __forceinline__ float shifted_nominal(const Params& p, const float* _
 template <bool KNOT_SPACE, bool COHERENT>
 __device__ __forceinline__ void finalize_env(const Params& p, const float* partial, uint32_t nb, uint32_t W,
                                              const float* u_nom_in, float* u_nom_out, float* __restrict__ Q_out,
-                                             uint32_t env, uint32_t* host_ticket = nullptr) {
+                                             uint32_t env, uint32_t* host_ticket = nullptr,
+                                             const GatherSync gs = GatherSync{nullptr, 0u, 0u, 0u}) {
   __shared__ float u_new[CPMPPI_MAX_HORIZON];
   __shared__ float bz[KNOT_SPACE ? (CPMPPI_MAX_HORIZON + 2) : 1];
   const uint32_t tid = threadIdx.x, H = p.H;
@@ -133,6 +157,12 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
     u_new[k] = v;
   }
   __syncthreads();                          // every read of the old nominal sequence is done
+  if (gs.flags && gs.need) {
+    // the all-gather that still reads the buffer written next (two steps back with alternating buffers) must be complete:
+    // by now it has had a whole step to run, so this practically never spins
+    if (tid == 0) spin_until_reached(gs.flags + 2, gs.need, gs.flags + 3);
+    __syncthreads();
+  }
   for (uint32_t k = tid; k < H; k += BLOCK) uo[k] = u_new[k];
   if (tid == 0 && Q_out) Q_out[env] = u_new[0];
   if (tid == 0 && host_ticket) {
@@ -140,6 +170,19 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
     // in the same pinned, fine-grained block; system-scope release so that the control is visible before the ticket
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __hip_atomic_fetch_add(host_ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (gs.flags) {
+    // publish "every env of this step has written its sequence" to the side stream's waiter: stores drained, block
+    // barrier, one lane's agent-scope release + arrival count; the last env's block publishes the step number
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t arrived = __hip_atomic_fetch_add(gs.flags, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived == gs.envs - 1u) {
+        __hip_atomic_store(gs.flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gs.flags + 1, gs.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -531,7 +574,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         __hip_atomic_store(a.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       }
       __syncthreads();
-      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom, a.u_nom_out, a.Q_out, env, a.host_ticket);
+      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom, a.u_nom_out, a.Q_out, env, a.host_ticket, a.gs);
     }
   }
   CPMPPI_DBG_STAMP(3);

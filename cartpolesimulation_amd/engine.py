@@ -359,12 +359,14 @@ class MPPIEngine:
     # ------------------------------------------------------------------ the fused hot path
     def step(self, s0, u_nom, target_position, target_equilibrium, L=None, delta_u=None, knots=None, seed=None,
              offset=0, env_offset=0, u_prev=None, Q_out=None, S_out=None, predictor="ODE_v0", h0=None,
-             previous_input=None, offset_dev=None, delta_u_tiled=None, u_nom_out=None, _prepare=False):
+             previous_input=None, offset_dev=None, delta_u_tiled=None, u_nom_out=None, gather_into=None, _prepare=False):
         """One MPPI optimizer step for E envs.  ``u_nom`` [E,H] is updated IN PLACE, or — with ``u_nom_out`` [E,H] — only
         read, the updated sequence going to ``u_nom_out`` (two buffers used alternately: shard.NativeGather).
 
         Exactly one noise source: ``delta_u`` [E,N,H], ``knots`` [E,N,P], ``seed`` (in-kernel Philox) or
         ``delta_u_tiled`` (a buffer from sample_tiled / tile_delta_u).
+        ``gather_into`` [world, E*H] (needs a communicator, shard.NativeGather): cpmppi_step_gather — the step plus the
+        all-gather of the sequences it writes, ordered on the device, nothing but the kernel on the launch stream.
         Returns (Q_out[E], S_out or None).
         """
         if not (torch.is_tensor(u_nom) and u_nom.is_cuda and u_nom.dtype == torch.float32 and u_nom.is_contiguous()):
@@ -431,7 +433,10 @@ class MPPIEngine:
             # every tensor the argument block points into is kept alive by the returned object
             return PreparedStep(self, a, (s0, u_nom, tp, te, Lt, noise, u_prev, Q_out, S_out, h0, previous_input, offset_dev, u_nom_out),
                                 Q_out, S_out)
-        self._check(self.lib.cpmppi_step(self._h, C.byref(a), self._stream()))
+        if gather_into is not None:
+            self._check(self.lib.cpmppi_step_gather(self._h, C.byref(a), gather_into.data_ptr(), self._stream()))
+        else:
+            self._check(self.lib.cpmppi_step(self._h, C.byref(a), self._stream()))
         # keep the temporaries alive until the launch is enqueued (stream-ordered frees are safe in torch's allocator)
         return Q_out, S_out
 
@@ -463,11 +468,14 @@ class PreparedStep:
     def __init__(self, engine, args, keep, Q_out, S_out):
         self.engine, self.args, self._keep, self.Q_out, self.S_out = engine, args, keep, Q_out, S_out
 
-    def run(self, offset=None):
+    def run(self, offset=None, gather_into=None):
         if offset is not None:
             self.args.offset = int(offset)
         e = self.engine
-        e._check(e.lib.cpmppi_step(e._h, C.byref(self.args), e._stream()))
+        if gather_into is not None:
+            e._check(e.lib.cpmppi_step_gather(e._h, C.byref(self.args), gather_into.data_ptr(), e._stream()))
+        else:
+            e._check(e.lib.cpmppi_step(e._h, C.byref(self.args), e._stream()))
         return self.Q_out, self.S_out
 
 

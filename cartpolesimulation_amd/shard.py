@@ -136,6 +136,10 @@ class NativeGather:
         b = (i + 1) & 1
         e._check(e.lib.cpmppi_comm_gather(e._h, b, self.u[b].data_ptr(), self.gathered[b].data_ptr(), e.E * e.H, e._stream()))
 
+    def recv(self, i):
+        """The buffer the gather of step i's result goes to."""
+        return self.gathered[(i + 1) & 1]
+
     def u_in(self, i):
         return self.u[i & 1]
 

@@ -335,6 +335,17 @@ int cpmppi_comm_wait(cpmppi_handle* h, uint32_t slot, void* stream);
 int cpmppi_comm_sync(cpmppi_handle* h);
 int cpmppi_comm_destroy(cpmppi_handle* h);
 
+/* cpmppi_step + the all-gather of its result in ONE call - the production form of the per-step collective:
+ * recv_all[world][E*H] <- all-gather of the nominal sequences this step writes (args->u_nom_out, or args->u_nom when the
+ * step runs in place).  The launch stream receives the rollout kernel and nothing else; step and gather are ordered
+ * through device memory (the kernel's finalizing blocks publish the step, a one-lane kernel on the side stream waits
+ * for it; the finalize of a later step that overwrites a buffer still being gathered waits for that gather).  Use two
+ * u_nom buffers alternately (step i: u_nom = B[i & 1], u_nom_out = B[(i + 1) & 1]) so that the gather of step i runs
+ * under step i + 1; in place is correct too, but then step i + 1's finalize waits for gather i.  recv_all must stay
+ * untouched until cpmppi_comm_sync (host) returns or a later cpmppi_comm_gather/wait pair orders the reader.
+ * cpmppi_comm_sync returns CPMPPI_ERR_COMM if a device-side wait timed out (~2 s). */
+int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* args, float* recv_all, void* stream);
+
 /* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */
 const char* cpmppi_version(void);
 

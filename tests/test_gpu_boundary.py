@@ -473,6 +473,20 @@ def test_native_gather_one_rank():
         torch.cuda.synchronize()
         assert torch.equal(g.u_out(i), u_ref), i
         assert torch.equal(g.gathered[(i + 1) & 1].view(E, H), u_ref), i
+    # the production form: cpmppi_step_gather (one call; step and gather ordered through device memory), host running
+    # far ahead of the device; alternating buffers, then in place
+    for i in range(9, 60):
+        eng.step(s0, g.u_in(i), tp, te, seed=2, offset=i, u_nom_out=g.u_out(i), gather_into=g.recv(i))
+        ref.step(s0, u_ref, tp, te, seed=2, offset=i)
+    g.sync()
+    torch.cuda.synchronize()
+    assert torch.equal(g.u_out(59), u_ref) and torch.equal(g.recv(59).view(E, H), u_ref)
+    inplace, rec = g.u_out(59).clone(), torch.zeros(1, E * H, device=u_ref.device)
+    for i in range(60, 75):
+        eng.step(s0, inplace, tp, te, seed=2, offset=i, gather_into=rec)
+        ref.step(s0, u_ref, tp, te, seed=2, offset=i)
+    g.sync()
+    assert torch.equal(inplace, u_ref) and torch.equal(rec.view(E, H), u_ref)
     assert eng.lib.cpmppi_comm_gather(eng._h, 9, g.u[0].data_ptr(), g.gathered[0].data_ptr(), E * H, None) == -1   # slot out of range
     g.close()
     assert eng.lib.cpmppi_comm_gather(eng._h, 0, g.u[0].data_ptr(), g.gathered[0].data_ptr(), E * H, None) == -1   # no communicator
