@@ -869,6 +869,8 @@ void fill_params(const cpmppi_config& c, Params& p) {
   memcpy(p.w, c.cost_w, sizeof(p.w));
   p.R = c.R; p.LBD = c.LBD; p.NU = c.NU; p.cc_weight = c.cc_weight; p.sigma = c.sigma;
   p.lo = c.action_low; p.hi = c.action_high;
+  const bool clip_run = c.control_mode == CPMPPI_CONTROL_CLIP;
+  p.run_lo = clip_run ? c.action_low : -INFINITY; p.run_hi = clip_run ? c.action_high : INFINITY;
   p.horizon_reduce = c.horizon_reduce; p.control_mode = c.control_mode; p.shift_mode = c.shift_mode;
   p.correction_u = c.correction_u;
   p.interp_f32 = (c.math_mode == CPMPPI_MATH_FAST) ? 1u : 0u;

@@ -101,7 +101,7 @@ struct CommState {
 __global__ void wait_published_kernel(unsigned* flags, unsigned need) {
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   while ((int)(__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(64);      // (~4096 cycles between polls: the wave shares a SIMD with a rollout wave)
     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
       __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;

@@ -73,6 +73,8 @@ struct Params {
   float w[24];
   float R, LBD, NU, cc_weight, sigma;
   float lo, hi;
+  float run_lo, run_hi;              // limits of the control a rollout applies: (lo, hi) when control_mode clips, (-inf, inf)
+                                     // otherwise - the clamp is then unconditional (no select on the mode per control step)
   uint32_t horizon_reduce, control_mode, shift_mode, correction_u;
   uint32_t interp_f32;               // FAST + device-generated knots: interpolate with one float32 FMA (<= 1 ulp of the
                                      // float64 scipy form, which stays in force for caller-provided knots)
@@ -83,6 +85,7 @@ struct EnvConst {
   float L, Lh;
   float kp1, kp1_mt;                 // (k+1), (k+1)*(m_cart+m_pole)
   float mg, JinvLh, kmLh, kM, g_i, cT_i, inv_kLh, inv_halfL;
+  float t1_i;                        // inv_kLh / m_pole: g_i s - cT_i w = t1_i (m_p g s - J/Lh w), the bracket xDD's numerator forms anyway
   float tg_i, tcT_i, tinv_kLh;       // the same three angleDD coefficients times the substep length t
 };
 
@@ -103,6 +106,7 @@ __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
   c.g_i = (float)((double)p.g * inv_kLh);
   c.cT_i = (float)((double)p.J_fric / ((double)p.m_pole * Lh) * inv_kLh);
   c.inv_halfL = (float)(1.0 / (0.5 * (double)L));
+  c.t1_i = (float)(inv_kLh / (double)p.m_pole);
   const double t = (double)p.t_step;
   c.tg_i = (float)(t * (double)p.g * inv_kLh);
   c.tcT_i = (float)(t * ((double)p.J_fric / ((double)p.m_pole * Lh) * inv_kLh));
@@ -120,7 +124,7 @@ __device__ __forceinline__ EnvConst make_env_const_uniform(const Params& p, floa
   u.L = uniform_(c.L); u.Lh = uniform_(c.Lh); u.kp1 = uniform_(c.kp1); u.kp1_mt = uniform_(c.kp1_mt);
   u.mg = uniform_(c.mg); u.JinvLh = uniform_(c.JinvLh); u.kmLh = uniform_(c.kmLh); u.kM = uniform_(c.kM);
   u.g_i = uniform_(c.g_i); u.cT_i = uniform_(c.cT_i); u.inv_kLh = uniform_(c.inv_kLh); u.inv_halfL = uniform_(c.inv_halfL);
-  u.tg_i = uniform_(c.tg_i); u.tcT_i = uniform_(c.tcT_i); u.tinv_kLh = uniform_(c.tinv_kLh);
+  u.tg_i = uniform_(c.tg_i); u.tcT_i = uniform_(c.tcT_i); u.tinv_kLh = uniform_(c.tinv_kLh); u.t1_i = uniform_(c.t1_i);
   return u;
 }
 
@@ -128,24 +132,48 @@ __device__ __forceinline__ EnvConst make_env_const_uniform(const Params& p, floa
 // float / float2 helpers
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int R> struct Lanes;
-template <> struct Lanes<1> { using F = float; };
-template <> struct Lanes<2> { using F = f2; };
+// Two rollouts per lane WITHOUT packed instructions: the same two float chains as f2, but every operation is two
+// independent v_*_f32.  For a wave that has its SIMD to itself the instruction issue overhead, not the ALU, sets the
+// pace (tools/valu_peak.hip, 1 wave per SIMD: v_pk_fma_f32 4.04 ns dependent / 2.37 ns with four independent chains;
+// v_fma_f32 2.69 / 1.99 (two chains) / 0.96 ns (eight)): two plain FMAs of two independent rollouts cost less than one
+// packed FMA once the scheduler has a few independent chains to interleave.  Bit-identical results (same IEEE ops).
+struct u2 {
+  float x, y;
+};
+__device__ __forceinline__ u2 operator+(u2 a, u2 b) { return u2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ u2 operator-(u2 a, u2 b) { return u2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ u2 operator*(u2 a, u2 b) { return u2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ u2 operator/(u2 a, u2 b) { return u2{a.x / b.x, a.y / b.y}; }
+__device__ __forceinline__ u2 operator-(u2 a) { return u2{-a.x, -a.y}; }
+__device__ __forceinline__ u2& operator+=(u2& a, u2 b) { a.x += b.x; a.y += b.y; return a; }
+
+template <int R, bool UNPACKED = false> struct Lanes;
+template <bool U> struct Lanes<1, U> { using F = float; };
+template <> struct Lanes<2, false> { using F = f2; };
+template <> struct Lanes<2, true> { using F = u2; };
 
 template <class F> struct Width;
 template <> struct Width<float> { static constexpr int value = 1; };
 template <> struct Width<f2> { static constexpr int value = 2; };
+template <> struct Width<u2> { static constexpr int value = 2; };
 
 __device__ __forceinline__ float get(float v, int) { return v; }
 __device__ __forceinline__ float get(f2 v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float get(u2 v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ void put(u2& v, int i, float x) { if (i == 0) v.x = x; else v.y = x; }
 __device__ __forceinline__ void put(float& v, int, float x) { v = x; }
 __device__ __forceinline__ void put(f2& v, int i, float x) { if (i == 0) v.x = x; else v.y = x; }
 template <class F> __device__ __forceinline__ F splat(float x);
 template <> __device__ __forceinline__ float splat<float>(float x) { return x; }
 template <> __device__ __forceinline__ f2 splat<f2>(float x) { return f2{x, x}; }
+template <> __device__ __forceinline__ u2 splat<u2>(float x) { return u2{x, x}; }
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ u2 fma_(u2 a, u2 b, u2 c) { return u2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ u2 rcp_(u2 a) { return u2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ u2 rint_(u2 a) { return u2{__builtin_rintf(a.x), __builtin_rintf(a.y)}; }
+__device__ __forceinline__ u2 abs_(u2 a) { return u2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
 __device__ __forceinline__ float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
 #ifndef CPMPPI_RCP_SHARED
 #define CPMPPI_RCP_SHARED 0     // float2: one v_rcp_f32 (a quarter-rate instruction) for both lanes, 1/(ab) * (b, a)
@@ -164,8 +192,10 @@ __device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ f2 abs_(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
 __device__ __forceinline__ float clamp_(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
 __device__ __forceinline__ f2 clamp_(f2 a, float lo, float hi) { return f2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
+__device__ __forceinline__ u2 clamp_(u2 a, float lo, float hi) { return u2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
 __device__ __forceinline__ float cos_(float a) { return cosf(a); }
 __device__ __forceinline__ f2 cos_(f2 a) { return f2{cosf(a.x), cosf(a.y)}; }
+__device__ __forceinline__ u2 cos_(u2 a) { return u2{cosf(a.x), cosf(a.y)}; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // sincos on [-pi_f32, pi_f32] (the angle is wrapped every substep, so the argument never leaves this range).
@@ -306,6 +336,12 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
 #ifndef CPMPPI_FOLD_T
 #define CPMPPI_FOLD_T 0         // 1: fold t into the angleDD coefficients (-1 instruction; measured: 2.4x the deviation, so off)
 #endif
+#ifndef CPMPPI_T1_REUSE
+#define CPMPPI_T1_REUSE 1       // angleDD from the numerator's own bracket (-1 instruction per substep)
+#endif
+#ifndef CPMPPI_SAFE_STEP
+#define CPMPPI_SAFE_STEP 1      // packed mapping: control steps proved clear of the track edge run without the per-substep test
+#endif
 #ifndef CPMPPI_HOIST_SPIN
 #define CPMPPI_HOIST_SPIN 1     // test |w t| once per control step (<= 0.1) instead of every substep (<= 0.125)
 #endif
@@ -339,6 +375,12 @@ __device__ __forceinline__ void ode_euler_fast(const State<F>& st, F uK, float t
 #if CPMPPI_FOLD_T
   // w + t*aDD with t folded into the three coefficients (each product still rounds relative to its own size)
   w1 = fma_(splat<F>(e.tg_i), s, fma_(xDD * c, splat<F>(e.tinv_kLh), fma_(w, splat<F>(-e.tcT_i), w)));
+#elif CPMPPI_T1_REUSE
+  // g s + T/(m_p Lh) is the bracket t1 = m_p g s - (J/Lh) w of xDD's numerator divided by m_p: one product instead of a
+  // product and an FMA per substep (same formula, one rounding placed differently)
+  const F aDD = fma_(xDD * c, splat<F>(e.inv_kLh), t1 * splat<F>(e.t1_i));
+  w1 = fma_(aDD, tt, w);
+  if (aDD_out) *aDD_out = aDD;
 #else
   const F aDD = fma_(splat<F>(e.g_i), s, fma_(xDD * c, splat<F>(e.inv_kLh), -(w * splat<F>(e.cT_i))));
   w1 = fma_(aDD, tt, w);
@@ -458,15 +500,18 @@ __device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
 
 // One Euler substep, FAST, with the reference's per-substep wrap and sin/cos evaluation (the control step's LAST
 // substep of the rotating flavours, every substep of the plain one).
-template <class F>
-__device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e) {
+// CHECK = false: the caller has PROVED that no lane can reach the track edge within this control step (SafeStep below).
+template <class F, bool CHECK = true>
+__device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e, bool check = true) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
-  bool rare = false;
+  uint64_t rare = 0;
+  if (CHECK && check) {
 #pragma unroll
-  for (int i = 0; i < W; ++i) rare |= (__builtin_fabsf(get(x1, i)) >= p.THL);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
+    for (int i = 0; i < W; ++i) rare |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), p.THL, 3);
+  }
+  if (CHECK && __builtin_expect(rare != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
     CPMPPI_DBG(3, 1);
     // cos of the integrated angle by rotating the previous pair through d = w t; lanes beyond the rotation range (deep)
     const F d = st.w * splat<F>(t);
@@ -584,9 +629,11 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
 // lanes has bounced: a rollout caught beyond the edge bounces on EVERY substep, and behind the branch each of those
 // costs ~500 cycles (exec-mask and SGPR shuffling around 45 instructions) against ~300 for the whole substep; inline
 // and scheduled with the rest it costs ~100.  Returns whether an event occurred (wave-uniform).
+// `check` (wave-uniform, CPMPPI_SAFE_STEP == 2): false = the caller has proved this control step clear of the track edge
+// (SafeStep): the two compares and everything behind them are skipped with one scalar branch.
 template <class F, bool BOUNCY, bool MASK_ONLY = false>
 __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
-                                                             F& cd, F& sd, F& xlim) {
+                                                             F& cd, F& sd, F& xlim, bool check = true) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1, aDD;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1, &aDD);
@@ -596,9 +643,11 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
   F cd1 = fma_(-eps, fma_(eps, splat<F>(0.5f), sd), cd);            // cd - eps sd - eps^2/2  (cd ~ 1: the eps^2 term matters)
   F sd1 = fma_(cd, eps, sd);                                         // sd + eps cd
   uint64_t fired = 0;                                               // wave mask (a scalar register pair; the loops' exit tests read it)
+  if (check) {
 #pragma unroll
-  for (int i = 0; i < W; ++i)                                       // edge, or a lane flagged `beyond`  (3 = ordered >=)
-    fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), get(xlim, i), 3);
+    for (int i = 0; i < W; ++i)                                     // edge, or a lane flagged `beyond`  (3 = ordered >=)
+      fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), get(xlim, i), 3);
+  }
   if (!MASK_ONLY && (BOUNCY || __builtin_expect(fired != 0, 0))) {
     if (!BOUNCY) CPMPPI_DBG(0, 1);
     // plain bounces (lanes inside the rotation range): masked, both rollouts of all lanes at once — about one substep's
@@ -640,10 +689,50 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
   return fired;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "Safe" control steps (packed mapping).  The edge test of cartpole_equations.py:342 runs every substep, and with it two
+// compares, a mask merge and a branch per substep - 7 % of the substep's vector instructions - although a cart in the
+// middle of the track cannot reach the edge within 20 ms.  Once per control step a wave checks, for all of its lanes,
+//     |w| <= W0,   |v| <= V0,   |x| + dt |v| <= XS
+// with XS = nearlim - a_max dt^2 / 2 (minus slack), where a_max bounds |positionDD| for ANY state with |w| <= W0 + DW,
+// |v| <= V0 + DV, |u| <= u_max (cartpole_equations.py:76-87 term by term, |cos sin| <= 1/2, A >= (k+1)(m_c+m_p) - m_p) and
+// the bounds are checked to be self-consistent (dt * aDD_max <= DW, DV from the friction fixed point).  Then
+// |x| < nearlim <= THL at every substep of the control step: no bounce can occur (the S substeps run without the test,
+// bit-identical to the tested ones), no lane's |w t| leaves the rotation range (W0 + DW << ROT_LIMIT / t), and at the
+// next stage the boundary cost of quadratic_boundary_grad(_minimal) - nonzero only for |x| > fraction * THL = nearlim - is
+// exactly zero.  Anything else (near the edge, fast, not clipped) takes the tested path as before.
+struct SafeStep {
+  float W0, V0, XS, dt, nearlim;
+};
+constexpr float SAFE_W0 = 12.0f, SAFE_DW = 6.0f, SAFE_V0 = 0.6f;
+
+__device__ __forceinline__ SafeStep make_safe_step(const Params& p, const EnvConst& e, float near_fraction) {
+  SafeStep s;
+  const float dt = (float)p.S * p.t_step;
+  const float frac = __builtin_fminf(near_fraction, 1.0f);
+  s.nearlim = frac * p.THL;                                   // (a negative fraction: every state is "near", never safe)
+  const float Wm = SAFE_W0 + SAFE_DW;
+  const float A_min = e.kp1_mt - p.m_pole;
+  const float u_abs = e.kp1 * __builtin_fabsf(p.u_max) * __builtin_fmaxf(__builtin_fabsf(p.run_lo), __builtin_fabsf(p.run_hi));
+  const float a0 = (0.5f * e.mg + e.JinvLh * Wm + e.kmLh * Wm * Wm + u_abs) / A_min;
+  const float fr = e.kM / A_min;
+  const float den = 1.0f - dt * fr;
+  const float dV = dt * (a0 + fr * SAFE_V0) / den;
+  const float a_max = a0 + fr * (SAFE_V0 + dV);
+  const float aDD_max = e.g_i + e.inv_kLh * a_max + e.cT_i * Wm;
+  const float xs = s.nearlim - 1.1f * (0.5f * a_max * dt * dt) - 1.0e-4f * p.THL;
+  const bool ok = (A_min > 0.0f) && (den > 0.2f) && (dt * aDD_max <= SAFE_DW) && (Wm * p.t_step <= 0.5f * ROT_LIMIT) && (xs > 0.0f);
+  s.W0 = uniform_(SAFE_W0); s.V0 = uniform_(SAFE_V0); s.dt = uniform_(dt); s.nearlim = uniform_(s.nearlim);
+  s.XS = uniform_(ok ? xs : -1.0f);                           // (NaN / inf anywhere above: ok is false)
+  return s;
+}
+
 // One control step of S substeps under a held control (FAST).
+// Returns whether any lane of the wave ends the step with |x| >= ss->nearlim (wave-uniform; always true where it is
+// not tracked): the caller's next stage evaluates the boundary cost only then.
 template <class F, bool TWO_LOOPS = false>
-__device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
-                                                  const EnvConst& e) {
+__device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
+                                                  const EnvConst& e, const SafeStep* ss = nullptr) {
 #if CPMPPI_ROTATE && CPMPPI_HOIST_SPIN
   if constexpr (Width<F>::value == 1) {
     // one rollout per lane is the small-launch (latency-bound) mapping: there the per-substep test, which overlaps with
@@ -652,16 +741,47 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
     // 63 -> 72 us — the lone wave of this mapping gains nothing from longer basic blocks and pays for the bookkeeping)
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
     substep_fast<F>(st, uK, t, p, e);
-    return;
+    return true;
   }
   // The seed needs |w t| <= ROT_LIMIT.  Tested once per control step: without a bounce w cannot leave the range within
   // one control step by more than the polynomials' margin, and a lane that bounces is re-tested.  Lanes beyond the
   // range are flagged and take the exact sincos on every substep.
 #if CPMPPI_INCR_ROT
-  F xlim;
-  const float wlim = ROT_LIMIT / t;             // |w t| > ROT_LIMIT as one compare with a free abs modifier per lane
+  bool check = true;
+#if CPMPPI_SAFE_STEP
+  if (ss != nullptr) {
+    uint64_t unsafe = 0;                          // wave mask; 10 = unordered or greater (a NaN lane is not safe)
 #pragma unroll
-  for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
+    for (int i = 0; i < Width<F>::value; ++i) {
+      unsafe |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.w, i)), ss->W0, 10);
+      unsafe |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.v, i)), ss->V0, 10);
+      unsafe |= __builtin_amdgcn_fcmpf(__builtin_fmaf(__builtin_fabsf(get(st.v, i)), ss->dt, __builtin_fabsf(get(st.x, i))), ss->XS, 10);
+    }
+    if (CPMPPI_SAFE_STEP == 2) {
+      check = unsafe != 0;
+    } else if (__builtin_expect(unsafe == 0, 1)) {
+      F cd, sd, unused = splat<F>(0.0f);
+      rot_pair<F>(st.w * splat<F>(t), cd, sd);
+      uint32_t left = S - 1u;
+      if constexpr (TWO_LOOPS) {
+        for (; left >= 3u; left -= 3u) {
+          substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
+          substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
+          substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
+        }
+      }
+      for (; left != 0u; --left) substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
+      substep_fast<F, false>(st, uK, t, p, e);
+      return false;
+    }
+  }
+#endif
+  F xlim = splat<F>(p.THL);
+  const float wlim = ROT_LIMIT / t;             // |w t| > ROT_LIMIT as one compare with a free abs modifier per lane
+  if (check) {
+#pragma unroll
+    for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
+  }
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
   if constexpr (TWO_LOOPS) {
@@ -674,9 +794,9 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
     while (left >= 3u && fired == 0) {
       const State<F> st0 = st;
       const F cd0 = cd, sd0 = sd;
-      fired = substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim);
-      fired |= substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim);
-      fired |= substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim);
+      fired = substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, check);
+      fired |= substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, check);
+      fired |= substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, check);
       if (__builtin_expect(fired != 0, 0)) {
         asm volatile("" ::: "memory");            // (keeps this a branch: as selects the rollback costs 16 v_cndmask per triple)
         st = st0; cd = cd0; sd = sd0;
@@ -689,9 +809,17 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
       --left;
     }
   } else {
-    for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim);
+    for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
   }
-  substep_fast<F>(st, uK, t, p, e);
+  substep_fast<F>(st, uK, t, p, e, check);
+  if (!check) return false;
+  if (ss != nullptr) {
+    uint64_t near = 0;                            // 11 = unordered or greater-equal
+#pragma unroll
+    for (int i = 0; i < Width<F>::value; ++i) near |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.x, i)), ss->nearlim, 11);
+    return near != 0;
+  }
+  return true;
 #else
   bool spin = false;
 #pragma unroll
@@ -705,12 +833,15 @@ __device__ __forceinline__ void control_step_fast(State<F>& st, F uK, uint32_t S
     }
   }
   for (; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);       // the last substep always; all remaining after a bounce
+  return true;
 #endif
 #elif CPMPPI_ROTATE
   for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
   substep_fast<F>(st, uK, t, p, e);
+  return true;
 #else
   for (uint32_t sub = 0; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);
+  return true;
 #endif
 }
 // ------------------------------------------------------------------------------------------------------------------
@@ -725,12 +856,19 @@ __device__ __forceinline__ F div_uniform(F x, float c) {
   else return x / splat<F>(c);
 }
 
+// near = false: the caller knows |x| < permissible_track_fraction * THL for every lane, i.e. the boundary term is exactly
+// zero and dd + 0 == dd: it is left out (wave-uniform branch), bit-identical.
 template <class F, bool FAST = false>
-__device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang, F u, float x_t, float te) {
+__device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang, F u, float x_t, float te, bool near = true) {
 #pragma clang fp contract(off)     // every product and sum rounds once, wherever the function is inlined
   const float THL = p.THL;
   const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
   const F dd = (d * d) * splat<F>(p.w[0]);
+  const F e1 = splat<F>(1.0f) - cosang * splat<F>(te);
+  const F ep = (e1 * e1) * splat<F>(p.w[2]);
+  const F ekp = (w_ang * w_ang) * splat<F>(p.w[3]);
+  const F cc = ((u * u) * splat<F>(p.w[5])) * splat<F>(p.w[4]);
+  if (!near) return dd + ep + ekp + cc;
   const float ptf = p.w[6];
   const F ax = abs_(x);
   // indicator(|x| > ptf THL) * b^2 == (max(|x| - ptf THL, 0) / ...)^2: the same value without compare + select
@@ -739,10 +877,6 @@ __device__ __forceinline__ F stage_qbgm(const Params& p, F x, F cosang, F w_ang,
   for (int i = 0; i < Width<F>::value; ++i) put(over, i, __builtin_fmaxf(get(over, i), 0.0f));
   const F b = div_uniform<FAST, F>(over, (1.0f - ptf) * THL);
   const F db = (b * b) * splat<F>(p.w[1]);
-  const F e1 = splat<F>(1.0f) - cosang * splat<F>(te);
-  const F ep = (e1 * e1) * splat<F>(p.w[2]);
-  const F ekp = (w_ang * w_ang) * splat<F>(p.w[3]);
-  const F cc = ((u * u) * splat<F>(p.w[5])) * splat<F>(p.w[4]);
   return dd + db + ep + ekp + cc;
 }
 

@@ -24,6 +24,12 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
 #endif
+#ifndef CPMPPI_MID_UNPACKED
+#define CPMPPI_MID_UNPACKED 0
+#endif
+#ifndef CPMPPI_MID_VGPR_CONSTS
+#define CPMPPI_MID_VGPR_CONSTS 1    // mid-size build: substep constants in VGPRs (the packed form wants register pairs)
+#endif
 constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
 constexpr int TK = CPMPPI_TK;                // time-steps per LDS perturbation tile
 constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
@@ -73,6 +79,21 @@ struct StepPtrs {
   uint32_t* host_ticket; // cpmppi_step_host: counter in pinned host memory, +1 (system scope) per finalized env; NULL otherwise
   GatherSync gs;
 };
+
+// The StepPtrs kernel argument re-read from the kernarg segment at the point of call (the kernels here take
+// (const Params, const StepPtrs): the second argument sits at the first 8-byte boundary after the first).
+__device__ __forceinline__ StepPtrs late_step_ptrs() {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  static_assert(alignof(StepPtrs) == 8 && sizeof(StepPtrs) % 8 == 0, "kernarg layout");
+  const __attribute__((address_space(4))) uint64_t* w =
+      (const __attribute__((address_space(4))) uint64_t*)(k + ((sizeof(Params) + 7u) & ~(size_t)7u));
+  union { StepPtrs s; uint64_t w[sizeof(StepPtrs) / 8]; } u;
+#pragma unroll
+  for (size_t i = 0; i < sizeof(StepPtrs) / 8; ++i) u.w[i] = w[i];       // (only the words of fields used later survive)
+  return u.s;
+}
 
 // Nominal control for stage k after the configured shift (a18).
 __device__ __forceinline__ float shifted_nominal(const Params& p, const float* __restrict__ un, uint32_t k) {
@@ -194,7 +215,9 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
 // mapping for mid-sized launches (same code except where the loop constants live, see below).
 template <int COST, bool FAST, int NOISE, int R, int VARIANT>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
-  using F = typename Lanes<R>::F;
+  // mid-size build (one to four waves per SIMD): two rollouts per lane as two PLAIN float chains (u2) instead of packed
+  // float2 when CPMPPI_MID_UNPACKED - a (nearly) lone wave is bound by instruction issue, not by the ALU
+  using F = typename Lanes<R, (VARIANT == 2 && CPMPPI_MID_UNPACKED != 0)>::F;
   static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");
   __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * R * TILE_STRIDE : 1];
   __shared__ float red[2 * WAVES];
@@ -224,10 +247,10 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // 8192 envs).  The same variant runs the substeps that follow a rare event in their own loop (control_step_fast).
   Params ph = p;
   EnvConst eh = ec;
-  if constexpr (VARIANT == 2 && R == 2) {
+  if constexpr (VARIANT == 2 && R == 2 && CPMPPI_MID_VGPR_CONSTS != 0) {
 #define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
     CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
-    CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.g_i); CPMPPI_TO_VGPR(eh.inv_kLh); CPMPPI_TO_VGPR(eh.cT_i);
+    CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.t1_i); CPMPPI_TO_VGPR(eh.inv_kLh);
 #undef CPMPPI_TO_VGPR
   }
   const float x_t = a.x_t[env], te = a.te[env];
@@ -239,6 +262,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+  // packed FAST mapping: control steps proved clear of the track edge skip the per-substep edge test, and stages whose
+  // |x| is known to be below the boundary cost's threshold skip that term (SafeStep, cpmppi_device.hpp); `near` is
+  // wave-uniform (stage 0: the shared initial state)
+  constexpr bool TRACK_NEAR = FAST && R == 2 && CPMPPI_SAFE_STEP != 0;
+  const SafeStep ss = make_safe_step(p, ec, COST == COST_QBGM ? p.w[6] : 1.0f);
+  bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < ss.nearlim);
 
   // Latency build: the nominal control (and the legacy cost's previous sequence) of step k + 1 is requested while step k
   // integrates - a scalar load consumed a few instructions after its issue is ~100 ns of exposed latency per control step
@@ -260,9 +289,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       if constexpr (COST == COST_LEGACY) upk = up[k];
     }
     F ur = splat<F>(uk) + du;
-    if (p.control_mode == CPMPPI_CONTROL_CLIP) ur = clamp_(ur, p.lo, p.hi);
+    ur = clamp_(ur, p.run_lo, p.run_hi);
     if constexpr (COST == COST_QBGM) {
-      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te);
+      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
       cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh);
+      near = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, TRACK_NEAR ? &ss : nullptr);
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }
@@ -426,6 +455,11 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     cpmppi::g_wave_cycles[blockIdx.x * WAVES + wave] = __builtin_amdgcn_s_memtime() - dbg_t0;
   CPMPPI_DBG_STAMP(1);
 #endif
+  // Everything the epilogue needs from the launch descriptor (output pointers, the partials workspace, the tickets) is read
+  // from the kernarg segment HERE, behind an opaque copy of its address: as plain uses of `a` the compiler loads all of
+  // them at kernel entry and keeps ~20 more scalar registers live through the horizon loop, which the packed builds pay
+  // for with SGPR spills (v_writelane / v_readlane) inside the loop.
+  const StepPtrs la = late_step_ptrs();
   // ---- per-rollout total cost ------------------------------------------------------------------------------------
   F S_total;
   if constexpr (COST == COST_LEGACY) {
@@ -437,7 +471,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   }
 #pragma unroll
   for (int i = 0; i < R; ++i)
-    if (a.S_out && valid[i]) a.S_out[(size_t)env * p.N + n[i]] = get(S_total, i);
+    if (la.S_out && valid[i]) la.S_out[(size_t)env * p.N + n[i]] = get(S_total, i);
 
   // ---- block-level soft-min partials (a16) -----------------------------------------------------------------------
   float m_l = INFINITY;
@@ -458,7 +492,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const float a_w = wave_sum(e_l);
   if (lane == 0) red[WAVES + wave] = a_w;
 
-  const uint32_t W = a.W;
+  const uint32_t W = la.W;
   float* __restrict__ my_bsum = bsum + wave * W;
   if constexpr (NOISE == NOISE_PHILOX) {
     const float* __restrict__ kstash = bsum + WAVES * W + tid;         // each lane reads back what it wrote itself
@@ -466,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       float v = 0.0f;
 #pragma unroll
       for (int i = 0; i < R; ++i)
-        v += e[i] * (a.stash ? kstash[(j * R + i) * BLOCK]
+        v += e[i] * (la.stash ? kstash[(j * R + i) * BLOCK]
                              : philox_knot(a.seed, step_offset, a.env_offset + env, valid[i] ? n[i] : 0, j, p.sigma));
       v = wave_sum(v);
       if (lane == 0) my_bsum[j] = v;
@@ -538,7 +572,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     }
   }
   __syncthreads();
-  float* __restrict__ out = a.partial + ((size_t)env * a.nb + blk) * (2 + W);
+  float* __restrict__ out = la.partial + ((size_t)env * la.nb + blk) * (2 + W);
   if (tid == 0) {
     float a_b = red[WAVES];
 #pragma unroll
@@ -557,24 +591,24 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // Placement-independent hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, the
   // block's barrier, one lane's agent-scope release, then the ticket; the consumer block does one agent-scope acquire
   // (invalidates this CU's L1), drains, barriers, and additionally reads the partials with sc1 loads.
-  if (a.counter) {
+  if (la.counter) {
     __shared__ uint32_t ticket;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ticket = __hip_atomic_fetch_add(a.counter + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __hip_atomic_fetch_add(la.counter + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (ticket == a.nb - 1) {                               // uniform over the block
+    if (ticket == la.nb - 1) {                               // uniform over the block
       if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __hip_atomic_store(la.counter + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       }
       __syncthreads();
-      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, a.partial, a.nb, W, a.u_nom, a.u_nom_out, a.Q_out, env, a.host_ticket, a.gs);
+      finalize_env<(NOISE == NOISE_KNOTS || NOISE == NOISE_PHILOX), true>(p, la.partial, la.nb, W, la.u_nom, la.u_nom_out, la.Q_out, env, la.host_ticket, la.gs);
     }
   }
   CPMPPI_DBG_STAMP(3);

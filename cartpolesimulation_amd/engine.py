@@ -202,7 +202,7 @@ class MPPIEngine:
                                       and tuple(t.shape[1:]) == tail):
                 raise ValueError(f"{name} must be a contiguous float32 ROCm tensor [T, {', '.join(map(str, tail))}]")
         # control periods the logs can take; the kernel itself refuses to write outside them (device counter case)
-        log_rows = min([states_log.shape[0] - 1] * (states_log is not None) + [Q_log.shape[0]] * (Q_log is not None))
+        log_rows = min(([states_log.shape[0] - 1] if states_log is not None else []) + ([Q_log.shape[0]] if Q_log is not None else []))
         if row_dev is None:
             if not 0 <= row < log_rows:
                 raise IndexError(f"row {row} outside the logs")

@@ -64,6 +64,28 @@ def make_config(cfg, p=None, mode="f32"):
     return c
 
 
+_fma = None
+
+
+def fma_lib():
+    """Mode C of the checker (oracle/Makefile liboracle_fma.so): float32 substeps with FMA contraction and libm float
+    trig.  None when the host has no FMA or no compiler (callers then use modes A and B only)."""
+    global _fma
+    if _fma is None:
+        path = os.path.join(HERE, "liboracle_fma.so")
+        try:
+            if " fma " not in open("/proc/cpuinfo").read():
+                raise OSError("host CPU without FMA")
+            if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(HERE, "cpmppi_oracle.c")):
+                subprocess.check_call(["make", "-s", "-C", HERE, "liboracle_fma.so"])
+            _fma = C.CDLL(path)
+            _fma.oracle_max_threads.restype = C.c_int
+            _fma.oracle_max_threads()
+        except Exception:
+            _fma = False
+    return _fma or None
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

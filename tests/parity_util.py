@@ -70,28 +70,39 @@ def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0, strict=F
     _check(off, flagged, what, strict)
 
 
-def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False):
-    """Per-rollout costs: |S - S_a| <= rtol |S_a| + |S_a - S_b| for every unflagged rollout.  flag_sensitive: a rollout on
-    which the reference's OWN two arithmetic modes disagree by more than the band (|S_a - S_b| > rtol |S_a|: a chaotic
-    trajectory that amplifies 1e-7 roundings beyond the tolerance) joins the flagged bucket - no evaluation in float32,
-    the reference's included, pins it to the band."""
+def envelope(ref_a, *others):
+    """max_k |ref_a - other_k|: how far the reference's own realisations (mode B float64 substeps, mode C float32 with
+    FMA + float trig, mode A from an initial state one ulp away) sit from mode A, element-wise.  None entries are skipped."""
+    a = np.asarray(ref_a, np.float64)
+    gap = np.zeros(a.shape)
+    for o in others:
+        if o is not None:
+            gap = np.maximum(gap, np.abs(a - np.asarray(o, np.float64)))
+    return gap
+
+
+def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False, S_alt=()):
+    """Per-rollout costs: |S - S_a| <= rtol |S_a| + gap for every unflagged rollout, gap = the envelope of the reference's
+    own realisations around mode A (S_b and any S_alt).  flag_sensitive: a rollout on which those realisations disagree
+    among THEMSELVES by more than the band (gap > rtol |S_a|: a chaotic trajectory that amplifies 1e-7 roundings beyond
+    the tolerance) joins the flagged bucket - no evaluation in float32, the reference's included, pins it to the band."""
     S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
-    gap = np.abs(S_a - np.asarray(S_b, np.float64)) if S_b is not None else 0.0
+    gap = envelope(S_a, S_b, *S_alt) if (S_b is not None or len(S_alt)) else 0.0
     off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap
     flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
-    if flag_sensitive and S_b is not None:
+    if flag_sensitive and (S_b is not None or len(S_alt)):
         flagged = flagged | (gap > rtol * np.abs(S_a))
     _check(off, flagged, what, strict)
 
 
-def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None):
+def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None, u_alt=()):
     """Updated control sequence / Q: 1e-4 absolute (north_star) around the reference's own [A, B] interval.  The soft-min
     update amplifies cost differences by |S| / LBD (costs of ~5e4 at LBD = 100 turn a 1e-5 relative cost difference into
     a 0.5 % weight change), so where the reference's two arithmetic modes themselves disagree on u by more than the
     band, the allowance widens by exactly that disagreement (max over the horizon) — an oracle quantity.  `allowance`
     (optional, per control): softmin_allowance(...) of the oracle's costs, for ill-conditioned updates."""
     u, u_a = np.asarray(u, np.float64), np.asarray(u_a, np.float64)
-    gap = float(np.abs(u_a - np.asarray(u_b, np.float64)).max()) if u_b is not None else 0.0
+    gap = float(envelope(u_a, u_b, *u_alt).max()) if (u_b is not None or len(u_alt)) else 0.0
     extra = 0.0 if allowance is None else np.asarray(allowance, np.float64)
     d = np.abs(u - u_a)
     assert np.all(d <= atol + np.maximum(gap, extra)), (f"{what}: max |u - u_ref| = {d.max():.3e} > {atol:g} + oracle allowance "
@@ -128,15 +139,28 @@ def oracle_step_both_modes(s0, u_nom, du, target_position, target_equilibrium, c
     return a, b
 
 
-def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None, cost=None):
+def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None, cost=None, probes=False):
     """The plain-C oracle's MPPI step for E envs in BOTH reference arithmetic modes, plus the H2 flags of every rollout
     from the oracle's own trajectories (default glue: shift repeat-last, clip); with ``cost`` ("default" / "legacy") also
-    the rollouts within reach of that plugin's indicator thresholds.  -> dict(S_a, S_b, u_a, u_b, Q_a, flags)."""
+    the rollouts within reach of that plugin's indicator thresholds.  -> dict(S_a, S_b, u_a, u_b, Q_a, flags) and, with
+    ``probes``, two more realisations of the REFERENCE for the rounding-sensitivity envelope: S_c / u_c = mode C (float32
+    with FMA contraction and libm float trig, what a fastmath float32 build computes; None on a host without FMA) and
+    S_p / u_p = mode A started one float32 ulp away in the angular velocity."""
     from oracle import oracle_c as OC
     E, N, H = du.shape
     ca, cb = OC.make_config(ocfg, params), OC.make_config(ocfg, params, mode="f64sub")
     u_a, Q_a, S_a = OC.step(ca, s0, u0, du, tp, te, L=L)
     u_b, _, S_b = OC.step(cb, s0, u0, du, tp, te, L=L)
+    extra = {}
+    if probes:
+        fma = OC.fma_lib()
+        if fma is not None:
+            extra["u_c"], _, extra["S_c"] = OC.step(ca, s0, u0, du, tp, te, L=L, use_lib=fma)
+        else:
+            extra["u_c"] = extra["S_c"] = None
+        s0p = np.array(s0, f32).reshape(E, 6).copy()
+        s0p[:, O.ANGLED_IDX] = np.nextafter(s0p[:, O.ANGLED_IDX], f32(np.inf))
+        extra["u_p"], _, extra["S_p"] = OC.step(ca, s0p, u0, du, tp, te, L=L)
     if ocfg.shift_mode == "repeat_last":
         u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1)
     elif ocfg.shift_mode == "append_zero":
@@ -158,4 +182,4 @@ def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=N
         tr = traj.reshape(E, N, H + 1, 6)
         for e in range(E):
             flags[e] |= flag_indicators(tr[e], cost, float(np.asarray(tp).reshape(-1)[e]))
-    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags)
+    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags, **extra)

@@ -36,11 +36,12 @@ for tag, kw in (("fast_r2", dict(rollouts_per_lane=2)), ("fast_r1", dict(rollout
 ocfg = O.MPPIConfig(N=N, H=H)
 THL = PU.THL
 CH = 8
-tot = {t: dict(clear_off=0, flagged_off=0, clear=0, flagged=0, sens_off=0, worst_clear=0.0, u_worst=0.0) for t in outs}
+tot = {t: dict(clear_off=0, flagged_off=0, clear=0, flagged=0, sens_off=0, worst_clear=0.0, u_worst=0.0,
+               env_clear=0, env_sens=0, env_clear_off=0, env_sens_off=0, env_worst_clear=0.0, u_off_envs=0, u_off_envs_env=0) for t in outs}
 for e0 in range(0, E, CH):
     sl = slice(e0, e0 + CH)
     du = np.stack([O.interpolate_knots(kn_h[e], H) for e in range(e0, e0 + CH)])
-    ref = PU.c_oracle_step_with_flags(ocfg, s0[sl], u0[sl], du, tp[sl], te[sl], L=Lv[sl])
+    ref = PU.c_oracle_step_with_flags(ocfg, s0[sl], u0[sl], du, tp[sl], te[sl], L=Lv[sl], probes=True)
     # the oracle's trajectories once more for the offenders' features
     u_shift = np.concatenate([u0[sl, 1:], u0[sl, -1:]], axis=1)
     u_run = np.clip(u_shift[:, None, :] + du, -1, 1).astype(f32).reshape(CH * N, H)
@@ -60,6 +61,24 @@ for e0 in range(0, E, CH):
             exc = dev / (1e-4 * np.abs(Sa) + gap)
             T["worst_clear"] = max(T["worst_clear"], float(exc[~fl].max()))
             T["u_worst"] = max(T["u_worst"], float(np.abs(u_m[e] - ref["u_a"][i]).max()))
+            # rule with the envelope of the reference's own realisations (B, C = fma float32, P = one ulp away)
+            genv = PU.envelope(Sa, Sb, ref["S_c"][i] if ref["S_c"] is not None else None, ref["S_p"][i])
+            sens_e = genv > 1e-4 * np.abs(Sa)
+            off_e = dev > 1e-4 * np.abs(Sa) + genv
+            bucket = fl | sens_e
+            T["env_clear"] += int((~bucket).sum()); T["env_sens"] += int((sens_e & ~fl).sum())
+            T["env_clear_off"] += int((off_e & ~bucket).sum()); T["env_sens_off"] += int((off_e & bucket).sum())
+            if (~bucket).any():
+                T["env_worst_clear"] = max(T["env_worst_clear"], float((dev / (1e-4 * np.abs(Sa) + genv))[~bucket].max()))
+            allow = PU.softmin_allowance(Sa, Sb, du[i])
+            ugap = float(PU.envelope(ref["u_a"][i], ref["u_b"][i]).max())
+            ugap_e = float(PU.envelope(ref["u_a"][i], ref["u_b"][i], ref["u_c"][i] if ref["u_c"] is not None else None, ref["u_p"][i]).max())
+            du_ = np.abs(u_m[e] - ref["u_a"][i])
+            T["u_off_envs"] += int((du_ > 1e-4 + np.maximum(ugap, allow)).any())
+            T["u_off_envs_env"] += int((du_ > 1e-4 + np.maximum(ugap_e, allow)).any())
+            for n in np.nonzero(off_e & ~bucket)[0][:6]:
+                print(json.dumps({"rule": "envelope", "tag": t, "env": e, "rollout": int(n), "rel_dev": float(dev[n] / abs(Sa[n])),
+                                  "rel_env": float(genv[n] / abs(Sa[n])), "rel_gapAB": float(gap[n] / abs(Sa[n])), "S_a": float(Sa[n])}))
             for n in np.nonzero(off & ~fl)[0][:6]:
                 tr = traj[i, n]
                 print(json.dumps({"tag": t, "env": e, "rollout": int(n), "S": float(S_m[e][n]), "S_a": float(Sa[n]), "S_b": float(Sb[n]),
