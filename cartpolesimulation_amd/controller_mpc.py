@@ -131,7 +131,7 @@ class controller_mpc(template_controller):
 
     def step(self, s, time=None, updated_attributes=None):
         self.update_attributes(updated_attributes)
-        u = self.optimizer.step(np.asarray(s, dtype=np.float32) if not hasattr(s, "is_cuda") else s, time)
+        u = self.optimizer.step(s, time)          # (host arrays and device tensors alike: the optimizer converts what it needs)
         if self.controller_logging:
             self.controller_data_for_csv = dict(self.optimizer.logging_values)
         return u

@@ -340,7 +340,11 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
 #define CPMPPI_T1_REUSE 1       // angleDD from the numerator's own bracket (-1 instruction per substep)
 #endif
 #ifndef CPMPPI_SAFE_STEP
-#define CPMPPI_SAFE_STEP 1      // packed mapping: control steps proved clear of the track edge run without the per-substep test
+#define CPMPPI_SAFE_STEP 0      // packed mapping: control steps proved clear of the track edge run without the per-substep test.
+                                // OFF: measured on MI355X (tools/kbench.py, 8192 envs): the second copy of the substep loop costs
+                                // 10-12 VGPRs (122 -> 134: three waves per SIMD instead of four) and the launch gets 6 % SLOWER
+                                // (2.39 -> 2.55 ms) although each safe step issues 5 % fewer vector instructions; gating the test
+                                // inside one loop (== 2) makes the compiler if-convert the event code into the loop (137 instructions)
 #endif
 #ifndef CPMPPI_HOIST_SPIN
 #define CPMPPI_HOIST_SPIN 1     // test |w t| once per control step (<= 0.1) instead of every substep (<= 0.125)

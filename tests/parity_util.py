@@ -143,9 +143,10 @@ def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=N
     """The plain-C oracle's MPPI step for E envs in BOTH reference arithmetic modes, plus the H2 flags of every rollout
     from the oracle's own trajectories (default glue: shift repeat-last, clip); with ``cost`` ("default" / "legacy") also
     the rollouts within reach of that plugin's indicator thresholds.  -> dict(S_a, S_b, u_a, u_b, Q_a, flags) and, with
-    ``probes``, two more realisations of the REFERENCE for the rounding-sensitivity envelope: S_c / u_c = mode C (float32
-    with FMA contraction and libm float trig, what a fastmath float32 build computes; None on a host without FMA) and
-    S_p / u_p = mode A started one float32 ulp away in the angular velocity."""
+    ``probes``, S_alt / u_alt: lists of further realisations of the REFERENCE for the rounding-sensitivity envelope -
+    mode C (float32 with FMA contraction and libm float trig, what a fastmath float32 build computes; absent on a host
+    without FMA) and mode A re-run one float32 ulp away in the angular velocity, the cart velocity, the position, the
+    perturbations and the pole length.  Per rollout, in each list entry [E, N] (costs) / [E, H] (controls)."""
     from oracle import oracle_c as OC
     E, N, H = du.shape
     ca, cb = OC.make_config(ocfg, params), OC.make_config(ocfg, params, mode="f64sub")
@@ -153,14 +154,26 @@ def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=N
     u_b, _, S_b = OC.step(cb, s0, u0, du, tp, te, L=L)
     extra = {}
     if probes:
+        # more realisations of the REFERENCE, each one rounding-level away from mode A: how far they scatter is what "the
+        # reference's result" means for a rollout (a chaotic one amplifies 1e-7 to 1e-3 within a hundred control steps)
         fma = OC.fma_lib()
-        if fma is not None:
-            extra["u_c"], _, extra["S_c"] = OC.step(ca, s0, u0, du, tp, te, L=L, use_lib=fma)
-        else:
-            extra["u_c"] = extra["S_c"] = None
-        s0p = np.array(s0, f32).reshape(E, 6).copy()
-        s0p[:, O.ANGLED_IDX] = np.nextafter(s0p[:, O.ANGLED_IDX], f32(np.inf))
-        extra["u_p"], _, extra["S_p"] = OC.step(ca, s0p, u0, du, tp, te, L=L)
+        alt_S, alt_u = [], []
+        if fma is not None:                                     # mode C: float32 with FMA contraction + libm float trig
+            u_c, _, S_c = OC.step(ca, s0, u0, du, tp, te, L=L, use_lib=fma)
+            alt_S.append(S_c); alt_u.append(u_c)
+        s0a = np.array(s0, f32).reshape(E, 6)
+        one_up = lambda a: np.nextafter(a, f32(np.inf)).astype(f32)  # noqa: E731
+        for col in (O.ANGLED_IDX, O.POSITIOND_IDX, O.POSITION_IDX):  # mode A from an initial state one float32 ulp away
+            s0p = s0a.copy()
+            s0p[:, col] = one_up(s0p[:, col])
+            u_p, _, S_p = OC.step(ca, s0p, u0, du, tp, te, L=L)
+            alt_S.append(S_p); alt_u.append(u_p)
+        u_p, _, S_p = OC.step(ca, s0, u0, one_up(np.asarray(du, f32)), tp, te, L=L)     # every perturbation one ulp up
+        alt_S.append(S_p); alt_u.append(u_p)
+        if L is not None:                                       # the pole length one ulp longer
+            u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=one_up(np.asarray(L, f32)))
+            alt_S.append(S_p); alt_u.append(u_p)
+        extra = {"S_alt": alt_S, "u_alt": alt_u}
     if ocfg.shift_mode == "repeat_last":
         u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1)
     elif ocfg.shift_mode == "append_zero":

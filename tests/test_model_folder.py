@@ -159,3 +159,31 @@ def test_predictor_output_augmentation_matches_the_reference():
         np.testing.assert_allclose(yt.numpy(), g[f"{name}/y"], atol=1e-6)
     diff = predictor_output_augmentation(SimpleNamespace(outputs=["D_angle_cos", "D_angle_sin", "D_position"]), differential_network=True)
     assert diff.get_features_augmentation() == ["angle"]
+
+
+def test_conversion_is_pinned_to_keras():
+    """tests/golden/keras_gru/{weights_keras.npz, keras_io.npz}: weights and outputs of a REAL Keras GRU(32) -> GRU(32) ->
+    Dense(5), written by tools/export_keras_gru.py in a TensorFlow environment (none exists on this image, so the fixture
+    may be absent: skipped then).  When present, the converted model must reproduce Keras' own outputs through
+    torch.nn.GRU and through the numpy GRU oracle — the conversion is then pinned to Keras, not to the restatement of
+    its equations above."""
+    torch = pytest.importorskip("torch")
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_gru")
+    if not (os.path.exists(os.path.join(d, "weights_keras.npz")) and os.path.exists(os.path.join(d, "keras_io.npz"))):
+        pytest.skip("no Keras fixture: run tools/export_keras_gru.py once in a TensorFlow environment and commit tests/golden/keras_gru/")
+    z = np.load(os.path.join(d, "weights_keras.npz"))
+    io = np.load(os.path.join(d, "keras_io.npz"))
+    model = MF.keras_gru_weights_to_model([z[f"arr_{i}"] for i in range(len(z.files))])
+    x, y = io["x"].astype(np.float32), io["y"]
+    gru = torch.nn.GRU(6, 32, num_layers=2, batch_first=True)
+    head = torch.nn.Linear(32, 5)
+    with torch.no_grad():
+        for l in range(2):
+            getattr(gru, f"weight_ih_l{l}").copy_(torch.tensor(model[f"w_ih{l}"]))
+            getattr(gru, f"weight_hh_l{l}").copy_(torch.tensor(model[f"w_hh{l}"]))
+            getattr(gru, f"bias_ih_l{l}").copy_(torch.tensor(model[f"b_ih{l}"]))
+            getattr(gru, f"bias_hh_l{l}").copy_(torch.tensor(model[f"b_hh{l}"]))
+        head.weight.copy_(torch.tensor(model["w_out"]))
+        head.bias.copy_(torch.tensor(model["b_out"]))
+        y_t = head(gru(torch.tensor(x))[0]).numpy()
+    np.testing.assert_allclose(y_t, y, atol=2e-5, rtol=1e-5)

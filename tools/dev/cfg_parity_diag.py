@@ -35,6 +35,7 @@ for tag, kw in (("fast_r2", dict(rollouts_per_lane=2)), ("fast_r1", dict(rollout
     e.close()
 ocfg = O.MPPIConfig(N=N, H=H)
 THL = PU.THL
+SENS = float(os.environ.get("DIAG_SENS", "0.25e-4"))
 CH = 8
 tot = {t: dict(clear_off=0, flagged_off=0, clear=0, flagged=0, sens_off=0, worst_clear=0.0, u_worst=0.0,
                env_clear=0, env_sens=0, env_clear_off=0, env_sens_off=0, env_worst_clear=0.0, u_off_envs=0, u_off_envs_env=0) for t in outs}
@@ -62,8 +63,8 @@ for e0 in range(0, E, CH):
             T["worst_clear"] = max(T["worst_clear"], float(exc[~fl].max()))
             T["u_worst"] = max(T["u_worst"], float(np.abs(u_m[e] - ref["u_a"][i]).max()))
             # rule with the envelope of the reference's own realisations (B, C = fma float32, P = one ulp away)
-            genv = PU.envelope(Sa, Sb, ref["S_c"][i] if ref["S_c"] is not None else None, ref["S_p"][i])
-            sens_e = genv > 1e-4 * np.abs(Sa)
+            genv = PU.envelope(Sa, Sb, *[a[i] for a in ref["S_alt"]])
+            sens_e = genv > SENS * np.abs(Sa)
             off_e = dev > 1e-4 * np.abs(Sa) + genv
             bucket = fl | sens_e
             T["env_clear"] += int((~bucket).sum()); T["env_sens"] += int((sens_e & ~fl).sum())
@@ -72,7 +73,7 @@ for e0 in range(0, E, CH):
                 T["env_worst_clear"] = max(T["env_worst_clear"], float((dev / (1e-4 * np.abs(Sa) + genv))[~bucket].max()))
             allow = PU.softmin_allowance(Sa, Sb, du[i])
             ugap = float(PU.envelope(ref["u_a"][i], ref["u_b"][i]).max())
-            ugap_e = float(PU.envelope(ref["u_a"][i], ref["u_b"][i], ref["u_c"][i] if ref["u_c"] is not None else None, ref["u_p"][i]).max())
+            ugap_e = float(PU.envelope(ref["u_a"][i], ref["u_b"][i], *[a[i] for a in ref["u_alt"]]).max())
             du_ = np.abs(u_m[e] - ref["u_a"][i])
             T["u_off_envs"] += int((du_ > 1e-4 + np.maximum(ugap, allow)).any())
             T["u_off_envs_env"] += int((du_ > 1e-4 + np.maximum(ugap_e, allow)).any())
