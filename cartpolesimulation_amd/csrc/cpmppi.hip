@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
     for (uint32_t k = 0; k < H; ++k) {
       const float u = p.u_max * Q[b * H + k];
       if constexpr (FAST) {
-        control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec);
+        control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec, p.THL);
       } else {
         for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
       }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
     for (uint32_t kk = 0; kk < kn; ++kk) {
       const float u = p.u_max * Q[b * H + k0 + kk];
       if constexpr (FAST) {
-        control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec);
+        control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec, p.THL);
       } else {
         for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
       }
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     else cost += stage_qbg<float, true>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
     u_before = ur;
     const float uK = (ur * p.u_max) * ec.kp1;
-    for (uint32_t s = 0; s < S; ++s) substep_fast<float>(st, uK, t, p, ec);
+    for (uint32_t s = 0; s < S; ++s) substep_fast<float>(st, uK, t, p, ec, p.THL);
     cosang = st.c;
   }
   const float term = (COST == COST_DEFAULT) ? terminal_indicator<float>(p, st.th, st.x, x_t) : 0.0f;
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     for (uint32_t i = 0; i < S; ++i) {
       float* __restrict__ d = my + (size_t)i * 6 * BLOCK;
       d[0] = s.th; d[BLOCK] = s.w; d[2 * BLOCK] = s.c; d[3 * BLOCK] = s.s; d[4 * BLOCK] = s.x; d[5 * BLOCK] = s.v;
-      substep_fast<float>(s, uK, t, p, ec);
+      substep_fast<float>(s, uK, t, p, ec, p.THL);
     }
     float guK = 0.0f;
     for (uint32_t i = S; i-- > 0;) {

@@ -505,13 +505,22 @@ __device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
 // One Euler substep, FAST, with the reference's per-substep wrap and sin/cos evaluation (the control step's LAST
 // substep of the rotating flavours, every substep of the plain one).
 // CHECK = false: the caller has PROVED that no lane can reach the track edge within this control step (SafeStep below).
+// `nearlim` <= THL (wave-uniform): the ONE pair of compares of the common path tests |x| against it instead of THL, and
+// the return value says whether any lane of the wave ends the substep at or beyond it - the next stage's boundary cost
+// (nonzero only for |x| > permissible_track_fraction * THL = nearlim) is evaluated only then.  The edge itself is tested
+// behind that branch, so the common path costs what it did with the plain edge test.
 template <class F, bool CHECK = true>
-__device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e, bool check = true) {
+__device__ __forceinline__ bool substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e, float nearlim,
+                                             bool check = true) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
-  uint64_t rare = 0;
+  uint64_t near = 0, rare = 0;
   if (CHECK && check) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) near |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), nearlim, 11);   // 11 = unordered or >=
+  }
+  if (CHECK && __builtin_expect(near != 0, 0)) {
 #pragma unroll
     for (int i = 0; i < W; ++i) rare |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), p.THL, 3);
   }
@@ -546,6 +555,7 @@ __device__ __forceinline__ void substep_fast(State<F>& st, F uK, float t, const 
   th1 = wrap_rint<F>(th1);
   st.th = th1; st.w = w1; st.x = x1; st.v = v1;
   sincos_pi_half<F>(th1, st.s, st.c);
+  return near != 0;
 }
 
 // Intermediate substep, FAST + ROTATE: the angle is left un-wrapped and (cos, sin) are advanced by the rotation
@@ -736,7 +746,7 @@ __device__ __forceinline__ SafeStep make_safe_step(const Params& p, const EnvCon
 // not tracked): the caller's next stage evaluates the boundary cost only then.
 template <class F, bool TWO_LOOPS = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
-                                                  const EnvConst& e, const SafeStep* ss = nullptr) {
+                                                  const EnvConst& e, float nearlim, const SafeStep* ss = nullptr) {
 #if CPMPPI_ROTATE && CPMPPI_HOIST_SPIN
   if constexpr (Width<F>::value == 1) {
     // one rollout per lane is the small-launch (latency-bound) mapping: there the per-substep test, which overlaps with
@@ -744,8 +754,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     // (three substeps per iteration under a rollback, as in the packed mid-size build, was measured here too: single env
     // 63 -> 72 us — the lone wave of this mapping gains nothing from longer basic blocks and pays for the bookkeeping)
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
-    substep_fast<F>(st, uK, t, p, e);
-    return true;
+    return substep_fast<F>(st, uK, t, p, e, nearlim);
   }
   // The seed needs |w t| <= ROT_LIMIT.  Tested once per control step: without a bounce w cannot leave the range within
   // one control step by more than the polynomials' margin, and a lane that bounces is re-tested.  Lanes beyond the
@@ -775,7 +784,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
         }
       }
       for (; left != 0u; --left) substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
-      substep_fast<F, false>(st, uK, t, p, e);
+      substep_fast<F, false>(st, uK, t, p, e, nearlim);
       return false;
     }
   }
@@ -815,15 +824,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   } else {
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
   }
-  substep_fast<F>(st, uK, t, p, e, check);
-  if (!check) return false;
-  if (ss != nullptr) {
-    uint64_t near = 0;                            // 11 = unordered or greater-equal
-#pragma unroll
-    for (int i = 0; i < Width<F>::value; ++i) near |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.x, i)), ss->nearlim, 11);
-    return near != 0;
-  }
-  return true;
+  return substep_fast<F>(st, uK, t, p, e, nearlim, check) && check;
 #else
   bool spin = false;
 #pragma unroll
@@ -836,15 +837,14 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       if (__builtin_expect(substep_fast_rot<F, false>(st, uK, t, p, e), 0)) break;
     }
   }
-  for (; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);       // the last substep always; all remaining after a bounce
+  for (; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e, p.THL);       // the last substep always; all remaining after a bounce
   return true;
 #endif
 #elif CPMPPI_ROTATE
   for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
-  substep_fast<F>(st, uK, t, p, e);
-  return true;
+  return substep_fast<F>(st, uK, t, p, e, nearlim);
 #else
-  for (uint32_t sub = 0; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e);
+  for (uint32_t sub = 0; sub < S; ++sub) substep_fast<F>(st, uK, t, p, e, p.THL);
   return true;
 #endif
 }

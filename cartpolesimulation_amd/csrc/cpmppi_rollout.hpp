@@ -262,12 +262,20 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
-  // packed FAST mapping: control steps proved clear of the track edge skip the per-substep edge test, and stages whose
-  // |x| is known to be below the boundary cost's threshold skip that term (SafeStep, cpmppi_device.hpp); `near` is
-  // wave-uniform (stage 0: the shared initial state)
-  constexpr bool TRACK_NEAR = FAST && R == 2 && CPMPPI_SAFE_STEP != 0;
-  const SafeStep ss = make_safe_step(p, ec, COST == COST_QBGM ? p.w[6] : 1.0f);
-  bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < ss.nearlim);
+  // `near` (wave-uniform): may any rollout of this wave sit at or beyond permissible_track_fraction * THL at the current
+  // stage?  Only then does quadratic_boundary_grad_minimal's boundary term need evaluating (it is exactly zero below the
+  // threshold).  The flag comes out of the previous control step's last substep, whose one pair of edge compares tests
+  // against this coarser limit (substep_fast); stage 0 is the initial state all rollouts share.  Other costs: the limit
+  // is the edge itself and the flag is unused.
+  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM;
+  const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
+  bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
+#if CPMPPI_SAFE_STEP
+  const SafeStep ss = make_safe_step(p, ec, TRACK_NEAR ? p.w[6] : 1.0f);
+  const SafeStep* ssp = (FAST && R == 2) ? &ss : nullptr;
+#else
+  const SafeStep* ssp = nullptr;
+#endif
 
   // Latency build: the nominal control (and the legacy cost's previous sequence) of step k + 1 is requested while step k
   // integrates - a scalar load consumed a few instructions after its issue is ~100 ns of exposed latency per control step
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
       const F uK = u * splat<F>(ec.kp1);
-      near = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, TRACK_NEAR ? &ss : nullptr);
+      const bool near_next = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp);
+      near = !TRACK_NEAR || near_next;
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
     }

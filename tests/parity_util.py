@@ -81,17 +81,23 @@ def envelope(ref_a, *others):
     return gap
 
 
-def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False, S_alt=()):
+def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False, S_alt=(),
+                 sens_rtol=None):
     """Per-rollout costs: |S - S_a| <= rtol |S_a| + gap for every unflagged rollout, gap = the envelope of the reference's
     own realisations around mode A (S_b and any S_alt).  flag_sensitive: a rollout on which those realisations disagree
-    among THEMSELVES by more than the band (gap > rtol |S_a|: a chaotic trajectory that amplifies 1e-7 roundings beyond
-    the tolerance) joins the flagged bucket - no evaluation in float32, the reference's included, pins it to the band."""
+    among THEMSELVES by more than sens_rtol |S_a| (default: the band; the full-size C3 / C4 tests use a QUARTER of it, as
+    flag_rounding_sensitive does: a chaotic trajectory that amplifies 1e-7 roundings to a visible fraction of the
+    tolerance) joins the flagged bucket - no evaluation in float32, the reference's included, pins it to the band.
+    Measured on MI355X (tools/dev/cfg_parity_diag.py, C3 = 64 x 4096 rollouts of 1000 substeps from random states up to 21
+    rad/s): with the seven realisations of c_oracle_step_with_flags(probes=True) and the quarter-band rule NO clear
+    rollout is outside its allowance in FAST (both lane mappings) or PRECISE (worst: 0.95 of it); with modes A / B alone
+    25 of 199 887 are - PRECISE, the reference's own operand order, among them."""
     S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
     gap = envelope(S_a, S_b, *S_alt) if (S_b is not None or len(S_alt)) else 0.0
     off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap
     flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
     if flag_sensitive and (S_b is not None or len(S_alt)):
-        flagged = flagged | (gap > rtol * np.abs(S_a))
+        flagged = flagged | (gap > (rtol if sens_rtol is None else sens_rtol) * np.abs(S_a))
     _check(off, flagged, what, strict)
 
 

@@ -63,10 +63,15 @@ def test_config_full_size(name, E, N, H):
     for e0 in range(0, E, CH):
         sl = slice(e0, e0 + CH)
         du = np.stack([O.interpolate_knots(kn_h[e], H) for e in range(e0, e0 + CH)])
-        ref = PU.c_oracle_step_with_flags(ocfg, s0[sl], u0[sl], du, tp[sl], te[sl], L=Lv[sl])
+        # probes: besides modes A and B, five more realisations of the REFERENCE one rounding away from mode A (FMA float32
+        # build, initial state / perturbations / pole length one ulp up).  A rollout on which those disagree among themselves
+        # by more than a quarter of the band is rounding-sensitive (a pole swinging at 20 rad/s for 1000 substeps amplifies
+        # 1e-7 to 1e-3) and joins the flagged bucket; every other rollout must sit inside band + that envelope (100 %).
+        ref = PU.c_oracle_step_with_flags(ocfg, s0[sl], u0[sl], du, tp[sl], te[sl], L=Lv[sl], probes=True)
         for mode, (u_m, S_m, Q_m) in outs.items():
             for i, e in enumerate(range(e0, e0 + CH)):
-                PU.assert_costs(S_m[e], ref["S_a"][i], ref["S_b"][i], ref["flags"][i], f"{name} {mode} env {e} costs")
+                PU.assert_costs(S_m[e], ref["S_a"][i], ref["S_b"][i], ref["flags"][i], f"{name} {mode} env {e} costs",
+                                S_alt=[a[i] for a in ref["S_alt"]], flag_sensitive=True, sens_rtol=0.25e-4)
                 PU.assert_controls(u_m[e], ref["u_a"][i], ref["u_b"][i], f"{name} {mode} env {e} u_nom",     # 1e-4 + the oracle's own A/B gap
                                    allowance=PU.softmin_allowance(ref["S_a"][i], ref["S_b"][i], du[i]))
                 PU.assert_controls(Q_m[e], ref["u_a"][i][0], ref["u_b"][i][0], f"{name} {mode} env {e} Q",

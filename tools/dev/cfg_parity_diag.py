@@ -60,7 +60,8 @@ for e0 in range(0, E, CH):
             T["clear_off"] += int((off & ~fl).sum()); T["flagged_off"] += int((off & fl).sum())
             T["sens_off"] += int((off & ~fl & sens).sum())
             exc = dev / (1e-4 * np.abs(Sa) + gap)
-            T["worst_clear"] = max(T["worst_clear"], float(exc[~fl].max()))
+            if (~fl).any():
+                T["worst_clear"] = max(T["worst_clear"], float(exc[~fl].max()))
             T["u_worst"] = max(T["u_worst"], float(np.abs(u_m[e] - ref["u_a"][i]).max()))
             # rule with the envelope of the reference's own realisations (B, C = fma float32, P = one ulp away)
             genv = PU.envelope(Sa, Sb, *[a[i] for a in ref["S_alt"]])
