@@ -548,6 +548,22 @@ def main():
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": k1 * 1e3, "finalize_kernel_us": float(np.median(f1)) * 1e3,
                                  "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time = HIP events around groups of 10 launches / 10"}
+            if args.predictor == "ode" and args.math == "fast":
+                # the simulator's own call: state and attributes on the HOST, the control back on the host
+                # (CartPole/__init__.py:509-520) through cpmppi_step_host - PCIe-inclusive, never `value`
+                s_h = w1.s0.cpu().numpy().copy()
+                tp_h, te_h, L_h = (x.cpu().numpy().copy() for x in (w1.tp, w1.te, w1.L))
+                q_h = np.zeros(1, np.float32)
+                for i in range(20):
+                    e1.step_host(s_h, w1.u_nom, tp_h, te_h, L_h, w1.seed, 1000 + i, q_h)
+                t2 = time.perf_counter()
+                for i in range(reps):
+                    e1.step_host(s_h, w1.u_nom, tp_h, te_h, L_h, w1.seed, 2000 + i, q_h)
+                dt2 = (time.perf_counter() - t2) / reps
+                out["single_env"]["host_seam"] = {
+                    "us_per_call": dt2 * 1e6, "rollouts_per_s": N / dt2,
+                    "note": "cpmppi_step_host: state / attributes read from pinned host memory by the kernel, the control "
+                            "delivered into it with a system-scope ticket the caller spins on (no copies, no stream wait)"}
             if args.predictor == "ode":
                 out["single_env"]["roofline_valu"] = {
                     "bound": "fp32-valu", "achieved": algorithmic_flops_per_rollout(H) * N / (k1 * 1e-3) / 1e12,

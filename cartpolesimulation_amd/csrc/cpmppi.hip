@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
     for (uint32_t k = 0; k < H; ++k) {
       const float u = p.u_max * Q[b * H + k];
       if constexpr (FAST) {
-        control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec, p.THL);
+        control_step_fast<float>(st, ec.uK_scale * Q[b * H + k], p.S, p.t_step, p, ec, p.THL);
       } else {
         for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
       }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
     for (uint32_t kk = 0; kk < kn; ++kk) {
       const float u = p.u_max * Q[b * H + k0 + kk];
       if constexpr (FAST) {
-        control_step_fast<float>(st, ec.kp1 * u, p.S, p.t_step, p, ec, p.THL);
+        control_step_fast<float>(st, ec.uK_scale * Q[b * H + k0 + kk], p.S, p.t_step, p, ec, p.THL);
       } else {
         for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
       }
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     else if constexpr (COST == COST_DEFAULT) cost += stage_default<float, true>(p, st.x, cosang, ur, x_t, te);
     else cost += stage_qbg<float, true>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
     u_before = ur;
-    const float uK = (ur * p.u_max) * ec.kp1;
+    const float uK = ur * ec.uK_scale;
     for (uint32_t s = 0; s < S; ++s) substep_fast<float>(st, uK, t, p, ec, p.THL);
     cosang = st.c;
   }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     const float q = Q[k];
     const bool clipped = clip && (q < p.lo || q > p.hi);
     const float ur = clip ? clamp_(q, p.lo, p.hi) : q;
-    const float uK = (ur * p.u_max) * ec.kp1;
+    const float uK = ur * ec.uK_scale;
     State<float> s = st0;
     for (uint32_t i = 0; i < S; ++i) {
       float* __restrict__ d = my + (size_t)i * 6 * BLOCK;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     lam.x = __builtin_fmaf(scale, sg.x, lam.x);
     lam.w = __builtin_fmaf(scale, sg.w, lam.w);
     lam.th = __builtin_fmaf(scale * sg.cosang, -sa, lam.th);
-    const float gk = __builtin_fmaf(guK, ec.kp1 * p.u_max, scale * sg.u + carry);
+    const float gk = __builtin_fmaf(guK, ec.uK_scale, scale * sg.u + carry);
     carry = scale * sg.u_before;
     a.grad[g * H + k] = clipped ? 0.0f : gk;
   }

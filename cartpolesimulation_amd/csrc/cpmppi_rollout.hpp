@@ -267,6 +267,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // threshold).  The flag comes out of the previous control step's last substep, whose one pair of edge compares tests
   // against this coarser limit (substep_fast); stage 0 is the initial state all rollouts share.  Other costs: the limit
   // is the edge itself and the flag is unused.
+  const QbgmFolded qf = make_qbgm_folded(p, te);
   constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM;
   const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
   bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     F ur = splat<F>(uk) + du;
     ur = clamp_(ur, p.run_lo, p.run_hi);
     if constexpr (COST == COST_QBGM) {
-      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near);
+      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near, FAST ? &qf : nullptr);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
       cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     }
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
-      const F uK = u * splat<F>(ec.kp1);
+      const F uK = ur * splat<F>(ec.uK_scale);   // (k+1) u_max Q: the form in which the control enters positionDD's numerator
       const bool near_next = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp);
       near = !TRACK_NEAR || near_next;
     } else {
