@@ -544,6 +544,7 @@ def main():
             for i in range(50):
                 w1.step(400 + i)
             r1, f1 = e1.get_profile()
+            e1.set_profiling(False)
             k1 = float(np.median(r1))
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": k1 * 1e3, "finalize_kernel_us": float(np.median(f1)) * 1e3,

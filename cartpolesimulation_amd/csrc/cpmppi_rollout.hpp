@@ -268,7 +268,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // against this coarser limit (substep_fast); stage 0 is the initial state all rollouts share.  Other costs: the limit
   // is the edge itself and the flag is unused.
   const QbgmFolded qf = make_qbgm_folded(p, te);
-  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM;
+  // (not in the latency build: there the flag's compare -> scalar branch hand-over sits on the lone wave's critical path
+  // once per control step - measured 56 -> 66 us for a single env - while the eight instructions it saves are hidden)
+  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0;
   const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
   bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
 #if CPMPPI_SAFE_STEP
@@ -328,25 +330,50 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     // The 64*R rollouts of a wave are one contiguous span of 64*R*H floats in delta_u[E,N,H]; a tile of TK time-steps
     // is fetched in whole row segments (TK*4 bytes per row), parked in registers while the previous tile is
     // integrated, then written to LDS and read back one row per lane (odd row stride: conflict-free).
-    constexpr int NLOAD = R * TK;            // elements per lane per tile
+    // Round 3: the tile is fetched in 16-byte pieces.  Lane l owns column piece l % (TK/4) of rows l / (TK/4) + (256/TK) i:
+    // one lane-dependent offset, every other address term wave-uniform, and for a tile that lies wholly inside the rows
+    // and the horizon (all but the last tile of a horizon that is no multiple of TK, and the last wave of an env whose N
+    // is no multiple of 64 R) R*TK/4 unconditional dwordx4 loads.  (Round 2 issued R*TK predicated dword loads with R*TK
+    // row pointers held in registers: ~160 instructions and 32 address registers per tile.)
+    static_assert(TK % 4 == 0 && 64 % (TK / 4) == 0, "TK: a multiple of 4 that divides 256");
+    constexpr int PPR = TK / 4;              // 16-byte pieces per row segment
+    constexpr int NV = R * TK / 4;           // pieces per lane per tile
+    constexpr uint32_t ROWS_PER_PASS = 64 / PPR;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // rows are only 4-byte aligned (H * 4 bytes apart)
     const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * H;
     float* __restrict__ my_tile = tile + wave * (64 * R * TILE_STRIDE);
-    float pre[NLOAD];
+    const uint32_t lrow = lane / PPR, lcol = 4u * (lane % PPR);
+    const uint32_t lane_off = lrow * H + lcol;                              // floats; + (ROWS_PER_PASS i) H + k0, both uniform
+    const bool rows_inside = row0 + 64u * R <= p.N;
+    float4 pre[NV];
     auto gload = [&](uint32_t k0) __attribute__((always_inline)) {
+      if (__builtin_expect(rows_inside && k0 + TK <= H, 1)) {
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
-        const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
-        const uint32_t k = k0 + col;
-        pre[i] = (row0 + row < p.N && k < H) ? src[(size_t)row * H + k] : 0.0f;
+        for (int i = 0; i < NV; ++i) {
+          const float* sp = src + (size_t)(ROWS_PER_PASS * (uint32_t)i * H + k0);      // wave-uniform
+          const f4u v = *reinterpret_cast<const f4u*>(sp + lane_off);
+          pre[i] = float4{v.x, v.y, v.z, v.w};
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const uint32_t row = lrow + ROWS_PER_PASS * (uint32_t)i, k = k0 + lcol;
+          const float* sp = src + (size_t)(ROWS_PER_PASS * (uint32_t)i * H + k0) + lane_off;
+          const bool rv = row0 + row < p.N;
+          pre[i].x = (rv && k < H) ? sp[0] : 0.0f;
+          pre[i].y = (rv && k + 1 < H) ? sp[1] : 0.0f;
+          pre[i].z = (rv && k + 2 < H) ? sp[2] : 0.0f;
+          pre[i].w = (rv && k + 3 < H) ? sp[3] : 0.0f;
+        }
       }
     };
     gload(0);
     for (uint32_t k0 = 0; k0 < H; k0 += TK) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
-        const uint32_t idx = lane + 64u * i, row = idx / TK, col = idx % TK;
-        my_tile[row * TILE_STRIDE + col] = pre[i];
+      for (int i = 0; i < NV; ++i) {
+        float* dst = my_tile + (lrow + ROWS_PER_PASS * (uint32_t)i) * TILE_STRIDE + lcol;
+        dst[0] = pre[i].x; dst[1] = pre[i].y; dst[2] = pre[i].z; dst[3] = pre[i].w;
       }
       __syncthreads();
       if (k0 + TK < H) gload(k0 + TK);
