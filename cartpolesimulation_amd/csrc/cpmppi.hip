@@ -37,6 +37,7 @@ using namespace cpmppi_k;
 // cpmppi_rollout_mid.hip (2), each with its own compiler flags; nothing of it may be instantiated here
 namespace cpmppi_k {
 CPMPPI_LATENCY_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
+CPMPPI_LATENCY_BUFFER_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_MID_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 }  // namespace cpmppi_k

@@ -349,6 +349,12 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
                                 // (2.39 -> 2.55 ms) although each safe step issues 5 % fewer vector instructions; gating the test
                                 // inside one loop (== 2) makes the compiler if-convert the event code into the loop (137 instructions)
 #endif
+#ifndef CPMPPI_LATENCY_NEAR
+#define CPMPPI_LATENCY_NEAR 0   // one rollout per lane: the last substep tests the edge directly (no coarser "near" limit)
+#endif
+#ifndef CPMPPI_QBGM_FOLD
+#define CPMPPI_QBGM_FOLD 1      // FAST: folded factors in quadratic_boundary_grad_minimal's stage cost
+#endif
 #ifndef CPMPPI_HOIST_SPIN
 #define CPMPPI_HOIST_SPIN 1     // test |w t| once per control step (<= 0.1) instead of every substep (<= 0.125)
 #endif
@@ -512,20 +518,27 @@ __device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
 // the return value says whether any lane of the wave ends the substep at or beyond it - the next stage's boundary cost
 // (nonzero only for |x| > permissible_track_fraction * THL = nearlim) is evaluated only then.  The edge itself is tested
 // behind that branch, so the common path costs what it did with the plain edge test.
-template <class F, bool CHECK = true>
+// NEAR = false: `nearlim` is not used, the common path tests the edge itself (the latency build).
+template <class F, bool CHECK = true, bool NEAR = true>
 __device__ __forceinline__ bool substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e, float nearlim,
                                              bool check = true) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
   uint64_t near = 0, rare = 0;
-  if (CHECK && check) {
+  if constexpr (NEAR) {
+    if (CHECK && check) {
 #pragma unroll
-    for (int i = 0; i < W; ++i) near |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), nearlim, 11);   // 11 = unordered or >=
-  }
-  if (CHECK && __builtin_expect(near != 0, 0)) {
+      for (int i = 0; i < W; ++i) near |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), nearlim, 11);   // 11 = unordered or >=
+    }
+    if (CHECK && __builtin_expect(near != 0, 0)) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) rare |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), p.THL, 3);
+    }
+  } else if (CHECK && check) {
 #pragma unroll
     for (int i = 0; i < W; ++i) rare |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), p.THL, 3);
+    near = ~0ull;
   }
   if (CHECK && __builtin_expect(rare != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
     CPMPPI_DBG(3, 1);
@@ -757,7 +770,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     // (three substeps per iteration under a rollback, as in the packed mid-size build, was measured here too: single env
     // 63 -> 72 us — the lone wave of this mapping gains nothing from longer basic blocks and pays for the bookkeeping)
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
-    return substep_fast<F>(st, uK, t, p, e, nearlim);
+    return substep_fast<F, true, (CPMPPI_LATENCY_NEAR != 0)>(st, uK, t, p, e, nearlim);
   }
   // The seed needs |w t| <= ROT_LIMIT.  Tested once per control step: without a bounce w cannot leave the range within
   // one control step by more than the polynomials' margin, and a lane that bounces is re-tested.  Lanes beyond the

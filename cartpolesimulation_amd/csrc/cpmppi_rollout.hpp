@@ -15,14 +15,17 @@ using namespace cpmppi;
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
-#ifndef CPMPPI_TK
-#define CPMPPI_TK 8
-#endif
 #ifndef CPMPPI_GRU_MIN_WAVES
 #define CPMPPI_GRU_MIN_WAVES 2      // waves per SIMD the GRU kernels are compiled for (register budget 512 / this)
 #endif
 #ifndef CPMPPI_MIN_WAVES
 #define CPMPPI_MIN_WAVES 1
+#endif
+#ifndef CPMPPI_DMA_TK
+#define CPMPPI_DMA_TK 8             // control steps per direct-to-LDS tile (two tiles per wave)
+#endif
+#ifndef CPMPPI_DMA_TK_THROUGHPUT
+#define CPMPPI_DMA_TK_THROUGHPUT 16 // ... in the throughput build (one tile per wave)
 #endif
 #ifndef CPMPPI_MID_UNPACKED
 #define CPMPPI_MID_UNPACKED 0
@@ -31,8 +34,6 @@ constexpr int WAVES = BLOCK / 64;
 #define CPMPPI_MID_VGPR_CONSTS 1    // mid-size build: substep constants in VGPRs (the packed form wants register pairs)
 #endif
 constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
-constexpr int TK = CPMPPI_TK;                // time-steps per LDS perturbation tile
-constexpr int TILE_STRIDE = TK + 1;          // odd stride: conflict-free lane-per-row reads
 
 // Device-side ordering between a step and the all-gather of its result (cpmppi_step_gather, cpmppi_comm.hip) without any
 // packet on the launch stream: flags[0] envs finalized by this launch, flags[1] steps published, flags[2] gathers
@@ -79,6 +80,17 @@ struct StepPtrs {
   uint32_t* host_ticket; // cpmppi_step_host: counter in pinned host memory, +1 (system scope) per finalized env; NULL otherwise
   GatherSync gs;
 };
+
+// 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform `lds`) + 16 * lane - gfx950's
+// global_load_lds_dwordx4; tracked by vmcnt.  (The builtin exists in the device pass only; the host pass, which merely
+// emits the kernel's launch stub, sees an empty body.)
+__device__ __forceinline__ void load16_to_lds(const float* gptr, float* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(gptr, lds, 16, 0, 0);
+#else
+  (void)gptr; (void)lds;
+#endif
+}
 
 // The StepPtrs kernel argument re-read from the kernarg segment at the point of call (the kernels here take
 // (const Params, const StepPtrs): the second argument sits at the first 8-byte boundary after the first).
@@ -219,7 +231,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // float2 when CPMPPI_MID_UNPACKED - a (nearly) lone wave is bound by instruction issue, not by the ALU
   using F = typename Lanes<R, (VARIANT == 2 && CPMPPI_MID_UNPACKED != 0)>::F;
   static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");
-  __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * 64 * R * TILE_STRIDE : 1];
+  // wave-private tiles (direct-to-LDS loads): two of 8 control steps in the latency / mid-size builds (the next tile streams
+  // in under the current one), ONE of 16 in the throughput build (same LDS; every 128-byte line of a 200-byte row is then
+  // requested about twice instead of four times, and the three other waves of the SIMD cover the wait)
+  constexpr uint32_t DMA_TK = (VARIANT == 1) ? CPMPPI_DMA_TK_THROUGHPUT : CPMPPI_DMA_TK;
+  constexpr uint32_t DMA_BUFS = (VARIANT == 1) ? 1u : 2u;
+  __shared__ float tile[NOISE == NOISE_DELTA_U ? WAVES * DMA_BUFS * 64 * R * DMA_TK : 1];
   __shared__ float red[2 * WAVES];
   extern __shared__ float bsum[];            // [WAVES][W]
 
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     F ur = splat<F>(uk) + du;
     ur = clamp_(ur, p.run_lo, p.run_hi);
     if constexpr (COST == COST_QBGM) {
-      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near, FAST ? &qf : nullptr);
+      cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near, (FAST && CPMPPI_QBGM_FOLD != 0) ? &qf : nullptr);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
       cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
@@ -327,62 +344,72 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 
   // ---- rollout over the horizon ----------------------------------------------------------------------------------
   if constexpr (NOISE == NOISE_DELTA_U) {
-    // The 64*R rollouts of a wave are one contiguous span of 64*R*H floats in delta_u[E,N,H]; a tile of TK time-steps
-    // is fetched in whole row segments (TK*4 bytes per row), parked in registers while the previous tile is
-    // integrated, then written to LDS and read back one row per lane (odd row stride: conflict-free).
-    // Round 3: the tile is fetched in 16-byte pieces.  Lane l owns column piece l % (TK/4) of rows l / (TK/4) + (256/TK) i:
-    // one lane-dependent offset, every other address term wave-uniform, and for a tile that lies wholly inside the rows
-    // and the horizon (all but the last tile of a horizon that is no multiple of TK, and the last wave of an env whose N
-    // is no multiple of 64 R) R*TK/4 unconditional dwordx4 loads.  (Round 2 issued R*TK predicated dword loads with R*TK
-    // row pointers held in registers: ~160 instructions and 32 address registers per tile.)
-    static_assert(TK % 4 == 0 && 64 % (TK / 4) == 0, "TK: a multiple of 4 that divides 256");
-    constexpr int PPR = TK / 4;              // 16-byte pieces per row segment
-    constexpr int NV = R * TK / 4;           // pieces per lane per tile
-    constexpr uint32_t ROWS_PER_PASS = 64 / PPR;
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // rows are only 4-byte aligned (H * 4 bytes apart)
-    const float* __restrict__ src = a.noise + ((size_t)env * p.N + row0) * H;
-    float* __restrict__ my_tile = tile + wave * (64 * R * TILE_STRIDE);
-    const uint32_t lrow = lane / PPR, lcol = 4u * (lane % PPR);
-    const uint32_t lane_off = lrow * H + lcol;                              // floats; + (ROWS_PER_PASS i) H + k0, both uniform
-    const bool rows_inside = row0 + 64u * R <= p.N;
-    float4 pre[NV];
-    auto gload = [&](uint32_t k0) __attribute__((always_inline)) {
-      if (__builtin_expect(rows_inside && k0 + TK <= H, 1)) {
+    // delta_u[E,N,H] in the REFERENCE's rollout-major layout (controller_mppi_cartpole.py:434-446,479-483: the tensor at
+    // the optimizer / predictor seam).  A lane needs one row, a memory transaction wants neighbouring lanes on neighbouring
+    // addresses: the transposition is done by the load itself.  global_load_lds_dwordx4 (gfx950) moves 16 bytes per lane
+    // from a per-lane global address straight into LDS at (wave-uniform base) + 16 * lane, no vector registers in between:
+    // lane l asks for columns [k0 + 4 part, +4) of ITS OWN row, so each of the tile's R * DTK/4 loads deposits one
+    // "column piece" of 64 rows as 64 consecutive 16-byte slots, and at control step kk the lane reads word kk % 4 of its
+    // slot in piece kk / 4.  Two tiles per wave: the next one streams in while the current one is integrated; the tile is
+    // private to its wave, so one s_waitcnt vmcnt(0) orders load and use - no block barrier, no staging registers (round 2:
+    // 16 predicated dword loads into 16 registers + 16 LDS stores + two block barriers per tile, 161 VGPRs).  Rows past N are
+    // clamped to the env's last row (their lanes are masked out of every result); a horizon that is no multiple of the tile depth ends
+    // with a tile that starts at H - DTK and overlaps its predecessor, so every load lies inside its row.
+    constexpr uint32_t DTK = DMA_TK, NBUF = DMA_BUFS;
+    static_assert(DTK % 4 == 0 && (NBUF == 1 || NBUF == 2), "tile depth: a multiple of 4; one or two tiles per wave");
+    constexpr int PPR = DTK / 4;                      // 16-byte column pieces per tile
+    constexpr uint32_t TILE_FLOATS = 64u * R * DTK;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    float* const wave_tile = tile + wave_u * (NBUF * TILE_FLOATS);
+    const float* __restrict__ env_src = a.noise + (size_t)env * p.N * H;     // wave-uniform
+    uint32_t row_off[R];                                                       // floats from env_src to the lane's rows
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const float* sp = src + (size_t)(ROWS_PER_PASS * (uint32_t)i * H + k0);      // wave-uniform
-          const f4u v = *reinterpret_cast<const f4u*>(sp + lane_off);
-          pre[i] = float4{v.x, v.y, v.z, v.w};
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const uint32_t row = lrow + ROWS_PER_PASS * (uint32_t)i, k = k0 + lcol;
-          const float* sp = src + (size_t)(ROWS_PER_PASS * (uint32_t)i * H + k0) + lane_off;
-          const bool rv = row0 + row < p.N;
-          pre[i].x = (rv && k < H) ? sp[0] : 0.0f;
-          pre[i].y = (rv && k + 1 < H) ? sp[1] : 0.0f;
-          pre[i].z = (rv && k + 2 < H) ? sp[2] : 0.0f;
-          pre[i].w = (rv && k + 3 < H) ? sp[3] : 0.0f;
-        }
-      }
+    for (int i = 0; i < R; ++i) row_off[i] = (n[i] < p.N ? n[i] : p.N - 1u) * H;
+    auto tile_start = [&](uint32_t t) __attribute__((always_inline)) -> uint32_t {
+      const uint32_t k0 = t * DTK;
+      return (k0 + DTK <= H) ? k0 : H - DTK;
     };
-    gload(0);
-    for (uint32_t k0 = 0; k0 < H; k0 += TK) {
-      __syncthreads();
+    auto dma = [&](uint32_t ks, uint32_t buf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        float* dst = my_tile + (lrow + ROWS_PER_PASS * (uint32_t)i) * TILE_STRIDE + lcol;
-        dst[0] = pre[i].x; dst[1] = pre[i].y; dst[2] = pre[i].z; dst[3] = pre[i].w;
+      for (int part = 0; part < PPR; ++part)
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+          load16_to_lds(env_src + row_off[i] + ks + 4u * (uint32_t)part,
+                        wave_tile + buf * TILE_FLOATS + (uint32_t)(part * R + i) * 256u);
+    };
+    const bool streamed = H >= DTK;          // (a horizon shorter than one tile is filled element by element, below)
+    const uint32_t ntiles = streamed ? (H + DTK - 1u) / DTK : 1u;
+    if (!streamed) {
+      for (uint32_t k = 0; k < H; ++k)
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+          wave_tile[((k >> 2) * R + (uint32_t)i) * 256u + lane * 4u + (k & 3u)] = env_src[row_off[i] + k];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (NBUF == 2) {
+      dma(0u, 0u);
+    }
+    for (uint32_t t = 0; t < ntiles; ++t) {
+      const uint32_t ks = streamed ? tile_start(t) : 0u, k_first = t * DTK;      // (k_first > ks only in an overlapping last tile)
+      if (streamed) {
+        if (NBUF == 1) dma(ks, 0u);                                             // (the other waves of the SIMD cover the wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // tile t has landed in LDS
+        if (NBUF == 2 && t + 1u < ntiles) dma(tile_start(t + 1u), (t + 1u) & 1u);
       }
-      __syncthreads();
-      if (k0 + TK < H) gload(k0 + TK);
-      const uint32_t kend = (H - k0 < (uint32_t)TK) ? (H - k0) : (uint32_t)TK;
-      for (uint32_t kk = 0; kk < kend; ++kk) {
-        F du;
+      const float4* __restrict__ cur_tile = reinterpret_cast<const float4*>(wave_tile + (NBUF == 2 ? (t & 1u) : 0u) * TILE_FLOATS) + lane;
+      for (uint32_t q = 0; q < (uint32_t)PPR; ++q) {
+        float4 quad[R];                                                         // one conflict-free 16-byte read per four control steps
 #pragma unroll
-        for (int i = 0; i < R; ++i) put(du, i, my_tile[(i * 64 + lane) * TILE_STRIDE + kk]);
-        control_step(k0 + kk, du);
+        for (int i = 0; i < R; ++i) quad[i] = cur_tile[(q * R + (uint32_t)i) * 64u];
+        for (uint32_t c = 0; c < 4u; ++c) {
+          const uint32_t k = ks + 4u * q + c;
+          F du;
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            put(du, i, quad[i].x);
+            quad[i].x = quad[i].y; quad[i].y = quad[i].z; quad[i].z = quad[i].w;
+          }
+          if (k >= k_first && k < H) control_step(k, du);
+        }
       }
     }
   } else if constexpr (NOISE == NOISE_TILED) {
@@ -662,7 +689,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #define CPMPPI_FOR_NOISES(X, FAST, R, V)                                                        \
   CPMPPI_FOR_COSTS(X, FAST, NOISE_DELTA_U, R, V) CPMPPI_FOR_COSTS(X, FAST, NOISE_KNOTS, R, V)   \
   CPMPPI_FOR_COSTS(X, FAST, NOISE_PHILOX, R, V) CPMPPI_FOR_COSTS(X, FAST, NOISE_TILED, R, V)
-#define CPMPPI_LATENCY_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 1, 0)
+// (the latency build is two units: the reference-layout buffer kernel schedules best with iterative-ilp, the others with
+// max-memory-clause - single env 1024 x 50 on MI355X: Philox 59.2 vs 56.2 us, knots 59.6 vs 58.2, buffer 61.8 vs 68.0)
+#define CPMPPI_LATENCY_INSTANCES(X)                                                                                     \
+  CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 1, 0) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 1, 0)                              \
+  X(COST_QBGM, true, NOISE_PHILOX, 1, 0) X(COST_LEGACY, true, NOISE_PHILOX, 1, 0) X(COST_QBG, true, NOISE_PHILOX, 1, 0)
+// (... and the `default`-cost Philox kernel, which max-memory-clause leaves with a 20-byte scratch slot for two spilled
+// scalar registers - tests/test_abi_and_host.py keeps scratch out of every instantiation)
+#define CPMPPI_LATENCY_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 1, 0) X(COST_DEFAULT, true, NOISE_PHILOX, 1, 0)
 #define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 2)
 #define CPMPPI_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)

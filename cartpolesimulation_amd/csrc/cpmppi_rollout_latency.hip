@@ -1,5 +1,6 @@
 // Explicit instantiations of the rollout kernel, latency build (VARIANT 0: one rollout per lane, launches of at most
-// one wave per SIMD); compiled with -amdgpu-sched-strategy=iterative-ilp (see __graft_entry__.build).
+// one wave per SIMD), noise from knots / in-kernel Philox / the tiled buffer; compiled with
+// -amdgpu-sched-strategy=max-memory-clause (see __graft_entry__.build).
 #include "cpmppi_rollout.hpp"
 
 namespace cpmppi_k {
