@@ -555,11 +555,12 @@ def main():
                 s_h = w1.s0.cpu().numpy().copy()
                 tp_h, te_h, L_h = (x.cpu().numpy().copy() for x in (w1.tp, w1.te, w1.L))
                 q_h = np.zeros(1, np.float32)
+                u_h = e1.zeros(1, H)                     # (its own plan buffer: with the collective the workload's live elsewhere)
                 for i in range(20):
-                    e1.step_host(s_h, w1.u_nom, tp_h, te_h, L_h, w1.seed, 1000 + i, q_h)
+                    e1.step_host(s_h, u_h, tp_h, te_h, L_h, w1.seed, 1000 + i, q_h)
                 t2 = time.perf_counter()
                 for i in range(reps):
-                    e1.step_host(s_h, w1.u_nom, tp_h, te_h, L_h, w1.seed, 2000 + i, q_h)
+                    e1.step_host(s_h, u_h, tp_h, te_h, L_h, w1.seed, 2000 + i, q_h)
                 dt2 = (time.perf_counter() - t2) / reps
                 out["single_env"]["host_seam"] = {
                     "us_per_call": dt2 * 1e6, "rollouts_per_s": N / dt2,

@@ -3,7 +3,10 @@
  *   consumer <config.bin> <E> <seed> <steps>
  * Reads a cpmppi_config blob (written by the test from the ctypes mirror), runs `steps` fused MPPI steps for E envs
  * from fixed states with in-kernel Philox noise through cpmppi_step (device pointers) and again through cpmppi_step_host
- * (host pointers), prints Q of every env per step ("Q ..." / "Qh ...") and the final nominal sequence of env 0. */
+ * (host pointers), prints Q of every env per step ("Q ..." / "Qh ...") and the final nominal sequence of env 0; then the
+ * same steps a third time through the multi-GPU entry points with ONE rank (cpmppi_comm_unique_id / cpmppi_comm_init /
+ * cpmppi_step_gather with two alternating nominal-sequence buffers / cpmppi_comm_sync): "Qg ..." per step, and "g ..." =
+ * the gathered copy of env 0's final sequence (must equal "u ..."). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -73,6 +76,37 @@ int main(int argc, char** argv) {
   printf("u");
   for (uint32_t k = 0; k < H; ++k) printf(" %.9g", hu[k]);
   printf("\n");
+  /* ---- one rank of the env-sharded form: step + all-gather of its result in one call ---- */
+  {
+    unsigned char id[CPMPPI_COMM_ID_BYTES];
+    float *ub[2], *recv[2];
+    if (cpmppi_comm_unique_id(id, NULL) != CPMPPI_OK) { fprintf(stderr, "comm id: %s\n", cpmppi_last_error(NULL)); return 6; }
+    if (cpmppi_comm_init(h, id, 1, 0, NULL) != CPMPPI_OK) { fprintf(stderr, "comm init: %s\n", cpmppi_last_error(h)); return 6; }
+    for (int b = 0; b < 2; ++b) {
+      HIPCHECK(hipMalloc((void**)&ub[b], (size_t)E * H * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&recv[b], (size_t)E * H * sizeof(float)));
+      HIPCHECK(hipMemset(ub[b], 0, (size_t)E * H * sizeof(float)));
+    }
+    for (int it = 0; it < steps; ++it) {
+      cpmppi_step_args a;
+      memset(&a, 0, sizeof a);
+      a.E = E; a.s0 = s0; a.u_nom = ub[it & 1]; a.u_nom_out = ub[(it + 1) & 1];
+      a.target_position = tgt; a.target_equilibrium = tgt + E; a.L = tgt + 2 * E;
+      a.noise_kind = CPMPPI_NOISE_PHILOX; a.seed = seed; a.offset = (uint64_t)it; a.Q_out = Q;
+      if (cpmppi_step_gather(h, &a, recv[(it + 1) & 1], NULL) != CPMPPI_OK) { fprintf(stderr, "step_gather: %s\n", cpmppi_last_error(h)); return 7; }
+      HIPCHECK(hipDeviceSynchronize());
+      HIPCHECK(hipMemcpy(hq, Q, (size_t)E * sizeof(float), hipMemcpyDeviceToHost));
+      printf("Qg");
+      for (uint32_t e = 0; e < E; ++e) printf(" %.9g", hq[e]);
+      printf("\n");
+    }
+    if (cpmppi_comm_sync(h) != CPMPPI_OK) { fprintf(stderr, "comm sync: %s\n", cpmppi_last_error(h)); return 8; }
+    HIPCHECK(hipMemcpy(hu, recv[steps & 1], (size_t)H * sizeof(float), hipMemcpyDeviceToHost));
+    printf("g");
+    for (uint32_t k = 0; k < H; ++k) printf(" %.9g", hu[k]);
+    printf("\n");
+    cpmppi_comm_destroy(h);
+  }
   cpmppi_destroy(h);
   return 0;
 }

@@ -35,10 +35,14 @@ def test_c_consumer_matches_the_python_binding(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
     assert lines[0].startswith("cpmppi 1 gfx950")
-    Q_c = np.array([[np.float32(x) for x in l.split()[1:]] for l in lines[1:1 + steps]], dtype=np.float32)
-    Qh_c = np.array([[np.float32(x) for x in l.split()[1:]] for l in lines[1 + steps:1 + 2 * steps]], dtype=np.float32)
-    assert all(l.startswith("Qh") for l in lines[1 + steps:1 + 2 * steps]) and np.array_equal(Qh_c, Q_c)   # host-pointer entry point
-    u_c = np.array([np.float32(x) for x in lines[1 + 2 * steps].split()[1:]], dtype=np.float32)
+    rows = lambda tag: [np.array([np.float32(x) for x in l.split()[1:]], dtype=np.float32)  # noqa: E731
+                        for l in lines if l.split(" ", 1)[0] == tag]       # (RCCL prints its banner on stdout too)
+    Q_c, Qh_c, Qg_c = (np.stack(rows(t)) for t in ("Q", "Qh", "Qg"))
+    assert Q_c.shape == Qh_c.shape == Qg_c.shape == (steps, E)
+    assert np.array_equal(Qh_c, Q_c)                                       # host-pointer entry point
+    (u_c,), (g_c,) = rows("u"), rows("g")
+    # the multi-GPU entry points from plain C, one rank: the same controls again, and the gathered copy of the result
+    assert np.array_equal(Qg_c, Q_c) and np.array_equal(g_c, u_c)
     # the same through the Python binding
     eng = MPPIEngine(E, mppi)
     f32 = np.float32

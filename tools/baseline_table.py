@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 CONFIGS = {"C1": (1, 256, 20), "C2": (1, 1024, 50), "C2x8192": (8192, 1024, 50), "C3": (64, 4096, 100), "C4": (64, 2048, 50)}
 out = {"cpu": bench.cpu_model()}
-ctx = {"world": 1, "rank": 0, "local_rank": 0, "device": torch.device("cuda", 0)}
+ctx = {"world": 1, "rank": 0, "local_rank": 0, "device": torch.device("cuda", 0), "collective": False, "backend": "nccl"}
 torch.cuda.set_device(0)
 for name, (E, N, H) in CONFIGS.items():
     steps = 20 if E >= 4096 else 400

@@ -1,7 +1,7 @@
 import sys, time, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 import bench
-ctx = {"world": 1, "rank": 0, "local_rank": 0, "device": torch.device("cuda", 0), "collective": False}
+ctx = {"world": 1, "rank": 0, "local_rank": 0, "device": torch.device("cuda", 0), "collective": False, "backend": "nccl"}
 torch.cuda.set_device(0)
 for name, (E, N, H) in (("C4", (64, 2048, 50)), ("C3", (64, 4096, 100)), ("E1", (1, 1024, 50))):
     w = bench.Workload(ctx, E, N, H)
