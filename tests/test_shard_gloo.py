@@ -79,3 +79,33 @@ def test_two_rank_gather_matches_single_process():
     assert ret[0][:2] == (0, 3) and ret[1][:2] == (3, 2)
     for r in (0, 1):
         assert np.array_equal(ret[r][2], u_ref.numpy()) and np.array_equal(ret[r][3], q_ref.numpy())
+
+
+def _id_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cartpolesimulation_amd import _lib
+        from cartpolesimulation_amd.shard import exchange_unique_id
+        ret[rank] = bytes(exchange_unique_id(_lib.load(), rank, key="test_comm_id"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_unique_id_reaches_every_rank_through_the_store():
+    """The bootstrap of the library's own RCCL communicator (cpmppi_comm_unique_id on rank 0, the 128 bytes handed to the
+    other ranks through the process group's key-value store): every rank ends up with the same id.  (Creating an id
+    needs RCCL but no GPU; the communicator itself is covered on the GPU box with one rank.)"""
+    import ctypes as C
+    from cartpolesimulation_amd import _lib
+    probe = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    if _lib.load().cpmppi_comm_unique_id(probe, None) != 0:
+        pytest.skip("RCCL not available on this host: " + _lib.load().cpmppi_last_error(None).decode())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_id_worker, args=(3, port, ret), nprocs=3, join=True)
+    assert len(ret[0]) == _lib.COMM_ID_BYTES and ret[0] == ret[1] == ret[2] and ret[0] != probe.raw
