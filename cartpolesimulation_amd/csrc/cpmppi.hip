@@ -920,10 +920,11 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 // Which build of the kernel a launch gets (measured on MI355X, tools/kbench.py / tools/dev/step_series.py):
 //   one rollout per lane : latency build up to one wave per SIMD (1024 SIMDs x 64 lanes), throughput build above
 //   two rollouts per lane: mid-size build (loop constants in VGPRs, separate loop after a rare event) up to 4 packed
-//                          waves per SIMD = 524288 rollouts, throughput build above.  64..2048 envs x 1024 x 50, mid-size
+//                          waves per SIMD = 524288 rollouts (round 3: up to 1572864), throughput build above.  64..2048 envs x 1024 x 50, mid-size
 //                          vs throughput build: 128 envs 76 vs 82 us, 256 envs 145 vs 162 us, 1024 envs 406 vs 400 us
 #ifndef CPMPPI_MID_SIZE_MAX
-#define CPMPPI_MID_SIZE_MAX 524288ull
+#define CPMPPI_MID_SIZE_MAX 1572864ull    // round 3 (one edge test per triple in the mid-size build): 768 envs x 1024 x 50 292 vs 301 us,
+                                          // 1024 envs 364 vs 371, 2048 envs 664 vs 663, 8192 envs 2.42 vs 2.35 ms (mid-size vs throughput)
 #endif
 constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
