@@ -1029,6 +1029,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
 
 void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
+  DeviceGuard guard(h->device);                    // (frees, the side stream and the communicator belong to the handle's device)
   if (h->comm) { cpmppi_comm::destroy(h->comm); h->comm = nullptr; }
   if (h->workspace) (void)hipFree(h->workspace);
   if (h->gru_image) (void)hipFree(h->gru_image);
