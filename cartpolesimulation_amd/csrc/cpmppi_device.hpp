@@ -28,6 +28,9 @@ static __device__ unsigned long long g_dbg[8];        // unused slots kept for a
 static __device__ unsigned long long g_wave_cycles[16384];
 static __device__ unsigned int g_wave_cold[16384];    // cold-branch entries of each wave (all substep flavours)
 static __device__ unsigned long long g_wave_t[16384][4];   // s_memrealtime (100 MHz, chip-wide): entry, loop end, partials written, exit
+// -DCPMPPI_SECTION_STAMPS on top (tools/dev/sections.py): s_memtime at the section boundaries of a control step, summed per
+// wave.  `sec[0..6]` accumulate shader cycles per section, `sec[7]` holds the previous stamp.
+static __device__ unsigned int g_wave_sec[16384][8];
 #define CPMPPI_DBG_STAMP(slot)                                                                       \
   do {                                                                                               \
     const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                        \
@@ -45,6 +48,10 @@ static __device__ unsigned long long g_wave_t[16384][4];   // s_memrealtime (100
       if (hipMemcpyToSymbol(HIP_SYMBOL(cpmppi::g_wave_cold), z, sizeof(z)) != hipSuccess) return -1;                   \
     }                                                                                                                  \
     return 0;                                                                                                          \
+  }
+#define CPMPPI_SECTION_READER(NAME)                                                                                     \
+  extern "C" int NAME(unsigned int* sections, unsigned n_waves) {                                                      \
+    return hipMemcpyFromSymbol(sections, HIP_SYMBOL(cpmppi::g_wave_sec), (size_t)n_waves * 32) == hipSuccess ? 0 : -1; \
   }
 #define CPMPPI_DBG(i, n)                                                                             \
   do {                                                                                               \
@@ -265,6 +272,19 @@ __device__ __forceinline__ void sincos_pi_half(F x, F& sn, F& cs) {
 #define CPMPPI_SINCOS_MODE 1    // 0: pi/4 reduction + quadrant selects   1: pi/2 reduction + sign multiply
 #endif
 #ifndef CPMPPI_WRAP_MODE
+#if defined(CPMPPI_DEBUG_COUNTERS) && defined(CPMPPI_SECTION_STAMPS)
+// the state is pinned in front of the stamp (an opaque asm it passes through), so a section's arithmetic cannot drift
+// across its boundary
+#define CPMPPI_SEC(sec, i, ST)                                                                                          \
+  do {                                                                                                                 \
+    asm volatile("" : "+v"((ST).th), "+v"((ST).w), "+v"((ST).c), "+v"((ST).s), "+v"((ST).x), "+v"((ST).v));           \
+    const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();                                                      \
+    (sec)[i] += now_ - (sec)[7];                                                                                       \
+    (sec)[7] = now_;                                                                                                   \
+  } while (0)
+#else
+#define CPMPPI_SEC(sec, i, ST) ((void)0)
+#endif
 #define CPMPPI_WRAP_MODE 1      // 0: the reference's two comparisons     1: theta - 2pi*rint(theta/2pi)
 #endif
 
@@ -521,7 +541,7 @@ __device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
 // NEAR = false: `nearlim` is not used, the common path tests the edge itself (the latency build).
 template <class F, bool CHECK = true, bool NEAR = true>
 __device__ __forceinline__ bool substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e, float nearlim,
-                                             bool check = true) {
+                                             bool check = true, bool* at_edge = nullptr) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1);
@@ -540,6 +560,7 @@ __device__ __forceinline__ bool substep_fast(State<F>& st, F uK, float t, const 
     for (int i = 0; i < W; ++i) rare |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), p.THL, 3);
     near = ~0ull;
   }
+  if (at_edge) *at_edge = rare != 0;
   if (CHECK && __builtin_expect(rare != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
     CPMPPI_DBG(3, 1);
     // cos of the integrated angle by rotating the previous pair through d = w t; lanes beyond the rotation range (deep)
@@ -762,7 +783,12 @@ __device__ __forceinline__ SafeStep make_safe_step(const Params& p, const EnvCon
 // not tracked): the caller's next stage evaluates the boundary cost only then.
 template <class F, bool TWO_LOOPS = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
-                                                  const EnvConst& e, float nearlim, const SafeStep* ss = nullptr) {
+                                                  const EnvConst& e, float nearlim, const SafeStep* ss = nullptr,
+                                                  unsigned* sec = nullptr, bool* at_edge = nullptr) {
+  // `at_edge` (in/out, wave-uniform, mid-size build): did a rollout of this wave END the previous control step at or beyond
+  // the track edge?  It bounces on the very next substep - and, caught beyond the edge, on every one after it
+  // (cartpole_equations.py:341-347 flips v whichever way it points) - so a quiet triple is a certain loss: the step goes
+  // straight to the loop with the event arithmetic inline.
 #if CPMPPI_ROTATE && CPMPPI_HOIST_SPIN
   if constexpr (Width<F>::value == 1) {
     // one rollout per lane is the small-launch (latency-bound) mapping: there the per-substep test, which overlaps with
@@ -814,12 +840,13 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
   if constexpr (TWO_LOOPS) {
+    if (sec) { asm volatile("" : "+v"(cd), "+v"(sd), "+v"(xlim)); CPMPPI_SEC(sec, 2, st); }
     // Three substeps at a time WITHOUT event handling — one exit test, one loop latch and one VALU -> scalar hand-over
     // per triple, and a basic block three substeps long for the scheduler — under a rollback: the edge masks of the
     // three are or-ed, and if any lane fired the triple is discarded and the rest of the control step is integrated
     // substep by substep with the event arithmetic inline (BOUNCY).  S - 1 = 9 intermediate substeps = 3 triples.
     uint32_t left = S - 1u;
-    uint64_t fired = 0;
+    uint64_t fired = (at_edge != nullptr && *at_edge) ? 1u : 0u;
     while (left >= 3u && fired == 0) {
       const State<F> st0 = st;
       const F cd0 = cd, sd0 = sd;
@@ -852,10 +879,13 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
       --left;
     }
+    if (sec) CPMPPI_SEC(sec, 3, st);
   } else {
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
   }
-  return substep_fast<F>(st, uK, t, p, e, nearlim, check) && check;
+  const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, check, at_edge) && check;
+  if (sec) CPMPPI_SEC(sec, 4, st);
+  return near_end;
 #else
   bool spin = false;
 #pragma unroll

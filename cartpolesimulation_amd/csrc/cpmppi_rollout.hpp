@@ -30,6 +30,12 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_MID_UNPACKED
 #define CPMPPI_MID_UNPACKED 0
 #endif
+#ifndef CPMPPI_NOMINAL_IN_LANES
+#define CPMPPI_NOMINAL_IN_LANES 3   // FAST, bit v = build VARIANT v: nominal sequence held in lanes, fetched with v_readlane_b32 (latency + throughput builds)
+#endif
+#ifndef CPMPPI_MID_STICKY_EVENTS
+#define CPMPPI_MID_STICKY_EVENTS 1  // mid-size build: a wave with a rollout at the edge integrates the next control step without speculation
+#endif
 #ifndef CPMPPI_MID_VGPR_CONSTS
 #define CPMPPI_MID_VGPR_CONSTS 1    // mid-size build: substep constants in VGPRs (the packed form wants register pairs)
 #endif
@@ -301,12 +307,50 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // integrates - a scalar load consumed a few instructions after its issue is ~100 ns of exposed latency per control step
   // for a wave that has its SIMD to itself (single env 60.5 -> 57.2 us; measured neutral at C4 and 8192 envs, +2 % at C3,
   // so the packed builds load it where it is used).
-  constexpr bool PREFETCH_NOMINAL = (VARIANT == 0);
+  // (measured, round 3: 8192 envs 2.61 -> 2.47 ms per launch; single env with knots from memory 57.6 -> 54.9 us, with
+  // Philox / a delta_u buffer +0.5 / +1 % - those keep the one-step-ahead load; mid-size build: C4 -1..-3 %, C3 and 256 envs
+  // +2 %, not enabled)
+  constexpr bool NOMINAL_IN_LANES = FAST && (((CPMPPI_NOMINAL_IN_LANES) >> VARIANT) & 1) != 0 && (VARIANT != 0 || NOISE == NOISE_KNOTS);
+  constexpr bool PREFETCH_NOMINAL = (VARIANT == 0) && !NOMINAL_IN_LANES;
   float uk_next = PREFETCH_NOMINAL ? shifted_nominal(p, un, 0) : 0.0f;
-  float up_next = (PREFETCH_NOMINAL && COST == COST_LEGACY) ? up[0] : 0.0f;
+  float up_next = (VARIANT == 0 && COST == COST_LEGACY) ? up[0] : 0.0f;
+  // Round 3: the env's nominal sequence (after the configured shift) is held in ONE register, lane l holding stage 64 c + l of
+  // the current chunk c of 64 stages, and a control step fetches its stage with v_readlane_b32: one vector load per 64
+  // control steps instead of one per step.  (The sequence is written by this same launch's finalize, so the compiler may
+  // not use scalar loads for it: it was a vector load plus s_waitcnt vmcnt(0) per control step.)
+  float un_lane = 0.0f;
+  if constexpr (NOMINAL_IN_LANES) {
+    if (lane < H) un_lane = shifted_nominal(p, un, lane);
+  }
+#if defined(CPMPPI_DEBUG_COUNTERS) && defined(CPMPPI_SECTION_STAMPS)
+  // sections: 0 two adjacent stamps (the stamp's own cost), 1 nominal + clamp + stage cost + correction, 2 rotation seed and
+  // spin test, 3 intermediate substeps, 4 last substep, 5 between control steps (noise, interpolation, loop)
+  unsigned sec[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, (unsigned)__builtin_amdgcn_s_memtime()};
+  unsigned* const secp = sec;
+#else
+  unsigned* const secp = nullptr;
+#endif
+  // mid-size build: did a rollout of this wave end the previous control step at or beyond the track edge?  (wave-uniform)
+  constexpr bool STICKY_EVENTS = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_STICKY_EVENTS != 0);
+  bool at_edge = false;
   auto control_step = [&](uint32_t k, F du) __attribute__((always_inline)) {
+    if (secp) { asm volatile("" : "+v"(du)); CPMPPI_SEC(secp, 5, st); CPMPPI_SEC(secp, 0, st); }
     float uk, upk = 0.0f;
-    if constexpr (PREFETCH_NOMINAL) {
+    if constexpr (NOMINAL_IN_LANES) {
+      if (__builtin_expect((k & 63u) == 0u && k != 0u, 0)) {
+        const uint32_t kl = k + lane;
+        un_lane = (kl < H) ? shifted_nominal(p, un, kl) : 0.0f;
+      }
+      uk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(un_lane), (int)(k & 63u)));
+      if constexpr (COST == COST_LEGACY) {
+        if constexpr (VARIANT == 0) {
+          upk = up_next;
+          if (k + 1 < H) up_next = up[k + 1];
+        } else {
+          upk = up[k];
+        }
+      }
+    } else if constexpr (PREFETCH_NOMINAL) {
       uk = uk_next; upk = up_next;
       if (k + 1 < H) {
         uk_next = shifted_nominal(p, un, k + 1);
@@ -333,8 +377,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     }
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (FAST) {
-      const F uK = ur * splat<F>(ec.uK_scale);   // (k+1) u_max Q: the form in which the control enters positionDD's numerator
-      const bool near_next = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp);
+      F uK = ur * splat<F>(ec.uK_scale);         // (k+1) u_max Q: the form in which the control enters positionDD's numerator
+      if (secp) { asm volatile("" : "+v"(uK), "+v"(cost), "+v"(corr)); CPMPPI_SEC(secp, 1, st); }
+      bool near_next;
+      if constexpr (STICKY_EVENTS) {
+        near_next = control_step_fast<F, true>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
+      } else {
+        near_next = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
+      }
       near = !TRACK_NEAR || near_next;
     } else {
       for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
@@ -518,6 +568,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   if (lane == 0 && blockIdx.x * WAVES + wave < 16384u)
     cpmppi::g_wave_cycles[blockIdx.x * WAVES + wave] = __builtin_amdgcn_s_memtime() - dbg_t0;
   CPMPPI_DBG_STAMP(1);
+#ifdef CPMPPI_SECTION_STAMPS
+  if (lane == 0 && blockIdx.x * WAVES + wave < 16384u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cpmppi::g_wave_sec[blockIdx.x * WAVES + wave][i] = sec[i];
+  }
+#endif
 #endif
   // Everything the epilogue needs from the launch descriptor (output pointers, the partials workspace, the tickets) is read
   // from the kernarg segment HERE, behind an opaque copy of its address: as plain uses of `a` the compiler loads all of

@@ -1,0 +1,210 @@
+// Micro-benchmark (development tool): what the rollout kernel's own control-step code costs a wave as a function of the
+// waves that share its SIMD - the pieces of `control_step_fast<f2, true>` (cpmppi_device.hpp) timed in isolation, with the
+// product's compiler flags, on 1 / 2 / 4 waves per SIMD.  Answers: is a lone wave (BASELINE C4: one packed wave per SIMD)
+// bound by issue (~5 cycles per packed instruction), by dependent latency (~9), or by something else?
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I include -I cartpolesimulation_amd/csrc -mllvm -amdgpu-sched-strategy=iterative-ilp
+//         -mllvm -disable-vector-combine tools/dev/lone_wave.hip -o build_variants/lone_wave
+#include "cpmppi_device.hpp"
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+using namespace cpmppi;
+
+#define TO_VGPR(x) asm volatile("" : "+v"(x))
+
+struct Env {
+  Params ph;
+  EnvConst eh;
+};
+__device__ __forceinline__ void make_env(const Params& p, Params& ph, EnvConst& eh, bool vgpr) {
+  ph = p;
+  eh = make_env_const_uniform(p, p.L_default);
+  if (vgpr) {
+    TO_VGPR(ph.m_pole); TO_VGPR(eh.kp1_mt); TO_VGPR(eh.mg); TO_VGPR(eh.JinvLh);
+    TO_VGPR(eh.kmLh); TO_VGPR(eh.kM); TO_VGPR(eh.t1_i); TO_VGPR(eh.inv_kLh);
+  }
+}
+
+__device__ __forceinline__ State<f2> load_state(const float* in, int o) {
+  const int l = threadIdx.x & 63;
+  const float a = in[l] * 1e-3f + 0.01f * o;
+  State<f2> st;
+  st.th = f2{0.3f + a, -0.2f - a};
+  st.w = f2{0.5f + a, -0.7f + a};
+  st.c = f2{cosf(st.th.x), cosf(st.th.y)};
+  st.s = f2{sinf(st.th.x), sinf(st.th.y)};
+  st.x = f2{0.01f + a, -0.02f - a};
+  st.v = f2{0.1f * a, -0.1f * a};
+  return st;
+}
+__device__ __forceinline__ void sink(float* out, const State<f2>& st) {
+  const float z = st.th.x + st.th.y + st.w.x + st.w.y + st.c.x + st.c.y + st.s.x + st.s.y + st.x.x + st.x.y + st.v.x + st.v.y;
+  if (z == 123.456f) out[0] = z;
+}
+
+// KIND 0: whole control steps (seed the rotation pair, 3 triples with one edge test each, last substep with wrap + sincos)
+// KIND 1: triples only (the loop of the mid-size build: 3 substeps without event handling + v_max3 test)
+// KIND 2: two independent triples interleaved in one wave (what more ILP would buy)
+// KIND 3: last substep only (substep_fast: wrap + polynomial sincos + near test)
+// KIND 4: triples without the test (counted loop)
+// KIND 5: single substeps with the per-substep test behind a wave-uniform branch (BOUNCY = false)
+template <int KIND, bool VG>
+__global__ __launch_bounds__(256) void k(const float* in, float* out, Params p, int iters) {
+  Params ph; EnvConst eh;
+  make_env(p, ph, eh, VG);
+  State<f2> st = load_state(in, 0), st2 = load_state(in, 1);
+  const float t = p.t_step;
+  f2 uK = f2{0.3f, -0.2f} * eh.uK_scale;
+  f2 xlim = splat<f2>(p.THL);
+  f2 cd, sd, cd2, sd2;
+  rot_pair<f2>(st.w * splat<f2>(t), cd, sd);
+  rot_pair<f2>(st2.w * splat<f2>(t), cd2, sd2);
+  const float nearlim = uniform_(0.85f * p.THL);
+  int it = 0;
+  for (; it < iters; ++it) {
+    if constexpr (KIND == 0) {
+      control_step_fast<f2, true>(st, uK, p.S, t, ph, eh, nearlim);
+      uK = -uK;
+    } else if constexpr (KIND == 1 || KIND == 4) {
+      substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
+      const f2 xa = st.x;
+      substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
+      const f2 xb = st.x;
+      substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
+      if (KIND == 1) {
+        uint64_t fired = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float m = __builtin_fmaxf(__builtin_fabsf(get(xa, i)), __builtin_fmaxf(__builtin_fabsf(get(xb, i)), __builtin_fabsf(get(st.x, i))));
+          fired |= __builtin_amdgcn_fcmpf(m, get(xlim, i), 3);
+        }
+        if (__builtin_expect(fired != 0, 0)) break;
+      }
+    } else if constexpr (KIND == 2) {
+      substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
+      substep_fast_rot_carried<f2, false, true>(st2, uK, t, ph, eh, cd2, sd2, xlim, false);
+      const f2 xa = st.x, xa2 = st2.x;
+      substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
+      substep_fast_rot_carried<f2, false, true>(st2, uK, t, ph, eh, cd2, sd2, xlim, false);
+      const f2 xb = st.x, xb2 = st2.x;
+      substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
+      substep_fast_rot_carried<f2, false, true>(st2, uK, t, ph, eh, cd2, sd2, xlim, false);
+      uint64_t fired = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float m = __builtin_fmaxf(__builtin_fabsf(get(xa, i)), __builtin_fmaxf(__builtin_fabsf(get(xb, i)), __builtin_fabsf(get(st.x, i))));
+        const float m2 = __builtin_fmaxf(__builtin_fabsf(get(xa2, i)), __builtin_fmaxf(__builtin_fabsf(get(xb2, i)), __builtin_fabsf(get(st2.x, i))));
+        fired |= __builtin_amdgcn_fcmpf(__builtin_fmaxf(m, m2), get(xlim, i), 3);
+      }
+      if (__builtin_expect(fired != 0, 0)) break;
+    } else if constexpr (KIND == 3) {
+      substep_fast<f2>(st, uK, t, ph, eh, nearlim, true);
+      uK = -uK;
+    } else if constexpr (KIND == 5) {
+      if (substep_fast_rot_carried<f2, false>(st, uK, t, ph, eh, cd, sd, xlim, true) != 0) uK = -uK;
+    }
+  }
+  sink(out, st); sink(out, st2);
+  if (it == -1) out[1] = cd.x + sd.y + cd2.x + sd2.y;
+}
+
+// v_pk_fma_f32 / v_pk_mul_f32 with every operand a VGPR pair (the rollout kernel's form), ILP independent chains per lane
+template <int ILP, int MODE>
+__global__ __launch_bounds__(256) void kv(const float* in, float* out, int iters) {
+  const int l = threadIdx.x & 63;
+  f2 y[ILP], a = f2{1.0001f + in[l] * 1e-6f, 0.9999f}, b = f2{0.5f, in[l] * 1e-3f};
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) y[i] = f2{in[l] + i, in[l] + 1.0f + i};
+  TO_VGPR(a); TO_VGPR(b);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        if (MODE == 0) y[i] = __builtin_elementwise_fma(y[i], a, b);        // 3 VGPR pairs
+        else if (MODE == 1) y[i] = y[i] * a;                               // v_pk_mul, 2 VGPR pairs
+        else if (MODE == 2) y[i] = __builtin_elementwise_fma(y[i], y[i], b);   // same pair twice
+        else { y[i].x = __builtin_fmaf(y[i].x, a.x, b.x); y[i].y = __builtin_fmaf(y[i].y, a.y, b.y); }   // two plain FMAs (needs -fno-slp-vectorize to stay plain)
+      }
+    }
+  }
+  float z = 0;
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) z += y[i].x + y[i].y;
+  if (z == 123.456f) out[0] = z;
+}
+template <int ILP, int MODE>
+float runv(const float* in, float* out, int iters, int blocks) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((kv<ILP, MODE>), dim3(blocks), dim3(256), 0, 0, in, out, 10);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kv<ILP, MODE>), dim3(blocks), dim3(256), 0, 0, in, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = fminf(best, ms);
+  }
+  return best * 1e6f / ((float)iters * 16.0f * ILP * (MODE == 3 ? 2 : 1));   // ns per wave instruction
+}
+
+template <int KIND, bool VG>
+float run(const float* in, float* out, const Params& p, int iters, int blocks) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<KIND, VG>), dim3(blocks), dim3(256), 0, 0, in, out, p, 10);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<KIND, VG>), dim3(blocks), dim3(256), 0, 0, in, out, p, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = fminf(best, ms);
+  }
+  return best * 1e6f / iters;     // ns per iteration
+}
+
+int main() {
+  float *in, *out;
+  hipMalloc(&in, 1024); hipMalloc(&out, 1024);
+  float h[64]; for (int i = 0; i < 64; ++i) h[i] = (float)i;
+  hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+  Params p; memset(&p, 0, sizeof(p));
+  p.E = 1; p.N = 1024; p.H = 50; p.S = 10; p.P = 6; p.period = 10; p.t_step = 0.002f;
+  p.k = 1.0f / 3.0f; p.m_cart = 0.23f; p.m_pole = 0.087f; p.g = 9.81f; p.J_fric = 5e-5f; p.M_fric = 3.22f; p.u_max = 1.77f;
+  p.THL = 1.0e6f;                  // no rollout reaches the edge: the clean path
+  p.L_default = 0.395f;
+  p.w[6] = 0.85f;
+  p.run_lo = -1.0f; p.run_hi = 1.0f; p.lo = -1.0f; p.hi = 1.0f;
+  const int iters = 20000;
+  printf("ns per loop iteration (min of 5 launches of %d iterations); per substep in brackets\n", iters);
+  printf("%-44s %10s %10s %10s\n", "waves per SIMD", "1", "2", "4");
+#define ROW(KIND, VG, name, subs)                                                                          \
+  {                                                                                                        \
+    printf("%-44s", name);                                                                                 \
+    for (int blocks : {256, 512, 1024}) { float ns = run<KIND, VG>(in, out, p, iters, blocks); printf(" %7.1f (%5.1f)", ns, ns / (subs)); } \
+    printf("\n");                                                                                          \
+  }
+  ROW(0, true, "control step (10 substeps), VGPR consts", 10)
+  ROW(0, false, "control step (10 substeps), SGPR consts", 10)
+  ROW(1, true, "triple + max3 test, VGPR consts", 3)
+  ROW(1, false, "triple + max3 test, SGPR consts", 3)
+  ROW(4, true, "triple, no test, VGPR consts", 3)
+  ROW(2, true, "two independent triples, VGPR consts", 6)
+  ROW(3, true, "last substep (wrap + sincos), VGPR consts", 1)
+  ROW(5, true, "single substep, test behind branch, VGPR", 1)
+  printf("\nns per wave64 instruction, all operands VGPRs\n%-44s %10s %10s %10s\n", "waves per SIMD", "1", "2", "4");
+#define ROWV(ILP, MODE, name)                                                                              \
+  {                                                                                                        \
+    printf("%-44s", name);                                                                                 \
+    for (int blocks : {256, 512, 1024}) printf(" %10.3f", runv<ILP, MODE>(in, out, 20000, blocks));         \
+    printf("\n");                                                                                          \
+  }
+  ROWV(1, 0, "v_pk_fma_f32 v,v,v   1 chain") ROWV(2, 0, "v_pk_fma_f32 v,v,v   2 chains") ROWV(3, 0, "v_pk_fma_f32 v,v,v   3 chains")
+  ROWV(4, 0, "v_pk_fma_f32 v,v,v   4 chains") ROWV(8, 0, "v_pk_fma_f32 v,v,v   8 chains")
+  ROWV(1, 1, "v_pk_mul_f32 v,v     1 chain") ROWV(2, 1, "v_pk_mul_f32 v,v     2 chains") ROWV(4, 1, "v_pk_mul_f32 v,v     4 chains")
+  ROWV(1, 2, "v_pk_fma_f32 y,y,v   1 chain") ROWV(4, 2, "v_pk_fma_f32 y,y,v   4 chains")
+  ROWV(1, 3, "2 x v_fma_f32 v,v,v  1 chain pair") ROWV(2, 3, "2 x v_fma_f32 v,v,v  2 chain pairs") ROWV(4, 3, "2 x v_fma_f32 v,v,v  4 chain pairs")
+  return 0;
+}

@@ -87,7 +87,8 @@ def main():
                 a.seed, a.offset = 1234, 0
                 u_nom.zero_()
                 lib.cpmppi_set_profiling(h, 1)
-                for _ in range(args.steps):
+                for it in range(args.steps):
+                    a.offset = it                 # (a different noise draw per step: the same ones for every variant)
                     rc = lib.cpmppi_step(h, C.byref(a), stream)
                     assert rc == 0, lib.cpmppi_last_error(h)
                 ra = (f * 64)(); rb = (f * 64)(); n = u32(0)
@@ -96,12 +97,12 @@ def main():
                 if rnd > 0:
                     res.setdefault((name, math, noise), []).extend(list(ra[:n.value]))
                 res.setdefault(("chk", name, math, noise), float(u_nom.abs().sum()))
-    print(f"E={E} N={N} H={H}: rollout_cost_kernel ms per launch (median / min), rollouts/s at median")
+    print(f"E={E} N={N} H={H}: rollout_cost_kernel ms per launch (median / min / mean / p90), rollouts/s at median")
     for k, v in res.items():
         if k[0] == "chk":
             continue
         med, mn = float(np.median(v)), float(np.min(v))
-        print(f"  {k[0]:28s} {k[1]:8s} {k[2]:7s} median {med:8.4f}  min {mn:8.4f}  {E * N / med * 1e3:.3e} rollouts/s   "
+        print(f"  {k[0]:28s} {k[1]:8s} {k[2]:7s} median {med:8.4f}  min {mn:8.4f}  mean {float(np.mean(v)):8.4f}  p90 {float(np.percentile(v, 90)):8.4f}  {E * N / med * 1e3:.3e} rollouts/s   "
               f"checksum {res[('chk',) + k]:.6f}")
 
 
