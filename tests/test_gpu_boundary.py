@@ -321,15 +321,20 @@ def test_predict_large_launch_equals_small_launches(math_mode):
     eng.close()
 
 
-@pytest.mark.parametrize("rpl,small_E,big_E", [(2, 200, 600), (1, 32, 100)])
-def test_builds_of_the_kernel_agree_bit_for_bit(rpl, small_E, big_E):
+@pytest.mark.parametrize("noise", ["philox", "knots"])
+@pytest.mark.parametrize("rpl,small_E,big_E,H", [(2, 200, 1600, 70), (1, 32, 100, 70), (1, 32, 100, 150)])
+def test_builds_of_the_kernel_agree_bit_for_bit(rpl, small_E, big_E, H, noise):
     """The rollout kernel exists in three builds chosen by launch size (latency / mid-size / throughput: different
-    scheduling strategies, constants in scalar or vector registers, triples with rollback or not).  An env's result must
-    not depend on which build integrated it: the first envs of a large launch (throughput build) equal, bit for bit, the
-    same envs in a launch small enough for the mid-size (two rollouts per lane) or latency (one per lane) build."""
+    scheduling strategies, constants in scalar or vector registers, triples with rollback or not, the nominal sequence
+    read from memory per control step or held in lanes and fetched with v_readlane).  An env's result must not depend on
+    which build integrated it: the first envs of a large launch (throughput build: > 1.5 M rollouts with two per lane,
+    > 65 536 with one) equal, bit for bit, the same envs in a launch small enough for the mid-size (two rollouts per lane)
+    or latency (one per lane) build.  The nominal sequence is nonzero and the horizon longer than 64 steps (the lanes of
+    one register; 150: three register loads), with in-kernel noise and with knots from memory (the latency build holds
+    the sequence in lanes only then)."""
     from cartpolesimulation_amd.engine import MPPIEngine
     from cartpolesimulation_amd.configs import MPPIConfig
-    N, H = 1024, 20
+    N = 1024
     cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=rpl)
     rng = Generator(SFC64(17))
     ang = rng.uniform(-np.pi, np.pi, big_E)
@@ -338,15 +343,21 @@ def test_builds_of_the_kernel_agree_bit_for_bit(rpl, small_E, big_E):
     s0[:, 4], s0[:, 5] = rng.uniform(-0.18, 0.18, big_E), rng.uniform(-0.5, 0.5, big_E)      # some near the edge: rare events too
     tp = rng.uniform(-0.1, 0.1, big_E).astype(f32)
     Lv = rng.uniform(0.25, 0.45, big_E).astype(f32)
+    u0 = rng.uniform(-0.6, 0.6, (big_E, H)).astype(f32)
     outs = []
     for E in (big_E, small_E):
         eng = MPPIEngine(E, cfg)
-        un, S = eng.zeros(E, H), eng.empty(E, N)
-        Q, _ = eng.step(s0[:E], un, tp[:E], np.ones(E, f32), L=Lv[:E], seed=5, offset=3, env_offset=0, S_out=S)
+        un, S = eng.tensor(u0[:E].copy()), eng.empty(E, N)
+        if noise == "knots":
+            kn, _ = eng.sample(seed=5, offset=3, env_offset=0)
+            Q, _ = eng.step(s0[:E], un, tp[:E], np.ones(E, f32), L=Lv[:E], knots=kn, S_out=S)
+        else:
+            Q, _ = eng.step(s0[:E], un, tp[:E], np.ones(E, f32), L=Lv[:E], seed=5, offset=3, env_offset=0, S_out=S)
         outs.append((Q.cpu().numpy()[:small_E], un.cpu().numpy()[:small_E], S.cpu().numpy()[:small_E]))
         eng.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+    assert np.abs(outs[0][1] - u0[:small_E]).max() > 1e-3                   # the step did update the sequence
 
 
 def test_host_seam_staging_equals_device_inputs():

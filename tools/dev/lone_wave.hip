@@ -108,6 +108,50 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, Params p, 
   if (it == -1) out[1] = cd.x + sd.y + cd2.x + sd2.y;
 }
 
+// One rollout per lane (the latency build's mapping): KIND 0 whole control steps, 1 intermediate substeps (rotation by
+// polynomial, per-substep test behind a wave-uniform branch), 2 the same without test, 3 the last substep
+template <int KIND>
+__global__ __launch_bounds__(256) void k1(const float* in, float* out, Params p, int iters) {
+  Params ph = p;
+  EnvConst eh = make_env_const_uniform(p, p.L_default);
+  const State<f2> s2 = load_state(in, 0);
+  State<float> st{s2.th.x, s2.w.x, s2.c.x, s2.s.x, s2.x.x, s2.v.x};
+  const float t = p.t_step;
+  float uK = 0.3f * eh.uK_scale;
+  const float nearlim = uniform_(p.THL);
+  int it = 0;
+  for (; it < iters; ++it) {
+    if constexpr (KIND == 0) {
+      control_step_fast<float, false>(st, uK, p.S, t, ph, eh, nearlim);
+      uK = -uK;
+    } else if constexpr (KIND == 1) {
+      substep_fast_rot<float>(st, uK, t, ph, eh);
+    } else if constexpr (KIND == 2) {
+      substep_fast_rot<float, false, 0>(st, uK, t, ph, eh);
+    } else {
+      substep_fast<float, true, false>(st, uK, t, ph, eh, nearlim);
+      uK = -uK;
+    }
+  }
+  const float z = st.th + st.w + st.c + st.s + st.x + st.v;
+  if (z == 123.456f || it == -1) out[0] = z;
+}
+template <int KIND>
+float run1(const float* in, float* out, const Params& p, int iters, int blocks) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k1<KIND>), dim3(blocks), dim3(256), 0, 0, in, out, p, 10);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k1<KIND>), dim3(blocks), dim3(256), 0, 0, in, out, p, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = fminf(best, ms);
+  }
+  return best * 1e6f / iters;
+}
+
 // v_pk_fma_f32 / v_pk_mul_f32 with every operand a VGPR pair (the rollout kernel's form), ILP independent chains per lane
 template <int ILP, int MODE>
 __global__ __launch_bounds__(256) void kv(const float* in, float* out, int iters) {
@@ -194,6 +238,17 @@ int main() {
   ROW(2, true, "two independent triples, VGPR consts", 6)
   ROW(3, true, "last substep (wrap + sincos), VGPR consts", 1)
   ROW(5, true, "single substep, test behind branch, VGPR", 1)
+  printf("\none rollout per lane (latency build's mapping)\n");
+#define ROW1(KIND, name, subs)                                                                             \
+  {                                                                                                        \
+    printf("%-44s", name);                                                                                 \
+    for (int blocks : {256, 512, 1024}) { float ns = run1<KIND>(in, out, p, iters, blocks); printf(" %7.1f (%5.1f)", ns, ns / (subs)); } \
+    printf("\n");                                                                                          \
+  }
+  ROW1(0, "control step (10 substeps)", 10)
+  ROW1(1, "intermediate substep, test behind branch", 1)
+  ROW1(2, "intermediate substep, no test", 1)
+  ROW1(3, "last substep (wrap + sincos)", 1)
   printf("\nns per wave64 instruction, all operands VGPRs\n%-44s %10s %10s %10s\n", "waves per SIMD", "1", "2", "4");
 #define ROWV(ILP, MODE, name)                                                                              \
   {                                                                                                        \

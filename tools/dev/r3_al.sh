@@ -1,0 +1,8 @@
+#!/bin/bash
+out=gpurun_out/$1; shift
+mkdir -p $out
+K="timeout 300 python tools/kbench.py $@"
+$K --envs 64 --rollouts 2048 --horizon 50 --noise philox --rounds 8 --steps 40 > $out/kb_c4.txt 2>&1
+$K --envs 64 --rollouts 4096 --horizon 100 --noise philox --rounds 6 --steps 30 > $out/kb_c3.txt 2>&1
+$K --envs 1 --rollouts 1024 --horizon 50 --noise philox knots buffer --rounds 6 --steps 30 > $out/kb_single.txt 2>&1
+grep -h "E=\|\.so" $out/kb_*.txt
