@@ -793,8 +793,9 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   if constexpr (Width<F>::value == 1) {
     // one rollout per lane is the small-launch (latency-bound) mapping: there the per-substep test, which overlaps with
     // the arithmetic, is faster than the shorter loop with its test at the head (single env: 70 us vs 80 us)
-    // (three substeps per iteration under a rollback, as in the packed mid-size build, was measured here too: single env
-    // 63 -> 72 us — the lone wave of this mapping gains nothing from longer basic blocks and pays for the bookkeeping)
+    // (three substeps per loop iteration without event handling, under a rollback, as in the packed mid-size build, was
+    // measured here twice: with three compare pairs or-ed (round 2: single env 63 -> 72 us) and with ONE test on v_max3 of
+    // the positions and of the rotation angles (round 3: 56.6 -> 58.3 us) - this mapping gains nothing from it)
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
     return substep_fast<F, true, (CPMPPI_LATENCY_NEAR != 0)>(st, uK, t, p, e, nearlim);
   }

@@ -2,6 +2,13 @@
 // waves that share its SIMD - the pieces of `control_step_fast<f2, true>` (cpmppi_device.hpp) timed in isolation, with the
 // product's compiler flags, on 1 / 2 / 4 waves per SIMD.  Answers: is a lone wave (BASELINE C4: one packed wave per SIMD)
 // bound by issue (~5 cycles per packed instruction), by dependent latency (~9), or by something else?
+// What it told (round 3): the triple of the mid-size build runs at the lone wave's ISSUE limit (184 ns for 81 instructions =
+// 2.27 ns each, the rate of independent v_pk_fma_f32), so no scheduling change can speed it up, and two independent triples
+// interleaved are no faster per substep.  What it could NOT tell: the cost of the event test - variants predicted here to
+// save 25-45 % of a control step (compare issued before the third substep and branched on after it; triples for the
+// one-rollout-per-lane mapping) measured 0 to -3 % in the real kernel (tools/kbench.py), where registers, code layout
+// and the code around the substeps differ.  Trust the A/B of the real kernel, not these rows, for anything but the
+// issue-rate facts.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I include -I cartpolesimulation_amd/csrc -mllvm -amdgpu-sched-strategy=iterative-ilp
 //         -mllvm -disable-vector-combine tools/dev/lone_wave.hip -o build_variants/lone_wave
 #include "cpmppi_device.hpp"
@@ -128,6 +135,19 @@ __global__ __launch_bounds__(256) void k1(const float* in, float* out, Params p,
       substep_fast_rot<float>(st, uK, t, ph, eh);
     } else if constexpr (KIND == 2) {
       substep_fast_rot<float, false, 0>(st, uK, t, ph, eh);
+    } else if constexpr (KIND == 4) {
+      // three substeps without event handling, ONE test: max3 of the positions against the edge, max3 of the rotation
+      // angles against the polynomial's range
+      const float d0 = st.w * t;
+      substep_fast_rot<float, true, 0>(st, uK, t, ph, eh);
+      const float xa = st.x, d1 = st.w * t;
+      substep_fast_rot<float, true, 0>(st, uK, t, ph, eh);
+      const float xb = st.x, d2 = st.w * t;
+      substep_fast_rot<float, true, 0>(st, uK, t, ph, eh);
+      const float mx = __builtin_fmaxf(__builtin_fabsf(xa), __builtin_fmaxf(__builtin_fabsf(xb), __builtin_fabsf(st.x)));
+      const float md = __builtin_fmaxf(__builtin_fabsf(d0), __builtin_fmaxf(__builtin_fabsf(d1), __builtin_fabsf(d2)));
+      const uint64_t fired = __builtin_amdgcn_fcmpf(mx, ph.THL, 3) | __builtin_amdgcn_fcmpf(md, ROT_LIMIT_LO, 2);
+      if (__builtin_expect(fired != 0, 0)) break;
     } else {
       substep_fast<float, true, false>(st, uK, t, ph, eh, nearlim);
       uK = -uK;
@@ -248,6 +268,7 @@ int main() {
   ROW1(0, "control step (10 substeps)", 10)
   ROW1(1, "intermediate substep, test behind branch", 1)
   ROW1(2, "intermediate substep, no test", 1)
+  ROW1(4, "triple + one test (max3 x, max3 d)", 3)
   ROW1(3, "last substep (wrap + sincos)", 1)
   printf("\nns per wave64 instruction, all operands VGPRs\n%-44s %10s %10s %10s\n", "waves per SIMD", "1", "2", "4");
 #define ROWV(ILP, MODE, name)                                                                              \
