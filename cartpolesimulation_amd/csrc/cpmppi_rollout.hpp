@@ -36,6 +36,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_MID_STICKY_EVENTS
 #define CPMPPI_MID_STICKY_EVENTS 1  // mid-size build: a wave with a rollout at the edge integrates the next control step without speculation
 #endif
+#ifndef CPMPPI_WAVE_PRIORITY
+#define CPMPPI_WAVE_PRIORITY 1
+#endif
 #ifndef CPMPPI_MID_VGPR_CONSTS
 #define CPMPPI_MID_VGPR_CONSTS 1    // mid-size build: substep constants in VGPRs (the packed form wants register pairs)
 #endif
@@ -248,6 +251,13 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 
   const uint32_t env = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#if CPMPPI_WAVE_PRIORITY
+  // Small launches (one or two waves per SIMD) end with their slowest wave, and the all-gather of the previous step's result
+  // runs UNDER this kernel on another stream (cpmppi_step_gather): a wave of that kernel sharing a SIMD with one of ours
+  // takes issue slots from it for its whole duration.  Raised wave priority makes the arbiter serve the rollout wave first;
+  // a lone rollout wave leaves more than half of the issue slots unused, so the guest still runs.
+  if constexpr (VARIANT != 1) __builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef CPMPPI_DEBUG_COUNTERS
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
   CPMPPI_DBG_STAMP(0);
