@@ -795,9 +795,17 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     // the arithmetic, is faster than the shorter loop with its test at the head (single env: 70 us vs 80 us)
     // (three substeps per loop iteration without event handling, under a rollback, as in the packed mid-size build, was
     // measured here twice: with three compare pairs or-ed (round 2: single env 63 -> 72 us) and with ONE test on v_max3 of
-    // the positions and of the rotation angles (round 3: 56.6 -> 58.3 us) - this mapping gains nothing from it)
+    // the positions and of the rotation angles (round 3: 56.6 -> 58.3 us; with section stamps: 1730 -> 1850 cycles for the
+    // nine intermediate substeps) - this mapping gains nothing from it.  Nor from instruction order: the substep written
+    // as ONE asm block with the links of the loop-carried chain spaced apart (tools/dev/lone_wave.hip, bit-identical) runs
+    // at 61 ns against the compiler's 64 - a lone wave issues these three-operand instructions at ~4.5 cycles each
+    // whatever their order, so only fewer instructions would help)
+    if (sec) CPMPPI_SEC(sec, 2, st);
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
-    return substep_fast<F, true, (CPMPPI_LATENCY_NEAR != 0)>(st, uK, t, p, e, nearlim);
+    if (sec) CPMPPI_SEC(sec, 3, st);
+    const bool near_one = substep_fast<F, true, (CPMPPI_LATENCY_NEAR != 0)>(st, uK, t, p, e, nearlim);
+    if (sec) CPMPPI_SEC(sec, 4, st);
+    return near_one;
   }
   // The seed needs |w t| <= ROT_LIMIT.  Tested once per control step: without a bounce w cannot leave the range within
   // one control step by more than the polynomials' margin, and a lane that bounces is re-tested.  Lanes beyond the

@@ -115,6 +115,50 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, Params p, 
   if (it == -1) out[1] = cd.x + sd.y + cd2.x + sd2.y;
 }
 
+// The intermediate substep of the one-rollout-per-lane mapping (ode_euler_fast + rot_pair_lo + rotation, no event test) as
+// ONE asm block in a hand-chosen order: the nine links of the loop-carried chain (w -> t1 -> numerator -> xDD -> aDD -> w')
+// are spaced two or three independent instructions apart.  Same operations as the compiler's code (bit-identical results).
+struct AsmConsts { float m, K, JLh, mg, kmLh, kM, t1i, ikLh, c5, c3, c4; };
+__device__ __forceinline__ void substep_asm(State<float>& st, float uK, float t, const AsmConsts& k) {
+  float twj, tcm, ww, d, t1, A, wk, d2, n, r, tt1, pc, ps, d3, cd, sd, xDD, ssd, csd, xc, aDD;
+  asm volatile(
+      "v_mul_f32 %[twj], %[w], %[JLh]\n"
+      "v_mul_f32 %[tcm], %[c], %[m]\n"
+      "v_mul_f32 %[ww], %[w], %[w]\n"
+      "v_mul_f32 %[d], %[w], %[t]\n"
+      "v_fma_f32 %[t1], %[mg], %[s], -%[twj]\n"
+      "v_fma_f32 %[A], -%[tcm], %[c], %[K]\n"
+      "v_mul_f32 %[wk], %[ww], %[kmLh]\n"
+      "v_mul_f32 %[d2], %[d], %[d]\n"
+      "v_fma_f32 %[n], %[c], %[t1], %[uK]\n"
+      "v_rcp_f32 %[r], %[A]\n"
+      "v_mul_f32 %[tt1], %[t1], %[t1i]\n"
+      "v_fma_f32 %[pc], %[d2], %[c4], -0.5\n"
+      "v_fma_f32 %[n], -%[wk], %[s], %[n]\n"
+      "v_fma_f32 %[ps], %[d2], %[c5], %[c3]\n"
+      "v_mul_f32 %[d3], %[d], %[d2]\n"
+      "v_fma_f32 %[th], %[w], %[t], %[th]\n"
+      "v_fma_f32 %[n], -%[kM], %[v], %[n]\n"
+      "v_fma_f32 %[x], %[v], %[t], %[x]\n"
+      "v_fma_f32 %[cd], %[d2], %[pc], 1.0\n"
+      "v_fma_f32 %[sd], %[d3], %[ps], %[d]\n"
+      "v_mul_f32 %[xDD], %[n], %[r]\n"
+      "v_mul_f32 %[ssd], %[s], %[sd]\n"
+      "v_mul_f32 %[csd], %[c], %[sd]\n"
+      "v_mul_f32 %[xc], %[xDD], %[c]\n"
+      "v_fma_f32 %[v], %[xDD], %[t], %[v]\n"
+      "v_fma_f32 %[c], %[c], %[cd], -%[ssd]\n"
+      "v_fma_f32 %[s], %[s], %[cd], %[csd]\n"
+      "v_fma_f32 %[aDD], %[xc], %[ikLh], %[tt1]\n"
+      "v_fma_f32 %[w], %[aDD], %[t], %[w]\n"
+      : [th] "+v"(st.th), [w] "+v"(st.w), [c] "+v"(st.c), [s] "+v"(st.s), [x] "+v"(st.x), [v] "+v"(st.v),
+        [twj] "=&v"(twj), [tcm] "=&v"(tcm), [ww] "=&v"(ww), [d] "=&v"(d), [t1] "=&v"(t1), [A] "=&v"(A), [wk] "=&v"(wk),
+        [d2] "=&v"(d2), [n] "=&v"(n), [r] "=&v"(r), [tt1] "=&v"(tt1), [pc] "=&v"(pc), [ps] "=&v"(ps), [d3] "=&v"(d3),
+        [cd] "=&v"(cd), [sd] "=&v"(sd), [xDD] "=&v"(xDD), [ssd] "=&v"(ssd), [csd] "=&v"(csd), [xc] "=&v"(xc), [aDD] "=&v"(aDD)
+      : [uK] "v"(uK), [t] "s"(t), [m] "v"(k.m), [K] "v"(k.K), [JLh] "v"(k.JLh), [mg] "v"(k.mg), [kmLh] "v"(k.kmLh),
+        [kM] "v"(k.kM), [t1i] "v"(k.t1i), [ikLh] "v"(k.ikLh), [c5] "v"(k.c5), [c3] "v"(k.c3), [c4] "v"(k.c4));
+}
+
 // One rollout per lane (the latency build's mapping): KIND 0 whole control steps, 1 intermediate substeps (rotation by
 // polynomial, per-substep test behind a wave-uniform branch), 2 the same without test, 3 the last substep
 template <int KIND>
@@ -126,9 +170,28 @@ __global__ __launch_bounds__(256) void k1(const float* in, float* out, Params p,
   const float t = p.t_step;
   float uK = 0.3f * eh.uK_scale;
   const float nearlim = uniform_(p.THL);
+  AsmConsts ak{ph.m_pole, eh.kp1_mt, eh.JinvLh, eh.mg, eh.kmLh, eh.kM, eh.t1_i, eh.inv_kLh, 8.3333333e-3f, -1.6666667e-1f, 4.1666667e-2f};
+  TO_VGPR(ak.m); TO_VGPR(ak.K); TO_VGPR(ak.JLh); TO_VGPR(ak.mg); TO_VGPR(ak.kmLh); TO_VGPR(ak.kM); TO_VGPR(ak.t1i); TO_VGPR(ak.ikLh);
+  TO_VGPR(ak.c5); TO_VGPR(ak.c3); TO_VGPR(ak.c4);
+  const float ts = uniform_(t);
+  if constexpr (KIND == 6) {            // self-check: the asm substep against the compiler's, bit for bit
+    State<float> sa = st, sb = st;
+    unsigned bad = 0;
+    for (int i = 0; i < 1000; ++i) {
+      substep_asm(sa, uK, ts, ak);
+      substep_fast_rot<float, false, 0>(sb, uK, t, ph, eh);
+      bad |= (__float_as_uint(sa.th) ^ __float_as_uint(sb.th)) | (__float_as_uint(sa.w) ^ __float_as_uint(sb.w)) | (__float_as_uint(sa.c) ^ __float_as_uint(sb.c)) |
+             (__float_as_uint(sa.s) ^ __float_as_uint(sb.s)) | (__float_as_uint(sa.x) ^ __float_as_uint(sb.x)) | (__float_as_uint(sa.v) ^ __float_as_uint(sb.v));
+      if ((i & 63) == 63) uK = -uK;
+    }
+    if (bad != 0u) atomicAdd(reinterpret_cast<unsigned*>(out) + 2, 1u);
+    st = sa;
+  }
   int it = 0;
-  for (; it < iters; ++it) {
-    if constexpr (KIND == 0) {
+  for (; it < ((KIND == 6) ? 0 : iters); ++it) {
+    if constexpr (KIND == 5) {
+      substep_asm(st, uK, ts, ak);
+    } else if constexpr (KIND == 0) {
       control_step_fast<float, false>(st, uK, p.S, t, ph, eh, nearlim);
       uK = -uK;
     } else if constexpr (KIND == 1) {
@@ -268,8 +331,15 @@ int main() {
   ROW1(0, "control step (10 substeps)", 10)
   ROW1(1, "intermediate substep, test behind branch", 1)
   ROW1(2, "intermediate substep, no test", 1)
+  ROW1(5, "intermediate substep, no test, hand-ordered asm", 1)
   ROW1(4, "triple + one test (max3 x, max3 d)", 3)
   ROW1(3, "last substep (wrap + sincos)", 1)
+  {
+    hipMemset(out, 0, 64);
+    hipLaunchKernelGGL((k1<6>), dim3(256), dim3(256), 0, 0, in, out, p, 1);
+    unsigned h3[4]; hipMemcpy(h3, out, 16, hipMemcpyDeviceToHost);
+    printf("asm substep vs compiled substep over 1000 substeps: %u waves with a differing bit (0 = bit-identical)\n", h3[2]);
+  }
   printf("\nns per wave64 instruction, all operands VGPRs\n%-44s %10s %10s %10s\n", "waves per SIMD", "1", "2", "4");
 #define ROWV(ILP, MODE, name)                                                                              \
   {                                                                                                        \
