@@ -655,6 +655,9 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
   return fired;
 }
 
+#ifndef CPMPPI_LATENCY_UNROLL
+#define CPMPPI_LATENCY_UNROLL 1
+#endif
 #ifndef CPMPPI_INCR_ROT
 #define CPMPPI_INCR_ROT 1       // packed path: (cos d, sin d) of d = w t advanced by d' - d = angleDD t^2 instead of re-evaluated
 #endif
@@ -801,7 +804,20 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     // at 61 ns against the compiler's 64 - a lone wave issues these three-operand instructions at ~4.5 cycles each
     // whatever their order, so only fewer instructions would help)
     if (sec) CPMPPI_SEC(sec, 2, st);
-    for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
+#if CPMPPI_LATENCY_UNROLL
+    if (S == 10u) {
+      // the reference's intermediate_steps = 10 as straight-line code: a wave that has its SIMD to itself pays ~50 cycles
+      // for every TAKEN branch (the instruction buffer refills from the cache; how many depends on where the target
+      // falls, which is why this build's times moved by 10-25 % with unrelated changes of code layout), and the substep
+      // loop's back edge is one per 190-cycle substep.  Unrolled, the nine substeps fall through their untaken event
+      // branches: single env 56.3 -> 50.0 us, 256 x 20 27.9 -> 25.4 us, 3500 x 35 44.7 -> 39.1 us, 64 envs 62 -> 56 us.
+#pragma unroll
+      for (int sub = 0; sub < 9; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
+    } else
+#endif
+    {
+      for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
+    }
     if (sec) CPMPPI_SEC(sec, 3, st);
     const bool near_one = substep_fast<F, true, (CPMPPI_LATENCY_NEAR != 0)>(st, uK, t, p, e, nearlim);
     if (sec) CPMPPI_SEC(sec, 4, st);
@@ -855,8 +871,8 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     // three are or-ed, and if any lane fired the triple is discarded and the rest of the control step is integrated
     // substep by substep with the event arithmetic inline (BOUNCY).  S - 1 = 9 intermediate substeps = 3 triples.
     uint32_t left = S - 1u;
-    uint64_t fired = (at_edge != nullptr && *at_edge) ? 1u : 0u;
-    while (left >= 3u && fired == 0) {
+    // one triple under its rollback; returns whether it was discarded (the wave then leaves the triples for this control step)
+    auto triple = [&]() __attribute__((always_inline)) -> bool {
       const State<F> st0 = st;
       const F cd0 = cd, sd0 = sd;
       // ONE edge test per triple (round 3): the three positions are kept and v_max3_f32(|x1|, |x2|, |x3|) is compared with
@@ -869,7 +885,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
       const F xb = st.x;
       substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
-      fired = 0;
+      uint64_t fired = 0;
       if (check) {
 #pragma unroll
         for (int i = 0; i < Width<F>::value; ++i) {
@@ -880,8 +896,17 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       if (__builtin_expect(fired != 0, 0)) {
         asm volatile("" ::: "memory");            // (keeps this a branch: as selects the rollback costs 16 v_cndmask per triple)
         st = st0; cd = cd0; sd = sd0;
-      } else {
-        left -= 3u;
+        return true;
+      }
+      left -= 3u;
+      return false;
+    };
+    const bool skip = at_edge != nullptr && *at_edge;      // a rollout sits at the edge: no speculation (see the top)
+    // (the three triples as straight-line code for S = 10, like the one-rollout-per-lane mapping above: measured twice this
+    // round, C4 +3 %, C3 +2 % - a triple is 250 ns long, its taken branches matter less than the 8 more registers)
+    if (!skip) {
+      while (left >= 3u) {
+        if (triple()) break;
       }
     }
     while (left != 0u) {
