@@ -655,6 +655,12 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
   return fired;
 }
 
+#ifndef CPMPPI_TRIPLE_TEST_BEFORE_THIRD
+#define CPMPPI_TRIPLE_TEST_BEFORE_THIRD 1
+#endif
+#ifndef CPMPPI_MID_EVENT_UNROLL
+#define CPMPPI_MID_EVENT_UNROLL 1
+#endif
 #ifndef CPMPPI_LATENCY_UNROLL
 #define CPMPPI_LATENCY_UNROLL 1
 #endif
@@ -884,12 +890,21 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       const F xa = st.x;
       substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
       const F xb = st.x;
+#if CPMPPI_TRIPLE_TEST_BEFORE_THIRD
+      // The third position depends only on the second substep's results (x3 = x2 + v2 t: the very FMA the third substep
+      // performs), so the test sits in front of the third substep - where the compiler moved it anyway, but with the third
+      // substep in a block of its own that the hot path reached through a taken branch (~50 cycles for a lone wave).
+      // Written in this order the hot path falls through: two substeps, the test, the third substep, the back edge.
+      const F xc = fma_(st.v, splat<F>(t), st.x);
+#else
       substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
+      const F xc = st.x;
+#endif
       uint64_t fired = 0;
       if (check) {
 #pragma unroll
         for (int i = 0; i < Width<F>::value; ++i) {
-          const float m = __builtin_fmaxf(__builtin_fabsf(get(xa, i)), __builtin_fmaxf(__builtin_fabsf(get(xb, i)), __builtin_fabsf(get(st.x, i))));
+          const float m = __builtin_fmaxf(__builtin_fabsf(get(xa, i)), __builtin_fmaxf(__builtin_fabsf(get(xb, i)), __builtin_fabsf(get(xc, i))));
           fired |= __builtin_amdgcn_fcmpf(m, get(xlim, i), 3);
         }
       }
@@ -898,6 +913,9 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
         st = st0; cd = cd0; sd = sd0;
         return true;
       }
+#if CPMPPI_TRIPLE_TEST_BEFORE_THIRD
+      substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
+#endif
       left -= 3u;
       return false;
     };
@@ -909,6 +927,16 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
         if (triple()) break;
       }
     }
+#if CPMPPI_MID_EVENT_UNROLL
+    // (three per iteration: the wave that runs this loop is the one its launch waits for, and a taken branch per substep
+    // costs it ~50 cycles of ~300)
+    while (left >= 3u) {
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      left -= 3u;
+    }
+#endif
     while (left != 0u) {
       substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
       --left;
