@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-3 evidence run after the last kernel changes (GPU box): tests, bench lines, collective, profiles, parity statistics -> gpurun_out/r3final4/
+# round-3 evidence run after the last kernel changes (GPU box): tests, bench lines, collective, profiles, parity statistics -> gpurun_out/r3final5/
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r3final4
+O=$R/gpurun_out/r3final5
 mkdir -p $O
 cd $R
 V=build_variants
@@ -37,6 +37,7 @@ timeout 600 python tools/kbench.py $V/r3_base.so cartpolesimulation_amd/libcpmpp
 timeout 600 python tools/kbench.py $V/r3_base.so cartpolesimulation_amd/libcpmppi.so --envs 1024 --rounds 6 --steps 6 --noise philox > $O/kbench_1024.txt 2>&1
 CPMPPI_LIB=$V/sec.so timeout 250 python tools/dev/sections.py --config C4 > $O/sections_C4.txt 2>&1
 CPMPPI_LIB=$V/sec.so timeout 250 python tools/dev/sections.py --config C3 > $O/sections_C3.txt 2>&1
+CPMPPI_LIB=$V/sec.so timeout 250 python tools/dev/sections.py --config C2 > $O/sections_C2.txt 2>&1
 timeout 250 $V/lone_wave > $O/lone_wave.txt 2>&1
 unset RANK; export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 CPMPPI_BENCH_FORCE_COLLECTIVE=1
 timeout 400 python bench.py --gpus 1 --no-cpu-baseline > $O/bench_rccl_1rank_b.json 2> $O/bench_rccl_1rank_b.err
