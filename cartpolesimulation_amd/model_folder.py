@@ -6,12 +6,14 @@ NORMALIZE ...), ``normalization_vec_a.csv`` / ``normalization_vec_b.csv`` (one r
 a*x + b) and ``denormalization_vec_A.csv`` / ``denormalization_vec_B.csv`` (one value per OUTPUT: y = A*y_norm + B).
 Model names of the neural predictor: ``SI_Toolkit_ASF/config_predictors.yml:8-13`` (``GRU-6IN-32H1-32H2-5OUT-*``).
 
-Weights: the reference's folders carry TensorFlow checkpoints / ``.keras`` archives (a zip around ``model.weights.h5``),
-which need TensorFlow or h5py — neither exists on this image, and no GRU folder is in the tree.  What can be read here:
-``weights_keras.npz`` = ``np.savez(path, *model.get_weights())`` written once in the reference's environment (Keras
-layout, converted by ``keras_gru_weights_to_model``), a ``torch`` state_dict (``ckpt.pt``, the layout of
-``torch.nn.GRU`` + a ``Linear`` head) or ``weights.npz`` with the keys of ``MPPIEngine.set_gru``.  Anything else raises
-with the reason; there is no silent fallback.
+Weights: the reference's folders carry ``.keras`` archives (a zip around ``config.json`` + ``model.weights.h5``) and / or
+TensorFlow checkpoints.  The ``.keras`` archive is read directly (``hdf5_min.py``: a minimal reader of the classic HDF5
+layout Keras writes — no TensorFlow, no h5py; pinned on the reference's in-tree
+``GymlikeCartPole/Dense-7IN-32H1-32H2-1OUT-0/*.keras`` against that folder's own C export of the same weights).  Also
+read: ``weights_keras.npz`` = ``np.savez(path, *model.get_weights())`` (Keras layout, converted by
+``keras_gru_weights_to_model``), a ``torch`` state_dict (``ckpt.pt``, the layout of ``torch.nn.GRU`` + a ``Linear``
+head) or ``weights.npz`` with the keys of ``MPPIEngine.set_gru``.  A folder that holds ONLY a TensorFlow checkpoint
+(``ckpt.ckpt.*``) raises with the reason; there is no silent fallback.
 """
 import os
 import re
@@ -134,11 +136,21 @@ def _weights(folder):
         w["w_out"] = heads[-1][1]
         w["b_out"] = next(v for k, v in sd.items() if v.ndim == 1 and v.shape[0] == 5)
         return w
-    tf_like = [f for f in os.listdir(folder) if f.endswith((".keras", ".h5", ".index")) or ".ckpt" in f]
+    keras = sorted(f for f in os.listdir(folder) if f.endswith(".keras"))
+    if keras:
+        from .hdf5_min import read_keras_weights
+        arrays, owners = read_keras_weights(os.path.join(folder, keras[0]))
+        classes = [c for _, c in owners]
+        if classes != ["GRU", "GRU", "Dense"]:
+            raise NotImplementedError(f"{folder}/{keras[0]}: layers with variables are {classes}; the HIP predictor implements "
+                                      "GRU -> GRU -> Dense (GRU-6IN-32H1-32H2-5OUT)")
+        return keras_gru_weights_to_model(arrays)
+    tf_like = [f for f in os.listdir(folder) if f.endswith((".h5", ".index")) or ".ckpt" in f]
     if tf_like:
-        raise NotImplementedError(f"{folder}: only TensorFlow/Keras weights found ({', '.join(sorted(tf_like)[:3])}); reading them "
-                                  "needs TensorFlow or h5py, which this image does not have - export them once in the "
-                                  "reference's environment (INTEGRATION.md: np.savez('weights_keras.npz', *model.get_weights()))")
+        raise NotImplementedError(f"{folder}: only a TensorFlow checkpoint found ({', '.join(sorted(tf_like)[:3])}); its "
+                                  "SSTable / protobuf container is not read here - keep the .keras archive SI_Toolkit saves "
+                                  "next to it, or export once in the reference's environment (INTEGRATION.md: "
+                                  "np.savez('weights_keras.npz', *model.get_weights()))")
     raise FileNotFoundError(f"{folder}: no weights.npz or ckpt.pt")
 
 

@@ -6,6 +6,8 @@ import pytest
 
 from cartpolesimulation_amd import model_folder as MF
 
+f32 = np.float32
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 DENSE = os.path.join(HERE, "golden", "model_folder", "Dense-7IN-32H1-32H2-1OUT-0")
 
@@ -187,3 +189,95 @@ def test_conversion_is_pinned_to_keras():
         head.bias.copy_(torch.tensor(model["b_out"]))
         y_t = head(gru(torch.tensor(x))[0]).numpy()
     np.testing.assert_allclose(y_t, y, atol=2e-5, rtol=1e-5)
+
+
+# ---- .keras archives (zip of config.json + model.weights.h5) read without TensorFlow / h5py ---------------------------
+REF_KERAS = "/root/reference/GymlikeCartPole/Dense-7IN-32H1-32H2-1OUT-0/Dense-7IN-32H1-32H2-1OUT-0.keras"
+
+
+def test_hdf5_reader_round_trip():
+    """cartpolesimulation_amd/hdf5_min.py against files written from the format specification by tests/hdf5_writer.py:
+    nested groups, many children, float32 / float64 / float16 / int64 arrays, a scalar, an empty array."""
+    from cartpolesimulation_amd.hdf5_min import read_hdf5
+    from hdf5_writer import write_hdf5
+    rng = np.random.Generator(np.random.SFC64(4))
+    arrays = {"a/b/vars/0": rng.standard_normal((6, 96)).astype(np.float32),
+              "a/b/vars/1": rng.standard_normal((32, 96)),
+              "a/scalar": np.array(31260, np.int64),
+              "a/half": rng.standard_normal(5).astype(np.float16),
+              "top": np.arange(7, dtype=np.uint32),
+              "empty/none": np.zeros((0, 3), np.float32)}
+    arrays.update({f"many/child_{i:02d}": np.full((2, 2), i, np.float32) for i in range(20)})
+    got = read_hdf5(write_hdf5(arrays))
+    assert set(got) == set(arrays)
+    for k, v in arrays.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    with pytest.raises(ValueError, match="not an HDF5 file"):
+        read_hdf5(b"PK\x03\x04" + b"\x00" * 64)
+
+
+def _keras_archive(path, layers, arrays):
+    import json
+    import zipfile
+    from hdf5_writer import write_hdf5
+    config = {"module": "keras", "class_name": "Sequential", "config": {"name": "sequential", "layers": layers}}
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("metadata.json", json.dumps({"keras_version": "2.13.1"}))
+        z.writestr("config.json", json.dumps(config))
+        z.writestr("model.weights.h5", write_hdf5(arrays))
+
+
+def test_model_folder_with_a_keras_archive_of_the_gru_predictor(tmp_path):
+    """A GRU-6IN-32H1-32H2-5OUT folder whose weights exist only as <name>.keras — as SI_Toolkit saves them — loads: the
+    archive's variables come out in model.get_weights() order (each GRU layer's kernel, recurrent kernel, bias from its
+    cell; then the Dense head; optimizer slots and metrics ignored) and convert like an exported weights_keras.npz."""
+    rng = np.random.Generator(np.random.SFC64(21))
+    u = 32
+    g = lambda *s: (0.3 * rng.standard_normal(s)).astype(f32)  # noqa: E731
+    get_weights = [g(6, 3 * u), g(u, 3 * u), g(2, 3 * u), g(u, 3 * u), g(u, 3 * u), g(2, 3 * u), g(u, 5), g(5)]
+    top = "_layer_checkpoint_dependencies"
+    arrays = {}
+    for l, name in enumerate(("gru", "gru_1")):
+        for i in range(3):
+            arrays[f"{top}/{name}/cell/vars/{i}"] = get_weights[3 * l + i]
+    arrays[f"{top}/dense/vars/0"], arrays[f"{top}/dense/vars/1"] = get_weights[6], get_weights[7]
+    arrays["optimizer/vars/0"] = np.array(1000, np.int64)
+    arrays["optimizer/vars/1"] = g(6, 3 * u)
+    arrays["metrics/mean/vars/0"] = np.array(1.5, f32)
+    layers = [{"class_name": "InputLayer", "config": {"name": "input_1", "batch_input_shape": [None, None, 6]}},
+              {"class_name": "GRU", "config": {"name": "layers_0", "units": u}, "build_config": {"input_shape": [None, None, 6]}},
+              {"class_name": "GRU", "config": {"name": "layers_1", "units": u}, "build_config": {"input_shape": [None, None, u]}},
+              {"class_name": "Dense", "config": {"name": "layers_2", "units": 5}, "build_config": {"input_shape": [None, None, u]}}]
+    d = _write_gru_folder(str(tmp_path), MF.KERNEL_INPUTS, MF.KERNEL_OUTPUTS, {}, np.ones(6), np.zeros(6), np.ones(5), np.zeros(5))
+    os.remove(os.path.join(d, "weights.npz"))
+    _keras_archive(os.path.join(d, os.path.basename(d) + ".keras"), layers, arrays)
+    from cartpolesimulation_amd.hdf5_min import read_keras_weights
+    got, owners = read_keras_weights(os.path.join(d, os.path.basename(d) + ".keras"))
+    assert [c for _, c in owners] == ["GRU", "GRU", "Dense"] and len(got) == 8
+    for a, b in zip(got, get_weights):
+        assert np.array_equal(a, b)
+    m = MF.load_gru_model(d)
+    want = MF.keras_gru_weights_to_model(get_weights)
+    for k in ("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "w_out", "b_out"):
+        np.testing.assert_array_equal(m[k], want[k])
+    # a .keras archive of another architecture is refused by name, not mis-read
+    layers[1]["class_name"] = "LSTM"
+    arrays2 = {k.replace("/gru/", "/lstm/"): v for k, v in arrays.items()}
+    _keras_archive(os.path.join(d, os.path.basename(d) + ".keras"), layers, arrays2)
+    with pytest.raises(NotImplementedError, match="LSTM"):
+        MF.load_gru_model(d)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_KERAS), reason="the reference checkout is not on this machine")
+def test_reference_keras_archive_equals_its_own_c_export(golden_dir):
+    """The pin of the reader: the reference's in-tree model folder holds one trained network twice — as a .keras archive
+    (written by Keras 2.13 / h5py) and as C arrays written by the reference's own export (C_implementation/
+    network_parameters.c, parsed into tests/golden/keras_dense_c_export.npz by oracle/gen_golden_keras.py).  Read with
+    hdf5_min.py, the archive reproduces the C export bit for bit."""
+    from cartpolesimulation_amd.hdf5_min import read_keras_weights
+    arrays, owners = read_keras_weights(REF_KERAS)
+    assert [c for _, c in owners] == ["Dense", "Dense", "Dense"]
+    gold = np.load(os.path.join(golden_dir, "keras_dense_c_export.npz"))
+    for k in range(3):
+        assert arrays[2 * k].dtype == np.float32
+        assert np.array_equal(arrays[2 * k], gold[f"kernel{k}"]) and np.array_equal(arrays[2 * k + 1], gold[f"bias{k}"])
