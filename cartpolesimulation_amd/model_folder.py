@@ -12,8 +12,10 @@ layout Keras writes — no TensorFlow, no h5py; pinned on the reference's in-tre
 ``GymlikeCartPole/Dense-7IN-32H1-32H2-1OUT-0/*.keras`` against that folder's own C export of the same weights).  Also
 read: ``weights_keras.npz`` = ``np.savez(path, *model.get_weights())`` (Keras layout, converted by
 ``keras_gru_weights_to_model``), a ``torch`` state_dict (``ckpt.pt``, the layout of ``torch.nn.GRU`` + a ``Linear``
-head) or ``weights.npz`` with the keys of ``MPPIEngine.set_gru``.  A folder that holds ONLY a TensorFlow checkpoint
-(``ckpt.ckpt.*``) raises with the reason; there is no silent fallback.
+head) or ``weights.npz`` with the keys of ``MPPIEngine.set_gru``; and the TensorFlow checkpoint ``ckpt.ckpt.index`` +
+``ckpt.ckpt.data-*`` that ``keras.Model.save_weights`` writes next to the archive (``tf_bundle_min.py``: LevelDB table +
+``BundleEntryProto``, pinned on the same in-tree folder the same way).  Anything else raises with the reason; there is no
+silent fallback.
 """
 import os
 import re
@@ -145,11 +147,14 @@ def _weights(folder):
             raise NotImplementedError(f"{folder}/{keras[0]}: layers with variables are {classes}; the HIP predictor implements "
                                       "GRU -> GRU -> Dense (GRU-6IN-32H1-32H2-5OUT)")
         return keras_gru_weights_to_model(arrays)
-    tf_like = [f for f in os.listdir(folder) if f.endswith((".h5", ".index")) or ".ckpt" in f]
+    if os.path.exists(os.path.join(folder, "ckpt.ckpt.index")):       # keras.Model.save_weights('ckpt.ckpt'): Training.py:163
+        from .tf_bundle_min import read_keras_checkpoint_weights
+        return keras_gru_weights_to_model(read_keras_checkpoint_weights(os.path.join(folder, "ckpt.ckpt")))
+    tf_like = [f for f in os.listdir(folder) if f.endswith((".h5", ".index", ".pb")) or ".ckpt" in f]
     if tf_like:
-        raise NotImplementedError(f"{folder}: only a TensorFlow checkpoint found ({', '.join(sorted(tf_like)[:3])}); its "
-                                  "SSTable / protobuf container is not read here - keep the .keras archive SI_Toolkit saves "
-                                  "next to it, or export once in the reference's environment (INTEGRATION.md: "
+        raise NotImplementedError(f"{folder}: TensorFlow / Keras files found ({', '.join(sorted(tf_like)[:3])}) but neither a "
+                                  "<name>.keras archive nor a ckpt.ckpt.index + data pair, the two containers read here; "
+                                  "export once in the reference's environment (INTEGRATION.md: "
                                   "np.savez('weights_keras.npz', *model.get_weights()))")
     raise FileNotFoundError(f"{folder}: no weights.npz or ckpt.pt")
 

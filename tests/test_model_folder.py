@@ -74,7 +74,7 @@ def test_torch_state_dict_and_tensorflow_only_folders(tmp_path):
     np.testing.assert_array_equal(m["w_hh1"], gru.weight_hh_l1.detach().numpy())
     np.testing.assert_array_equal(m["w_out"], head.weight.detach().numpy())
     os.remove(os.path.join(d, "ckpt.pt"))
-    open(os.path.join(d, "ckpt.ckpt.index"), "w").close()
+    open(os.path.join(d, "saved_model.pb"), "w").close()           # a container that is not read: refused by name
     with pytest.raises(NotImplementedError, match="TensorFlow"):
         MF.load_gru_model(d)
 
@@ -281,3 +281,50 @@ def test_reference_keras_archive_equals_its_own_c_export(golden_dir):
     for k in range(3):
         assert arrays[2 * k].dtype == np.float32
         assert np.array_equal(arrays[2 * k], gold[f"kernel{k}"]) and np.array_equal(arrays[2 * k + 1], gold[f"bias{k}"])
+
+
+REF_CKPT = "/root/reference/GymlikeCartPole/Dense-7IN-32H1-32H2-1OUT-0/ckpt.ckpt"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CKPT + ".index"), reason="the reference checkout is not on this machine")
+def test_reference_tf_checkpoint_equals_its_own_c_export(golden_dir):
+    """The same pin for the other container: the in-tree folder's TensorFlow checkpoint (ckpt.ckpt.index + data shard,
+    written by keras.Model.save_weights, Training.py:163), read with tf_bundle_min.py, reproduces the reference's C export
+    of the network bit for bit; optimizer slots and the object graph are skipped."""
+    from cartpolesimulation_amd.tf_bundle_min import read_keras_checkpoint_weights, read_tf_checkpoint
+    arrays = read_keras_checkpoint_weights(REF_CKPT)
+    gold = np.load(os.path.join(golden_dir, "keras_dense_c_export.npz"))
+    assert len(arrays) == 6
+    for k in range(3):
+        assert np.array_equal(arrays[2 * k], gold[f"kernel{k}"]) and np.array_equal(arrays[2 * k + 1], gold[f"bias{k}"])
+    names = read_tf_checkpoint(REF_CKPT)
+    assert names["optimizer/_iterations/.ATTRIBUTES/VARIABLE_VALUE"].dtype == np.int64
+
+
+def test_model_folder_with_only_a_tf_checkpoint(tmp_path):
+    """A GRU-6IN-32H1-32H2-5OUT folder whose weights exist only as ckpt.ckpt.index + ckpt.ckpt.data-00000-of-00001 (written
+    here from the format descriptions by tests/tf_bundle_writer.py, several table blocks, prefix-compressed keys) loads
+    and converts like model.get_weights()."""
+    from tf_bundle_writer import write_tf_checkpoint
+    from cartpolesimulation_amd.tf_bundle_min import read_tf_checkpoint
+    rng = np.random.Generator(np.random.SFC64(22))
+    u = 32
+    g = lambda *s: (0.3 * rng.standard_normal(s)).astype(f32)  # noqa: E731
+    get_weights = [g(6, 3 * u), g(u, 3 * u), g(2, 3 * u), g(u, 3 * u), g(u, 3 * u), g(2, 3 * u), g(u, 5), g(5)]
+    t = {}
+    for l in range(2):
+        for i, kind in enumerate(("kernel", "recurrent_kernel", "bias")):
+            t[f"layer_with_weights-{l}/cell/{kind}/.ATTRIBUTES/VARIABLE_VALUE"] = get_weights[3 * l + i]
+    t["layer_with_weights-2/kernel/.ATTRIBUTES/VARIABLE_VALUE"] = get_weights[6]
+    t["layer_with_weights-2/bias/.ATTRIBUTES/VARIABLE_VALUE"] = get_weights[7]
+    t["optimizer/_iterations/.ATTRIBUTES/VARIABLE_VALUE"] = np.array(77, np.int64)
+    t["optimizer/_variables/1/.ATTRIBUTES/VARIABLE_VALUE"] = g(6, 3 * u)
+    d = _write_gru_folder(str(tmp_path), MF.KERNEL_INPUTS, MF.KERNEL_OUTPUTS, {}, np.ones(6), np.zeros(6), np.ones(5), np.zeros(5))
+    os.remove(os.path.join(d, "weights.npz"))
+    write_tf_checkpoint(os.path.join(d, "ckpt.ckpt"), t)
+    back = read_tf_checkpoint(os.path.join(d, "ckpt.ckpt"))
+    assert set(back) == set(t) and all(np.array_equal(back[k], t[k]) and back[k].dtype == t[k].dtype for k in t)
+    m = MF.load_gru_model(d)
+    want = MF.keras_gru_weights_to_model(get_weights)
+    for k in want:
+        np.testing.assert_array_equal(m[k], want[k])
