@@ -945,7 +945,9 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     }
     if (sec) CPMPPI_SEC(sec, 3, st);
   } else {
+    if (sec) { asm volatile("" : "+v"(cd), "+v"(sd), "+v"(xlim)); CPMPPI_SEC(sec, 2, st); }
     for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+    if (sec) CPMPPI_SEC(sec, 3, st);
   }
   const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, check, at_edge) && check;
   if (sec) CPMPPI_SEC(sec, 4, st);

@@ -31,13 +31,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C4")
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--noise", default="philox")
+ap.add_argument("--reader", default=None, help="cpmppi_debug_sections_{latency,mid,throughput} (default: by size)")
 args = ap.parse_args()
 E, N, H = {"C3": (64, 4096, 100), "C4": (64, 2048, 50), "E256": (256, 1024, 50), "C2": (1, 1024, 50), "C1": (1, 256, 20)}[args.config]
 latency = E * N < 131072                                   # one rollout per lane: the latency build
 dev = torch.device("cuda", 0)
 eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=1 if latency else 2), device=0)
 lib = L.load()
-fn = lib.cpmppi_debug_sections_latency if latency else lib.cpmppi_debug_sections_mid
+fn = getattr(lib, args.reader) if args.reader else (lib.cpmppi_debug_sections_latency if latency else lib.cpmppi_debug_sections_mid)
 fn.argtypes = [C.c_void_p, C.c_uint]
 n_waves = min(16384, E * ((N + (255 if latency else 511)) // (256 if latency else 512)) * 4)
 s0, tp, te, Lt = synthetic_inputs(E, H, 2, dev)
