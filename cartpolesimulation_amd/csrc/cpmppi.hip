@@ -39,6 +39,7 @@ namespace cpmppi_k {
 CPMPPI_LATENCY_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_LATENCY_BUFFER_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_MID_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
+CPMPPI_MID_BUFFER_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 }  // namespace cpmppi_k
 

@@ -975,6 +975,29 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   return true;
 #endif
 }
+// A control step of a wave one of whose rollouts ENDED the previous step at or beyond the track edge (`at_edge`): the
+// event arithmetic inline on every intermediate substep, no test, no speculation (see control_step_fast).  Used by the
+// phased horizon loop (cpmppi_rollout.hpp), which keeps this code out of the loop the quiet control steps run in.
+template <class F>
+__device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, uint32_t S, float t, const Params& p,
+                                                           const EnvConst& e, float nearlim, bool* at_edge) {
+  F xlim = splat<F>(p.THL);
+  const float wlim = ROT_LIMIT / t;
+#pragma unroll
+  for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
+  F cd, sd;
+  rot_pair<F>(st.w * splat<F>(t), cd, sd);
+  uint32_t left = S - 1u;
+  while (left >= 3u) {
+    substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+    substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+    substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+    left -= 3u;
+  }
+  for (; left != 0u; --left) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+  return substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Stage / terminal costs (generic over float / float2).  `x_t` target position, `te` target equilibrium, `u` the
 // control applied at this stage.

@@ -4,6 +4,7 @@
 // cpmppi_rollout_throughput.hip): a launch of at most one wave per SIMD is bound by the latency of a single wave's
 // instruction stream, larger ones by issue throughput, and the compiler's schedulers differ measurably on the two.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "cpmppi.h"
@@ -38,6 +39,9 @@ constexpr int WAVES = BLOCK / 64;
 #endif
 #ifndef CPMPPI_WAVE_PRIORITY
 #define CPMPPI_WAVE_PRIORITY 1
+#endif
+#ifndef CPMPPI_MID_PHASED
+#define CPMPPI_MID_PHASED 1         // mid-size build, noise generated or interpolated in the kernel: quiet and eventful control steps in separate loops
 #endif
 #ifndef CPMPPI_MID_VGPR_CONSTS
 #define CPMPPI_MID_VGPR_CONSTS 1    // mid-size build: substep constants in VGPRs (the packed form wants register pairs)
@@ -280,7 +284,17 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // 8192 envs).  The same variant runs the substeps that follow a rare event in their own loop (control_step_fast).
   Params ph = p;
   EnvConst eh = ec;
-  if constexpr (VARIANT == 2 && R == 2 && CPMPPI_MID_VGPR_CONSTS != 0) {
+  // Mid-size build, phased horizon loop (round 3, last): quiet control steps and eventful ones - a rollout of the wave ended
+  // the previous step at or beyond the track edge - run in SEPARATE loops over k.  The quiet loop is the throughput
+  // build's control step, untouched (its substep loop handles the rare first event behind a branch); the eventful loop
+  // integrates with the event arithmetic inline.  Kept apart like this, the quiet loop gets the registers and the layout
+  // of a kernel that has no eventful code: section stamps at C4 showed the median wave of the throughput build at 2680
+  // cycles per control step against 3240 for the triples-with-rollback build below, in EVERY section, identical source
+  // included - what that build paid for its event handling was the larger loop body (register copies, spill reloads), not
+  // the triples.  Measured: C4 84.1 -> 79.3 us (mean 85.1 -> 80.8), C3 239.3 -> 234.0, 256 envs 118.6 -> 114.5, 1024 envs
+  // 366.7 -> 341.6 us.  The buffer-fed kernels (tile loops around the control step) keep the triples.
+  constexpr bool PHASED = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_PHASED != 0) && (NOISE == NOISE_PHILOX || NOISE == NOISE_KNOTS);
+  if constexpr (VARIANT == 2 && R == 2 && CPMPPI_MID_VGPR_CONSTS != 0 && !PHASED) {
 #define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
     CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
     CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.t1_i); CPMPPI_TO_VGPR(eh.inv_kLh);
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // (measured, round 3: 8192 envs 2.61 -> 2.47 ms per launch; single env with knots from memory 57.6 -> 54.9 us, with
   // Philox / a delta_u buffer +0.5 / +1 % - those keep the one-step-ahead load; mid-size build: C4 -1..-3 %, C3 and 256 envs
   // +2 %, not enabled)
-  constexpr bool NOMINAL_IN_LANES = FAST && (((CPMPPI_NOMINAL_IN_LANES) >> VARIANT) & 1) != 0 && (VARIANT != 0 || NOISE == NOISE_KNOTS);
+  constexpr bool NOMINAL_IN_LANES = FAST && ((((CPMPPI_NOMINAL_IN_LANES) >> VARIANT) & 1) != 0 || PHASED) && (VARIANT != 0 || NOISE == NOISE_KNOTS);
   constexpr bool PREFETCH_NOMINAL = (VARIANT == 0) && !NOMINAL_IN_LANES;
   float uk_next = PREFETCH_NOMINAL ? shifted_nominal(p, un, 0) : 0.0f;
   float up_next = (VARIANT == 0 && COST == COST_LEGACY) ? up[0] : 0.0f;
@@ -341,9 +355,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   unsigned* const secp = nullptr;
 #endif
   // mid-size build: did a rollout of this wave end the previous control step at or beyond the track edge?  (wave-uniform)
-  constexpr bool STICKY_EVENTS = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_STICKY_EVENTS != 0);
+  constexpr bool STICKY_EVENTS = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_STICKY_EVENTS != 0) && !PHASED;
   bool at_edge = false;
-  auto control_step = [&](uint32_t k, F du) __attribute__((always_inline)) {
+  auto control_step = [&](uint32_t k, F du, auto eventful) __attribute__((always_inline)) {
     if (secp) { asm volatile("" : "+v"(du)); CPMPPI_SEC(secp, 5, st); CPMPPI_SEC(secp, 0, st); }
     float uk, upk = 0.0f;
     if constexpr (NOMINAL_IN_LANES) {
@@ -392,8 +406,11 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       bool near_next;
       if constexpr (STICKY_EVENTS) {
         near_next = control_step_fast<F, true>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
+      } else if constexpr (PHASED) {
+        if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
+        else near_next = control_step_fast<F, false>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
       } else {
-        near_next = control_step_fast<F, (VARIANT == 2)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
+        near_next = control_step_fast<F, (VARIANT == 2 && !PHASED)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
       }
       near = !TRACK_NEAR || near_next;
     } else {
@@ -468,7 +485,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
             put(du, i, quad[i].x);
             quad[i].x = quad[i].y; quad[i].y = quad[i].z; quad[i].z = quad[i].w;
           }
-          if (k >= k_first && k < H) control_step(k, du);
+          if (k >= k_first && k < H) control_step(k, du, std::false_type{});
         }
       }
     }
@@ -503,7 +520,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
           // compiler turns into a tree of scalar branches per control step
           cur[i].x = cur[i].y; cur[i].y = cur[i].z; cur[i].z = cur[i].w;
         }
-        control_step(4u * q + j, du);
+        control_step(4u * q + j, du, std::false_type{});
       }
 #pragma unroll
       for (int i = 0; i < R; ++i) cur[i] = nxt[i];
@@ -548,14 +565,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
     }
     uint32_t ii = 0, j = 0;
-    for (uint32_t k = 0; k < H; ++k) {
+    auto horizon_step = [&](uint32_t k, auto eventful) __attribute__((always_inline)) {
       F du;
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         if constexpr (F32_INTERP) put(du, i, interp_from_slope32(slope32[i], z_lo[i], ii));
         else put(du, i, interp_from_slope(slope[i], z_lo[i], ii));
       }
-      control_step(k, du);
+      control_step(k, du, eventful);
       if (++ii == p.period) {
         ii = 0; ++j;
 #pragma unroll
@@ -571,6 +588,15 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
           else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
         }
       }
+    };
+    if constexpr (PHASED) {
+      uint32_t k = 0;
+      while (k < H) {
+        for (; k < H && !at_edge; ++k) horizon_step(k, std::false_type{});
+        for (; k < H && at_edge; ++k) horizon_step(k, std::true_type{});
+      }
+    } else {
+      for (uint32_t k = 0; k < H; ++k) horizon_step(k, std::false_type{});
     }
   }
 
@@ -763,7 +789,10 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 // (... and the `default`-cost Philox kernel, which max-memory-clause leaves with a 20-byte scratch slot for two spilled
 // scalar registers - tests/test_abi_and_host.py keeps scratch out of every instantiation)
 #define CPMPPI_LATENCY_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 1, 0) X(COST_DEFAULT, true, NOISE_PHILOX, 1, 0)
-#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 2)
+// (the mid-size build is two units as well: the kernels with the phased horizon loop want the throughput unit's flags,
+// the buffer-fed ones, which keep the triples, iterative-ilp)
+#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 2)
+#define CPMPPI_MID_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 2)
 #define CPMPPI_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
 #define CPMPPI_DEFINE_ROLLOUT(COST, FAST, NOISE, R, V) \
