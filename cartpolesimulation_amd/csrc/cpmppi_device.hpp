@@ -866,9 +866,15 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
 #endif
   F xlim = splat<F>(p.THL);
   const float wlim = ROT_LIMIT / t;             // |w t| > ROT_LIMIT as one compare with a free abs modifier per lane
+  uint64_t spinning = 0;      // wave mask of lanes beyond the rotation range: the same compare as the select's (one v_cmp)
   if (check) {
 #pragma unroll
-    for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
+    for (int i = 0; i < Width<F>::value; ++i) {
+      const bool within = !(__builtin_fabsf(get(st.w, i)) > wlim);
+      put(xlim, i, within ? p.THL : -1.0f);
+      // (the select's own compare, in the sense the compiler emits it - v_cmp_ngt - so that no second compare is needed)
+      if (!TWO_LOOPS && at_edge != nullptr) spinning |= ~__builtin_amdgcn_ballot_w64(within) & __builtin_amdgcn_ballot_w64(true);
+    }
   }
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
@@ -950,6 +956,11 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     if (sec) CPMPPI_SEC(sec, 3, st);
   }
   const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, check, at_edge) && check;
+  if constexpr (!TWO_LOOPS) {
+    // phased horizon loop: a wave with a lane beyond the rotation range (it takes the event path on every substep, ~500
+    // cycles each behind the branch) goes to the loop with the event arithmetic inline like one with a rollout at the edge
+    if (at_edge != nullptr) *at_edge = *at_edge || spinning != 0;
+  }
   if (sec) CPMPPI_SEC(sec, 4, st);
   return near_end;
 #else
@@ -983,8 +994,13 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
                                                            const EnvConst& e, float nearlim, bool* at_edge) {
   F xlim = splat<F>(p.THL);
   const float wlim = ROT_LIMIT / t;
+  uint64_t spinning = 0;
 #pragma unroll
-  for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, (__builtin_fabsf(get(st.w, i)) > wlim) ? -1.0f : p.THL);
+  for (int i = 0; i < Width<F>::value; ++i) {
+    const bool within = !(__builtin_fabsf(get(st.w, i)) > wlim);
+    put(xlim, i, within ? p.THL : -1.0f);
+    spinning |= ~__builtin_amdgcn_ballot_w64(within) & __builtin_amdgcn_ballot_w64(true);
+  }
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
   uint32_t left = S - 1u;
@@ -995,7 +1011,9 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
     left -= 3u;
   }
   for (; left != 0u; --left) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-  return substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
+  const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
+  *at_edge = *at_edge || spinning != 0;          // (stays in this loop while the pole keeps spinning)
+  return near_end;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
