@@ -790,7 +790,7 @@ __device__ __forceinline__ SafeStep make_safe_step(const Params& p, const EnvCon
 // One control step of S substeps under a held control (FAST).
 // Returns whether any lane of the wave ends the step with |x| >= ss->nearlim (wave-uniform; always true where it is
 // not tracked): the caller's next stage evaluates the boundary cost only then.
-template <class F, bool TWO_LOOPS = false>
+template <class F, bool TWO_LOOPS = false, bool QUIET_UNROLL = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e, float nearlim, const SafeStep* ss = nullptr,
                                                   unsigned* sec = nullptr, bool* at_edge = nullptr) {
@@ -952,7 +952,15 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     if (sec) CPMPPI_SEC(sec, 3, st);
   } else {
     if (sec) { asm volatile("" : "+v"(cd), "+v"(sd), "+v"(xlim)); CPMPPI_SEC(sec, 2, st); }
-    for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+    if (QUIET_UNROLL && S == 10u) {
+      // the quiet control step of the phased mid-size build in a launch of one wave per SIMD, the reference's
+      // intermediate_steps = 10: the nine substeps as straight-line code - a lone wave pays ~50 cycles per taken branch
+      // (see the one-rollout-per-lane mapping above), and the loop's back edge is one per substep
+#pragma unroll
+      for (int sub = 0; sub < 9; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+    } else {
+      for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+    }
     if (sec) CPMPPI_SEC(sec, 3, st);
   }
   const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, check, at_edge) && check;

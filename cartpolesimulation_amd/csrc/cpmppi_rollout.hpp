@@ -238,8 +238,13 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
 // VARIANT selects the translation unit (hence the scheduling strategy) an instantiation is compiled in:
 // 0 = latency build (one rollout per lane, launches of at most one wave per SIMD), 1 = throughput build, 2 = packed
 // mapping for mid-sized launches (same code except where the loop constants live, see below).
-template <int COST, bool FAST, int NOISE, int R, int VARIANT>
+template <int COST, bool FAST, int NOISE, int R, int VARIANT_>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
+  // VARIANT_ 3 = the mid-size build for launches of at most ONE wave per SIMD: VARIANT 2 with the quiet control step's nine
+  // substeps as straight-line code (a lone wave pays ~50 cycles per taken branch: C4 80.1 -> 77.4 us; with two or more waves
+  // per SIMD the larger code costs 1.5-2.5 % instead, so those launches keep the loop)
+  constexpr int VARIANT = (VARIANT_ == 3) ? 2 : VARIANT_;
+  constexpr bool LONE_WAVE = VARIANT_ == 3;
   // mid-size build (one to four waves per SIMD): two rollouts per lane as two PLAIN float chains (u2) instead of packed
   // float2 when CPMPPI_MID_UNPACKED - a (nearly) lone wave is bound by instruction issue, not by the ALU
   using F = typename Lanes<R, (VARIANT == 2 && CPMPPI_MID_UNPACKED != 0)>::F;
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         near_next = control_step_fast<F, true>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
       } else if constexpr (PHASED) {
         if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
-        else near_next = control_step_fast<F, false>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
+        else near_next = control_step_fast<F, false, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
       } else {
         near_next = control_step_fast<F, (VARIANT == 2 && !PHASED)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
       }
@@ -791,7 +796,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #define CPMPPI_LATENCY_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 1, 0) X(COST_DEFAULT, true, NOISE_PHILOX, 1, 0)
 // (the mid-size build is two units as well: the kernels with the phased horizon loop want the throughput unit's flags,
 // the buffer-fed ones, which keep the triples, iterative-ilp)
-#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 2)
+#define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 2) \
+  CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 3) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 3)
 #define CPMPPI_MID_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 2)
 #define CPMPPI_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)

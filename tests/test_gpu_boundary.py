@@ -322,14 +322,15 @@ def test_predict_large_launch_equals_small_launches(math_mode):
 
 
 @pytest.mark.parametrize("noise", ["philox", "knots"])
-@pytest.mark.parametrize("rpl,small_E,big_E,H", [(2, 200, 1600, 70), (1, 32, 100, 70), (1, 32, 100, 150)])
+@pytest.mark.parametrize("rpl,small_E,big_E,H", [(2, 200, 1600, 70), (2, 100, 1600, 70), (1, 32, 100, 70), (1, 32, 100, 150)])
 def test_builds_of_the_kernel_agree_bit_for_bit(rpl, small_E, big_E, H, noise):
     """The rollout kernel exists in three builds chosen by launch size (latency / mid-size / throughput: different
     scheduling strategies, constants in scalar or vector registers, triples with rollback or not, the nominal sequence
     read from memory per control step or held in lanes and fetched with v_readlane).  An env's result must not depend on
     which build integrated it: the first envs of a large launch (throughput build: > 1.5 M rollouts with two per lane,
-    > 65 536 with one) equal, bit for bit, the same envs in a launch small enough for the mid-size (two rollouts per lane)
-    or latency (one per lane) build.  The nominal sequence is nonzero and the horizon longer than 64 steps (the lanes of
+    > 65 536 with one) equal, bit for bit, the same envs in a launch small enough for the mid-size (two rollouts per lane:
+    200 envs; 100 envs = at most one wave per SIMD, the build with the quiet control step unrolled) or latency (one per
+    lane) build.  The nominal sequence is nonzero and the horizon longer than 64 steps (the lanes of
     one register; 150: three register loads), with in-kernel noise and with knots from memory (the latency build holds
     the sequence in lanes only then)."""
     from cartpolesimulation_amd.engine import MPPIEngine
