@@ -539,7 +539,10 @@ __device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
 // (nonzero only for |x| > permissible_track_fraction * THL = nearlim) is evaluated only then.  The edge itself is tested
 // behind that branch, so the common path costs what it did with the plain edge test.
 // NEAR = false: `nearlim` is not used, the common path tests the edge itself (the latency build).
-template <class F, bool CHECK = true, bool NEAR = true>
+// INLINE_EVENTS: the bounce arithmetic is evaluated on every call under its mask instead of behind the wave-uniform branch
+// (the eventful loop of the phased build: a wave that is there bounces on nearly every control step, and behind the branch
+// the block costs ~500 cycles against ~150 inline).
+template <class F, bool CHECK = true, bool NEAR = true, bool INLINE_EVENTS = false>
 __device__ __forceinline__ bool substep_fast(State<F>& st, F uK, float t, const Params& p, const EnvConst& e, float nearlim,
                                              bool check = true, bool* at_edge = nullptr) {
   constexpr int W = Width<F>::value;
@@ -561,7 +564,7 @@ __device__ __forceinline__ bool substep_fast(State<F>& st, F uK, float t, const 
     near = ~0ull;
   }
   if (at_edge) *at_edge = rare != 0;
-  if (CHECK && __builtin_expect(rare != 0, 0)) {     // wave-uniform: no exec bookkeeping when cold
+  if (CHECK && (INLINE_EVENTS || __builtin_expect(rare != 0, 0))) {     // wave-uniform: no exec bookkeeping when cold
     CPMPPI_DBG(3, 1);
     // cos of the integrated angle by rotating the previous pair through d = w t; lanes beyond the rotation range (deep)
     const F d = st.w * splat<F>(t);
@@ -657,6 +660,9 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
 
 #ifndef CPMPPI_TRIPLE_TEST_BEFORE_THIRD
 #define CPMPPI_TRIPLE_TEST_BEFORE_THIRD 1
+#endif
+#ifndef CPMPPI_EVENTFUL_LAST_INLINE
+#define CPMPPI_EVENTFUL_LAST_INLINE 1
 #endif
 #ifndef CPMPPI_MID_EVENT_UNROLL
 #define CPMPPI_MID_EVENT_UNROLL 1
@@ -1019,7 +1025,7 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
     left -= 3u;
   }
   for (; left != 0u; --left) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-  const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
+  const bool near_end = substep_fast<F, true, true, (CPMPPI_EVENTFUL_LAST_INLINE != 0)>(st, uK, t, p, e, nearlim, true, at_edge);
   *at_edge = *at_edge || spinning != 0;          // (stays in this loop while the pole keeps spinning)
   return near_end;
 }
