@@ -935,17 +935,8 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3
   if (math == CPMPPI_MATH_FAST) {
     if (rpl == 2) {
       const bool mid = (uint64_t)grid.x * BLOCK * 2 <= MID_SIZE_MAX_ROLLOUTS;
-      // at most one wave per SIMD (256 CUs x 4) and noise made in the kernel: the phased build with the quiet step unrolled
-      const bool lone = (uint64_t)grid.x * WAVES <= 1024ull && (noise == CPMPPI_NOISE_KNOTS || noise == CPMPPI_NOISE_PHILOX);
-      if (lone) {
-        switch (noise) {
-          case CPMPPI_NOISE_KNOTS:
-            hipLaunchKernelGGL((rollout_cost_kernel<COST, true, NOISE_KNOTS, 2, 3>), grid, dim3(BLOCK), lds, s, p, a); break;
-          default:
-            hipLaunchKernelGGL((rollout_cost_kernel<COST, true, NOISE_PHILOX, 2, 3>), grid, dim3(BLOCK), lds, s, p, a); break;
-        }
-        return hipGetLastError();
-      }
+      // at most one wave per SIMD (256 CUs x 4): the phased build with the quiet control step unrolled
+      if ((uint64_t)grid.x * WAVES <= 1024ull) return launch_rollout_noise<COST, true, 2, 3>(noise, grid, lds, s, p, a);
       return mid ? launch_rollout_noise<COST, true, 2, 2>(noise, grid, lds, s, p, a)
                  : launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
     }

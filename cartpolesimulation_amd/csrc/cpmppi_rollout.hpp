@@ -298,7 +298,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // included - what that build paid for its event handling was the larger loop body (register copies, spill reloads), not
   // the triples.  Measured: C4 84.1 -> 79.3 us (mean 85.1 -> 80.8), C3 239.3 -> 234.0, 256 envs 118.6 -> 114.5, 1024 envs
   // 366.7 -> 341.6 us.  The buffer-fed kernels (tile loops around the control step) keep the triples.
-  constexpr bool PHASED = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_PHASED != 0) && (NOISE == NOISE_PHILOX || NOISE == NOISE_KNOTS);
+  constexpr bool PHASED = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_PHASED != 0);
   if constexpr (VARIANT == 2 && R == 2 && CPMPPI_MID_VGPR_CONSTS != 0 && !PHASED) {
 #define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
     CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
@@ -425,6 +425,15 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   };
 
   // ---- rollout over the horizon ----------------------------------------------------------------------------------
+  // phased build: `step(k, eventful)` performs control step k (fetching its perturbation itself); quiet and eventful steps
+  // in separate loops (see PHASED above)
+  auto run_phased = [&](auto&& step) __attribute__((always_inline)) {
+    uint32_t k = 0;
+    while (k < H) {
+      for (; k < H && !at_edge; ++k) step(k, std::false_type{});
+      for (; k < H && at_edge; ++k) step(k, std::true_type{});
+    }
+  };
   if constexpr (NOISE == NOISE_DELTA_U) {
     // delta_u[E,N,H] in the REFERENCE's rollout-major layout (controller_mppi_cartpole.py:434-446,479-483: the tensor at
     // the optimizer / predictor seam).  A lane needs one row, a memory transaction wants neighbouring lanes on neighbouring
@@ -470,6 +479,45 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     } else if (NBUF == 2) {
       dma(0u, 0u);
     }
+    if constexpr (PHASED) {
+      // the same tiles, walked by control step instead of by nested tile / piece / word loops (the phased driver owns the
+      // loop over k): tile t starts at step t * DTK; the quad is re-read every four columns of the tile; a last tile that
+      // overlaps its predecessor is entered in its middle (o > 0)
+      uint32_t t_next = 0u, ks = 0u;
+      const float4* __restrict__ cur_tile = reinterpret_cast<const float4*>(wave_tile) + lane;
+      float4 quad[R];
+      auto read_quad = [&](uint32_t piece) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) quad[i] = cur_tile[(piece * R + (uint32_t)i) * 64u];
+      };
+      auto shift_quad = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) { quad[i].x = quad[i].y; quad[i].y = quad[i].z; quad[i].z = quad[i].w; }
+      };
+      run_phased([&](uint32_t k, auto eventful) __attribute__((always_inline)) {
+        if (k == t_next * DTK) {
+          const uint32_t t = t_next;
+          ks = streamed ? tile_start(t) : 0u;
+          if (streamed) {
+            if (NBUF == 1) dma(ks, 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // tile t has landed in LDS
+            if (NBUF == 2 && t + 1u < ntiles) dma(tile_start(t + 1u), (t + 1u) & 1u);
+          }
+          cur_tile = reinterpret_cast<const float4*>(wave_tile + (NBUF == 2 ? (t & 1u) : 0u) * TILE_FLOATS) + lane;
+          t_next = t + 1u;
+          const uint32_t o = k - ks;
+          read_quad(o >> 2);
+          for (uint32_t w = 0; w < (o & 3u); ++w) shift_quad();
+        } else if (((k - ks) & 3u) == 0u) {
+          read_quad((k - ks) >> 2);
+        }
+        F du;
+#pragma unroll
+        for (int i = 0; i < R; ++i) put(du, i, quad[i].x);
+        shift_quad();
+        control_step(k, du, eventful);
+      });
+    } else
     for (uint32_t t = 0; t < ntiles; ++t) {
       const uint32_t ks = streamed ? tile_start(t) : 0u, k_first = t * DTK;      // (k_first > ks only in an overlapping last tile)
       if (streamed) {
@@ -510,6 +558,28 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     float4 cur[R], nxt[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) { cur[i] = src[i][0]; nxt[i] = cur[i]; }
+    if constexpr (PHASED) {
+      run_phased([&](uint32_t k, auto eventful) __attribute__((always_inline)) {
+        if ((k & 3u) == 0u) {                                 // a new quad: the one requested four steps ago; request the next
+          const uint32_t q = k >> 2;
+          if (q != 0u) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) cur[i] = nxt[i];
+          }
+          if (q + 1u < Hq) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) nxt[i] = src[i][(size_t)(q + 1u) * 64u];
+          }
+        }
+        F du;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          put(du, i, cur[i].x);
+          cur[i].x = cur[i].y; cur[i].y = cur[i].z; cur[i].z = cur[i].w;
+        }
+        control_step(k, du, eventful);
+      });
+    } else
     for (uint32_t q = 0; q < Hq; ++q) {
       if (q + 1 < Hq) {
 #pragma unroll
@@ -595,11 +665,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       }
     };
     if constexpr (PHASED) {
-      uint32_t k = 0;
-      while (k < H) {
-        for (; k < H && !at_edge; ++k) horizon_step(k, std::false_type{});
-        for (; k < H && at_edge; ++k) horizon_step(k, std::true_type{});
-      }
+      run_phased(horizon_step);
     } else {
       for (uint32_t k = 0; k < H; ++k) horizon_step(k, std::false_type{});
     }
@@ -798,7 +864,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 // the buffer-fed ones, which keep the triples, iterative-ilp)
 #define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 2) \
   CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 3) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 3)
-#define CPMPPI_MID_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 2)
+#define CPMPPI_MID_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 2) \
+  CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 3) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 3)
 #define CPMPPI_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
 #define CPMPPI_DEFINE_ROLLOUT(COST, FAST, NOISE, R, V) \
