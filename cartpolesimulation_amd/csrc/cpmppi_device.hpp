@@ -658,14 +658,8 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
   return fired;
 }
 
-#ifndef CPMPPI_TRIPLE_TEST_BEFORE_THIRD
-#define CPMPPI_TRIPLE_TEST_BEFORE_THIRD 1
-#endif
 #ifndef CPMPPI_EVENTFUL_LAST_INLINE
 #define CPMPPI_EVENTFUL_LAST_INLINE 1
-#endif
-#ifndef CPMPPI_MID_EVENT_UNROLL
-#define CPMPPI_MID_EVENT_UNROLL 1
 #endif
 #ifndef CPMPPI_LATENCY_UNROLL
 #define CPMPPI_LATENCY_UNROLL 1
@@ -796,14 +790,14 @@ __device__ __forceinline__ SafeStep make_safe_step(const Params& p, const EnvCon
 // One control step of S substeps under a held control (FAST).
 // Returns whether any lane of the wave ends the step with |x| >= ss->nearlim (wave-uniform; always true where it is
 // not tracked): the caller's next stage evaluates the boundary cost only then.
-template <class F, bool TWO_LOOPS = false, bool QUIET_UNROLL = false>
+template <class F, bool QUIET_UNROLL = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e, float nearlim, const SafeStep* ss = nullptr,
                                                   unsigned* sec = nullptr, bool* at_edge = nullptr) {
-  // `at_edge` (in/out, wave-uniform, mid-size build): did a rollout of this wave END the previous control step at or beyond
-  // the track edge?  It bounces on the very next substep - and, caught beyond the edge, on every one after it
-  // (cartpole_equations.py:341-347 flips v whichever way it points) - so a quiet triple is a certain loss: the step goes
-  // straight to the loop with the event arithmetic inline.
+  // `at_edge` (out, wave-uniform; the phased mid-size build passes it): does a rollout of this wave END the control step
+  // at or beyond the track edge, or spin beyond the rotation range?  It bounces on the very next substep - and, caught
+  // beyond the edge, on every one after it (cartpole_equations.py:341-347 flips v whichever way it points) - so the caller
+  // integrates the next control step with the event arithmetic inline (control_step_fast_eventful).
 #if CPMPPI_ROTATE && CPMPPI_HOIST_SPIN
   if constexpr (Width<F>::value == 1) {
     // one rollout per lane is the small-launch (latency-bound) mapping: there the per-substep test, which overlaps with
@@ -857,13 +851,6 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       F cd, sd, unused = splat<F>(0.0f);
       rot_pair<F>(st.w * splat<F>(t), cd, sd);
       uint32_t left = S - 1u;
-      if constexpr (TWO_LOOPS) {
-        for (; left >= 3u; left -= 3u) {
-          substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
-          substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
-          substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
-        }
-      }
       for (; left != 0u; --left) substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
       substep_fast<F, false>(st, uK, t, p, e, nearlim);
       return false;
@@ -879,84 +866,16 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       const bool within = !(__builtin_fabsf(get(st.w, i)) > wlim);
       put(xlim, i, within ? p.THL : -1.0f);
       // (the select's own compare, in the sense the compiler emits it - v_cmp_ngt - so that no second compare is needed)
-      if (!TWO_LOOPS && at_edge != nullptr) spinning |= ~__builtin_amdgcn_ballot_w64(within) & __builtin_amdgcn_ballot_w64(true);
+      if (at_edge != nullptr) spinning |= ~__builtin_amdgcn_ballot_w64(within) & __builtin_amdgcn_ballot_w64(true);
     }
   }
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
-  if constexpr (TWO_LOOPS) {
-    if (sec) { asm volatile("" : "+v"(cd), "+v"(sd), "+v"(xlim)); CPMPPI_SEC(sec, 2, st); }
-    // Three substeps at a time WITHOUT event handling — one exit test, one loop latch and one VALU -> scalar hand-over
-    // per triple, and a basic block three substeps long for the scheduler — under a rollback: the edge masks of the
-    // three are or-ed, and if any lane fired the triple is discarded and the rest of the control step is integrated
-    // substep by substep with the event arithmetic inline (BOUNCY).  S - 1 = 9 intermediate substeps = 3 triples.
-    uint32_t left = S - 1u;
-    // one triple under its rollback; returns whether it was discarded (the wave then leaves the triples for this control step)
-    auto triple = [&]() __attribute__((always_inline)) -> bool {
-      const State<F> st0 = st;
-      const F cd0 = cd, sd0 = sd;
-      // ONE edge test per triple (round 3): the three positions are kept and v_max3_f32(|x1|, |x2|, |x3|) is compared with
-      // the lane's limit (constant within a control step) - two vector and four scalar instructions fewer per triple than
-      // three compare pairs or-ed on the scalar side, which a lone wave pays for one by one (C4 87.7 -> 84.9 us, C3
-      // 256.8 -> 248.0 us, bit-identical).  [One test per CONTROL STEP with a sticky per-wave event mode was written too:
-      // this compiler's bdce pass crashes on every formulation of it that was tried.]
-      substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
-      const F xa = st.x;
-      substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
-      const F xb = st.x;
-#if CPMPPI_TRIPLE_TEST_BEFORE_THIRD
-      // The third position depends only on the second substep's results (x3 = x2 + v2 t: the very FMA the third substep
-      // performs), so the test sits in front of the third substep - where the compiler moved it anyway, but with the third
-      // substep in a block of its own that the hot path reached through a taken branch (~50 cycles for a lone wave).
-      // Written in this order the hot path falls through: two substeps, the test, the third substep, the back edge.
-      const F xc = fma_(st.v, splat<F>(t), st.x);
-#else
-      substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
-      const F xc = st.x;
-#endif
-      uint64_t fired = 0;
-      if (check) {
-#pragma unroll
-        for (int i = 0; i < Width<F>::value; ++i) {
-          const float m = __builtin_fmaxf(__builtin_fabsf(get(xa, i)), __builtin_fmaxf(__builtin_fabsf(get(xb, i)), __builtin_fabsf(get(xc, i))));
-          fired |= __builtin_amdgcn_fcmpf(m, get(xlim, i), 3);
-        }
-      }
-      if (__builtin_expect(fired != 0, 0)) {
-        asm volatile("" ::: "memory");            // (keeps this a branch: as selects the rollback costs 16 v_cndmask per triple)
-        st = st0; cd = cd0; sd = sd0;
-        return true;
-      }
-#if CPMPPI_TRIPLE_TEST_BEFORE_THIRD
-      substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, xlim, false);
-#endif
-      left -= 3u;
-      return false;
-    };
-    const bool skip = at_edge != nullptr && *at_edge;      // a rollout sits at the edge: no speculation (see the top)
-    // (the three triples as straight-line code for S = 10, like the one-rollout-per-lane mapping above: measured twice this
-    // round, C4 +3 %, C3 +2 % - a triple is 250 ns long, its taken branches matter less than the 8 more registers)
-    if (!skip) {
-      while (left >= 3u) {
-        if (triple()) break;
-      }
-    }
-#if CPMPPI_MID_EVENT_UNROLL
-    // (three per iteration: the wave that runs this loop is the one its launch waits for, and a taken branch per substep
-    // costs it ~50 cycles of ~300)
-    while (left >= 3u) {
-      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-      left -= 3u;
-    }
-#endif
-    while (left != 0u) {
-      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-      --left;
-    }
-    if (sec) CPMPPI_SEC(sec, 3, st);
-  } else {
+  // (Rounds 2 and 3 ran the packed mid-size build on three substeps at a time without event handling, under a rollback -
+  // one v_max3 test per triple, the discarded triple redone substep by substep with the event arithmetic inline - until
+  // section stamps showed that build's median wave 17 % slower per control step than this plain loop, in every section:
+  // DESIGN.md §4.  The phased horizon loop replaced it; the code is in the history.)
+  {
     if (sec) { asm volatile("" : "+v"(cd), "+v"(sd), "+v"(xlim)); CPMPPI_SEC(sec, 2, st); }
     if (QUIET_UNROLL && S == 10u) {
       // the quiet control step of the phased mid-size build in a launch of one wave per SIMD, the reference's
@@ -970,11 +889,9 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     if (sec) CPMPPI_SEC(sec, 3, st);
   }
   const bool near_end = substep_fast<F>(st, uK, t, p, e, nearlim, check, at_edge) && check;
-  if constexpr (!TWO_LOOPS) {
-    // phased horizon loop: a wave with a lane beyond the rotation range (it takes the event path on every substep, ~500
-    // cycles each behind the branch) goes to the loop with the event arithmetic inline like one with a rollout at the edge
-    if (at_edge != nullptr) *at_edge = *at_edge || spinning != 0;
-  }
+  // phased horizon loop: a wave with a lane beyond the rotation range (it takes the event path on every substep, ~500
+  // cycles each behind the branch) goes to the loop with the event arithmetic inline like one with a rollout at the edge
+  if (at_edge != nullptr) *at_edge = *at_edge || spinning != 0;
   if (sec) CPMPPI_SEC(sec, 4, st);
   return near_end;
 #else

@@ -34,17 +34,8 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_NOMINAL_IN_LANES
 #define CPMPPI_NOMINAL_IN_LANES 3   // FAST, bit v = build VARIANT v: nominal sequence held in lanes, fetched with v_readlane_b32 (latency + throughput builds)
 #endif
-#ifndef CPMPPI_MID_STICKY_EVENTS
-#define CPMPPI_MID_STICKY_EVENTS 1  // mid-size build: a wave with a rollout at the edge integrates the next control step without speculation
-#endif
 #ifndef CPMPPI_WAVE_PRIORITY
 #define CPMPPI_WAVE_PRIORITY 1
-#endif
-#ifndef CPMPPI_MID_PHASED
-#define CPMPPI_MID_PHASED 1         // mid-size build, noise generated or interpolated in the kernel: quiet and eventful control steps in separate loops
-#endif
-#ifndef CPMPPI_MID_VGPR_CONSTS
-#define CPMPPI_MID_VGPR_CONSTS 1    // mid-size build: substep constants in VGPRs (the packed form wants register pairs)
 #endif
 constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
 
@@ -282,29 +273,20 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
   const float L = a.L ? a.L[env] : p.L_default;
   const EnvConst ec = make_env_const_uniform(p, L);
-  // VARIANT 2 (packed mapping, launches of up to 4 waves per SIMD): the constants of the substep loop are held in vector
-  // registers instead of scalar ones.  The packed mapping wants every wave-uniform operand as a register PAIR and runs
-  // out of the 102 SGPRs; with them in VGPRs a lone wave's instruction stream is 4-7 % shorter in time (C3, C4), while
-  // at 64 waves per SIMD the scalar-operand form is 5 % faster (A/B in one process, tools/kbench.py: 2.44 vs 2.56 ms at
-  // 8192 envs).  The same variant runs the substeps that follow a rare event in their own loop (control_step_fast).
-  Params ph = p;
-  EnvConst eh = ec;
-  // Mid-size build, phased horizon loop (round 3, last): quiet control steps and eventful ones - a rollout of the wave ended
-  // the previous step at or beyond the track edge - run in SEPARATE loops over k.  The quiet loop is the throughput
-  // build's control step, untouched (its substep loop handles the rare first event behind a branch); the eventful loop
-  // integrates with the event arithmetic inline.  Kept apart like this, the quiet loop gets the registers and the layout
-  // of a kernel that has no eventful code: section stamps at C4 showed the median wave of the throughput build at 2680
-  // cycles per control step against 3240 for the triples-with-rollback build below, in EVERY section, identical source
-  // included - what that build paid for its event handling was the larger loop body (register copies, spill reloads), not
-  // the triples.  Measured: C4 84.1 -> 79.3 us (mean 85.1 -> 80.8), C3 239.3 -> 234.0, 256 envs 118.6 -> 114.5, 1024 envs
-  // 366.7 -> 341.6 us.  The buffer-fed kernels (tile loops around the control step) keep the triples.
-  constexpr bool PHASED = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_PHASED != 0);
-  if constexpr (VARIANT == 2 && R == 2 && CPMPPI_MID_VGPR_CONSTS != 0 && !PHASED) {
-#define CPMPPI_TO_VGPR(x) asm volatile("" : "+v"(x))
-    CPMPPI_TO_VGPR(ph.m_pole); CPMPPI_TO_VGPR(eh.kp1_mt); CPMPPI_TO_VGPR(eh.mg); CPMPPI_TO_VGPR(eh.JinvLh);
-    CPMPPI_TO_VGPR(eh.kmLh); CPMPPI_TO_VGPR(eh.kM); CPMPPI_TO_VGPR(eh.t1_i); CPMPPI_TO_VGPR(eh.inv_kLh);
-#undef CPMPPI_TO_VGPR
-  }
+  // Mid-size build (VARIANT 2 / 3, two rollouts per lane), phased horizon loop: quiet control steps and eventful ones - a
+  // rollout of the wave ended the previous step at or beyond the track edge, or its pole spins beyond the rotation range -
+  // run in SEPARATE loops over k (run_phased below).  The quiet loop is the throughput build's control step, untouched
+  // (its substep loop handles the rare first event behind a branch); the eventful loop integrates with the event
+  // arithmetic inline.  Kept apart like this, the quiet loop gets the registers and the layout of a kernel that has no
+  // eventful code: section stamps at C4 (tools/dev/sections.py) showed the median wave of the throughput build at 2680
+  // cycles per control step against 3240 for the build this replaced (three substeps at a time under a rollback, the
+  // event loop as an alternative inside the same loop body), in EVERY section, identical source included - that build
+  // paid for its event handling with a larger loop body (register copies, spill reloads), not with its triples.
+  // Measured: C4 84 -> 78 us, C3 243 -> 235, 256 envs 121 -> 117, 1024 envs 379 -> 353 us; buffer-fed kernels alike
+  // (C4 reference layout 87.5 -> 82.9 us).
+  constexpr bool PHASED = FAST && VARIANT == 2 && R == 2;
+  const Params& ph = p;
+  const EnvConst& eh = ec;
   const float x_t = a.x_t[env], te = a.te[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
@@ -359,8 +341,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #else
   unsigned* const secp = nullptr;
 #endif
-  // mid-size build: did a rollout of this wave end the previous control step at or beyond the track edge?  (wave-uniform)
-  constexpr bool STICKY_EVENTS = FAST && VARIANT == 2 && R == 2 && (CPMPPI_MID_STICKY_EVENTS != 0) && !PHASED;
+  // phased build: does a rollout of this wave sit at or beyond the track edge (or spin beyond the rotation range) as the
+  // next control step starts?  (wave-uniform)
   bool at_edge = false;
   auto control_step = [&](uint32_t k, F du, auto eventful) __attribute__((always_inline)) {
     if (secp) { asm volatile("" : "+v"(du)); CPMPPI_SEC(secp, 5, st); CPMPPI_SEC(secp, 0, st); }
@@ -409,13 +391,11 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       F uK = ur * splat<F>(ec.uK_scale);         // (k+1) u_max Q: the form in which the control enters positionDD's numerator
       if (secp) { asm volatile("" : "+v"(uK), "+v"(cost), "+v"(corr)); CPMPPI_SEC(secp, 1, st); }
       bool near_next;
-      if constexpr (STICKY_EVENTS) {
-        near_next = control_step_fast<F, true>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
-      } else if constexpr (PHASED) {
+      if constexpr (PHASED) {
         if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
-        else near_next = control_step_fast<F, false, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
+        else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
       } else {
-        near_next = control_step_fast<F, (VARIANT == 2 && !PHASED)>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
+        near_next = control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
       }
       near = !TRACK_NEAR || near_next;
     } else {
@@ -860,8 +840,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 // (... and the `default`-cost Philox kernel, which max-memory-clause leaves with a 20-byte scratch slot for two spilled
 // scalar registers - tests/test_abi_and_host.py keeps scratch out of every instantiation)
 #define CPMPPI_LATENCY_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 1, 0) X(COST_DEFAULT, true, NOISE_PHILOX, 1, 0)
-// (the mid-size build is two units as well: the kernels with the phased horizon loop want the throughput unit's flags,
-// the buffer-fed ones, which keep the triples, iterative-ilp)
+// (the mid-size build is two units as well, for compile time: 32 kernels each; VARIANT 3 = the build for launches of at
+// most one wave per SIMD)
 #define CPMPPI_MID_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 2) \
   CPMPPI_FOR_COSTS(X, true, NOISE_KNOTS, 2, 3) CPMPPI_FOR_COSTS(X, true, NOISE_PHILOX, 2, 3)
 #define CPMPPI_MID_BUFFER_INSTANCES(X) CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 2) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 2) \

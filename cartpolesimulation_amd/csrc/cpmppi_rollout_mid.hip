@@ -1,6 +1,6 @@
-// Explicit instantiations of the rollout kernel, mid-size build, noise generated or interpolated in the kernel (VARIANT 2,
-// NOISE_PHILOX / NOISE_KNOTS: two rollouts per lane, phased horizon loop; launches from one packed wave per SIMD up to
-// ~1.5 M rollouts); compiled with the throughput unit's flags (see __graft_entry__.build).
+// Explicit instantiations of the rollout kernel, mid-size build, noise generated or interpolated in the kernel (VARIANT 2
+// and 3, NOISE_PHILOX / NOISE_KNOTS: two rollouts per lane, phased horizon loop; VARIANT 3 = launches of at most one wave
+// per SIMD, VARIANT 2 up to ~1.5 M rollouts); compiled with the throughput unit's flags (see __graft_entry__.build).
 #include "cpmppi_rollout.hpp"
 
 namespace cpmppi_k {

@@ -1,6 +1,6 @@
-// Explicit instantiations of the rollout kernel, mid-size build, perturbations from a buffer (VARIANT 2, NOISE_DELTA_U /
-// NOISE_TILED: triples with rollback, loop constants in vector registers); compiled with
-// -amdgpu-sched-strategy=iterative-ilp (see __graft_entry__.build).
+// Explicit instantiations of the rollout kernel, mid-size build, perturbations from a buffer (VARIANT 2 / 3, NOISE_DELTA_U /
+// NOISE_TILED: phased horizon loop, the tiles walked by control step); a unit of its own so that the mid-size kernels
+// compile in parallel; same flags as cpmppi_rollout_mid.hip (see __graft_entry__.build).
 #include "cpmppi_rollout.hpp"
 
 namespace cpmppi_k {

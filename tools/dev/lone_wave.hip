@@ -1,5 +1,6 @@
 // Micro-benchmark (development tool): what the rollout kernel's own control-step code costs a wave as a function of the
-// waves that share its SIMD - the pieces of `control_step_fast<f2, true>` (cpmppi_device.hpp) timed in isolation, with the
+// waves that share its SIMD - the pieces of `control_step_fast<f2>` (cpmppi_device.hpp) and of the triples-with-rollback
+// control step it replaced (rows "triple ...") timed in isolation, with the
 // product's compiler flags, on 1 / 2 / 4 waves per SIMD.  Answers: is a lone wave (BASELINE C4: one packed wave per SIMD)
 // bound by issue (~5 cycles per packed instruction), by dependent latency (~9), or by something else?
 // What it told (round 3): the triple of the mid-size build runs at the lone wave's ISSUE limit (184 ns for 81 instructions =
@@ -49,7 +50,7 @@ __device__ __forceinline__ void sink(float* out, const State<f2>& st) {
   if (z == 123.456f) out[0] = z;
 }
 
-// KIND 0: whole control steps (seed the rotation pair, 3 triples with one edge test each, last substep with wrap + sincos)
+// KIND 0: whole control steps (seed the rotation pair, nine substeps each with its test, last substep with wrap + sincos)
 // KIND 1: triples only (the loop of the mid-size build: 3 substeps without event handling + v_max3 test)
 // KIND 2: two independent triples interleaved in one wave (what more ILP would buy)
 // KIND 3: last substep only (substep_fast: wrap + polynomial sincos + near test)
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, Params p, 
   int it = 0;
   for (; it < iters; ++it) {
     if constexpr (KIND == 0) {
-      control_step_fast<f2, true>(st, uK, p.S, t, ph, eh, nearlim);
+      control_step_fast<f2>(st, uK, p.S, t, ph, eh, nearlim);
       uK = -uK;
     } else if constexpr (KIND == 1 || KIND == 4) {
       substep_fast_rot_carried<f2, false, true>(st, uK, t, ph, eh, cd, sd, xlim, false);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k1(const float* in, float* out, Params p,
     if constexpr (KIND == 5) {
       substep_asm(st, uK, ts, ak);
     } else if constexpr (KIND == 0) {
-      control_step_fast<float, false>(st, uK, p.S, t, ph, eh, nearlim);
+      control_step_fast<float>(st, uK, p.S, t, ph, eh, nearlim);
       uK = -uK;
     } else if constexpr (KIND == 1) {
       substep_fast_rot<float>(st, uK, t, ph, eh);
