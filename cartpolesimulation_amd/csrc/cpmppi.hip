@@ -918,14 +918,15 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
   return hipGetLastError();
 }
 
-// Which build of the kernel a launch gets (measured on MI355X, tools/kbench.py / tools/dev/step_series.py):
+// Which build of the kernel a launch gets (measured on MI355X, tools/kbench.py / tools/dev/r3_cross.sh):
 //   one rollout per lane : latency build up to one wave per SIMD (1024 SIMDs x 64 lanes), throughput build above
-//   two rollouts per lane: mid-size build (loop constants in VGPRs, separate loop after a rare event) up to 4 packed
-//                          waves per SIMD = 524288 rollouts (round 3: up to 1572864), throughput build above.  64..2048 envs x 1024 x 50, mid-size
-//                          vs throughput build: 128 envs 76 vs 82 us, 256 envs 145 vs 162 us, 1024 envs 406 vs 400 us
+//   two rollouts per lane: mid-size build (phased horizon loop: quiet control steps and eventful ones in separate loops) up
+//                          to 1572864 rollouts - variant 3 (quiet step unrolled) while the launch has at most one wave
+//                          per SIMD, variant 2 above - and the throughput build beyond.  Phased mid-size vs throughput build,
+//                          envs x 1024 x 50: 256 envs 126 vs 133 us, 1024 envs 350 vs 355, 1536 envs 482 vs 495, 2048 envs
+//                          630 vs 636, 3072 envs 904 vs 890, 8192 envs 2.34 vs 2.29 ms
 #ifndef CPMPPI_MID_SIZE_MAX
-#define CPMPPI_MID_SIZE_MAX 1572864ull    // round 3 (one edge test per triple in the mid-size build): 768 envs x 1024 x 50 292 vs 301 us,
-                                          // 1024 envs 364 vs 371, 2048 envs 664 vs 663, 8192 envs 2.42 vs 2.35 ms (mid-size vs throughput)
+#define CPMPPI_MID_SIZE_MAX 1572864ull
 #endif
 constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
