@@ -142,48 +142,24 @@ __device__ __forceinline__ EnvConst make_env_const_uniform(const Params& p, floa
 // float / float2 helpers
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Two rollouts per lane WITHOUT packed instructions: the same two float chains as f2, but every operation is two
-// independent v_*_f32.  For a wave that has its SIMD to itself the instruction issue overhead, not the ALU, sets the
-// pace (tools/valu_peak.hip, 1 wave per SIMD: v_pk_fma_f32 4.04 ns dependent / 2.37 ns with four independent chains;
-// v_fma_f32 2.69 / 1.99 (two chains) / 0.96 ns (eight)): two plain FMAs of two independent rollouts cost less than one
-// packed FMA once the scheduler has a few independent chains to interleave.  Bit-identical results (same IEEE ops).
-struct u2 {
-  float x, y;
-};
-__device__ __forceinline__ u2 operator+(u2 a, u2 b) { return u2{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ u2 operator-(u2 a, u2 b) { return u2{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ u2 operator*(u2 a, u2 b) { return u2{a.x * b.x, a.y * b.y}; }
-__device__ __forceinline__ u2 operator/(u2 a, u2 b) { return u2{a.x / b.x, a.y / b.y}; }
-__device__ __forceinline__ u2 operator-(u2 a) { return u2{-a.x, -a.y}; }
-__device__ __forceinline__ u2& operator+=(u2& a, u2 b) { a.x += b.x; a.y += b.y; return a; }
-
-template <int R, bool UNPACKED = false> struct Lanes;
-template <bool U> struct Lanes<1, U> { using F = float; };
-template <> struct Lanes<2, false> { using F = f2; };
-template <> struct Lanes<2, true> { using F = u2; };
+template <int R> struct Lanes;
+template <> struct Lanes<1> { using F = float; };
+template <> struct Lanes<2> { using F = f2; };
 
 template <class F> struct Width;
 template <> struct Width<float> { static constexpr int value = 1; };
 template <> struct Width<f2> { static constexpr int value = 2; };
-template <> struct Width<u2> { static constexpr int value = 2; };
 
 __device__ __forceinline__ float get(float v, int) { return v; }
 __device__ __forceinline__ float get(f2 v, int i) { return i == 0 ? v.x : v.y; }
-__device__ __forceinline__ float get(u2 v, int i) { return i == 0 ? v.x : v.y; }
-__device__ __forceinline__ void put(u2& v, int i, float x) { if (i == 0) v.x = x; else v.y = x; }
 __device__ __forceinline__ void put(float& v, int, float x) { v = x; }
 __device__ __forceinline__ void put(f2& v, int i, float x) { if (i == 0) v.x = x; else v.y = x; }
 template <class F> __device__ __forceinline__ F splat(float x);
 template <> __device__ __forceinline__ float splat<float>(float x) { return x; }
 template <> __device__ __forceinline__ f2 splat<f2>(float x) { return f2{x, x}; }
-template <> __device__ __forceinline__ u2 splat<u2>(float x) { return u2{x, x}; }
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ u2 fma_(u2 a, u2 b, u2 c) { return u2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
-__device__ __forceinline__ u2 rcp_(u2 a) { return u2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
-__device__ __forceinline__ u2 rint_(u2 a) { return u2{__builtin_rintf(a.x), __builtin_rintf(a.y)}; }
-__device__ __forceinline__ u2 abs_(u2 a) { return u2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
 __device__ __forceinline__ float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
 #ifndef CPMPPI_RCP_SHARED
 #define CPMPPI_RCP_SHARED 0     // float2: one v_rcp_f32 (a quarter-rate instruction) for both lanes, 1/(ab) * (b, a)
@@ -202,10 +178,8 @@ __device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ f2 abs_(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
 __device__ __forceinline__ float clamp_(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
 __device__ __forceinline__ f2 clamp_(f2 a, float lo, float hi) { return f2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
-__device__ __forceinline__ u2 clamp_(u2 a, float lo, float hi) { return u2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
 __device__ __forceinline__ float cos_(float a) { return cosf(a); }
 __device__ __forceinline__ f2 cos_(f2 a) { return f2{cosf(a.x), cosf(a.y)}; }
-__device__ __forceinline__ u2 cos_(u2 a) { return u2{cosf(a.x), cosf(a.y)}; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // sincos on [-pi_f32, pi_f32] (the angle is wrapped every substep, so the argument never leaves this range).
@@ -361,13 +335,6 @@ __device__ __forceinline__ void plant_substep(State<float>& st, float aDD, float
 #endif
 #ifndef CPMPPI_T1_REUSE
 #define CPMPPI_T1_REUSE 1       // angleDD from the numerator's own bracket (-1 instruction per substep)
-#endif
-#ifndef CPMPPI_SAFE_STEP
-#define CPMPPI_SAFE_STEP 0      // packed mapping: control steps proved clear of the track edge run without the per-substep test.
-                                // OFF: measured on MI355X (tools/kbench.py, 8192 envs): the second copy of the substep loop costs
-                                // 10-12 VGPRs (122 -> 134: three waves per SIMD instead of four) and the launch gets 6 % SLOWER
-                                // (2.39 -> 2.55 ms) although each safe step issues 5 % fewer vector instructions; gating the test
-                                // inside one loop (== 2) makes the compiler if-convert the event code into the loop (137 instructions)
 #endif
 #ifndef CPMPPI_LATENCY_NEAR
 #define CPMPPI_LATENCY_NEAR 0   // one rollout per lane: the last substep tests the edge directly (no coarser "near" limit)
@@ -533,7 +500,7 @@ __device__ __forceinline__ void rotate_pair(F& c, F& s, F cd, F sd) {
 
 // One Euler substep, FAST, with the reference's per-substep wrap and sin/cos evaluation (the control step's LAST
 // substep of the rotating flavours, every substep of the plain one).
-// CHECK = false: the caller has PROVED that no lane can reach the track edge within this control step (SafeStep below).
+// CHECK = false: no edge test at all (callers that have excluded the event; none at present).
 // `nearlim` <= THL (wave-uniform): the ONE pair of compares of the common path tests |x| against it instead of THL, and
 // the return value says whether any lane of the wave ends the substep at or beyond it - the next stage's boundary cost
 // (nonzero only for |x| > permissible_track_fraction * THL = nearlim) is evaluated only then.  The edge itself is tested
@@ -689,8 +656,8 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
 // lanes has bounced: a rollout caught beyond the edge bounces on EVERY substep, and behind the branch each of those
 // costs ~500 cycles (exec-mask and SGPR shuffling around 45 instructions) against ~300 for the whole substep; inline
 // and scheduled with the rest it costs ~100.  Returns whether an event occurred (wave-uniform).
-// `check` (wave-uniform, CPMPPI_SAFE_STEP == 2): false = the caller has proved this control step clear of the track edge
-// (SafeStep): the two compares and everything behind them are skipped with one scalar branch.
+// `check` (wave-uniform): false = the two compares and everything behind them are skipped with one scalar branch (no caller
+// passes false at present: proving a control step clear of the edge beforehand was measured slower).
 template <class F, bool BOUNCY, bool MASK_ONLY = false>
 __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
                                                              F& cd, F& sd, F& xlim, bool check = true) {
@@ -749,51 +716,13 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
   return fired;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// "Safe" control steps (packed mapping).  The edge test of cartpole_equations.py:342 runs every substep, and with it two
-// compares, a mask merge and a branch per substep - 7 % of the substep's vector instructions - although a cart in the
-// middle of the track cannot reach the edge within 20 ms.  Once per control step a wave checks, for all of its lanes,
-//     |w| <= W0,   |v| <= V0,   |x| + dt |v| <= XS
-// with XS = nearlim - a_max dt^2 / 2 (minus slack), where a_max bounds |positionDD| for ANY state with |w| <= W0 + DW,
-// |v| <= V0 + DV, |u| <= u_max (cartpole_equations.py:76-87 term by term, |cos sin| <= 1/2, A >= (k+1)(m_c+m_p) - m_p) and
-// the bounds are checked to be self-consistent (dt * aDD_max <= DW, DV from the friction fixed point).  Then
-// |x| < nearlim <= THL at every substep of the control step: no bounce can occur (the S substeps run without the test,
-// bit-identical to the tested ones), no lane's |w t| leaves the rotation range (W0 + DW << ROT_LIMIT / t), and at the
-// next stage the boundary cost of quadratic_boundary_grad(_minimal) - nonzero only for |x| > fraction * THL = nearlim - is
-// exactly zero.  Anything else (near the edge, fast, not clipped) takes the tested path as before.
-struct SafeStep {
-  float W0, V0, XS, dt, nearlim;
-};
-constexpr float SAFE_W0 = 12.0f, SAFE_DW = 6.0f, SAFE_V0 = 0.6f;
-
-__device__ __forceinline__ SafeStep make_safe_step(const Params& p, const EnvConst& e, float near_fraction) {
-  SafeStep s;
-  const float dt = (float)p.S * p.t_step;
-  const float frac = __builtin_fminf(near_fraction, 1.0f);
-  s.nearlim = frac * p.THL;                                   // (a negative fraction: every state is "near", never safe)
-  const float Wm = SAFE_W0 + SAFE_DW;
-  const float A_min = e.kp1_mt - p.m_pole;
-  const float u_abs = e.kp1 * __builtin_fabsf(p.u_max) * __builtin_fmaxf(__builtin_fabsf(p.run_lo), __builtin_fabsf(p.run_hi));
-  const float a0 = (0.5f * e.mg + e.JinvLh * Wm + e.kmLh * Wm * Wm + u_abs) / A_min;
-  const float fr = e.kM / A_min;
-  const float den = 1.0f - dt * fr;
-  const float dV = dt * (a0 + fr * SAFE_V0) / den;
-  const float a_max = a0 + fr * (SAFE_V0 + dV);
-  const float aDD_max = e.g_i + e.inv_kLh * a_max + e.cT_i * Wm;
-  const float xs = s.nearlim - 1.1f * (0.5f * a_max * dt * dt) - 1.0e-4f * p.THL;
-  const bool ok = (A_min > 0.0f) && (den > 0.2f) && (dt * aDD_max <= SAFE_DW) && (Wm * p.t_step <= 0.5f * ROT_LIMIT) && (xs > 0.0f);
-  s.W0 = uniform_(SAFE_W0); s.V0 = uniform_(SAFE_V0); s.dt = uniform_(dt); s.nearlim = uniform_(s.nearlim);
-  s.XS = uniform_(ok ? xs : -1.0f);                           // (NaN / inf anywhere above: ok is false)
-  return s;
-}
-
 // One control step of S substeps under a held control (FAST).
-// Returns whether any lane of the wave ends the step with |x| >= ss->nearlim (wave-uniform; always true where it is
+// Returns whether any lane of the wave ends the step with |x| >= nearlim (wave-uniform; always true where it is
 // not tracked): the caller's next stage evaluates the boundary cost only then.
 template <class F, bool QUIET_UNROLL = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
-                                                  const EnvConst& e, float nearlim, const SafeStep* ss = nullptr,
-                                                  unsigned* sec = nullptr, bool* at_edge = nullptr) {
+                                                  const EnvConst& e, float nearlim, unsigned* sec = nullptr,
+                                                  bool* at_edge = nullptr) {
   // `at_edge` (out, wave-uniform; the phased mid-size build passes it): does a rollout of this wave END the control step
   // at or beyond the track edge, or spin beyond the rotation range?  It bounces on the very next substep - and, caught
   // beyond the edge, on every one after it (cartpole_equations.py:341-347 flips v whichever way it points) - so the caller
@@ -836,27 +765,6 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   // range are flagged and take the exact sincos on every substep.
 #if CPMPPI_INCR_ROT
   bool check = true;
-#if CPMPPI_SAFE_STEP
-  if (ss != nullptr) {
-    uint64_t unsafe = 0;                          // wave mask; 10 = unordered or greater (a NaN lane is not safe)
-#pragma unroll
-    for (int i = 0; i < Width<F>::value; ++i) {
-      unsafe |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.w, i)), ss->W0, 10);
-      unsafe |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.v, i)), ss->V0, 10);
-      unsafe |= __builtin_amdgcn_fcmpf(__builtin_fmaf(__builtin_fabsf(get(st.v, i)), ss->dt, __builtin_fabsf(get(st.x, i))), ss->XS, 10);
-    }
-    if (CPMPPI_SAFE_STEP == 2) {
-      check = unsafe != 0;
-    } else if (__builtin_expect(unsafe == 0, 1)) {
-      F cd, sd, unused = splat<F>(0.0f);
-      rot_pair<F>(st.w * splat<F>(t), cd, sd);
-      uint32_t left = S - 1u;
-      for (; left != 0u; --left) substep_fast_rot_carried<F, false, true>(st, uK, t, p, e, cd, sd, unused);
-      substep_fast<F, false>(st, uK, t, p, e, nearlim);
-      return false;
-    }
-  }
-#endif
   F xlim = splat<F>(p.THL);
   const float wlim = ROT_LIMIT / t;             // |w t| > ROT_LIMIT as one compare with a free abs modifier per lane
   uint64_t spinning = 0;      // wave mask of lanes beyond the rotation range: the same compare as the select's (one v_cmp)

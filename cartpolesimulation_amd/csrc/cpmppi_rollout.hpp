@@ -28,9 +28,6 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_DMA_TK_THROUGHPUT
 #define CPMPPI_DMA_TK_THROUGHPUT 16 // ... in the throughput build (one tile per wave)
 #endif
-#ifndef CPMPPI_MID_UNPACKED
-#define CPMPPI_MID_UNPACKED 0
-#endif
 #ifndef CPMPPI_NOMINAL_IN_LANES
 #define CPMPPI_NOMINAL_IN_LANES 3   // FAST, bit v = build VARIANT v: nominal sequence held in lanes, fetched with v_readlane_b32 (latency + throughput builds)
 #endif
@@ -236,9 +233,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // per SIMD the larger code costs 1.5-2.5 % instead, so those launches keep the loop)
   constexpr int VARIANT = (VARIANT_ == 3) ? 2 : VARIANT_;
   constexpr bool LONE_WAVE = VARIANT_ == 3;
-  // mid-size build (one to four waves per SIMD): two rollouts per lane as two PLAIN float chains (u2) instead of packed
-  // float2 when CPMPPI_MID_UNPACKED - a (nearly) lone wave is bound by instruction issue, not by the ALU
-  using F = typename Lanes<R, (VARIANT == 2 && CPMPPI_MID_UNPACKED != 0)>::F;
+  using F = typename Lanes<R>::F;
   static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");
   // wave-private tiles (direct-to-LDS loads): two of 8 control steps in the latency / mid-size builds (the next tile streams
   // in under the current one), ONE of 16 in the throughput build (same LDS; every 128-byte line of a 200-byte row is then
@@ -307,12 +302,6 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0;
   const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
   bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
-#if CPMPPI_SAFE_STEP
-  const SafeStep ss = make_safe_step(p, ec, TRACK_NEAR ? p.w[6] : 1.0f);
-  const SafeStep* ssp = (FAST && R == 2) ? &ss : nullptr;
-#else
-  const SafeStep* ssp = nullptr;
-#endif
 
   // Latency build: the nominal control (and the legacy cost's previous sequence) of step k + 1 is requested while step k
   // integrates - a scalar load consumed a few instructions after its issue is ~100 ns of exposed latency per control step
@@ -393,9 +382,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       bool near_next;
       if constexpr (PHASED) {
         if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
-        else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp, &at_edge);
+        else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, &at_edge);
       } else {
-        near_next = control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, ssp, secp);
+        near_next = control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp);
       }
       near = !TRACK_NEAR || near_next;
     } else {
