@@ -828,7 +828,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
 // A control step of a wave one of whose rollouts ENDED the previous step at or beyond the track edge (`at_edge`): the
 // event arithmetic inline on every intermediate substep, no test, no speculation (see control_step_fast).  Used by the
 // phased horizon loop (cpmppi_rollout.hpp), which keeps this code out of the loop the quiet control steps run in.
-template <class F>
+template <class F, bool UNROLL = false>
 __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                            const EnvConst& e, float nearlim, bool* at_edge) {
   F xlim = splat<F>(p.THL);
@@ -842,14 +842,19 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
   }
   F cd, sd;
   rot_pair<F>(st.w * splat<F>(t), cd, sd);
-  uint32_t left = S - 1u;
-  while (left >= 3u) {
-    substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-    substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-    substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
-    left -= 3u;
+  if (UNROLL && S == 10u) {                      // (launches of one wave per SIMD: no taken branch between the substeps)
+#pragma unroll
+    for (int sub = 0; sub < 9; ++sub) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+  } else {
+    uint32_t left = S - 1u;
+    while (left >= 3u) {
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
+      left -= 3u;
+    }
+    for (; left != 0u; --left) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
   }
-  for (; left != 0u; --left) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
   const bool near_end = substep_fast<F, true, true, (CPMPPI_EVENTFUL_LAST_INLINE != 0)>(st, uK, t, p, e, nearlim, true, at_edge);
   *at_edge = *at_edge || spinning != 0;          // (stays in this loop while the pole keeps spinning)
   return near_end;

@@ -31,6 +31,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_NOMINAL_IN_LANES
 #define CPMPPI_NOMINAL_IN_LANES 3   // FAST, bit v = build VARIANT v: nominal sequence held in lanes, fetched with v_readlane_b32 (latency + throughput builds)
 #endif
+#ifndef CPMPPI_EVENTFUL_UNROLL
+#define CPMPPI_EVENTFUL_UNROLL 1
+#endif
 #ifndef CPMPPI_WAVE_PRIORITY
 #define CPMPPI_WAVE_PRIORITY 1
 #endif
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       if (secp) { asm volatile("" : "+v"(uK), "+v"(cost), "+v"(corr)); CPMPPI_SEC(secp, 1, st); }
       bool near_next;
       if constexpr (PHASED) {
-        if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
+        if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F, (LONE_WAVE && CPMPPI_EVENTFUL_UNROLL != 0)>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
         else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, &at_edge);
       } else {
         near_next = control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp);

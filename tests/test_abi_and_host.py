@@ -202,10 +202,14 @@ def test_rollout_kernels_have_no_scratch_and_no_vgpr_spills():
     # 4 costs x 4 noise sources x (latency R1, throughput R1 fast + precise, throughput R2, mid R2, mid R2 for launches of one
     # wave per SIMD)
     assert len(hot) == 4 * 4 * 6, len(hot)
-    # the mid-size builds must keep three waves per SIMD (512 registers / 168)
+    # the mid-size build must keep three waves per SIMD (512 registers / 168); its variant for launches of at most one wave
+    # per SIMD (straight-line control steps) two, so that a guest kernel - the overlapped all-gather - still fits beside it
     for k in hot:
-        if k["name"].split("EEEv")[0].endswith(("ELi2ELi2", "ELi2ELi3")):
+        tail = k["name"].split("EEEv")[0]
+        if tail.endswith("ELi2ELi2"):
             assert k["vgpr_count"] + k["agpr_count"] <= 168, (k["name"], k["vgpr_count"])
+        if tail.endswith("ELi2ELi3"):
+            assert k["vgpr_count"] + k["agpr_count"] <= 256, (k["name"], k["vgpr_count"])
     bad = [(k["name"], k["private_segment_fixed_size"], k["vgpr_spill_count"]) for k in ks
            if k["private_segment_fixed_size"] != 0 or k["vgpr_spill_count"] != 0]
     assert not bad, bad
