@@ -620,7 +620,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         else put(du, i, interp_from_slope(slope[i], z_lo[i], ii));
       }
       control_step(k, du, eventful);
-      if (++ii == p.period) {
+      // (the branch weight is a LAYOUT hint: the nine of ten control steps that need no new knot fall through - 1024 envs
+      // -2.9 %, 256 envs -2.4 %, C3 -1.5 %; FAST only: in one PRECISE kernel the other layout left a scratch slot)
+      if (FAST ? __builtin_expect(++ii == p.period, 0) : (++ii == p.period)) {
         ii = 0; ++j;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
