@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-3 evidence run after the last kernel changes (GPU box): tests, bench lines, collective, profiles, parity statistics -> gpurun_out/r3final7/
+# round-3 evidence run after the last kernel changes (GPU box): tests, bench lines, collective, profiles, parity statistics -> gpurun_out/r3final8/
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r3final7
+O=$R/gpurun_out/r3final8
 mkdir -p $O
 cd $R
 V=build_variants
