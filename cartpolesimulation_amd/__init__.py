@@ -20,8 +20,8 @@ def __getattr__(name):
     # torch-dependent layers are imported lazily so that `import cartpolesimulation_amd` stays cheap
     import importlib
     lazy = {"MPPIEngine": "engine", "optimizer_mppi": "optimizer_mppi", "controller_mpc": "controller_mpc",
-            "PredictorWrapper": "predictors", "predictor_ODE_v0": "predictors",
-            "next_state_predictor_ODE_v0": "predictors", "CostFunctionWrapper": "cost_functions"}
+            "PredictorWrapper": "predictors", "predictor_ODE_v0": "predictors", "predictor_ODE": "predictors",
+            "next_state_predictor_ODE_v0": "predictors", "next_state_predictor_ODE": "predictors", "CostFunctionWrapper": "cost_functions"}
     if name in lazy:
         return getattr(importlib.import_module(f".{lazy[name]}", __name__), name)
     raise AttributeError(name)

@@ -5,13 +5,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPMPPI_LIB") or os.path.join(_HERE, "libcpmppi.so")   # CPMPPI_LIB: development builds (tools/)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG = 0, 1, 2, 3
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 CONTROL_CLIP, CONTROL_PENALISE = 0, 1
 SHIFT_REPEAT_LAST, SHIFT_APPEND_ZERO, SHIFT_NONE = 0, 1, 2
 CORRECTION_U_RUN, CORRECTION_U_NOM = 0, 1
 MATH_PRECISE, MATH_FAST = 0, 1
+ODE_V0, ODE_CROMER = 0, 1
 NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX, NOISE_DELTA_U_TILED = 0, 1, 2, 3
 
 EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
@@ -35,7 +36,8 @@ class cpmppi_config(C.Structure):
                 ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("cc_weight", C.c_float),
                 ("sigma", C.c_float), ("period", C.c_uint32), ("action_low", C.c_float), ("action_high", C.c_float),
                 ("horizon_reduce", C.c_uint32), ("control_mode", C.c_uint32), ("shift_mode", C.c_uint32),
-                ("correction_u", C.c_uint32), ("math_mode", C.c_uint32), ("rollouts_per_lane", C.c_uint32)]
+                ("correction_u", C.c_uint32), ("math_mode", C.c_uint32), ("rollouts_per_lane", C.c_uint32),
+                ("ode_predictor", C.c_uint32)]
 
 
 class cpmppi_step_args(C.Structure):

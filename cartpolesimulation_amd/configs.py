@@ -90,6 +90,7 @@ class MPPIConfig:
     correction_u: str = "u_run"          # "u_run" | "u_nom"
     math_mode: str = "fast"              # "fast" | "precise"
     rollouts_per_lane: int = 0           # 0 auto | 1 (latency mapping) | 2 (packed float2 throughput mapping)
+    predictor_type: str = "ODE_v0"       # "ODE_v0" | "ODE" (SI_Toolkit_ASF/config_predictors.yml:18-26; "ODE" = Euler-Cromer, no bounce)
     action_low: float = -1.0
     action_high: float = 1.0
 
@@ -109,6 +110,7 @@ _ENUMS = {
     "correction_u": {"u_run": L.CORRECTION_U_RUN, "u_nom": L.CORRECTION_U_NOM},
     "math_mode": {"precise": L.MATH_PRECISE, "fast": L.MATH_FAST},
 }
+ODE_PREDICTORS = {"ODE_v0": L.ODE_V0, "ODE": L.ODE_CROMER}
 
 
 def cost_vector(name, overrides=None):
@@ -154,6 +156,9 @@ def build_c_config(E, mppi: MPPIConfig, phys: PhysicalParameters = None):
             raise ValueError(f"{key}={val!r}; expected one of {sorted(table)}")
         setattr(c, key, table[val])
     c.rollouts_per_lane = int(mppi.rollouts_per_lane)
+    if mppi.predictor_type not in ODE_PREDICTORS:
+        raise ValueError(f"predictor_type={mppi.predictor_type!r}; expected one of {sorted(ODE_PREDICTORS)}")
+    c.ode_predictor = ODE_PREDICTORS[mppi.predictor_type]
     return c
 
 
@@ -188,6 +193,12 @@ def mppi_config_from_yaml(cfgs, **overrides):
               period_interpolation_inducing_points=opt["period_interpolation_inducing_points"],
               intermediate_steps=cfgs["predictors"]["predictors"]["ODE_v0_default"]["intermediate_steps"],
               cost_function_specification=name, cost_weights=weights)
+    # config_controllers.yml:3 predictor_specification: a predictor_type, or the name of an entry of config_predictors.yml
+    spec = str(ctrl.get("predictor_specification") or "ODE_v0").split(":")[0]
+    ptype = cfgs["predictors"]["predictors"].get(spec, {}).get("predictor_type", spec)
+    if ptype in ODE_PREDICTORS:                      # (a neural / GP specification is the caller's to resolve: gru_model=...)
+        kw["predictor_type"] = ptype
+        kw["intermediate_steps"] = cfgs["predictors"]["predictors"].get(f"{ptype}_default", {}).get("intermediate_steps", kw["intermediate_steps"])
     kw.update(overrides)
     return MPPIConfig(**kw)
 

@@ -96,6 +96,8 @@ class controller_mpc(template_controller):
                                              cost_function_specification=cost_name,
                                              weights=cfg.get("cost_weights"), phys=self.phys, device=self.device)
         spec = predictor_specification or cfg.pop("predictor_specification", None)
+        if spec is None and cfg.get("predictor_type") == "ODE":      # (a checkout's config_controllers.yml:3 read by config_root)
+            spec = "ODE"
         neural = spec is not None and str(spec).startswith("GRU-6IN-32H1-32H2-5OUT")
         if cfg.get("gru_model") is not None and spec is not None and not neural:
             raise ValueError(f"gru_model was given but predictor_specification={spec!r} selects the ODE predictor")

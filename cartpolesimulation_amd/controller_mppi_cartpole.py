@@ -55,10 +55,13 @@ class controller_mppi_cartpole(template_controller):
         if cfg["SAMPLING_TYPE"] not in SAMPLING_TYPES:
             raise ValueError(f"SAMPLING_TYPE must be one of {SAMPLING_TYPES}")
         spec = cfg["predictor_specification"]
-        if spec not in ("ODE_v0", "ODE_v0_default"):
-            # the shipped YAML says "ODE": that is next_state_predictor_ODE (Euler-Cromer, no bounce), a different integrator
-            raise NotImplementedError(f"predictor_specification {spec!r}: this controller is built on the ODE_v0 kernel "
-                                      "(set predictor_specification: 'ODE_v0')")
+        if spec in ("ODE", "ODE_default"):
+            # the shipped YAML (config_controllers.yml:14) says "ODE": next_state_predictor_ODE (Euler-Cromer, no bounce)
+            self.predictor_type = "ODE"
+        elif spec in ("ODE_v0", "ODE_v0_default"):
+            self.predictor_type = "ODE_v0"
+        else:
+            raise NotImplementedError(f"predictor_specification {spec!r}: this controller runs on the ODE_v0 and ODE kernels")
         self.config = cfg
         self.dt, self.p_Q = float(dt), float(actuator_noise)
         self.phys = phys or PhysicalParameters()
@@ -96,7 +99,7 @@ class controller_mppi_cartpole(template_controller):
         mcfg = legacy_mppi_config(num_rollouts=self.num_rollouts, mpc_horizon=self.mpc_horizon, mpc_timestep=self.dt,
                                   R=cfg["R"], LBD=cfg["LBD"], NU=cfg["NU"], SQRTRHOINV=cfg["SQRTRHOINV"],
                                   shift_mode="none",           # the shift is this class's own last step, as in the reference
-                                  math_mode=self.math_mode,
+                                  math_mode=self.math_mode, predictor_type=self.predictor_type,
                                   cost_weights=dict(dd_weight=w["dd_weight"], ep_weight=w["ep_weight"], ekp_weight=w["ekp_weight"],
                                                     ekc_weight=w["ekc_weight"], cc_weight=w["cc_weight"], ccrc_weight=w["ccrc_weight"]))
         old_u = getattr(self, "_u", None)

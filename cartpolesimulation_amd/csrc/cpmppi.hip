@@ -41,6 +41,8 @@ CPMPPI_LATENCY_BUFFER_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_MID_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_MID_BUFFER_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
+CPMPPI_ODE_LATENCY_INSTANCES(CPMPPI_DECLARE_ROLLOUT_ODE)
+CPMPPI_ODE_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT_ODE)
 }  // namespace cpmppi_k
 
 namespace {
@@ -102,7 +104,19 @@ constexpr int PRED_KS = 8;
 constexpr int PRED_ROW = PRED_KS * 6 + 1;
 // STAGED = false: every lane stores its own states directly — the shorter path for launches that do not fill the chip
 // (1024 rollouts: 59 us against 82 us staged; 262144 rollouts: 416 us against 280 us staged).
-template <bool FAST, bool STAGED>
+// INTEG: the in-tree ODE predictor (cpmppi_device.hpp: PREDICTOR_ODE_V0 | PREDICTOR_ODE).
+template <bool FAST, bool STAGED, int INTEG = PREDICTOR_ODE_V0>
+__device__ __forceinline__ void predict_control_step(State<float>& st, float Qk, const Params& p, const EnvConst& ec) {
+  if constexpr (INTEG == PREDICTOR_ODE) {
+    if constexpr (FAST) control_step_cromer_fast<float>(st, ec.uK_scale * Qk, p.S, p.t_step, p, ec);
+    else for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise_cromer(st, p.u_max * Qk, p.t_step, p, ec);
+  } else {
+    if constexpr (FAST) control_step_fast<float>(st, ec.uK_scale * Qk, p.S, p.t_step, p, ec, p.THL);
+    else for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, p.u_max * Qk, p.t_step, p, ec);
+  }
+}
+
+template <bool FAST, bool STAGED, int INTEG = PREDICTOR_ODE_V0>
 __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t B, uint32_t H,
                                                         const float* __restrict__ s0, const float* __restrict__ Q,
                                                         const float* __restrict__ Lp, float* __restrict__ traj) {
@@ -115,12 +129,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
     float* o = traj + b * (size_t)(H + 1) * 6;
     o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
     for (uint32_t k = 0; k < H; ++k) {
-      const float u = p.u_max * Q[b * H + k];
-      if constexpr (FAST) {
-        control_step_fast<float>(st, ec.uK_scale * Q[b * H + k], p.S, p.t_step, p, ec, p.THL);
-      } else {
-        for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
-      }
+      predict_control_step<FAST, STAGED, INTEG>(st, Q[b * H + k], p, ec);
       o += 6;
       o[0] = st.th; o[1] = st.w; o[2] = st.c; o[3] = st.s; o[4] = st.x; o[5] = st.v;
     }
@@ -143,12 +152,7 @@ __global__ __launch_bounds__(BLOCK) void predict_kernel(const Params p, uint32_t
   for (uint32_t k0 = 0; k0 < H; k0 += PRED_KS) {
     const uint32_t kn = (H - k0 < (uint32_t)PRED_KS) ? H - k0 : (uint32_t)PRED_KS;
     for (uint32_t kk = 0; kk < kn; ++kk) {
-      const float u = p.u_max * Q[b * H + k0 + kk];
-      if constexpr (FAST) {
-        control_step_fast<float>(st, ec.uK_scale * Q[b * H + k0 + kk], p.S, p.t_step, p, ec, p.THL);
-      } else {
-        for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise(st, u, p.t_step, p, ec);
-      }
+      predict_control_step<FAST, STAGED, INTEG>(st, Q[b * H + k0 + kk], p, ec);
       float* m = mine + kk * 6;
       m[0] = st.th; m[1] = st.w; m[2] = st.c; m[3] = st.s; m[4] = st.x; m[5] = st.v;
     }
@@ -902,18 +906,18 @@ struct DeviceGuard {
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
-template <int COST, bool FAST, int R, int V>
+template <int COST, bool FAST, int R, int V, int INTEG = PREDICTOR_ODE_V0>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                 const StepPtrs& a) {
   switch (noise) {
     case CPMPPI_NOISE_DELTA_U:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_DELTA_U, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_KNOTS:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_DELTA_U_TILED:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_TILED, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_TILED, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
     default:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V>), grid, dim3(BLOCK), lds, s, p, a); break;
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
   }
   return hipGetLastError();
 }
@@ -931,8 +935,16 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
 template <int COST>
-hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
+hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                                const Params& p, const StepPtrs& a) {
+  if (ode == CPMPPI_ODE_CROMER) {
+    // predictor_ODE has no events, hence no mid-size (phased) build: latency build up to one wave per SIMD with one rollout
+    // per lane, the throughput build otherwise
+    if (math != CPMPPI_MATH_FAST) return launch_rollout_noise<COST, false, 1, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
+    if (rpl == 2) return launch_rollout_noise<COST, true, 2, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
+    return ((uint64_t)grid.x * BLOCK <= 65536ull) ? launch_rollout_noise<COST, true, 1, 0, PREDICTOR_ODE>(noise, grid, lds, s, p, a)
+                                                  : launch_rollout_noise<COST, true, 1, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
+  }
   if (math == CPMPPI_MATH_FAST) {
     if (rpl == 2) {
       const bool mid = (uint64_t)grid.x * BLOCK * 2 <= MID_SIZE_MAX_ROLLOUTS;
@@ -952,10 +964,10 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t rpl, uint32_t noise, dim3
 hipError_t launch_rollout(const cpmppi_handle* h, const Params& prm, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds,
                           hipStream_t s, const StepPtrs& a) {
   switch (prm.cost_id) {
-    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
-    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
-    case CPMPPI_COST_QBG: return launch_rollout_math<COST_QBG>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
-    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, rpl, noise, grid, lds, s, prm, a);
+    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
+    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
+    case CPMPPI_COST_QBG: return launch_rollout_math<COST_QBG>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
+    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
   }
 }
 
@@ -977,7 +989,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   if (!(cfg->dt > 0.0f) || !(cfg->LBD > 0.0f) || !(cfg->NU > 0.0f) || !(cfg->L_default > 0.0f))
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: dt, LBD, NU, L_default must be > 0");
   if (cfg->cost_id > CPMPPI_COST_QBG || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
-      cfg->correction_u > 1 || cfg->math_mode > 1 || cfg->rollouts_per_lane > 2)
+      cfg->correction_u > 1 || cfg->math_mode > 1 || cfg->rollouts_per_lane > 2 || cfg->ode_predictor > CPMPPI_ODE_CROMER)
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: unknown enum value");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
@@ -1143,13 +1155,17 @@ int cpmppi_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* 
   // shorter path wins: measured 59 vs 82 us at 1024 rollouts, 416 vs 280 us at 262144)
   const bool staged = (uint64_t)B > 65536ull;
   const hipStream_t st = (hipStream_t)stream;
-  if (h->cfg.math_mode == CPMPPI_MATH_FAST) {
-    if (staged) hipLaunchKernelGGL((predict_kernel<true, true>), grid, dim3(BLOCK), 0, st, h->prm, B, horizon, s0, Q, L, traj_out);
-    else hipLaunchKernelGGL((predict_kernel<true, false>), grid, dim3(BLOCK), 0, st, h->prm, B, horizon, s0, Q, L, traj_out);
+#define CPMPPI_PREDICT_LAUNCH(FAST, STAGED, INTEG) \
+  hipLaunchKernelGGL((predict_kernel<FAST, STAGED, INTEG>), grid, dim3(BLOCK), 0, st, h->prm, B, horizon, s0, Q, L, traj_out)
+  const bool fast = h->cfg.math_mode == CPMPPI_MATH_FAST;
+  if (h->cfg.ode_predictor == CPMPPI_ODE_CROMER) {
+    if (fast) { if (staged) CPMPPI_PREDICT_LAUNCH(true, true, PREDICTOR_ODE); else CPMPPI_PREDICT_LAUNCH(true, false, PREDICTOR_ODE); }
+    else { if (staged) CPMPPI_PREDICT_LAUNCH(false, true, PREDICTOR_ODE); else CPMPPI_PREDICT_LAUNCH(false, false, PREDICTOR_ODE); }
   } else {
-    if (staged) hipLaunchKernelGGL((predict_kernel<false, true>), grid, dim3(BLOCK), 0, st, h->prm, B, horizon, s0, Q, L, traj_out);
-    else hipLaunchKernelGGL((predict_kernel<false, false>), grid, dim3(BLOCK), 0, st, h->prm, B, horizon, s0, Q, L, traj_out);
+    if (fast) { if (staged) CPMPPI_PREDICT_LAUNCH(true, true, PREDICTOR_ODE_V0); else CPMPPI_PREDICT_LAUNCH(true, false, PREDICTOR_ODE_V0); }
+    else { if (staged) CPMPPI_PREDICT_LAUNCH(false, true, PREDICTOR_ODE_V0); else CPMPPI_PREDICT_LAUNCH(false, false, PREDICTOR_ODE_V0); }
   }
+#undef CPMPPI_PREDICT_LAUNCH
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
@@ -1611,6 +1627,8 @@ int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, cons
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: bad argument");
   if (h->prm.cost_id == CPMPPI_COST_LEGACY)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: plugin costs only");
+  if (h->cfg.ode_predictor != CPMPPI_ODE_V0)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for predictor_ODE_v0 (cpmppi_config.ode_predictor = CPMPPI_ODE_V0)");
   if (h->cfg.math_mode != CPMPPI_MATH_FAST)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for the FAST arithmetic");
   const size_t lds = (size_t)h->cfg.S * 6 * BLOCK * sizeof(float);

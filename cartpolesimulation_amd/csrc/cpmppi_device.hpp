@@ -861,6 +861,105 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The OTHER in-tree ODE predictor: predictor_type "ODE" (SI_Toolkit_ASF/config_predictors.yml:22-26 - what the shipped
+// config_controllers.yml:3,14 name as the mpc controllers' predictor_specification).  next_state_predictor_ODE
+// (SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:25-69) -> CartPoleEquations.cartpole_fine_integration
+// (CartPole/cartpole_equations.py:181-259): per substep the same _cartpole_ode (:232), then EULER-CROMER (:293-304:
+// velocities first, angle and position advance by the NEW velocities), NO edge bounce (:241-243 is commented out in the
+// reference), cos / sin of the integrated angle (:245-246) and angle = atan2(sin, cos) (:248, 307-308).
+enum : int { PREDICTOR_ODE_V0 = 0, PREDICTOR_ODE = 1 };
+
+// PRECISE: the reference's operand grouping with IEEE divides, libm cos / sin / atan2, no FMA contraction.
+__device__ __forceinline__ void substep_precise_cromer(State<float>& st, float u, float t, const Params& p,
+                                                       const EnvConst& e) {
+#pragma clang fp contract(off)
+  float aDD, xDD;
+  ode_precise(st.c, st.s, st.w, st.v, u, p, e, aDD, xDD);
+  const float w1 = st.w + aDD * t;
+  const float v1 = st.v + xDD * t;
+  const float th1 = st.th + w1 * t;
+  const float x1 = st.x + v1 * t;
+  const float c1 = cosf(th1), s1 = sinf(th1);
+  st.th = atan2f(s1, c1);
+  st.w = w1; st.c = c1; st.s = s1; st.x = x1; st.v = v1;
+}
+
+// FAST: _cartpole_ode with the folded constants of ode_euler_fast (same formulas, same instruction sequence) followed by
+// the Euler-Cromer update.  Outputs the un-wrapped new state and angleDD.
+template <class F>
+__device__ __forceinline__ void ode_cromer_fast(const State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
+                                                F& th1, F& w1, F& x1, F& v1, F& aDD) {
+  const F c = st.c, s = st.s, w = st.w, v = st.v;
+  const F A = fma_(-(c * splat<F>(p.m_pole)), c, splat<F>(e.kp1_mt));
+  const F t1 = fma_(splat<F>(e.mg), s, -(w * splat<F>(e.JinvLh)));
+  F num = fma_(c, t1, uK);
+  num = fma_(-((w * w) * splat<F>(e.kmLh)), s, num);
+  num = fma_(splat<F>(-e.kM), v, num);
+  const F xDD = num * rcp_(A);
+  aDD = fma_(xDD * c, splat<F>(e.inv_kLh), t1 * splat<F>(e.t1_i));
+  const F tt = splat<F>(t);
+  w1 = fma_(aDD, tt, w);
+  v1 = fma_(xDD, tt, v);
+  th1 = fma_(w1, tt, st.th);
+  x1 = fma_(v1, tt, st.x);
+}
+
+// One control step of S Euler-Cromer substeps under a held control (FAST).  As in control_step_fast the angle is left
+// un-wrapped inside the control step and (cos, sin) advance by ROTATION: a substep moves the angle by d' = w' t with the
+// NEW angular velocity w' = w + angleDD t, i.e. by the previous substep's rotation angle plus eps = angleDD t^2, so the
+// carried pair (cos d, sin d) - seeded from the degree-7/6 polynomials of d = w t once per control step - is advanced by
+// eps FIRST and (cos, sin) are then rotated by it (substep_fast_rot_carried rotates first: simultaneous Euler moves the
+// angle by the OLD velocity).  The control step's last substep re-synchronises with the exact wrap + polynomial sincos;
+// theta - 2 pi rint(theta / 2 pi) is the value atan2(sin, cos) returns up to rounding (both in [-pi, pi]).  No edge
+// test anywhere: this predictor does not bounce.  A lane whose |w t| is beyond the rotation polynomials' range at the start
+// of the control step (|w| > 125 rad/s at t = 2 ms) takes the exact wrap + sincos on every substep - per lane, so a rollout's
+// arithmetic does not depend on its wave partners; the branch is wave-uniform and practically never taken.
+template <class F, bool UNROLL = false>
+__device__ __forceinline__ void control_step_cromer_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
+                                                         const EnvConst& e) {
+  constexpr int W = Width<F>::value;
+  const float wlim = ROT_LIMIT / t;
+  bool beyond[W];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < W; ++i) { beyond[i] = __builtin_fabsf(get(st.w, i)) > wlim; any |= beyond[i]; }
+  const bool any_beyond = __builtin_amdgcn_ballot_w64(any) != 0;
+  F cd, sd;
+  rot_pair<F>(st.w * splat<F>(t), cd, sd);
+  const F tt2 = splat<F>(t * t);
+  auto substep = [&]() __attribute__((always_inline)) {
+    F th1, w1, x1, v1, aDD;
+    ode_cromer_fast<F>(st, uK, t, p, e, th1, w1, x1, v1, aDD);
+    const F eps = aDD * tt2;
+    const F cd1 = fma_(-eps, fma_(eps, splat<F>(0.5f), sd), cd);     // cd - eps sd - eps^2/2
+    const F sd1 = fma_(cd, eps, sd);                                  // sd + eps cd
+    F c1 = fma_(st.c, cd1, -(st.s * sd1));
+    F s1 = fma_(st.s, cd1, st.c * sd1);
+    if (__builtin_expect(any_beyond, 0)) {
+      const F thw = wrap_rint<F>(th1);
+      F se, ce;
+      sincos_pi_half<F>(thw, se, ce);
+#pragma unroll
+      for (int i = 0; i < W; ++i)
+        if (beyond[i]) { put(th1, i, get(thw, i)); put(c1, i, get(ce, i)); put(s1, i, get(se, i)); }
+    }
+    cd = cd1; sd = sd1;
+    st.th = th1; st.w = w1; st.x = x1; st.v = v1; st.c = c1; st.s = s1;
+  };
+  if (UNROLL && S == 10u) {                     // (a lone wave pays ~50 cycles per taken branch: control_step_fast)
+#pragma unroll
+    for (int sub = 0; sub < 9; ++sub) substep();
+  } else {
+    for (uint32_t sub = 0; sub + 1 < S; ++sub) substep();
+  }
+  F th1, w1, x1, v1, aDD;
+  ode_cromer_fast<F>(st, uK, t, p, e, th1, w1, x1, v1, aDD);
+  th1 = wrap_rint<F>(th1);
+  st.th = th1; st.w = w1; st.x = x1; st.v = v1;
+  sincos_pi_half<F>(th1, st.s, st.c);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Stage / terminal costs (generic over float / float2).  `x_t` target position, `te` target equilibrium, `u` the
 // control applied at this stage.
 // quadratic_boundary_grad_minimal.py:64-126; w = {dd, db, ep, ekp, cc, R, permissible_track_fraction}

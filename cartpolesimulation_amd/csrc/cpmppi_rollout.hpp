@@ -229,8 +229,12 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
 // VARIANT selects the translation unit (hence the scheduling strategy) an instantiation is compiled in:
 // 0 = latency build (one rollout per lane, launches of at most one wave per SIMD), 1 = throughput build, 2 = packed
 // mapping for mid-sized launches (same code except where the loop constants live, see below).
-template <int COST, bool FAST, int NOISE, int R, int VARIANT_>
+// INTEG selects the in-tree ODE predictor the rollouts are integrated with: PREDICTOR_ODE_V0 (predictor_ODE_v0: simultaneous
+// Euler, edge bounce, fmod wrap - the north-star path) or PREDICTOR_ODE (predictor_ODE: Euler-Cromer, no bounce, atan2 wrap;
+// cpmppi_device.hpp).  The second has no events, hence no phased loop: it is built in the latency and throughput forms only.
+template <int COST, bool FAST, int NOISE, int R, int VARIANT_, int INTEG = PREDICTOR_ODE_V0>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
+  static_assert(INTEG == PREDICTOR_ODE_V0 || VARIANT_ <= 1, "predictor_ODE: latency / throughput builds only");
   // VARIANT_ 3 = the mid-size build for launches of at most ONE wave per SIMD: VARIANT 2 with the quiet control step's nine
   // substeps as straight-line code (a lone wave pays ~50 cycles per taken branch: C4 80.1 -> 77.4 us; with two or more waves
   // per SIMD the larger code costs 1.5-2.5 % instead, so those launches keep the loop)
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const QbgmFolded qf = make_qbgm_folded(p, te);
   // (not in the latency build: there the flag's compare -> scalar branch hand-over sits on the lone wave's critical path
   // once per control step - measured 56 -> 66 us for a single env - while the eight instructions it saves are hidden)
-  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0;
+  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0 && INTEG == PREDICTOR_ODE_V0;
   const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
   bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
 
@@ -379,7 +383,13 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       cost += stage_legacy<F, FAST>(p, st.x, cosang, st.w, st.v, uk, du, upk, x_t);
     }
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
-    if constexpr (FAST) {
+    if constexpr (INTEG == PREDICTOR_ODE) {
+      if constexpr (FAST) {
+        control_step_cromer_fast<F, (VARIANT == 0)>(st, ur * splat<F>(ec.uK_scale), p.S, p.t_step, p, ec);
+      } else {
+        for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise_cromer(st, u, p.t_step, p, ec);
+      }
+    } else if constexpr (FAST) {
       F uK = ur * splat<F>(ec.uK_scale);         // (k+1) u_max Q: the form in which the control enters positionDD's numerator
       if (secp) { asm volatile("" : "+v"(uK), "+v"(cost), "+v"(corr)); CPMPPI_SEC(secp, 1, st); }
       bool near_next;
@@ -842,6 +852,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   CPMPPI_FOR_COSTS(X, true, NOISE_DELTA_U, 2, 3) CPMPPI_FOR_COSTS(X, true, NOISE_TILED, 2, 3)
 #define CPMPPI_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
+// predictor_ODE (INTEG = PREDICTOR_ODE): latency build (one rollout per lane) and throughput build (both lane mappings, PRECISE)
+#define CPMPPI_ODE_LATENCY_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 1, 0)
+#define CPMPPI_ODE_THROUGHPUT_INSTANCES(X) \
+  CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
+#define CPMPPI_DEFINE_ROLLOUT_ODE(COST, FAST, NOISE, R, V) \
+  template __global__ void rollout_cost_kernel<COST, FAST, NOISE, R, V, PREDICTOR_ODE>(const Params, const StepPtrs);
+#define CPMPPI_DECLARE_ROLLOUT_ODE(COST, FAST, NOISE, R, V) \
+  extern template __global__ void rollout_cost_kernel<COST, FAST, NOISE, R, V, PREDICTOR_ODE>(const Params, const StepPtrs);
 #define CPMPPI_DEFINE_ROLLOUT(COST, FAST, NOISE, R, V) \
   template __global__ void rollout_cost_kernel<COST, FAST, NOISE, R, V>(const Params, const StepPtrs);
 #define CPMPPI_DECLARE_ROLLOUT(COST, FAST, NOISE, R, V) \

@@ -59,8 +59,13 @@ class optimizer_cem:
             self.cfg.mpc_timestep = float(dt)
         if num_envs is not None:
             self.num_envs = int(num_envs)
-        if predictor_specification not in (None, "ODE_v0", "ODE_v0_default"):     # "ODE" is a different integrator
-            raise NotImplementedError("only the ODE_v0 predictor is built into the fused kernel on this tier")
+        spec = None if predictor_specification is None else str(predictor_specification).split(":")[0]
+        if spec in ("ODE", "ODE_default"):        # next_state_predictor_ODE: Euler-Cromer, no bounce (config_controllers.yml:3)
+            if type(self)._refine is not optimizer_cem._refine:
+                raise NotImplementedError(f"{self.optimizer_name}: the adjoint kernel differentiates the ODE_v0 predictor only")
+            self.cfg.predictor_type = "ODE"
+        elif spec not in (None, "ODE_v0", "ODE_v0_default"):
+            raise NotImplementedError("the sampling optimizers run on the ODE_v0 and ODE predictors")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         self.optimizer_reset()
 

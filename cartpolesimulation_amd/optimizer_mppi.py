@@ -35,7 +35,7 @@ class optimizer_mppi:
                  mpc_timestep=0.02, num_envs=1, noise="philox", cost_function_specification=None, cost_weights=None,
                  horizon_reduce="sum", control_mode="clip", shift_mode="repeat_last", correction_u="u_run",
                  math_mode="fast", intermediate_steps=10, phys=None, device=0, variable_parameters=None, gru_model=None,
-                 SAMPLING_TYPE="interpolated", **kwargs):
+                 SAMPLING_TYPE="interpolated", predictor_type="ODE_v0", **kwargs):
         self.predictor, self.cost_function = predictor, cost_function
         low, high = (-1.0, 1.0) if control_limits is None else (float(np.asarray(control_limits[0]).reshape(-1)[0]),
                                                                   float(np.asarray(control_limits[1]).reshape(-1)[0]))
@@ -72,7 +72,7 @@ class optimizer_mppi:
                               "quadratic_boundary_grad_minimal",
                               cost_weights=dict(cost_weights or {}), horizon_reduce=horizon_reduce,
                               control_mode=control_mode, shift_mode=shift_mode, correction_u=correction_u,
-                              math_mode=math_mode, action_low=low, action_high=high)
+                              math_mode=math_mode, action_low=low, action_high=high, predictor_type=predictor_type)
         self.phys = phys or PhysicalParameters()
         self.device = device
         self.num_rollouts, self.mpc_horizon = self.cfg.num_rollouts, self.cfg.mpc_horizon
@@ -103,13 +103,16 @@ class optimizer_mppi:
         if neural and self.gru_model is None:
             raise ValueError("a GRU predictor_specification needs gru_model=dict(weights) or a model folder path "
                              "(no GRU model files ship in-tree)")
-        if predictor_specification in ("ODE", "ODE_default"):
-            # predictors_customization.py:25-69 is a DIFFERENT integrator (Euler-Cromer, atan2 angle, no edge bounce): one
-            # control step already lies 1.6e-3 from ODE_v0, so it must not be served by the ODE_v0 kernel
-            raise NotImplementedError(f"predictor {predictor_specification!r} (next_state_predictor_ODE: Euler-Cromer, no "
-                                      "bounce) is not built; the HIP path implements 'ODE_v0' and 'GRU-6IN-32H1-32H2-5OUT-*'")
-        if not neural and predictor_specification not in (None, "ODE_v0", "ODE_v0_default"):
-            raise NotImplementedError("built predictors: ODE_v0 and GRU-6IN-32H1-32H2-5OUT-*")
+        spec = None if predictor_specification is None else str(predictor_specification).split(":")[0]
+        if spec in ("ODE", "ODE_default"):
+            # predictors_customization.py:25-69 is a DIFFERENT integrator (Euler-Cromer, atan2 angle, no edge bounce; one
+            # control step already lies 1.6e-3 from ODE_v0): the rollout kernel's predictor_ODE form - what the
+            # shipped config_controllers.yml:3,14 select
+            self.cfg.predictor_type = "ODE"
+        elif spec in ("ODE_v0", "ODE_v0_default"):
+            self.cfg.predictor_type = "ODE_v0"
+        elif not neural and spec is not None:
+            raise NotImplementedError("built predictors: ODE_v0, ODE and GRU-6IN-32H1-32H2-5OUT-*")
         if self.gru_model is not None and not (neural or predictor_specification is None):
             raise ValueError(f"gru_model was given but predictor_specification={predictor_specification!r} selects the ODE "
                              "predictor: the model would be ignored")

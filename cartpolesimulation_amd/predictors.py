@@ -16,10 +16,10 @@ from .configs import MPPIConfig, PhysicalParameters
 from .state_utilities import STATE_INDICES, STATE_VARIABLES, CONTROL_INPUTS, create_cartpole_state  # noqa: F401
 
 
-def _engine(horizon, dt, intermediate_steps, phys, math_mode, device):
+def _engine(horizon, dt, intermediate_steps, phys, math_mode, device, predictor_type="ODE_v0"):
     from .engine import MPPIEngine
     cfg = MPPIConfig(num_rollouts=1, mpc_horizon=max(1, int(horizon)), mpc_timestep=float(dt),
-                     intermediate_steps=int(intermediate_steps), math_mode=math_mode)
+                     intermediate_steps=int(intermediate_steps), math_mode=math_mode, predictor_type=predictor_type)
     return MPPIEngine(1, cfg, phys, device=device)
 
 
@@ -32,8 +32,9 @@ def _pole_length(variable_parameters, phys):
 class next_state_predictor_ODE_v0:
     """Per-step hook: ``step(s[B,6], Q[B,1]) -> s_next[B,6]`` (one control step = ``intermediate_steps`` Euler
     substeps with edge bounce and angle wrap).  Honours ``variable_parameters.L`` only, like the reference (:47-50)."""
+    predictor_type = "ODE_v0"
 
-    def __init__(self, dt, intermediate_steps, batch_size, variable_parameters=None, phys=None, math_mode="precise",
+    def __init__(self, dt, intermediate_steps, batch_size=1, variable_parameters=None, phys=None, math_mode="precise",
                  device=0, **kwargs):
         self.phys = phys or PhysicalParameters()
         self.params = self.phys
@@ -41,7 +42,7 @@ class next_state_predictor_ODE_v0:
         self.intermediate_steps = int(intermediate_steps)
         self.t_step = float(dt / float(self.intermediate_steps))
         self.s = create_cartpole_state()
-        self._eng = _engine(1, dt, intermediate_steps, self.phys, math_mode, device)
+        self._eng = _engine(1, dt, intermediate_steps, self.phys, math_mode, device, self.predictor_type)
 
     def step(self, s, Q, as_tensor=False):
         assert Q.shape[0] == s.shape[0]
@@ -50,6 +51,21 @@ class next_state_predictor_ODE_v0:
         L = _pole_length(self.variable_parameters, self.phys)
         out = self._eng.predict(s, Q[:, :1], L=L)[:, 1]
         return out if as_tensor else out.cpu().numpy()
+
+
+class next_state_predictor_ODE(next_state_predictor_ODE_v0):
+    """``SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:25-69``: the per-step hook of predictor_type
+    "ODE" - ``intermediate_steps`` Euler-Cromer substeps (cartpole_equations.py:293-304), no edge bounce, angle =
+    atan2(sin, cos).  ``variable_parameters.L`` is honoured; ``variable_parameters.m_pole`` (:55-58) is not - the pole
+    mass is a handle-wide constant here - and raises."""
+    predictor_type = "ODE"
+
+    def __init__(self, dt, intermediate_steps, lib=None, batch_size=1, variable_parameters=None,
+                 disable_individual_compilation=False, **kwargs):
+        if variable_parameters is not None and hasattr(variable_parameters, "m_pole"):
+            raise NotImplementedError("variable_parameters.m_pole: the pole mass is fixed per handle (PhysicalParameters.m_pole)")
+        self.lib = lib
+        super().__init__(dt, intermediate_steps, batch_size, variable_parameters, **kwargs)
 
 
 class predictor_ODE_v0:
@@ -66,7 +82,7 @@ class predictor_ODE_v0:
         self.phys = phys or PhysicalParameters()
         self.params = self.phys
         self._math_mode, self._device = math_mode, device
-        self._eng = _engine(self.horizon, dt, intermediate_steps, self.phys, math_mode, device)
+        self._eng = _engine(self.horizon, dt, intermediate_steps, self.phys, math_mode, device, self.predictor_type)
         self.next_step_predictor = SimpleNamespace(params=self.phys)
 
     def predict_core(self, initial_state, Q, as_tensor=False):
@@ -87,6 +103,17 @@ class predictor_ODE_v0:
     def update(self, Q0=None, s=None):
         """No internal state for an ODE predictor (controller_mppi_cartpole.py:566-567 calls it regardless)."""
         return None
+
+
+class predictor_ODE(predictor_ODE_v0):
+    """predictor_type "ODE" (SI_Toolkit_ASF/config_predictors.yml:22-26; config_controllers.yml:3,14): the same seam on
+    next_state_predictor_ODE's integrator (Euler-Cromer, no edge bounce, atan2 angle)."""
+    predictor_type = "ODE"
+
+    def __init__(self, horizon, dt, intermediate_steps=10, batch_size=1, variable_parameters=None, **kwargs):
+        if variable_parameters is not None and hasattr(variable_parameters, "m_pole"):
+            raise NotImplementedError("variable_parameters.m_pole: the pole mass is fixed per handle (PhysicalParameters.m_pole)")
+        super().__init__(horizon, dt, intermediate_steps, batch_size, variable_parameters, **kwargs)
 
 
 class PredictorWrapper:
@@ -118,21 +145,24 @@ class PredictorWrapper:
 
     def update_predictor_config_from_specification(self, predictor_specification=None, **kwargs):
         spec = predictor_specification or "ODE_v0"
-        if str(spec).split(":")[0] in ("ODE", "ODE_default"):
-            # predictors_customization.py:25-69: Euler-Cromer, atan2 angle, no edge bounce — not the ODE_v0 integrator
-            raise NotImplementedError(f"predictor_specification {spec!r} is next_state_predictor_ODE, a different integrator "
-                                      "from ODE_v0 (1.6e-3 apart after one control step); only ODE_v0 is built")
-        if str(spec).split(":")[0] not in ("ODE_v0", "ODE_v0_default"):
-            raise NotImplementedError(f"predictor_specification {spec!r}: the predictor seam serves ODE_v0; the GRU predictor "
-                                      "runs inside the fused kernel (optimizer_mppi(gru_model=...))")
-        self.predictor_config = {"predictor_type": "ODE_v0", "model_name": None,
+        name = str(spec).split(":")[0]
+        if name in ("ODE", "ODE_default"):
+            # predictors_customization.py:25-69: Euler-Cromer, atan2 angle, no edge bounce - a different integrator from
+            # ODE_v0 (1.6e-3 apart after one control step), served by the kernels' predictor_ODE form
+            ptype = "ODE"
+        elif name in ("ODE_v0", "ODE_v0_default"):
+            ptype = "ODE_v0"
+        else:
+            raise NotImplementedError(f"predictor_specification {spec!r}: the predictor seam serves ODE_v0 and ODE; the GRU "
+                                      "predictor runs inside the fused kernel (optimizer_mppi(gru_model=...))")
+        self.predictor_config = {"predictor_type": ptype, "model_name": None,
                                  "intermediate_steps": self.predictor_config["intermediate_steps"]}
-        self.predictor_type = "ODE_v0"
+        self.predictor_type = ptype
 
     def _build(self):
-        self.predictor = predictor_ODE_v0(self._horizon, self.dt, self.predictor_config["intermediate_steps"],
-                                          self.batch_size, self.variable_parameters, self.phys, self._math_mode,
-                                          self._device)
+        cls = predictor_ODE if self.predictor_type == "ODE" else predictor_ODE_v0
+        self.predictor = cls(self._horizon, self.dt, self.predictor_config["intermediate_steps"], self.batch_size,
+                             self.variable_parameters, phys=self.phys, math_mode=self._math_mode, device=self._device)
 
     def configure(self, batch_size, horizon, dt, predictor_specification=None, variable_parameters=None, **kwargs):
         self.update_predictor_config_from_specification(predictor_specification)

@@ -41,7 +41,8 @@
 extern "C" {
 #endif
 
-#define CPMPPI_ABI_VERSION 2u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_* */
+#define CPMPPI_ABI_VERSION 3u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_*;
+                                   3: cpmppi_config.ode_predictor */
 #define CPMPPI_STATE_DIM 6u
 #define CPMPPI_MAX_HORIZON 1024u
 
@@ -78,6 +79,13 @@ enum { CPMPPI_MATH_PRECISE = 0,  /* IEEE divide, libm-grade sincos, no FMA contr
                                     by rotation through w*t and are re-synchronised by the exact wrap + sincos at the
                                     step's last substep, so states at control-step granularity carry rounding noise
                                     only (tools/deviation.py: median 1e-6, p99 1e-5 of the reference's own mode A) */
+enum { CPMPPI_ODE_V0 = 0,        /* predictor_ODE_v0 (predictors_customization_v0.py:22-57 -> cartpole_numba.py:55-78):
+                                    simultaneous forward Euler, elastic edge bounce, fmod angle wrap - the default */
+       CPMPPI_ODE_CROMER = 1 };  /* predictor_ODE, predictor_specification "ODE" - what the shipped config_controllers.yml:3,14
+                                    names (predictors_customization.py:25-69 -> cartpole_equations.py:181-259,293-308):
+                                    Euler-Cromer, NO edge bounce, angle = atan2(sin, cos).  Serves cpmppi_step*,
+                                    cpmppi_predict, cpmppi_rollout_cost and the CEM kernels; cpmppi_rollout_cost_grad
+                                    (the adjoint) is built for CPMPPI_ODE_V0 only and refuses a handle of this kind */
 enum { CPMPPI_NOISE_DELTA_U = 0, /* noise = delta_u[E,N,H]  (reference layout, rollout-major)              */
        CPMPPI_NOISE_KNOTS = 1,   /* noise = knots[E,N,P], P = ceil(H/period)+1; interpolated in-kernel       */
        CPMPPI_NOISE_PHILOX = 2,  /* knots generated in-kernel from (seed, offset): no perturbation buffer   */
@@ -111,11 +119,14 @@ typedef struct {
                                     >= 131072 rollouts = one packed wave on every SIMD, else 1; measured crossover),
                                     1 = one rollout per lane (lowest latency), 2 = two rollouts per lane as packed
                                     float2 (highest throughput) */
+  uint32_t ode_predictor;        /* CPMPPI_ODE_*: which in-tree ODE predictor integrates the rollouts (predictor_type of
+                                    SI_Toolkit_ASF/config_predictors.yml:18-26) */
 } cpmppi_config;
 
 typedef struct cpmppi_handle cpmppi_handle;
 
-enum { CPMPPI_PREDICTOR_ODE_V0 = 0, CPMPPI_PREDICTOR_GRU = 1 };
+enum { CPMPPI_PREDICTOR_ODE_V0 = 0,   /* the handle's ODE predictor (cpmppi_config.ode_predictor; the name is ABI 1's) */
+       CPMPPI_PREDICTOR_GRU = 1 };
 
 /* Neural predictor of BASELINE configs[4] (model naming SI_Toolkit_ASF/config_predictors.yml:8-13): two GRU layers of
  * 32 units and a dense head, torch.nn.GRU convention (gate rows r, z, n; b_ih and b_hh).  HOST pointers; inputs are

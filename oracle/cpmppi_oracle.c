@@ -43,6 +43,9 @@ typedef struct {
   uint32_t shift_mode;         /* 0 repeat last, 1 append zero, 2 none */
   uint32_t correction_u;       /* 0 u_run, 1 u_nom */
   uint32_t f64_substeps;       /* 0 = mode A (strict float32), 1 = mode B (float64 substeps, float32 store) */
+  uint32_t integrator;         /* 0 = predictor_ODE_v0 (simultaneous Euler, edge bounce, fmod wrap), 1 = predictor_ODE
+                                  (predictors_customization.py:25-69 -> cartpole_equations.py:229-249,293-308:
+                                  Euler-Cromer, no bounce, angle = atan2(sin, cos)) */
 } oracle_config;
 
 #define PI_F 3.14159274101257324f
@@ -71,6 +74,13 @@ static inline void ode_f32(const oracle_config* p, float L, float ca, float sa, 
 static inline void substep_f32(const oracle_config* p, float L, float t, float u, float s[6]) {
   float aDD, xDD;
   ode_f32(p, L, s[2], s[3], s[1], s[5], u, &aDD, &xDD);
+  if (p->integrator == 1) {                      /* Euler-Cromer: velocities first, positions with the NEW velocities */
+    const float w1 = s[1] + aDD * t, v1 = s[5] + xDD * t;
+    const float th1 = s[0] + w1 * t, x1 = s[4] + v1 * t;
+    const float c1 = cos32(th1), s1 = sin32(th1);
+    s[0] = atan2f(s1, c1); s[1] = w1; s[2] = c1; s[3] = s1; s[4] = x1; s[5] = v1;
+    return;
+  }
   float th = s[0] + s[1] * t, w = s[1] + aDD * t, x = s[4] + s[5] * t, v = s[5] + xDD * t;
   const float cb = cos32(th);
   if (x >= p->THL || -x >= p->THL) {
@@ -94,6 +104,13 @@ static inline void substep_f64(const oracle_config* p, double L, double t, doubl
   const double xDD = ((double)p->m_pole * (double)p->g * s[3] * s[2] + ((T * s[2]) / Lh) +
                       kp1 * (-((double)p->m_pole * Lh * (s[1] * s[1]) * s[3]) + F + u)) / A;
   const double aDD = ((double)p->g * s[3] + xDD * s[2] + T / ((double)p->m_pole * Lh)) / (kp1 * Lh);
+  if (p->integrator == 1) {                      /* (a rounding-sensitivity probe only: the ODE predictor is float32 throughout) */
+    const double w1 = s[1] + aDD * t, v1 = s[5] + xDD * t;
+    const double th1 = s[0] + w1 * t, x1 = s[4] + v1 * t;
+    const double c1 = cos(th1), s1 = sin(th1);
+    s[0] = atan2(s1, c1); s[1] = w1; s[2] = c1; s[3] = s1; s[4] = x1; s[5] = v1;
+    return;
+  }
   double th = s[0] + s[1] * t, w = s[1] + aDD * t, x = s[4] + s[5] * t, v = s[5] + xDD * t;
   const double cb = cos(th);
   if (x >= (double)p->THL || -x >= (double)p->THL) {

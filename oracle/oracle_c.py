@@ -16,7 +16,8 @@ class oracle_config(C.Structure):
                 ("M_fric", C.c_float), ("u_max", C.c_float), ("THL", C.c_float), ("cost_id", C.c_uint32),
                 ("w", C.c_float * 16), ("R", C.c_float), ("LBD", C.c_float), ("NU", C.c_float), ("cc_weight", C.c_float),
                 ("lo", C.c_float), ("hi", C.c_float), ("horizon_reduce", C.c_uint32), ("control_mode", C.c_uint32),
-                ("shift_mode", C.c_uint32), ("correction_u", C.c_uint32), ("f64_substeps", C.c_uint32)]
+                ("shift_mode", C.c_uint32), ("correction_u", C.c_uint32), ("f64_substeps", C.c_uint32),
+                ("integrator", C.c_uint32)]
 
 
 def build(force=False):
@@ -61,6 +62,7 @@ def make_config(cfg, p=None, mode="f32"):
     c.shift_mode = {"repeat_last": 0, "append_zero": 1, "none": 2}[cfg.shift_mode]
     c.correction_u = {"u_run": 0, "u_nom": 1}[cfg.correction_u]
     c.f64_substeps = {"f32": 0, "f64sub": 1}[mode]
+    c.integrator = {"ODE_v0": 0, "ODE": 1}[getattr(cfg, "integrator", "ODE_v0")]
     return c
 
 
@@ -90,13 +92,13 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def predict(cfg_c, s0, Q, L=None, L_default=0.395, n_threads=0):
+def predict(cfg_c, s0, Q, L=None, L_default=0.395, n_threads=0, use_lib=None):
     Q = np.ascontiguousarray(Q, dtype=f32)
     B, H = Q.shape
     s0 = np.ascontiguousarray(np.broadcast_to(np.asarray(s0, dtype=f32), (B, 6)))
     L = None if L is None else np.ascontiguousarray(np.broadcast_to(np.asarray(L, dtype=f32), (B,)))
     traj = np.empty((B, H + 1, 6), dtype=f32)
-    lib().oracle_predict(C.byref(cfg_c), C.c_uint32(B), C.c_uint32(H), _p(s0), _p(Q), _p(L), C.c_float(L_default),
+    (use_lib or lib()).oracle_predict(C.byref(cfg_c), C.c_uint32(B), C.c_uint32(H), _p(s0), _p(Q), _p(L), C.c_float(L_default),
                          _p(traj), C.c_int(n_threads))
     return traj
 

@@ -18,7 +18,7 @@ Arithmetic modes
   * ``"f64sub"`` — mode B, substeps carried in float64 and rounded to float32 once per control step: closest
     emulation of numba's typing of the same source (``array(float32) * float64 -> float64``).
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 import numpy as np
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -133,10 +133,51 @@ def ode_v0_step(s, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32"):
     return out
 
 
+# The OTHER in-tree ODE predictor, predictor_type "ODE" (SI_Toolkit_ASF/config_predictors.yml:22-26; the shipped
+# config_controllers.yml:3,14 name it as the mpc controllers' predictor_specification):
+#   SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:25-69 (next_state_predictor_ODE._step: L / m_pole
+#   override, Q[..., 0], Q2u) -> CartPole/cartpole_equations.py:181-259 (cartpole_fine_integration: per substep
+#   _cartpole_ode :232, Euler-Cromer :293-304 - velocities first, positions with the NEW velocities -, NO edge bounce
+#   (:241-243 commented out), cos / sin of the integrated angle :245-246, angle = atan2(sin, cos) :248,307-308).
+def fine_integration_cromer(angle, angleD, ca, sa, position, positionD, u, t_step, S, L, p=DEFAULT_PARAMS):
+    for _ in range(S):
+        angleDD, positionDD = cartpole_ode(ca, sa, angleD, positionD, u, L, p)
+        angleD = angleD + angleDD * t_step                                                 # cartpole_equations.py:297
+        positionD = positionD + positionDD * t_step                                        # :298
+        angle = angle + angleD * t_step                                                    # :301
+        position = position + positionD * t_step                                           # :302
+        ca, sa = np.cos(angle), np.sin(angle)                                              # :245-246
+        angle = np.arctan2(sa, ca)                                                         # :248
+    return angle, angleD, ca, sa, position, positionD
+
+
+def ode_step(s, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32", m_pole=None):
+    """One control step of predictor_ODE (next_state_predictor_ODE).  s[N,6] f32, Q[N] f32 -> s_next[N,6] f32.
+    mode "f64sub" (float64 substeps, float32 store) is NOT a reference arithmetic here - TensorFlow / numpy float32
+    throughout - it only serves as a rounding-sensitivity probe, like the perturbed realisations of tests/parity_util.py."""
+    s = np.asarray(s, dtype=f32)
+    Q = np.asarray(Q, dtype=f32).reshape(s.shape[0])
+    L = p.L if L is None else f32(L)
+    if m_pole is not None:                                        # predictors_customization.py:55-58 (variable_parameters.m_pole)
+        p = replace(p, m_pole=f32(m_pole))
+    t_step = float(dt / float(S))                                 # predictors_customization.py:37 (python float)
+    u = Q2u(Q, p)
+    cols = [s[:, ANGLE_IDX], s[:, ANGLED_IDX], s[:, ANGLE_COS_IDX], s[:, ANGLE_SIN_IDX], s[:, POSITION_IDX],
+            s[:, POSITIOND_IDX]]
+    if mode == "f64sub":
+        cols = [c.astype(np.float64) for c in cols]
+        u = u.astype(np.float64)
+    elif mode != "f32":
+        raise ValueError(mode)
+    a, ad, ca, sa, x, xd = fine_integration_cromer(*cols, u, t_step, S, L, p)
+    return np.stack([a, ad, ca, sa, x, xd], axis=1).astype(f32)    # cartpole_equations.py:211
+
+
 # a11 — the absent predictor_ODE_v0.predict_core, witnessed by controller_mppi_cartpole.py:191 and
 #   SI_Toolkit_ASF/ToolkitCustomization/Modules/ODE_module.py:46-50: out[:,0]=s0; out[:,k+1]=step(out[:,k], Q[:,k])
-def predict_core(s0, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32"):
-    """s0[N,6] (or [6]), Q[N,H] (or [N,H,1]) -> trajectories [N,H+1,6] float32."""
+def predict_core(s0, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32", integrator="ODE_v0"):
+    """s0[N,6] (or [6]), Q[N,H] (or [N,H,1]) -> trajectories [N,H+1,6] float32.  integrator: "ODE_v0" | "ODE"."""
+    step = {"ODE_v0": ode_v0_step, "ODE": ode_step}[integrator]
     Q = np.asarray(Q, dtype=f32)
     if Q.ndim == 3:
         Q = Q[:, :, 0]
@@ -147,7 +188,7 @@ def predict_core(s0, Q, dt=0.02, S=10, L=None, p=DEFAULT_PARAMS, mode="f32"):
     out = np.zeros((N, H + 1, 6), dtype=f32)
     out[:, 0] = s0
     for k in range(H):
-        out[:, k + 1] = ode_v0_step(out[:, k], Q[:, k], dt, S, L, p, mode)
+        out[:, k + 1] = step(out[:, k], Q[:, k], dt, S, L, p, mode)
     return out
 
 
@@ -359,6 +400,7 @@ class MPPIConfig:
     control_mode: str = "clip"        # "clip" (recalled optimizer_mppi) | "penalise" (legacy, in-tree)
     shift_mode: str = "repeat_last"   # "repeat_last" (recalled) | "append_zero" (legacy, in-tree) | "none"
     correction_u: str = "u_run"       # which u enters a15: "u_run" (recalled) | "u_nom" (legacy, in-tree)
+    integrator: str = "ODE_v0"        # predictor_type: "ODE_v0" | "ODE" (config_predictors.yml:18-26)
     cost: CostConfig = field(default_factory=CostConfig)
 
     @property
@@ -369,7 +411,7 @@ class MPPIConfig:
 def legacy_rollout_costs(s, u, delta_u, u_prev, target_position, cfg, L=None, p=DEFAULT_PARAMS, mode="f32"):
     """controller_mppi_cartpole.py:164-199 (trajectory_rollouts): predict(tile(s), u+delta_u), sum_k q + phi."""
     N = delta_u.shape[0]
-    traj = predict_core(np.tile(s, (N, 1)), (u + delta_u), cfg.dt, cfg.S, L, p, mode)
+    traj = predict_core(np.tile(s, (N, 1)), (u + delta_u), cfg.dt, cfg.S, L, p, mode, cfg.integrator)
     q = legacy_stage_cost(traj[:, :-1], u, delta_u, u_prev, target_position, cfg.R, cfg.NU, p, cfg.cost)
     return np.sum(q, axis=1) + legacy_terminal_cost(traj[:, -1], target_position, p), traj
 
@@ -406,7 +448,7 @@ def mppi_step(s, u_nom, delta_u, target_position, target_equilibrium, cfg, u_pre
     u_run = u_nom[None, :] + delta_u
     if cfg.control_mode == "clip":
         u_run = np.clip(u_run, f32(low), f32(high))
-    traj = predict_core(np.tile(s, (delta_u.shape[0], 1)), u_run, cfg.dt, cfg.S, L, p, mode)
+    traj = predict_core(np.tile(s, (delta_u.shape[0], 1)), u_run, cfg.dt, cfg.S, L, p, mode, cfg.integrator)
     S_cost = trajectory_cost(cfg.cost_id, traj, u_run, target_position, target_equilibrium, cfg.horizon_reduce, p,
                              cfg.cost)
     u_corr = u_run if cfg.correction_u == "u_run" else u_nom[None, :]

@@ -145,8 +145,12 @@ class NumpyLibrary:
         return gen.uniform(low, high, size=shape).astype(dtype)
 
     @staticmethod
-    def loop(fn, *a, **k):
-        raise NotImplementedError
+    def loop(body_fn, state, steps, counter=0):
+        """The contract CartPole/cartpole_equations.py:251-258 shows at its call site (the class itself is in the absent
+        SI_Toolkit submodule): body_fn(counter, *state) -> (counter, *state), `steps` times; returns (counter, *state)."""
+        for _ in range(int(steps)):
+            counter, *state = body_fn(counter, *state)
+        return (counter, *state)
 
 
 class _Unavailable:

@@ -151,6 +151,7 @@ def test_reading_a_reference_checkout_reproduces_the_defaults():
     for k in ("mpc_horizon", "num_rollouts", "cc_weight", "R", "LBD", "NU", "SQRTRHOINV", "mpc_timestep",
               "period_interpolation_inducing_points", "intermediate_steps", "cost_function_specification"):
         assert getattr(m, k) == getattr(d, k), k
+    assert m.predictor_type == "ODE"        # config_controllers.yml:3 ships predictor_specification: "ODE" (Euler-Cromer, no bounce)
 
 
 def test_state_utilities_mirror():
@@ -183,6 +184,7 @@ def test_controller_reads_a_checkout():
     assert c.config_optimizer["mpc_horizon"] == 35 and c.config_optimizer["num_rollouts"] == 512
     assert c.config_optimizer["cost_function_specification"] == "quadratic_boundary_grad_minimal"
     assert c.config_optimizer["cost_weights"]["db_weight_up"] == 10000 and c.has_optimizer
+    assert c.config_optimizer["predictor_type"] == "ODE"
     with pytest.raises(ValueError):
         controller_mpc("Pendulum")
 
@@ -200,12 +202,16 @@ def test_rollout_kernels_have_no_scratch_and_no_vgpr_spills():
     ks = [k for k in code_objects.kernels(_lib.LIB_PATH) if "rollout_cost_kernel" in k["name"]]
     hot = [k for k in ks if "19rollout_cost_kernel" in k["name"]]
     # 4 costs x 4 noise sources x (latency R1, throughput R1 fast + precise, throughput R2, mid R2, mid R2 for launches of one
-    # wave per SIMD)
-    assert len(hot) == 4 * 4 * 6, len(hot)
+    # wave per SIMD) for predictor_ODE_v0 + (latency R1, throughput R1 fast + precise, throughput R2) for predictor_ODE
+    assert len(hot) == 4 * 4 * (6 + 4), len(hot)
     # the mid-size build must keep three waves per SIMD (512 registers / 168); its variant for launches of at most one wave
     # per SIMD (straight-line control steps) two, so that a guest kernel - the overlapped all-gather - still fits beside it
     for k in hot:
         tail = k["name"].split("EEEv")[0]
+        assert tail.endswith(("ELi0", "ELi1")), tail            # the last template argument: the ODE predictor
+        if tail.endswith("ELi1"):
+            assert tail[:-4].endswith(("ELi0", "ELi1")), tail   # predictor_ODE: latency / throughput builds only
+        tail = tail[:-4]
         if tail.endswith("ELi2ELi2"):
             assert k["vgpr_count"] + k["agpr_count"] <= 168, (k["name"], k["vgpr_count"])
         if tail.endswith("ELi2ELi3"):
@@ -216,5 +222,5 @@ def test_rollout_kernels_have_no_scratch_and_no_vgpr_spills():
     # the headline kernel (quadratic_boundary_grad_minimal, FAST, Philox, two rollouts per lane, throughput build) must
     # keep four waves per SIMD (512 registers / 128)
     for k in hot:
-        if "kernelILi0ELb1ELi2ELi2ELi1E" in k["name"]:
+        if "kernelILi0ELb1ELi2ELi2ELi1ELi" in k["name"]:      # (both ODE predictors)
             assert k["vgpr_count"] + k["agpr_count"] <= 128, (k["name"], k["vgpr_count"])

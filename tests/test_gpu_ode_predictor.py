@@ -1,0 +1,237 @@
+"""GPU parity of predictor_type "ODE" (next_state_predictor_ODE: Euler-Cromer substeps, no edge bounce, angle = atan2(sin,
+cos) - SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:25-69, CartPole/cartpole_equations.py:181-259,293-308;
+the predictor_specification the shipped config_controllers.yml:3,14 name) through the C ABI (cpmppi_config.ode_predictor =
+CPMPPI_ODE_CROMER): the predictor seam against rollouts of the reference's OWN class (tests/golden/ode_predictor.npz), the
+fused MPPI step against the C oracle, in both math modes and lane mappings.
+
+Tolerance: the 1e-4 band of BASELINE.json's north star around the reference's result, widened - per element - by how far
+the reference's own FLOAT32 realisations scatter (mode C: FMA contraction + libm float trig; mode A from an initial state one
+ulp away): an oracle quantity (tests/parity_util.py).  The float64-substep mode of predictor_ODE_v0 is NOT used here: this
+predictor is float32 throughout in the reference (TensorFlow / numpy float32), so it is no second reference arithmetic."""
+import os
+
+import numpy as np
+import pytest
+from numpy.random import SFC64, Generator
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402  (the checker)
+from oracle import oracle_c as OC  # noqa: E402
+import parity_util as PU  # noqa: E402
+
+f32 = np.float32
+MATH_MODES = ["precise", "fast"]
+LANE_MODES = [("precise", 1), ("fast", 1), ("fast", 2)]
+REGIMES = ["upright", "hanging", "edge", "spin", "fastspin"]
+
+
+def engine(E, N, H, **kw):
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    return MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, predictor_type="ODE", **kw))
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "ode_predictor.npz"))
+
+
+def one_up(a):
+    return np.nextafter(np.asarray(a, f32), f32(np.inf)).astype(f32)
+
+
+def f32_realisations(s0, Q, L=None, **cfg_kw):
+    """Trajectories of the reference's float32 realisations other than mode A (C oracle): mode C, and mode A from an initial
+    state one float32 ulp away in the angular velocity / the cart velocity / the position."""
+    N, H = Q.shape
+    cfg = OC.make_config(O.MPPIConfig(N=N, H=H, integrator="ODE", **cfg_kw))
+    s0 = np.ascontiguousarray(np.broadcast_to(np.asarray(s0, f32), (N, 6)))
+    outs = []
+    fma = OC.fma_lib()
+    if fma is not None:
+        outs.append(OC.predict(cfg, s0, Q, L=L, use_lib=fma))
+    for col in (O.ANGLED_IDX, O.POSITIOND_IDX, O.POSITION_IDX):
+        sp = s0.copy()
+        sp[:, col] = one_up(sp[:, col])
+        outs.append(OC.predict(cfg, sp, Q, L=L))
+    return outs
+
+
+def state_diff(a, b):
+    """a - b with the angle column compared on the circle (atan2 returns either of +-pi for the same point)."""
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    d[..., O.ANGLE_IDX] = np.angle(np.exp(1j * d[..., O.ANGLE_IDX]))
+    return d
+
+
+def assert_states_in_band(out, ref, alts, what, scale=1.0):
+    gap = np.zeros(np.asarray(ref).shape)
+    for a in alts:
+        gap = np.maximum(gap, np.abs(state_diff(a, ref)))
+    off = np.abs(state_diff(out, ref)) > PU.band(ref, scale) + gap
+    rows = off.reshape(off.shape[0], -1).any(axis=1)
+    worst = float((np.abs(state_diff(out, ref)) / (PU.band(ref, scale) + gap)).max())
+    assert not rows.any(), f"{what}: {int(rows.sum())} of {rows.size} rollouts outside band + float32 scatter (worst {worst:.2f})"
+
+
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+def test_predict_single_control_step(g, math_mode):
+    s, Q = g["kat/s"], g["kat/Q"]
+    for key, ekw, okw, L in (("s_next", {}, {}, None), ("s_next_L030", {}, {}, 0.30),
+                             ("s_next_dt04_S4", dict(mpc_timestep=0.04, intermediate_steps=4), dict(dt=0.04, S=4), None)):
+        eng = engine(1, 256, 1, math_mode=math_mode, **ekw)
+        out = eng.predict(s, Q[:, None], L=L)[:, 1].cpu().numpy()
+        alts = [t[:, 1] for t in f32_realisations(s, Q[:, None], L=L, **okw)]
+        assert_states_in_band(out, g[f"kat/{key}"], alts, f"{key} ({math_mode})", scale=0.1)       # a tenth of the band
+        eng.close()
+    # beyond the track edge the cart keeps going: no bounce in this predictor
+    beyond = np.abs(s[:, O.POSITION_IDX]) > PU.THL
+    assert beyond.sum() > 20
+
+
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+@pytest.mark.parametrize("name", REGIMES)
+def test_predict_seam_vs_reference_rollouts(g, name, math_mode):
+    """[N, H+1, 6] trajectories of the reference's own next_state_predictor_ODE (50 control steps = 500 Euler-Cromer substeps):
+    upright, hanging, leaving the track (|x| up to 0.36 m, THL = 0.198), spinning (48 rad/s) and spinning beyond the rotation
+    polynomials' range (150 rad/s: the FAST kernel's exact wrap + sincos path)."""
+    s0, Q, ref = g[f"{name}/s0"], g[f"{name}/Q"], g[f"{name}/traj"]
+    N, H = Q.shape
+    eng = engine(1, N, H, math_mode=math_mode)
+    traj = eng.predict(s0, Q).cpu().numpy()
+    assert traj.shape == ref.shape and np.array_equal(traj[:, 0], ref[:, 0])
+    assert_states_in_band(traj, ref, f32_realisations(s0, Q), f"{name} ({math_mode})")
+    assert np.abs(traj[..., O.ANGLE_IDX]).max() <= np.pi + 1e-6
+    eng.close()
+
+
+@pytest.mark.parametrize("math_mode,rpl", LANE_MODES)
+@pytest.mark.parametrize("flags", [
+    dict(),
+    dict(horizon_reduce="mean", shift_mode="append_zero", correction_u="u_nom"),
+    dict(cost_function_specification="default", control_mode="penalise"),
+])
+def test_fused_step_vs_oracle(math_mode, rpl, flags):
+    """Full optimizer step (shift, clip, Euler-Cromer rollouts, cost, correction, soft-min update) for several envs with per-env
+    pole length and targets, N not a multiple of the block (ragged last block), against the C oracle."""
+    E, N, H = 4, 1000, 30
+    eng = engine(E, N, H, math_mode=math_mode, rollouts_per_lane=rpl, **flags)
+    rng = Generator(SFC64(41))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-0.8, 0.8), rng.uniform(-3, 3), rng.uniform(-0.12, 0.12),
+                                           rng.uniform(-0.3, 0.3)) for _ in range(E)])
+    tp = rng.uniform(-0.08, 0.08, E).astype(f32)
+    te = np.ones(E, dtype=f32)
+    Lv = rng.uniform(0.25, 0.45, E).astype(f32)
+    u0 = (0.3 * rng.standard_normal((E, H))).astype(f32)
+    du = np.stack([O.sample_delta_u(rng, N, H, np.float64(eng.mppi.sigma)) for _ in range(E)])
+    un = eng.tensor(u0.copy())
+    S = eng.empty(E, N)
+    Q, _ = eng.step(s0, un, tp, te, L=Lv, delta_u=du, S_out=S)
+    un, S, Q = un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy()
+    m = eng.mppi
+    cid = {"quadratic_boundary_grad_minimal": O.COST_QBGM, "default": O.COST_DEFAULT}[m.cost_function_specification]
+    ocfg = O.MPPIConfig(N=N, H=H, cc_weight=m.cc_weight, R=m.R, LBD=m.LBD, NU=m.NU, cost_id=cid,
+                        horizon_reduce=m.horizon_reduce, control_mode=m.control_mode, shift_mode=m.shift_mode,
+                        correction_u=m.correction_u, integrator="ODE")
+    r = PU.c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=Lv, cost=("default" if cid == O.COST_DEFAULT else None), probes=True)
+    # float32 realisations only (no float64-substep mode for this predictor, see the module docstring)
+    PU.assert_costs(S, r["S_a"], None, r["flags"] & (cid == O.COST_DEFAULT), "costs", S_alt=r["S_alt"], flag_sensitive=True)
+    PU.assert_controls(un, r["u_a"], None, "u_new", u_alt=r["u_alt"])
+    np.testing.assert_allclose(Q, r["Q_a"], atol=1e-4 + float(PU.envelope(r["u_a"], *r["u_alt"]).max()))
+    # the numpy oracle (pinned to the reference's class) agrees with the C one on env 0
+    ref = O.mppi_step(s0[0], u0[0], du[0], tp[0], te[0], ocfg, L=Lv[0])
+    np.testing.assert_allclose(r["S_a"][0], ref["S"], rtol=3e-5)
+    # ... and the other ODE predictor would not have passed
+    other = O.mppi_step(s0[0], u0[0], du[0], tp[0], te[0], O.MPPIConfig(**{**ocfg.__dict__, "integrator": "ODE_v0"}), L=Lv[0])
+    assert np.abs(other["S"] - ref["S"]).max() > 1e-3 * np.abs(ref["S"]).max()
+    eng.close()
+
+
+@pytest.mark.parametrize("math_mode,rpl", LANE_MODES)
+def test_noise_sources_agree(math_mode, rpl):
+    """delta_u buffer == in-kernel Philox of the same (seed, offset) == the tiled buffer == knots (PRECISE: bit for bit)."""
+    E, N, H = 3, 700, 35
+    eng = engine(E, N, H, math_mode=math_mode, rollouts_per_lane=rpl)
+    rng = Generator(SFC64(8))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-5, 5), rng.uniform(-0.15, 0.15),
+                                           rng.uniform(-0.3, 0.3)) for _ in range(E)])
+    tp = rng.uniform(-0.1, 0.1, E).astype(f32)
+    Lv = rng.uniform(0.2, 0.5, E).astype(f32)
+    u0 = (0.2 * rng.standard_normal((E, H))).astype(f32)
+    kn, du = eng.sample(seed=1234, offset=5, env_offset=11, knots=True, delta_u=True)
+    tiled = eng.sample_tiled(seed=1234, offset=5, env_offset=11)
+    outs = []
+    for kw in (dict(delta_u=du), dict(knots=kn), dict(seed=1234, offset=5, env_offset=11), dict(delta_u_tiled=tiled)):
+        un = eng.tensor(u0.copy())
+        S = eng.empty(E, N)
+        Q, _ = eng.step(s0, un, tp, 1.0, L=Lv, S_out=S, **kw)
+        outs.append((un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy()))
+    assert np.array_equal(outs[2][1], outs[0][1]) and np.array_equal(outs[3][1], outs[0][1])
+    if math_mode == "precise":
+        assert np.array_equal(outs[1][1], outs[0][1])
+    else:
+        np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5)
+    for o in outs[1:]:
+        np.testing.assert_allclose(o[0], outs[0][0], atol=5e-6)
+        np.testing.assert_allclose(o[2], outs[0][2], atol=5e-6)
+    eng.close()
+
+
+def test_latency_and_throughput_builds_agree_bit_for_bit():
+    """One rollout per lane: a launch of at most one wave per SIMD runs the latency build (nine substeps unrolled, its own
+    scheduling strategy), a larger one the throughput build.  Same env, same result, bit for bit."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    N, H, small_E, big_E = 1024, 70, 32, 100
+    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=1, predictor_type="ODE")
+    rng = Generator(SFC64(19))
+    ang = rng.uniform(-np.pi, np.pi, big_E)
+    s0 = np.zeros((big_E, 6), f32)
+    s0[:, 0], s0[:, 1], s0[:, 2], s0[:, 3] = ang, rng.uniform(-6, 6, big_E), np.cos(ang), np.sin(ang)
+    s0[:, 4], s0[:, 5] = rng.uniform(-0.18, 0.18, big_E), rng.uniform(-0.5, 0.5, big_E)
+    tp = rng.uniform(-0.1, 0.1, big_E).astype(f32)
+    u0 = rng.uniform(-0.6, 0.6, (big_E, H)).astype(f32)
+    outs = []
+    for E in (big_E, small_E):
+        eng = MPPIEngine(E, cfg)
+        un, S = eng.tensor(u0[:E].copy()), eng.empty(E, N)
+        Q, _ = eng.step(s0[:E], un, tp[:E], np.ones(E, f32), seed=5, offset=3, env_offset=0, S_out=S)
+        outs.append((Q.cpu().numpy()[:small_E], un.cpu().numpy()[:small_E], S.cpu().numpy()[:small_E]))
+        eng.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_seams_with_the_shipped_predictor_specification():
+    """`predictor_specification: "ODE"` (config_controllers.yml:3,14) through the reference-shaped classes: PredictorWrapper's
+    trajectories equal the engine's with predictor_type "ODE" and differ from ODE_v0's; controller_mpc('mppi') and the legacy
+    controller configure and step with it; the adjoint (gradient optimizers) refuses it."""
+    from cartpolesimulation_amd.predictors import PredictorWrapper, next_state_predictor_ODE, predictor_ODE
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    rng = Generator(SFC64(2))
+    N, H = 64, 12
+    s0 = O.create_cartpole_state(0.4, 1.0, 0.05, 0.2)
+    Q = rng.uniform(-1, 1, (N, H, 1)).astype(f32)
+    w = PredictorWrapper(math_mode="precise")
+    w.configure(batch_size=N, horizon=H, dt=0.02, predictor_specification="ODE")
+    assert isinstance(w.predictor, predictor_ODE) and w.predictor_type == "ODE"
+    traj = w.predict_core(s0, Q)
+    ref = O.predict_core(s0, Q, integrator="ODE")
+    assert np.abs(state_diff(traj, ref)).max() < 2e-4
+    w0 = PredictorWrapper(math_mode="precise")
+    w0.configure(batch_size=N, horizon=H, dt=0.02, predictor_specification="ODE_v0")
+    assert np.abs(w0.predict_core(s0, Q) - traj).max() > 1e-3
+    nxt = next_state_predictor_ODE(0.02, 10, batch_size=N, math_mode="precise")
+    np.testing.assert_allclose(nxt.step(np.tile(s0, (N, 1)), Q[:, 0]), traj[:, 1], atol=1e-6)
+    ctrl = controller_mpc(environment_name="CartPole", initial_environment_attributes={"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
+                          control_limits=(np.array([-1.0]), np.array([1.0])))
+    ctrl.configure(optimizer_name="mppi", predictor_specification="ODE", num_rollouts=512, mpc_horizon=20, seed=3)
+    q = ctrl.step(s0, 0.0, {"target_position": 0.02})
+    assert np.isfinite(q).all() and ctrl.optimizer.cfg.predictor_type == "ODE"
+    eng = engine(1, 64, 8)
+    with pytest.raises(RuntimeError, match="predictor_ODE_v0"):
+        eng.rollout_cost_grad(s0[None], np.zeros((1, 64, 8), f32), 0.0, 1.0)
+    eng.close()
