@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--predictor", choices=["ode", "gru"], default="ode",
                     help="ode: predictor_ODE_v0 (the headline path); gru: GRU-6IN-32H1-32H2-5OUT on the matrix "
                          "cores inside the same MPPI loop (BASELINE configs[4], synthetic weights)")
+    ap.add_argument("--predictor-type", choices=["ODE_v0", "ODE"], default="ODE_v0",
+                    help="which in-tree ODE predictor integrates the rollouts: ODE_v0 (the headline path: predictor_ODE_v0) or ODE "
+                         "(predictor_ODE - the shipped config_controllers.yml's predictor_specification: Euler-Cromer, no edge bounce)")
     ap.add_argument("--config", choices=["C2", "C3", "C4"], default=None,
                     help="BASELINE.json config presets: C2 = 1024x50 (the metric's shape, 8192 envs per GPU, the default); "
                          "C3 = 64 envs x 4096 x 100 in one launch; C4 = 64 envs per GPU x 2048 x 50 (512 envs over 8 GPUs)")
@@ -129,7 +132,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(N, H, budget_s=8.0):
+def cpu_baseline(N, H, budget_s=8.0, integrator="ODE_v0"):
     """The plain-C oracle (validated against the golden vectors) timed on this host's cores: same step, same shape.
     Three builds of the same source (oracle/Makefile): the checker itself (-O2, strict float32, sin/cos through double)
     and two timing-only builds compiled here for this host (-O3 -march=native with libm float trig, without and with
@@ -137,7 +140,7 @@ def cpu_baseline(N, H, budget_s=8.0):
     import numpy as np
     from oracle import oracle_np as O
     from oracle import oracle_c as OC
-    cfg = O.MPPIConfig(N=N, H=H)
+    cfg = O.MPPIConfig(N=N, H=H, integrator=integrator)
     c = OC.make_config(cfg)
     threads = OC.max_threads()
     rng = np.random.Generator(np.random.SFC64(4))
@@ -179,13 +182,13 @@ def cpu_baseline(N, H, budget_s=8.0):
 class Workload:
     """One engine + its synthetic inputs; `run(steps, warmup)` times K steps between barriers (max over ranks)."""
 
-    def __init__(self, ctx, E, N, H, noise="philox", math="fast", predictor="ode", rpl=0):
+    def __init__(self, ctx, E, N, H, noise="philox", math="fast", predictor="ode", rpl=0, predictor_type="ODE_v0"):
         import numpy as np
         import torch
         from cartpolesimulation_amd.engine import MPPIEngine
         from cartpolesimulation_amd.configs import MPPIConfig
         self.ctx, self.E, self.N, self.H, self.noise, self.predictor = ctx, E, N, H, noise, predictor
-        self.cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=rpl)
+        self.cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math, rollouts_per_lane=rpl, predictor_type=predictor_type)
         self.eng = MPPIEngine(E, self.cfg, device=ctx["local_rank"])
         dev = ctx["device"]
         self.s0, self.tp, self.te, self.L = synthetic_inputs(E, H, seed=2 + ctx["rank"], device=dev)
@@ -440,13 +443,15 @@ def main():
     ctx = {"world": world, "rank": rank, "local_rank": local_rank, "device": device, "collective": collective,
            "backend": backend}
     E, N, H = args.envs, args.rollouts, args.horizon
-    main_wl = Workload(ctx, E, N, H, noise=args.noise, math=args.math, predictor=args.predictor, rpl=args.rpl)
+    main_wl = Workload(ctx, E, N, H, noise=args.noise, math=args.math, predictor=args.predictor, rpl=args.rpl,
+                       predictor_type=args.predictor_type)
     r = main_wl.run(args.steps, args.warmup)
     cfg = main_wl.cfg
 
     # BASELINE's other configurations, measured by EVERY rank (the collective is part of them), reported by rank 0
     extras = {}
-    if not args.no_extra_configs and args.config is None and args.predictor == "ode" and args.noise == "philox" and args.math == "fast":
+    if (not args.no_extra_configs and args.config is None and args.predictor == "ode" and args.predictor_type == "ODE_v0"
+            and args.noise == "philox" and args.math == "fast"):
         side = [("C4", PRESETS["C4"], "ode", 200, 20)]
         if world == 1:
             side = [("C3", PRESETS["C3"], "ode", 100, 10)] + side + [("C5_gru", (256, 1024, 50), "gru", 20, 3)]
@@ -502,7 +507,9 @@ def main():
                                    + ("" if args.config in ("C3", "C4") else " (BASELINE configs[1] shape)"),
                        "envs_per_gpu": E, "rollouts": N, "horizon": H, "substeps": 10,
                        "cost": cfg.cost_function_specification, "noise": args.noise, "math": args.math,
-                       "predictor": "predictor_ODE_v0" if args.predictor == "ode" else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",
+                       "predictor": ("predictor_ODE_v0" if args.predictor_type == "ODE_v0" else
+                                     "predictor_ODE (Euler-Cromer, no edge bounce: config_controllers.yml:3)") if args.predictor == "ode"
+                       else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",
                        "parallelism": f"env-sharded x{world}, one RCCL all-gather of u_nom per step" if world > 1
                        else "single GPU",
                        **({"collective": main_wl.collective_impl} if main_wl.collective_impl else {})},
@@ -529,7 +536,7 @@ def main():
             out["configs"] = extras
         if not args.no_single_env and world == 1:
             # latency of ONE problem instance (BASELINE configs[1] literally: single env), same kernels
-            w1 = Workload(ctx, 1, N, H, noise="philox", math=args.math, predictor=args.predictor)
+            w1 = Workload(ctx, 1, N, H, noise="philox", math=args.math, predictor=args.predictor, predictor_type=args.predictor_type)
             e1 = w1.eng
             for i in range(5):
                 w1.step(i)
@@ -574,7 +581,7 @@ def main():
                     "note": f"{N} rollouts = {N // 64} waves on 1024 SIMDs: latency of one wave's dependency chain, not throughput"}
             w1.close()
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
-            out["cpu_baseline"] = cpu_baseline(N, H)
+            out["cpu_baseline"] = cpu_baseline(N, H, integrator=args.predictor_type)
         print(json.dumps(out), flush=True)
     if in_rank:
         dist.barrier()

@@ -911,14 +911,18 @@ __device__ __forceinline__ void ode_cromer_fast(const State<F>& st, F uK, float 
 // eps FIRST and (cos, sin) are then rotated by it (substep_fast_rot_carried rotates first: simultaneous Euler moves the
 // angle by the OLD velocity).  The control step's last substep re-synchronises with the exact wrap + polynomial sincos;
 // theta - 2 pi rint(theta / 2 pi) is the value atan2(sin, cos) returns up to rounding (both in [-pi, pi]).  No edge
-// test anywhere: this predictor does not bounce.  A lane whose |w t| is beyond the rotation polynomials' range at the start
-// of the control step (|w| > 125 rad/s at t = 2 ms) takes the exact wrap + sincos on every substep - per lane, so a rollout's
-// arithmetic does not depend on its wave partners; the branch is wave-uniform and practically never taken.
+// test anywhere: this predictor does not bounce.  The carried pair is second order in eps: its truncation, eps^2 |sin d| / 2
+// per substep, stays below 1e-7 while |d| = |w t| <= ~0.1 (the centrifugal term makes eps ~ 0.11 d^2 at worst: 0.006 d^5);
+// a lane that starts a control step beyond CROMER_CARRY_LIMIT (45 rad/s at t = 2 ms - a pole released from rest tops out
+// near 20) takes the exact wrap + sincos on every substep instead - per lane, so a rollout's arithmetic does not depend on
+// its wave partners; the branch is wave-uniform and practically never taken.  (Found by the reference-generated "fastspin"
+// fixture, 150 rad/s decaying through 100: with the limit at the polynomials' 0.25 every rollout left the band.)
+constexpr float CROMER_CARRY_LIMIT = 0.09f;
 template <class F, bool UNROLL = false>
 __device__ __forceinline__ void control_step_cromer_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                          const EnvConst& e) {
   constexpr int W = Width<F>::value;
-  const float wlim = ROT_LIMIT / t;
+  const float wlim = CROMER_CARRY_LIMIT / t;
   bool beyond[W];
   bool any = false;
 #pragma unroll

@@ -120,4 +120,8 @@ def test_update_every_sampling_types_and_horizon_change():
     c4.update_control_vector()
     np.testing.assert_array_equal(c4.u, head)
     with pytest.raises(NotImplementedError):
-        make(N, H, 1, 0.0, "fast", predictor_specification="ODE")
+        make(N, H, 1, 0.0, "fast", predictor_specification="SGP_10")
+    # the shipped YAML's "ODE" (config_controllers.yml:14) = next_state_predictor_ODE: its own kernels, other controls
+    c5, c6 = make(N, H, 9, 0.0, "fast", predictor_specification="ODE"), make(N, H, 9, 0.0, "fast")
+    q5, q6 = c5.step(s, 0.0), c6.step(s, 0.0)
+    assert c5.engine.mppi.predictor_type == "ODE" and np.isfinite(q5) and q5 != q6
