@@ -15,7 +15,7 @@ MATH_PRECISE, MATH_FAST = 0, 1
 ODE_V0, ODE_CROMER = 0, 1
 NOISE_DELTA_U, NOISE_KNOTS, NOISE_PHILOX, NOISE_DELTA_U_TILED = 0, 1, 2, 3
 
-EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights",
+EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_config", "cpmppi_set_cost_weights", "cpmppi_set_pole_mass",
            "cpmppi_sample", "cpmppi_interpolate", "cpmppi_predict", "cpmppi_trajectory_cost", "cpmppi_step",
            "cpmppi_reward_weighted_average", "cpmppi_plant_advance", "cpmppi_plant_advance_record", "cpmppi_step_host", "cpmppi_set_profiling", "cpmppi_get_profile",
            "cpmppi_set_gru", "cpmppi_gru_predict", "cpmppi_rollout_cost", "cpmppi_cem_sample", "cpmppi_cem_update",
@@ -90,6 +90,7 @@ def load():
     lib.cpmppi_last_error.restype = C.c_char_p
     lib.cpmppi_get_config.argtypes = [vp, C.POINTER(cpmppi_config)]
     lib.cpmppi_set_cost_weights.argtypes = [vp, u32, C.POINTER(f), u32]
+    lib.cpmppi_set_pole_mass.argtypes = [vp, f]
     lib.cpmppi_sample.argtypes = [vp, u32, u64, u64, u32, vp, vp, vp]
     lib.cpmppi_interpolate.argtypes = [vp, u32, vp, vp, vp]
     lib.cpmppi_predict.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]

@@ -1074,6 +1074,13 @@ int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cos
   return CPMPPI_OK;
 }
 
+int cpmppi_set_pole_mass(cpmppi_handle* h, float m_pole) {
+  if (!h || !(m_pole > 0.0f) || !(m_pole < INFINITY)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_pole_mass: m_pole must be a positive number");
+  h->cfg.m_pole = m_pole;
+  h->prm.m_pole = m_pole;
+  return CPMPPI_OK;
+}
+
 int cpmppi_sample(cpmppi_handle* h, uint32_t E, uint64_t seed, uint64_t offset, uint32_t env_offset, float* knots_out,
                   float* delta_u_out, void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;

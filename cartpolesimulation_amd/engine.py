@@ -28,6 +28,7 @@ class MPPIEngine:
         self.E, self.N, self.H = int(E), int(self.mppi.num_rollouts), int(self.mppi.mpc_horizon)
         self.P = self.mppi.num_knots
         self._cfg = build_c_config(self.E, self.mppi, self.phys)
+        self._m_pole = float(np.float32(self.phys.m_pole))
         self._h = C.c_void_p()
         rc = self.lib.cpmppi_create(C.byref(self._cfg), self.device.index, C.byref(self._h))
         if rc != 0:
@@ -116,6 +117,13 @@ class MPPIEngine:
         cost_id, w = cost_vector(name, overrides)
         arr = (C.c_float * len(w))(*w)
         self._check(self.lib.cpmppi_set_cost_weights(self._h, cost_id, arr, len(w)))
+
+    def set_pole_mass(self, m_pole):
+        """The pole mass every later call computes with (predictor_ODE: variable_parameters.m_pole).  No-op when unchanged."""
+        m = float(np.float32(m_pole))
+        if m != self._m_pole:
+            self._check(self.lib.cpmppi_set_pole_mass(self._h, m))
+            self._m_pole = m
 
     def sample(self, seed, offset=0, env_offset=0, E=None, knots=True, delta_u=False):
         E = self.E if E is None else int(E)

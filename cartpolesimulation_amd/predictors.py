@@ -23,6 +23,13 @@ def _engine(horizon, dt, intermediate_steps, phys, math_mode, device, predictor_
     return MPPIEngine(1, cfg, phys, device=device)
 
 
+def _apply_pole_mass(eng, variable_parameters):
+    """predictor_ODE reads variable_parameters.m_pole at every call (predictors_customization.py:55-58)."""
+    m = getattr(variable_parameters, "m_pole", None) if variable_parameters is not None else None
+    if m is not None:
+        eng.set_pole_mass(float(np.asarray(m.cpu() if hasattr(m, "cpu") else m, dtype=np.float32).reshape(-1)[0]))
+
+
 def _pole_length(variable_parameters, phys):
     if variable_parameters is not None and hasattr(variable_parameters, "L"):
         return float(np.asarray(variable_parameters.L).reshape(-1)[0])
@@ -49,6 +56,8 @@ class next_state_predictor_ODE_v0:
         assert Q.ndim == 2
         assert s.ndim == 2
         L = _pole_length(self.variable_parameters, self.phys)
+        if self.predictor_type == "ODE":
+            _apply_pole_mass(self._eng, self.variable_parameters)
         out = self._eng.predict(s, Q[:, :1], L=L)[:, 1]
         return out if as_tensor else out.cpu().numpy()
 
@@ -56,14 +65,12 @@ class next_state_predictor_ODE_v0:
 class next_state_predictor_ODE(next_state_predictor_ODE_v0):
     """``SI_Toolkit_ASF/ToolkitCustomization/predictors_customization.py:25-69``: the per-step hook of predictor_type
     "ODE" - ``intermediate_steps`` Euler-Cromer substeps (cartpole_equations.py:293-304), no edge bounce, angle =
-    atan2(sin, cos).  ``variable_parameters.L`` is honoured; ``variable_parameters.m_pole`` (:55-58) is not - the pole
-    mass is a handle-wide constant here - and raises."""
+    atan2(sin, cos).  ``variable_parameters.L`` and ``variable_parameters.m_pole`` (:45-58) are read at every call, as
+    in the reference."""
     predictor_type = "ODE"
 
     def __init__(self, dt, intermediate_steps, lib=None, batch_size=1, variable_parameters=None,
                  disable_individual_compilation=False, **kwargs):
-        if variable_parameters is not None and hasattr(variable_parameters, "m_pole"):
-            raise NotImplementedError("variable_parameters.m_pole: the pole mass is fixed per handle (PhysicalParameters.m_pole)")
         self.lib = lib
         super().__init__(dt, intermediate_steps, batch_size, variable_parameters, **kwargs)
 
@@ -95,6 +102,8 @@ class predictor_ODE_v0:
         s0 = eng.tensor(initial_state)
         if s0.dim() == 2 and s0.shape[0] == 1 and Q.shape[0] != 1:
             s0 = s0[0]
+        if self.predictor_type == "ODE":
+            _apply_pole_mass(eng, self.variable_parameters)
         out = eng.predict(s0, Q.contiguous(), L=_pole_length(self.variable_parameters, self.phys))
         return out if as_tensor else out.cpu().numpy()
 
@@ -109,11 +118,6 @@ class predictor_ODE(predictor_ODE_v0):
     """predictor_type "ODE" (SI_Toolkit_ASF/config_predictors.yml:22-26; config_controllers.yml:3,14): the same seam on
     next_state_predictor_ODE's integrator (Euler-Cromer, no edge bounce, atan2 angle)."""
     predictor_type = "ODE"
-
-    def __init__(self, horizon, dt, intermediate_steps=10, batch_size=1, variable_parameters=None, **kwargs):
-        if variable_parameters is not None and hasattr(variable_parameters, "m_pole"):
-            raise NotImplementedError("variable_parameters.m_pole: the pole mass is fixed per handle (PhysicalParameters.m_pole)")
-        super().__init__(horizon, dt, intermediate_steps, batch_size, variable_parameters, **kwargs)
 
 
 class PredictorWrapper:

@@ -183,6 +183,11 @@ int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out);
 
 /* Mutable per-call knobs (GUI sliders / attribute updates in the reference mutate these between steps). */
 int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cost_w, uint32_t n);
+/* The pole mass every later call of this handle computes with (config.m_pole until then): predictor_ODE takes it from
+ * variable_parameters.m_pole at every step (predictors_customization.py:55-58; the simulator sends 'm_pole' with every
+ * controller.step, CartPole/__init__.py:509-520).  Handle-wide (one value for all envs; the pole LENGTH is the per-env
+ * attribute); launches already enqueued - and captured graphs - keep the value they were enqueued with. */
+int cpmppi_set_pole_mass(cpmppi_handle* h, float m_pole);
 
 /* a17 — device sampler: knots ~ sigma * N(0,1) from Philox4x32-10 keyed by (seed), counter (rollout, env, knot pair,
  * offset); writes knots[E,N,P] and/or the interpolated delta_u[E,N,H] (either pointer may be NULL).

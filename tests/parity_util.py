@@ -82,7 +82,7 @@ def envelope(ref_a, *others):
 
 
 def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False, S_alt=(),
-                 sens_rtol=None):
+                 sens_rtol=None, sensitive_gap_scale=1.0):
     """Per-rollout costs: |S - S_a| <= rtol |S_a| + gap for every unflagged rollout, gap = the envelope of the reference's
     own realisations around mode A (S_b and any S_alt).  flag_sensitive: a rollout on which those realisations disagree
     among THEMSELVES by more than sens_rtol |S_a| (default: the band; the full-size C3 / C4 tests use a QUARTER of it, as
@@ -94,10 +94,16 @@ def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_s
     25 of 199 887 are - PRECISE, the reference's own operand order, among them."""
     S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
     gap = envelope(S_a, S_b, *S_alt) if (S_b is not None or len(S_alt)) else 0.0
-    off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap
     flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
+    sensitive = np.zeros(S.shape, bool)
     if flag_sensitive and (S_b is not None or len(S_alt)):
-        flagged = flagged | (gap > (rtol if sens_rtol is None else sens_rtol) * np.abs(S_a))
+        sensitive = gap > (rtol if sens_rtol is None else sens_rtol) * np.abs(S_a)
+        flagged = flagged | sensitive
+    # sensitive_gap_scale (predictor_ODE tests): `gap` is the LARGEST of k sampled realisations of a chaotic rollout's cost; one
+    # more realisation - the kernel's - exceeds the largest of k with probability 1 / (k + 1) (an eighth with the seven of
+    # c_oracle_step_with_flags), far above the flagged bucket's 2 % cap, so for the rollouts the oracle itself marks sensitive the
+    # sampled scatter is widened by this factor; every other rollout keeps the plain allowance
+    off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap * np.where(sensitive, sensitive_gap_scale, 1.0)
     _check(off, flagged, what, strict)
 
 

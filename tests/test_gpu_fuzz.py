@@ -136,17 +136,19 @@ def test_other_physical_parameters(rpl):
                            allowance=PU.softmin_allowance(ref["S_a"][e], ref["S_b"][e], duh[e]))
 
 
-def test_random_configurations_regression():
+@pytest.mark.parametrize("predictor_type,extra", [("ODE_v0", []), ("ODE", ["--probes"])])
+def test_random_configurations_regression(predictor_type, extra):
     """A fixed cut of tools/dev/shape_fuzz.py (60 random shape / substep / period / cost / glue / noise-source / lane-
     mapping / math-mode configurations, seed 33) must stay inside the parity rules: ragged rollout counts around wave and
-    block sizes, horizons that are not multiples of the knot period or of the tile quads, every glue flag."""
+    block sizes, horizons that are not multiples of the knot period or of the tile quads, every glue flag - for both in-tree
+    ODE predictors (predictor_ODE with the allowance of the full-size tests: the envelope of the reference's realisations)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "shape_fuzz.py"), "--n", "60", "--seed", "33"],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "shape_fuzz.py"), "--n", "60", "--seed", "33",
+                        "--predictor-type", predictor_type] + extra, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     summary = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert summary == {"configurations": 60, "passed": 60, "failed": 0, "seed": 33}, r.stdout[-3000:]
+    assert summary == {"configurations": 60, "passed": 60, "failed": 0, "seed": 33, "predictor_type": predictor_type}, r.stdout[-3000:]
