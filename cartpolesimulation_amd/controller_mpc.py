@@ -120,6 +120,9 @@ class controller_mpc(template_controller):
         cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
             "quadratic_boundary_grad_minimal"
         self.controller_logging = controller_logging
+        spec = predictor_specification or cfg.pop("predictor_specification", None)
+        if spec is None and cfg.get("predictor_type") == "ODE":      # (a checkout's config_controllers.yml:3 read by config_root)
+            spec = "ODE"
         self.cost_function_wrapper = CostFunctionWrapper()
         self.cost_function_wrapper.configure(variable_parameters=self.variable_parameters,
                                              environment_name=self.environment_name,
@@ -129,7 +132,7 @@ class controller_mpc(template_controller):
                                        control_limits=self.control_limits, optimizer_logging=controller_logging,
                                        phys=self.phys, device=self.device, num_envs=self.num_envs,
                                        variable_parameters=self.variable_parameters, **cfg)
-        self.optimizer.configure()
+        self.optimizer.configure(predictor_specification=spec)
 
     def step(self, s, time=None, updated_attributes=None):
         self.update_attributes(updated_attributes)

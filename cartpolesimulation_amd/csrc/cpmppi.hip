@@ -690,8 +690,12 @@ struct GradPtrs {
   float* ckpt; float* S_out; float* grad; uint32_t E;
 };
 
-template <int COST>
+template <int COST, int INTEG = PREDICTOR_ODE_V0>
 __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, const GradPtrs a) {
+  auto forward_substep = [&](State<float>& s, float uK, const EnvConst& e) __attribute__((always_inline)) {
+    if constexpr (INTEG == PREDICTOR_ODE) substep_cromer_plain(s, uK, p.t_step, p, e);
+    else substep_fast<float>(s, uK, p.t_step, p, e, p.THL);
+  };
   extern __shared__ float sub_states[];            // [S][6][BLOCK]
   const uint32_t tid = threadIdx.x;
   const size_t B = (size_t)a.E * p.N;
@@ -722,7 +726,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     else cost += stage_qbg<float, true>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
     u_before = ur;
     const float uK = ur * ec.uK_scale;
-    for (uint32_t s = 0; s < S; ++s) substep_fast<float>(st, uK, t, p, ec, p.THL);
+    for (uint32_t s = 0; s < S; ++s) forward_substep(st, uK, ec);
     cosang = st.c;
   }
   const float term = (COST == COST_DEFAULT) ? terminal_indicator<float>(p, st.th, st.x, x_t) : 0.0f;
@@ -743,13 +747,13 @@ __global__ __launch_bounds__(BLOCK) void rollout_grad_kernel(const Params p, con
     for (uint32_t i = 0; i < S; ++i) {
       float* __restrict__ d = my + (size_t)i * 6 * BLOCK;
       d[0] = s.th; d[BLOCK] = s.w; d[2 * BLOCK] = s.c; d[3 * BLOCK] = s.s; d[4 * BLOCK] = s.x; d[5 * BLOCK] = s.v;
-      substep_fast<float>(s, uK, t, p, ec, p.THL);
+      forward_substep(s, uK, ec);
     }
     float guK = 0.0f;
     for (uint32_t i = S; i-- > 0;) {
       const float* __restrict__ d = my + (size_t)i * 6 * BLOCK;
       const State<float> si{d[0], d[BLOCK], d[2 * BLOCK], d[3 * BLOCK], d[4 * BLOCK], d[5 * BLOCK]};
-      substep_reverse(si, uK, t, p, ec, lam, guK);
+      substep_reverse<(INTEG == PREDICTOR_ODE)>(si, uK, t, p, ec, lam, guK);
     }
     // stage k: its own state and control
     const float ca = (k == 0) ? cos0 : st0.c, sa = (k == 0) ? sin0 : st0.s;
@@ -1020,6 +1024,12 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_DEFAULT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_QBG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_QBGM, PREDICTOR_ODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_DEFAULT, PREDICTOR_ODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_grad_kernel<COST_QBG, PREDICTOR_ODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLER_LDS_MAX);
   // the CEM top-k sorts N (padded to a power of two) 8-byte records in LDS: 128 KB at N = 16384
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cem_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1634,8 +1644,6 @@ int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, cons
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: bad argument");
   if (h->prm.cost_id == CPMPPI_COST_LEGACY)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: plugin costs only");
-  if (h->cfg.ode_predictor != CPMPPI_ODE_V0)
-    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for predictor_ODE_v0 (cpmppi_config.ode_predictor = CPMPPI_ODE_V0)");
   if (h->cfg.math_mode != CPMPPI_MATH_FAST)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for the FAST arithmetic");
   const size_t lds = (size_t)h->cfg.S * 6 * BLOCK * sizeof(float);
@@ -1652,10 +1660,18 @@ int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, cons
   GradPtrs a{s0, inputs, target_position, target_equilibrium, L, previous_input, h->grad_ckpt, S_out, grad_out, E};
   const dim3 grid((unsigned)((B + BLOCK - 1) / BLOCK));
   hipStream_t st = (hipStream_t)stream;
-  switch (h->prm.cost_id) {
-    case CPMPPI_COST_QBGM: hipLaunchKernelGGL(rollout_grad_kernel<COST_QBGM>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
-    case CPMPPI_COST_DEFAULT: hipLaunchKernelGGL(rollout_grad_kernel<COST_DEFAULT>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
-    default: hipLaunchKernelGGL(rollout_grad_kernel<COST_QBG>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+  if (h->cfg.ode_predictor == CPMPPI_ODE_CROMER) {
+    switch (h->prm.cost_id) {
+      case CPMPPI_COST_QBGM: hipLaunchKernelGGL((rollout_grad_kernel<COST_QBGM, PREDICTOR_ODE>), grid, dim3(BLOCK), lds, st, h->prm, a); break;
+      case CPMPPI_COST_DEFAULT: hipLaunchKernelGGL((rollout_grad_kernel<COST_DEFAULT, PREDICTOR_ODE>), grid, dim3(BLOCK), lds, st, h->prm, a); break;
+      default: hipLaunchKernelGGL((rollout_grad_kernel<COST_QBG, PREDICTOR_ODE>), grid, dim3(BLOCK), lds, st, h->prm, a); break;
+    }
+  } else {
+    switch (h->prm.cost_id) {
+      case CPMPPI_COST_QBGM: hipLaunchKernelGGL(rollout_grad_kernel<COST_QBGM>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+      case CPMPPI_COST_DEFAULT: hipLaunchKernelGGL(rollout_grad_kernel<COST_DEFAULT>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+      default: hipLaunchKernelGGL(rollout_grad_kernel<COST_QBG>, grid, dim3(BLOCK), lds, st, h->prm, a); break;
+    }
   }
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;

@@ -19,8 +19,23 @@ struct Adjoint {
   float th, w, x, v;          // dJ/d(angle, angleD, position, positionD); angle_cos / angle_sin are functions of angle
 };
 
+// Forward substep of predictor_ODE (Euler-Cromer, no bounce) with the exact wrap + polynomial sincos on EVERY substep - the
+// plain form the adjoint differentiates (the rollout kernel's control_step_cromer_fast advances (cos, sin) by rotation inside a
+// control step: the same function of the state to float32 rounding).
+__device__ __forceinline__ void substep_cromer_plain(State<float>& st, float uK, float t, const Params& p, const EnvConst& e) {
+  float th1, w1, x1, v1, aDD;
+  ode_cromer_fast<float>(st, uK, t, p, e, th1, w1, x1, v1, aDD);
+  th1 = wrap_rint<float>(th1);
+  st.th = th1; st.w = w1; st.x = x1; st.v = v1;
+  sincos_pi_half<float>(th1, st.s, st.c);
+}
+
 // Reverse of one FAST substep.  `st` = state at the START of the substep, `uK` = (k+1) u; `lam` enters as the adjoint of
 // the substep's END state and leaves as the adjoint of its START state; `guK` accumulates dJ/d(uK).
+// CROMER: predictor_ODE's substep - w1 = w + aDD t, v1 = v + xDD t, th1 = th + w1 t, x1 = x + v1 t (cartpole_equations.py:
+// 293-304), no bounce, derivative 1 through atan2(sin, cos): the adjoints of w1 / v1 first collect t times those of th1 / x1,
+// and the angle and the position no longer feed the OLD velocities forward.
+template <bool CROMER = false>
 __device__ __forceinline__ void substep_reverse(const State<float>& st, float uK, float t, const Params& p,
                                                 const EnvConst& e, Adjoint& lam, float& guK) {
   const float c = st.c, s = st.s, w = st.w, v = st.v;
@@ -40,8 +55,12 @@ __device__ __forceinline__ void substep_reverse(const State<float>& st, float uK
   (void)w1;
 
   float lth = lam.th, lw = lam.w, lx = lam.x, lv = lam.v;
+  if constexpr (CROMER) {
+    lw = __builtin_fmaf(lth, t, lw);
+    lv = __builtin_fmaf(lx, t, lv);
+  }
   // ---- edge bounce (taken branch): w2 = w1 - 2 v1 cos(th1) / (L/2); th2 = th1 + w2 t; v2 = -v1; x2 = x1 + v2 t
-  if (__builtin_fabsf(x1) >= p.THL) {
+  if (!CROMER && __builtin_fabsf(x1) >= p.THL) {
     float sb, cb;
     sincosf(th1, &sb, &cb);
     const float lw2 = __builtin_fmaf(lth, t, lw);
@@ -63,9 +82,9 @@ __device__ __forceinline__ void substep_reverse(const State<float>& st, float uK
   const float da_dv = ic * dx_dv;
   const float da_du = ic * dx_du;
   lam.th = __builtin_fmaf(t, __builtin_fmaf(lw, da_dth, lv * dx_dth), lth);
-  lam.w = __builtin_fmaf(t, lth + __builtin_fmaf(lw, da_dw, lv * dx_dw), lw);
+  lam.w = __builtin_fmaf(t, (CROMER ? 0.0f : lth) + __builtin_fmaf(lw, da_dw, lv * dx_dw), lw);
   lam.x = lx;
-  lam.v = __builtin_fmaf(t, lx + __builtin_fmaf(lw, da_dv, lv * dx_dv), lv);
+  lam.v = __builtin_fmaf(t, (CROMER ? 0.0f : lx) + __builtin_fmaf(lw, da_dv, lv * dx_dv), lv);
   guK = __builtin_fmaf(t, __builtin_fmaf(lw, da_du, lv * dx_du), guK);
 }
 

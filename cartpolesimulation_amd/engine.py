@@ -118,6 +118,20 @@ class MPPIEngine:
         arr = (C.c_float * len(w))(*w)
         self._check(self.lib.cpmppi_set_cost_weights(self._h, cost_id, arr, len(w)))
 
+    def apply_pole_mass_of(self, variable_parameters):
+        """predictor_ODE takes the pole's mass from variable_parameters at every step (predictors_customization.py:55-58;
+        the simulator sends 'm_pole' with every controller.step, CartPole/__init__.py:516); predictor_ODE_v0 does not."""
+        if self.mppi.predictor_type != "ODE":
+            return
+        m = getattr(variable_parameters, "m_pole", None)
+        if m is None or m is getattr(self, "_m_pole_obj", None):
+            return
+        self._m_pole_obj = m
+        a = np.asarray(m.cpu() if hasattr(m, "cpu") else m, dtype=np.float32).reshape(-1)
+        if a.size == 0 or not np.all(a == a[0]):
+            raise NotImplementedError(f"m_pole must be the same for every env of a handle (got {a[:4]}...)")
+        self.set_pole_mass(float(a[0]))
+
     def set_pole_mass(self, m_pole):
         """The pole mass every later call computes with (predictor_ODE: variable_parameters.m_pole).  No-op when unchanged."""
         m = float(np.float32(m_pole))

@@ -61,10 +61,10 @@ class optimizer_cem:
             self.num_envs = int(num_envs)
         spec = None if predictor_specification is None else str(predictor_specification).split(":")[0]
         if spec in ("ODE", "ODE_default"):        # next_state_predictor_ODE: Euler-Cromer, no bounce (config_controllers.yml:3)
-            if type(self)._refine is not optimizer_cem._refine:
-                raise NotImplementedError(f"{self.optimizer_name}: the adjoint kernel differentiates the ODE_v0 predictor only")
             self.cfg.predictor_type = "ODE"
-        elif spec not in (None, "ODE_v0", "ODE_v0_default"):
+        elif spec in ("ODE_v0", "ODE_v0_default"):
+            self.cfg.predictor_type = "ODE_v0"
+        elif spec is not None:
             raise NotImplementedError("the sampling optimizers run on the ODE_v0 and ODE predictors")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         self.optimizer_reset()
@@ -84,6 +84,7 @@ class optimizer_cem:
         if self.engine is None:
             self.configure()
         eng = self.engine
+        eng.apply_pole_mass_of(self.variable_parameters)
         s_t = eng.tensor(s)
         single = s_t.dim() == 1
         s_t = s_t.reshape(-1, 6)
@@ -133,6 +134,7 @@ class optimizer_cem_gmm(optimizer_cem):
         if self.engine is None:
             self.configure()
         eng = self.engine
+        eng.apply_pole_mass_of(self.variable_parameters)
         s_t = eng.tensor(s)
         single = s_t.dim() == 1
         s_t = s_t.reshape(-1, 6)
@@ -223,6 +225,7 @@ class optimizer_random_action(optimizer_cem):
         if self.engine is None:
             self.configure()
         eng = self.engine
+        eng.apply_pole_mass_of(self.variable_parameters)
         s_t = eng.tensor(s)
         single = s_t.dim() == 1
         s_t = s_t.reshape(-1, 6)

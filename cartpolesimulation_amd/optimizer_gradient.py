@@ -75,8 +75,13 @@ class _GradientBase:
             self.cfg.SQRTRHOINV = s * math.sqrt(float(dt))
         if num_envs is not None:
             self.num_envs = int(num_envs)
-        if predictor_specification not in (None, "ODE_v0", "ODE_v0_default"):     # "ODE" is a different integrator
-            raise NotImplementedError("the adjoint kernel differentiates the ODE_v0 predictor only")
+        spec = None if predictor_specification is None else str(predictor_specification).split(":")[0]
+        if spec in ("ODE", "ODE_default"):      # next_state_predictor_ODE (Euler-Cromer, no bounce): the shipped config_controllers.yml:2-3
+            self.cfg.predictor_type = "ODE"     # pairs it with `optimizer: rpgd`; the adjoint kernel has that substep's reverse too
+        elif spec in ("ODE_v0", "ODE_v0_default"):
+            self.cfg.predictor_type = "ODE_v0"
+        elif spec is not None:
+            raise NotImplementedError("the adjoint kernel differentiates the ODE_v0 and ODE predictors")
         self.engine = MPPIEngine(self.num_envs, self.cfg, self.phys, device=self.device)
         self.optimizer_reset()
 
@@ -100,6 +105,7 @@ class _GradientBase:
     # -- one control step ----------------------------------------------------------------------------------------
     def _targets(self, E):
         vp = self.variable_parameters
+        self.engine.apply_pole_mass_of(vp)
         t = self.engine.tensor      # (uploaded once per control step; every gradient / cost launch below reuses the tensors)
         return (t(_vec(getattr(vp, "target_position", None), E, 0.0)), t(_vec(getattr(vp, "target_equilibrium", None), E, 1.0)),
                 t(_vec(getattr(vp, "L", None), E, self.phys.L)))

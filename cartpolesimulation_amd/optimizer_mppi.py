@@ -26,14 +26,6 @@ def _vec(x, E, default):
     return np.full(E, x[0], dtype=np.float32) if x.size == 1 else x.astype(np.float32)
 
 
-def _uniform_scalar(x, name):
-    """A per-handle attribute given as a scalar or as an array of equal values (it is one kernel argument for all envs)."""
-    a = np.asarray(x.cpu() if hasattr(x, "cpu") else x, dtype=np.float32).reshape(-1)
-    if a.size == 0 or not np.all(a == a[0]):
-        raise NotImplementedError(f"{name} must be the same for every env of a handle (got {a[:4]}...)")
-    return float(a[0])
-
-
 class optimizer_mppi:
     optimizer_name = "mppi"
 
@@ -96,7 +88,6 @@ class optimizer_mppi:
         self._hblock = self._hview = self._dblock = self._h2d_done = self._hq = self._q_done = None
         self._prepared = self._prepared_key = None     # pinned staging of the host seam
         self._fast = None                              # single-env host call: preallocated arrays + argument objects
-        self._m_pole_seen = None                       # predictor_ODE: the variable_parameters.m_pole object applied last
 
     # ------------------------------------------------------------------
     def configure(self, dt=None, predictor_specification=None, num_envs=None, **kwargs):
@@ -233,12 +224,7 @@ class optimizer_mppi:
             self.configure()
         eng = self.engine
         if self.cfg.predictor_type == "ODE":
-            # next_state_predictor_ODE takes the pole's mass from variable_parameters at every step
-            # (predictors_customization.py:55-58; the simulator sends 'm_pole' with every call, CartPole/__init__.py:516)
-            m = getattr(self.variable_parameters, "m_pole", None)
-            if m is not None and m is not self._m_pole_seen:
-                self._m_pole_seen = m
-                eng.set_pole_mass(_uniform_scalar(m, "m_pole"))
+            eng.apply_pole_mass_of(self.variable_parameters)      # (predictors_customization.py:55-58)
         host_state = not hasattr(s, "is_cuda")
         if (host_state and self.u_nom.is_cuda and self.noise == "philox" and self.h is None and not as_tensor
                 and not self.optimizer_logging and not self.calculate_optimal_trajectory

@@ -26,7 +26,7 @@ def _engine(horizon, dt, intermediate_steps, phys, math_mode, device, predictor_
 def _apply_pole_mass(eng, variable_parameters):
     """predictor_ODE reads variable_parameters.m_pole at every call (predictors_customization.py:55-58)."""
     m = getattr(variable_parameters, "m_pole", None) if variable_parameters is not None else None
-    if m is not None:
+    if m is not None:                      # (by value: the attribute may be mutated in place between calls)
         eng.set_pole_mass(float(np.asarray(m.cpu() if hasattr(m, "cpu") else m, dtype=np.float32).reshape(-1)[0]))
 
 

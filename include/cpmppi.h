@@ -83,9 +83,9 @@ enum { CPMPPI_ODE_V0 = 0,        /* predictor_ODE_v0 (predictors_customization_v
                                     simultaneous forward Euler, elastic edge bounce, fmod angle wrap - the default */
        CPMPPI_ODE_CROMER = 1 };  /* predictor_ODE, predictor_specification "ODE" - what the shipped config_controllers.yml:3,14
                                     names (predictors_customization.py:25-69 -> cartpole_equations.py:181-259,293-308):
-                                    Euler-Cromer, NO edge bounce, angle = atan2(sin, cos).  Serves cpmppi_step*,
-                                    cpmppi_predict, cpmppi_rollout_cost and the CEM kernels; cpmppi_rollout_cost_grad
-                                    (the adjoint) is built for CPMPPI_ODE_V0 only and refuses a handle of this kind */
+                                    Euler-Cromer, NO edge bounce, angle = atan2(sin, cos).  Serves every entry point
+                                    that integrates the ODE: cpmppi_step*, cpmppi_predict, cpmppi_rollout_cost (the CEM
+                                    family) and cpmppi_rollout_cost_grad (the adjoint of this substep) */
 enum { CPMPPI_NOISE_DELTA_U = 0, /* noise = delta_u[E,N,H]  (reference layout, rollout-major)              */
        CPMPPI_NOISE_KNOTS = 1,   /* noise = knots[E,N,P], P = ceil(H/period)+1; interpolated in-kernel       */
        CPMPPI_NOISE_PHILOX = 2,  /* knots generated in-kernel from (seed, offset): no perturbation buffer   */

@@ -37,9 +37,10 @@ def _ode(ca, sa, angleD, positionD, u, L, p):
     return angleDD, positionDD
 
 
-def predict_core(s0, Q, dt=0.02, S=10, L=None, p=O.DEFAULT_PARAMS):
+def predict_core(s0, Q, dt=0.02, S=10, L=None, p=O.DEFAULT_PARAMS, integrator="ODE_v0"):
     """s0[6] or [N,6], Q[N,H] (torch float64, Q may require grad) -> list of H+1 states, each a 6-tuple of [N] tensors
-    (angle, angleD, cos, sin, position, positionD)."""
+    (angle, angleD, cos, sin, position, positionD).  integrator "ODE": predictor_ODE (oracle_np.fine_integration_cromer:
+    Euler-Cromer, no edge bounce, angle = atan2(sin, cos) - cartpole_equations.py:229-249,293-308)."""
     N, H = Q.shape
     s0 = torch.as_tensor(np.asarray(s0, dtype=np.float64)).reshape(-1, 6).expand(N, 6)
     L = float(p.L) if L is None else float(L)
@@ -52,6 +53,12 @@ def predict_core(s0, Q, dt=0.02, S=10, L=None, p=O.DEFAULT_PARAMS):
         u = float(p.u_max) * Q[:, k]
         for _ in range(S):
             aDD, xDD = _ode(ca, sa, ad, xd, u, L, p)
+            if integrator == "ODE":
+                ad, xd = ad + aDD * t, xd + xDD * t
+                a, x = a + ad * t, x + xd * t
+                ca, sa = torch.cos(a), torch.sin(a)
+                a = torch.atan2(sa, ca)
+                continue
             a, ad, x, xd = a + ad * t, ad + aDD * t, x + xd * t, xd + xDD * t
             cb = torch.cos(a)
             hit = (x >= THL) | (-x >= THL)
@@ -122,12 +129,13 @@ def trajectory_cost(cost_id, traj, inputs, target_position, target_equilibrium, 
 
 
 def cost_and_grad(cost_id, s0, Q, target_position, target_equilibrium, L=None, dt=0.02, S=10, horizon_reduce="sum",
-                  previous_input=0.0, qbg_weights=None, clip=(-1.0, 1.0), p=O.DEFAULT_PARAMS, c=O.DEFAULT_COST):
+                  previous_input=0.0, qbg_weights=None, clip=(-1.0, 1.0), p=O.DEFAULT_PARAMS, c=O.DEFAULT_COST,
+                  integrator="ODE_v0"):
     """numpy in / numpy out: (cost[N], grad[N,H]) of the trajectory cost w.r.t. the inputs Q[N,H], float64.
     ``clip``: the optimizer-style clip of the applied control (gradient zero where clipped); None = no clip."""
     Qt = torch.tensor(np.asarray(Q, dtype=np.float64), requires_grad=True)
     Qa = Qt.clamp(clip[0], clip[1]) if clip is not None else Qt
-    traj = predict_core(s0, Qa, dt, S, L, p)
+    traj = predict_core(s0, Qa, dt, S, L, p, integrator)
     J = trajectory_cost(cost_id, traj, Qa, target_position, target_equilibrium, horizon_reduce, previous_input, qbg_weights,
                         p, c)
     (g,) = torch.autograd.grad(J.sum(), Qt)

@@ -220,8 +220,8 @@ def test_latency_and_throughput_builds_agree_bit_for_bit():
 
 def test_seams_with_the_shipped_predictor_specification(g):
     """`predictor_specification: "ODE"` (config_controllers.yml:3,14) through the reference-shaped classes: PredictorWrapper's
-    trajectories equal the engine's with predictor_type "ODE" and differ from ODE_v0's; controller_mpc('mppi') and the legacy
-    controller configure and step with it; the adjoint (gradient optimizers) refuses it."""
+    trajectories equal the engine's with predictor_type "ODE" and differ from ODE_v0's; controller_mpc('mppi') and the shipped
+    pairing controller_mpc('rpgd') configure and step with it."""
     from cartpolesimulation_amd.predictors import PredictorWrapper, next_state_predictor_ODE, predictor_ODE
     from cartpolesimulation_amd.controller_mpc import controller_mpc
     rng = Generator(SFC64(2))
@@ -262,7 +262,16 @@ def test_seams_with_the_shipped_predictor_specification(g):
     assert ctrl2.optimizer.engine._m_pole == float(np.float32(0.2)) and np.isfinite(q2).all() and not np.array_equal(q, q2)
     q3 = ctrl2.step(s0, 0.02, {"target_position": 0.02, "m_pole": 0.087})
     assert ctrl2.optimizer.engine._m_pole == float(np.float32(0.087)) and np.isfinite(q3).all()
+    # the shipped pairing: `optimizer: rpgd` on this predictor (config_controllers.yml:2-3) - the adjoint's forward value is the
+    # cost-only launch's (the gradient itself: tests/test_gpu_grad.py against autograd of the float64 restatement)
     eng = engine(1, 64, 8)
-    with pytest.raises(RuntimeError, match="predictor_ODE_v0"):
-        eng.rollout_cost_grad(s0[None], np.zeros((1, 64, 8), f32), 0.0, 1.0)
+    Qg = rng.uniform(-1, 1, (1, 64, 8)).astype(f32)
+    Sg, G = eng.rollout_cost_grad(s0[None], Qg, 0.0, 1.0)
+    np.testing.assert_allclose(Sg.cpu().numpy(), eng.rollout_cost(s0[None], Qg, 0.0, 1.0).cpu().numpy(), rtol=2e-4)
+    assert np.isfinite(G.cpu().numpy()).all() and np.abs(G.cpu().numpy()).max() > 0
     eng.close()
+    ctrl3 = controller_mpc(environment_name="CartPole", initial_environment_attributes={"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
+                           control_limits=(np.array([-1.0]), np.array([1.0])))
+    ctrl3.configure(optimizer_name="rpgd", predictor_specification="ODE", seed=3)
+    q4 = ctrl3.step(s0, 0.0, {"target_position": 0.02, "m_pole": 0.087})
+    assert np.isfinite(q4).all() and ctrl3.optimizer.cfg.predictor_type == "ODE"
