@@ -53,9 +53,12 @@ class controller_mpc(template_controller):
         if environment_name != "CartPole":
             raise ValueError("only the CartPole environment is built")
         self.config_optimizer = dict(config or {})     # overrides of config_optimizers.yml:87-97 + glue flags
+        self._user_config = dict(config or {})
+        self._yaml = None                              # a checkout's YAML files (config_root): sections of the other optimizers
         if config_root is not None:                    # read a CartPoleSimulation checkout's YAML files
             from .configs import as_dict, load_reference_yaml, mppi_config_from_yaml
             yaml_phys, cfgs = load_reference_yaml(config_root)
+            self._yaml = cfgs
             base = as_dict(mppi_config_from_yaml(cfgs))
             base.update(self.config_optimizer)
             self.config_optimizer = base
@@ -70,6 +73,10 @@ class controller_mpc(template_controller):
 
     def configure(self, optimizer_name=None, predictor_specification=None, cost_function_specification=None,
                   controller_logging=False, **kwargs):
+        # the reference's default is the checkout's config_controllers.yml `mpc: optimizer:` (shipped: rpgd); without a checkout
+        # this package's is the north-star path
+        if optimizer_name is None and self._yaml is not None:
+            optimizer_name = self._yaml["controllers"]["mpc"].get("optimizer")
         optimizer_name = optimizer_name or "mppi"
         others = {"cem": optimizer_cem, "cem-tf": optimizer_cem, "cem-gmm": optimizer_cem_gmm, "cem-gmm-tf": optimizer_cem_gmm,
                   "gradient": optimizer_gradient,
@@ -115,7 +122,20 @@ class controller_mpc(template_controller):
         self.optimizer.configure(dt=opt_probe.mpc_timestep, predictor_specification=spec)
 
     def _configure_other(self, cls, predictor_specification, cost_function_specification, controller_logging, **kwargs):
-        cfg = dict(self.config_optimizer)
+        if self._yaml is not None:
+            # with a checkout: THIS optimizer's section of config_optimizers.yml (the class's constructor keywords are its keys),
+            # the controller-level keys of config_controllers.yml `mpc:`, then the caller's overrides
+            sections = self._yaml["optimizers"]
+            name = cls.optimizer_name
+            cfg = dict(sections.get(name) or sections.get(name + "-tf") or {})
+            ctrl = self._yaml["controllers"]["mpc"]
+            cost_name = ctrl.get("cost_function_specification") or self._yaml["cost"]["cost_function_name_default"]
+            cfg.update(cost_function_specification=cost_name, cost_weights=dict(self._yaml["cost"]["CartPole"].get(cost_name, {})),
+                       predictor_type=self.config_optimizer.get("predictor_type", "ODE_v0"),
+                       intermediate_steps=self.config_optimizer.get("intermediate_steps", 10))
+            cfg.update(self._user_config)
+        else:
+            cfg = dict(self.config_optimizer)
         cfg.update(kwargs)
         cost_name = cost_function_specification or cfg.pop("cost_function_specification", None) or \
             "quadratic_boundary_grad_minimal"

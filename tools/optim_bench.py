@@ -2,7 +2,8 @@
 """Timing of one controller step per optimizer section of config_optimizers.yml at its shipped hyper-parameters, through
 the controller seam (controller_mpc.configure(name) / .step), for E problem instances at once (GPU box).
 
-  python tools/optim_bench.py [--envs 64] [--steps 30]
+  python tools/optim_bench.py [--envs 64] [--steps 30] [--predictor-specification ODE]
+(ODE = the shipped config_controllers.yml's predictor: Euler-Cromer, no edge bounce; default ODE_v0)
 Prints one JSON object per optimizer: ms per controller step (all envs), candidate plans evaluated per second.
 """
 import argparse
@@ -22,6 +23,7 @@ from oracle import oracle_np as O  # noqa: E402  (initial states only)
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=64)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--predictor-specification", default="ODE_v0")
 args = ap.parse_args()
 E = args.envs
 rng = np.random.Generator(np.random.SFC64(3))
@@ -30,7 +32,7 @@ s_host = np.stack([O.create_cartpole_state(rng.uniform(-0.3, 0.3), rng.uniform(-
 for name in ("mppi", "cem-tf", "cem-gmm-tf", "cem-naive-grad-tf", "cem-grad-bharadhwaj-tf", "gradient-tf", "rpgd", "random-action-tf"):
     ctrl = controller_mpc("CartPole", {"target_position": 0.0, "target_equilibrium": 1.0, "L": 0.395},
                           control_limits=([-1.0], [1.0]), num_envs=E, config=dict(seed=1))
-    ctrl.configure(name)
+    ctrl.configure(name, predictor_specification=args.predictor_specification)
     opt = ctrl.optimizer
     s = opt.engine.tensor(s_host)
     for _ in range(3):
@@ -41,7 +43,7 @@ for name in ("mppi", "cem-tf", "cem-gmm-tf", "cem-naive-grad-tf", "cem-grad-bhar
         ctrl.step(s, 0.0, {})
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    rec = {"optimizer": name, "envs": E, "num_rollouts": int(getattr(opt, "num_rollouts", 0)), "mpc_horizon": int(getattr(opt, "mpc_horizon", 0)),
+    rec = {"optimizer": name, "predictor": opt.cfg.predictor_type, "envs": E, "num_rollouts": int(getattr(opt, "num_rollouts", 0)), "mpc_horizon": int(getattr(opt, "mpc_horizon", 0)),
            "ms_per_controller_step": round(dt * 1e3, 3)}
     for k in ("outer_its", "cem_outer_it", "gradient_steps", "opt_iters", "num_iterations"):
         if hasattr(opt, k):
