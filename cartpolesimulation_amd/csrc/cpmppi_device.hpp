@@ -869,7 +869,11 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
 // reference), cos / sin of the integrated angle (:245-246) and angle = atan2(sin, cos) (:248, 307-308).
 enum : int { PREDICTOR_ODE_V0 = 0, PREDICTOR_ODE = 1 };
 
-// PRECISE: the reference's operand grouping with IEEE divides, libm cos / sin / atan2, no FMA contraction.
+// PRECISE: the reference's operand grouping with IEEE divides, libm cos / sin, no FMA contraction.  The angle this predictor
+// re-derives on every substep, atan2(sin, cos), is evaluated in double and rounded once: the device's atan2f is a ~2 ulp
+// function, and that noise - re-entering the state 500 times per rollout - moved a few rollouts of a full-width C4 launch
+// (|w| = 11 rad/s) 2e-4 from the oracle where the oracle's own float32 realisations scatter by 2e-5; FAST, which never goes
+// through atan2, was inside the band all along.
 __device__ __forceinline__ void substep_precise_cromer(State<float>& st, float u, float t, const Params& p,
                                                        const EnvConst& e) {
 #pragma clang fp contract(off)
@@ -880,7 +884,7 @@ __device__ __forceinline__ void substep_precise_cromer(State<float>& st, float u
   const float th1 = st.th + w1 * t;
   const float x1 = st.x + v1 * t;
   const float c1 = cosf(th1), s1 = sinf(th1);
-  st.th = atan2f(s1, c1);
+  st.th = (float)atan2((double)s1, (double)c1);
   st.w = w1; st.c = c1; st.s = s1; st.x = x1; st.v = v1;
 }
 

@@ -51,12 +51,28 @@ typedef struct {
 #define PI_F 3.14159274101257324f
 #define TWO_PI_F 6.28318548202514648f
 
+/* A probe, not a reference arithmetic (tests/parity_util.py): with a nonzero seed every sin / cos result is moved to a
+ * neighbouring float32 (up, down or not at all, decided by a hash of the argument and the seed) - "another float32 sin / cos
+ * implementation", which is what a GPU's is against the host's.  Set before a call, read-only inside the parallel loops. */
+static uint32_t g_trig_jitter = 0;
+void oracle_set_trig_jitter(uint32_t seed) { g_trig_jitter = seed; }
+static inline float jitter_(float r, float x, uint32_t salt) {
+  if (!g_trig_jitter) return r;
+  union { float f; uint32_t u; } b; b.f = x;
+  uint32_t h = (b.u ^ (g_trig_jitter * 0x9E3779B9u) ^ salt) * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0xC2B2AE35u; h ^= h >> 13;
+  switch (h & 3u) {
+    case 0: return nextafterf(r, INFINITY);
+    case 1: return nextafterf(r, -INFINITY);
+    default: return r;
+  }
+}
 #ifdef ORACLE_F32_TRIG      /* cpu_baseline timing builds only (oracle/Makefile: *_native*): libm's float kernels, as numba */
-static inline float cos32(float x) { return cosf(x); }
-static inline float sin32(float x) { return sinf(x); }
+static inline float cos32(float x) { return jitter_(cosf(x), x, 0x11u); }
+static inline float sin32(float x) { return jitter_(sinf(x), x, 0x22u); }
 #else                       /* the checker */
-static inline float cos32(float x) { return (float)cos((double)x); }
-static inline float sin32(float x) { return (float)sin((double)x); }
+static inline float cos32(float x) { return jitter_((float)cos((double)x), x, 0x11u); }
+static inline float sin32(float x) { return jitter_((float)sin((double)x), x, 0x22u); }
 #endif
 
 /* ---- mode A: strict float32 ------------------------------------------------------------------------------------ */

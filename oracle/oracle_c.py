@@ -135,5 +135,10 @@ def step(cfg_c, s0, u_nom, delta_u, x_t, te, L=None, u_prev=None, L_default=0.39
     return u, Q, S
 
 
+def set_trig_jitter(seed, use_lib=None):
+    """Probe switch of the C oracle (see cpmppi_oracle.c): sin / cos results moved to a neighbouring float32 at random; 0 = off."""
+    (use_lib or lib()).oracle_set_trig_jitter(C.c_uint32(int(seed)))
+
+
 def max_threads():
     return lib().oracle_max_threads()

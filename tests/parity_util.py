@@ -107,7 +107,7 @@ def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_s
     _check(off, flagged, what, strict)
 
 
-def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None, u_alt=()):
+def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None, u_alt=(), sensitive_gap_scale=1.0):
     """Updated control sequence / Q: 1e-4 absolute (north_star) around the reference's own [A, B] interval.  The soft-min
     update amplifies cost differences by |S| / LBD (costs of ~5e4 at LBD = 100 turn a 1e-5 relative cost difference into
     a 0.5 % weight change), so where the reference's two arithmetic modes themselves disagree on u by more than the
@@ -115,6 +115,8 @@ def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None
     (optional, per control): softmin_allowance(...) of the oracle's costs, for ill-conditioned updates."""
     u, u_a = np.asarray(u, np.float64), np.asarray(u_a, np.float64)
     gap = float(envelope(u_a, u_b, *u_alt).max()) if (u_b is not None or len(u_alt)) else 0.0
+    if gap > atol:          # an update the reference's own realisations disagree on by more than the band: see assert_costs on
+        gap *= sensitive_gap_scale      # why the largest of k samples is widened (predictor_ODE tests; 1.0 elsewhere)
     extra = 0.0 if allowance is None else np.asarray(allowance, np.float64)
     d = np.abs(u - u_a)
     assert np.all(d <= atol + np.maximum(gap, extra)), (f"{what}: max |u - u_ref| = {d.max():.3e} > {atol:g} + oracle allowance "
@@ -185,6 +187,18 @@ def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=N
         if L is not None:                                       # the pole length one ulp longer
             u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=one_up(np.asarray(L, f32)))
             alt_S.append(S_p); alt_u.append(u_p)
+        if getattr(ocfg, "integrator", "ODE_v0") == "ODE":
+            # predictor_ODE: three more, each with every sin / cos result moved to a neighbouring float32 at random - all the
+            # realisations above but mode C share ONE sin / cos implementation, and this predictor feeds sin / cos back into the
+            # ANGLE (atan2) on every substep: found at full-width C3, where four rollouts in 262 144 sat 1.5e-4 from mode A in
+            # FAST and PRECISE alike (3e-5 from each other) while the realisations above scattered by 1e-5
+            try:
+                for seed in (1, 2, 3):
+                    OC.set_trig_jitter(seed)
+                    u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=L)
+                    alt_S.append(S_p); alt_u.append(u_p)
+            finally:
+                OC.set_trig_jitter(0)
         extra = {"S_alt": alt_S, "u_alt": alt_u}
     if ocfg.shift_mode == "repeat_last":
         u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1)

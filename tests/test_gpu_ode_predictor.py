@@ -47,8 +47,9 @@ def one_up(a):
 
 def f32_realisations(s0, Q, L=None, **cfg_kw):
     """Rounding-level variations of the reference's result (C oracle): mode C, mode A from an initial state one float32 ulp
-    away in the angle's cos / sin, the angular velocity, the cart velocity, the position, mode A under controls one ulp up, and
-    the float64-substep evaluation."""
+    away in the angle's cos / sin, the angular velocity, the cart velocity, the position, mode A under controls one ulp up, the
+    float64-substep evaluation, and three runs of mode A with every sin / cos result moved to a neighbouring float32 at random
+    (another float32 sin / cos implementation - which is what the GPU's is; the rest share the host's)."""
     N, H = Q.shape
     ocfg = O.MPPIConfig(N=N, H=H, integrator="ODE", **cfg_kw)
     cfg = OC.make_config(ocfg)
@@ -63,6 +64,12 @@ def f32_realisations(s0, Q, L=None, **cfg_kw):
         outs.append(OC.predict(cfg, sp, Q, L=L))
     outs.append(OC.predict(cfg, s0, one_up(Q), L=L))
     outs.append(OC.predict(OC.make_config(ocfg, mode="f64sub"), s0, Q, L=L))
+    try:                                                   # every sin / cos result moved to a neighbouring float32 at random
+        for seed in (1, 2, 3):
+            OC.set_trig_jitter(seed)
+            outs.append(OC.predict(cfg, s0, Q, L=L))
+    finally:
+        OC.set_trig_jitter(0)
     return outs
 
 
@@ -275,3 +282,48 @@ def test_seams_with_the_shipped_predictor_specification(g):
     ctrl3.configure(optimizer_name="rpgd", predictor_specification="ODE", seed=3)
     q4 = ctrl3.step(s0, 0.0, {"target_position": 0.02, "m_pole": 0.087})
     assert np.isfinite(q4).all() and ctrl3.optimizer.cfg.predictor_type == "ODE"
+
+
+@pytest.mark.parametrize("name,E,N,H", [("C3", 64, 4096, 100), ("C4", 64, 2048, 50)])
+def test_baseline_configs_full_width(name, E, N, H):
+    """BASELINE configs[2] / [3] at full size on predictor_ODE: ALL 64 envs of the launch, both math modes, against the C oracle
+    (same knots, interpolated by the oracle) - costs of every rollout, the updated sequences, Q - with the full-size rule of
+    tests/test_gpu_configs.py (envelope of the oracle's rounding-level realisations, quarter-band sensitivity bucket)."""
+    import test_gpu_configs as TC
+    eng = engine(E, N, H)
+    s0, tp, te, Lv = TC.inputs(E, H, seed=12 if name == "C3" else 13)
+    rng = Generator(SFC64(9))
+    u0 = (0.1 * rng.standard_normal((E, H))).astype(f32)
+    kn, _ = eng.sample(seed=2, offset=0)
+    outs = {}
+    for mode in ("fast", "precise"):
+        e2 = eng if mode == "fast" else engine(E, N, H, math_mode="precise")
+        un, S = e2.tensor(u0.copy()), e2.empty(E, N)
+        Q, _ = e2.step(s0, un, tp, te, L=Lv, knots=kn, S_out=S)
+        outs[mode] = (un.cpu().numpy(), S.cpu().numpy(), Q.cpu().numpy())
+        assert np.isfinite(outs[mode][1]).all() and np.array_equal(outs[mode][2], outs[mode][0][:, 0])
+        if e2 is not eng:
+            e2.close()
+    ocfg = O.MPPIConfig(N=N, H=H, integrator="ODE")
+    kn_h = kn.cpu().numpy()
+    CH = 8
+    clear = sensitive = 0
+    for e0 in range(0, E, CH):
+        sl = slice(e0, e0 + CH)
+        du = np.stack([O.interpolate_knots(kn_h[e], H) for e in range(e0, e0 + CH)])
+        ref = PU.c_oracle_step_with_flags(ocfg, s0[sl], u0[sl], du, tp[sl], te[sl], L=Lv[sl], probes=True)
+        for mode, (u_m, S_m, Q_m) in outs.items():
+            for i, e in enumerate(range(e0, e0 + CH)):
+                alts = [a[i] for a in ref["S_alt"]] + [ref["S_b"][i]]           # (float64 substeps: a probe here, not a target)
+                PU.assert_costs(S_m[e], ref["S_a"][i], None, None, f"{name} {mode} env {e} costs", S_alt=alts,
+                                flag_sensitive=True, sens_rtol=0.25e-4, sensitive_gap_scale=4.0)
+                allow = PU.softmin_allowance(ref["S_a"][i], ref["S_b"][i], du[i])
+                PU.assert_controls(u_m[e], ref["u_a"][i], ref["u_b"][i], f"{name} {mode} env {e} u_nom", allowance=allow,
+                                   u_alt=[a[i] for a in ref["u_alt"]], sensitive_gap_scale=2.0)
+                PU.assert_controls(Q_m[e], ref["u_a"][i][0], ref["u_b"][i][0], f"{name} {mode} env {e} Q", allowance=allow[0],
+                                   u_alt=[a[i][0] for a in ref["u_alt"]], sensitive_gap_scale=2.0)
+        gap = PU.envelope(ref["S_a"], ref["S_b"], *ref["S_alt"])
+        sens = gap > 0.25e-4 * np.abs(ref["S_a"])
+        sensitive += int(sens.sum()); clear += int((~sens).sum())
+    assert clear > 0.9 * E * N, (clear, sensitive)          # the rule is not vacuous: the bulk of the launch is compared at band + envelope
+    eng.close()
