@@ -102,7 +102,7 @@ def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_s
     # sensitive_gap_scale (predictor_ODE tests): `gap` is the LARGEST of k sampled realisations of a chaotic rollout's cost; one
     # more realisation - the kernel's - exceeds the largest of k with probability 1 / (k + 1) (an eighth with the seven of
     # c_oracle_step_with_flags), far above the flagged bucket's 2 % cap, so for the rollouts the oracle itself marks sensitive the
-    # sampled scatter is widened by this factor; every other rollout keeps the plain allowance
+    # sampled scatter is widened by this factor (2 in the predictor_ODE tests); every other rollout keeps the plain allowance
     off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap * np.where(sensitive, sensitive_gap_scale, 1.0)
     _check(off, flagged, what, strict)
 

@@ -23,10 +23,10 @@ ap.add_argument("--n", type=int, default=100)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--probes", action="store_true", help="allowance from the envelope of seven reference realisations + the "
                 "quarter-band sensitivity flag (the rule of the full-size C3 / C4 tests) instead of modes A / B alone; with "
-                "--predictor-type ODE the sampled scatter of the rollouts the oracle marks sensitive is widened 4 x (that "
+                "--predictor-type ODE the sampled scatter of the rollouts the oracle marks sensitive is widened 2 x (that "
                 "predictor re-derives the angle from float32 sin / cos with atan2 on every substep: rounding noise of a few "
                 "1e-7 enters 500 times per rollout, and an eighth realisation exceeds the largest of seven one time in eight)")
-ap.add_argument("--sens-scale", type=float, default=4.0, help="the widening factor above (1 = the plain envelope)")
+ap.add_argument("--sens-scale", type=float, default=2.0, help="the widening factor above (1 = the plain envelope)")
 ap.add_argument("--predictor-type", default="ODE_v0", choices=["ODE_v0", "ODE"], help="which in-tree ODE predictor (ODE: Euler-Cromer, no bounce)")
 args = ap.parse_args()
 rng = np.random.Generator(np.random.SFC64(args.seed))
