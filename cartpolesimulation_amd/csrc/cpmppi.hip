@@ -43,6 +43,7 @@ CPMPPI_MID_BUFFER_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT)
 CPMPPI_ODE_LATENCY_INSTANCES(CPMPPI_DECLARE_ROLLOUT_ODE)
 CPMPPI_ODE_THROUGHPUT_INSTANCES(CPMPPI_DECLARE_ROLLOUT_ODE)
+CPMPPI_ODE_LONE_INSTANCES(CPMPPI_DECLARE_ROLLOUT_ODE)
 }  // namespace cpmppi_k
 
 namespace {
@@ -945,7 +946,9 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32
     // predictor_ODE has no events, hence no mid-size (phased) build: latency build up to one wave per SIMD with one rollout
     // per lane, the throughput build otherwise
     if (math != CPMPPI_MATH_FAST) return launch_rollout_noise<COST, false, 1, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
-    if (rpl == 2) return launch_rollout_noise<COST, true, 2, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
+    if (rpl == 2)
+      return ((uint64_t)grid.x * WAVES <= 1024ull) ? launch_rollout_noise<COST, true, 2, 3, PREDICTOR_ODE>(noise, grid, lds, s, p, a)
+                                                   : launch_rollout_noise<COST, true, 2, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
     return ((uint64_t)grid.x * BLOCK <= 65536ull) ? launch_rollout_noise<COST, true, 1, 0, PREDICTOR_ODE>(noise, grid, lds, s, p, a)
                                                   : launch_rollout_noise<COST, true, 1, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
   }

@@ -234,11 +234,12 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
 // cpmppi_device.hpp).  The second has no events, hence no phased loop: it is built in the latency and throughput forms only.
 template <int COST, bool FAST, int NOISE, int R, int VARIANT_, int INTEG = PREDICTOR_ODE_V0>
 __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(const Params p, const StepPtrs a) {
-  static_assert(INTEG == PREDICTOR_ODE_V0 || VARIANT_ <= 1, "predictor_ODE: latency / throughput builds only");
+  static_assert(INTEG == PREDICTOR_ODE_V0 || VARIANT_ != 2, "predictor_ODE: latency / throughput builds and the lone-wave form of the latter");
   // VARIANT_ 3 = the mid-size build for launches of at most ONE wave per SIMD: VARIANT 2 with the quiet control step's nine
   // substeps as straight-line code (a lone wave pays ~50 cycles per taken branch: C4 80.1 -> 77.4 us; with two or more waves
   // per SIMD the larger code costs 1.5-2.5 % instead, so those launches keep the loop)
-  constexpr int VARIANT = (VARIANT_ == 3) ? 2 : VARIANT_;
+  // (predictor_ODE has no events, hence no phased loop: its VARIANT_ 3 is the THROUGHPUT build's kernel with the substeps unrolled)
+  constexpr int VARIANT = (VARIANT_ == 3) ? (INTEG == PREDICTOR_ODE ? 1 : 2) : VARIANT_;
   constexpr bool LONE_WAVE = VARIANT_ == 3;
   using F = typename Lanes<R>::F;
   static_assert(FAST || R == 1, "the PRECISE path is one rollout per lane");
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // runs UNDER this kernel on another stream (cpmppi_step_gather): a wave of that kernel sharing a SIMD with one of ours
   // takes issue slots from it for its whole duration.  Raised wave priority makes the arbiter serve the rollout wave first;
   // a lone rollout wave leaves more than half of the issue slots unused, so the guest still runs.
-  if constexpr (VARIANT != 1) __builtin_amdgcn_s_setprio(3);
+  if constexpr (VARIANT != 1 || LONE_WAVE) __builtin_amdgcn_s_setprio(3);
 #endif
 #ifdef CPMPPI_DEBUG_COUNTERS
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     const F u = ur * splat<F>(p.u_max);     // Q2u, cartpole_equations.py:119-127
     if constexpr (INTEG == PREDICTOR_ODE) {
       if constexpr (FAST) {
-        control_step_cromer_fast<F, (VARIANT == 0)>(st, ur * splat<F>(ec.uK_scale), p.S, p.t_step, p, ec);
+        control_step_cromer_fast<F, (VARIANT == 0 || LONE_WAVE)>(st, ur * splat<F>(ec.uK_scale), p.S, p.t_step, p, ec);
       } else {
         for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise_cromer(st, u, p.t_step, p, ec);
       }
@@ -856,6 +857,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
 #define CPMPPI_ODE_LATENCY_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 1, 0)
 #define CPMPPI_ODE_THROUGHPUT_INSTANCES(X) \
   CPMPPI_FOR_NOISES(X, true, 1, 1) CPMPPI_FOR_NOISES(X, false, 1, 1) CPMPPI_FOR_NOISES(X, true, 2, 1)
+// (two rollouts per lane in a launch of at most one wave per SIMD: the substeps as straight-line code, raised wave priority)
+#define CPMPPI_ODE_LONE_INSTANCES(X) CPMPPI_FOR_NOISES(X, true, 2, 3)
 #define CPMPPI_DEFINE_ROLLOUT_ODE(COST, FAST, NOISE, R, V) \
   template __global__ void rollout_cost_kernel<COST, FAST, NOISE, R, V, PREDICTOR_ODE>(const Params, const StepPtrs);
 #define CPMPPI_DECLARE_ROLLOUT_ODE(COST, FAST, NOISE, R, V) \

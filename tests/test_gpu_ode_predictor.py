@@ -200,13 +200,15 @@ def test_noise_sources_agree(math_mode, rpl):
     eng.close()
 
 
-def test_latency_and_throughput_builds_agree_bit_for_bit():
-    """One rollout per lane: a launch of at most one wave per SIMD runs the latency build (nine substeps unrolled, its own
-    scheduling strategy), a larger one the throughput build.  Same env, same result, bit for bit."""
+@pytest.mark.parametrize("rpl,small_E,big_E", [(1, 32, 100), (2, 100, 300)])
+def test_latency_and_throughput_builds_agree_bit_for_bit(rpl, small_E, big_E):
+    """A launch of at most one wave per SIMD runs the latency build (one rollout per lane) or the lone-wave form of the
+    throughput build (two per lane) - nine substeps unrolled, their own scheduling / priority -, a larger one the throughput
+    build.  Same env, same result, bit for bit."""
     from cartpolesimulation_amd.engine import MPPIEngine
     from cartpolesimulation_amd.configs import MPPIConfig
-    N, H, small_E, big_E = 1024, 70, 32, 100
-    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=1, predictor_type="ODE")
+    N, H = 1024, 70
+    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=rpl, predictor_type="ODE")
     rng = Generator(SFC64(19))
     ang = rng.uniform(-np.pi, np.pi, big_E)
     s0 = np.zeros((big_E, 6), f32)
