@@ -124,9 +124,12 @@ class MPPIEngine:
         if self.mppi.predictor_type != "ODE":
             return
         m = getattr(variable_parameters, "m_pole", None)
-        if m is None or m is getattr(self, "_m_pole_obj", None):
+        if m is None:
             return
-        self._m_pole_obj = m
+        if isinstance(m, (float, int, np.floating)):            # immutable: the same object as last time means the same value
+            if m is getattr(self, "_m_pole_obj", None):
+                return
+            self._m_pole_obj = m                                # (arrays / tensors may be assigned in place: converted every time)
         a = np.asarray(m.cpu() if hasattr(m, "cpu") else m, dtype=np.float32).reshape(-1)
         if a.size == 0 or not np.all(a == a[0]):
             raise NotImplementedError(f"m_pole must be the same for every env of a handle (got {a[:4]}...)")
