@@ -24,6 +24,7 @@ QBG_W = dict(ccrc_weight_up=3.0, ccrc_weight_down=3.0, dd_linear_weight_up=2.0, 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--predictor-type", default="ODE_v0", choices=["ODE_v0", "ODE"])
 args = ap.parse_args()
 rng = np.random.Generator(np.random.SFC64(args.seed))
 fails = done = 0
@@ -38,7 +39,8 @@ for it in range(args.n):
     desc = dict(E=E, N=N, H=H, cost=name, te=te, reduce=reduce)
     try:
         eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, shift_mode="none", cost_function_specification=name,
-                                       horizon_reduce=reduce, cost_weights=QBG_W if cost_id == 3 else None))
+                                       horizon_reduce=reduce, cost_weights=QBG_W if cost_id == 3 else None,
+                                       predictor_type=args.predictor_type))
         s0 = np.stack([O.create_cartpole_state(rng.uniform(-0.8, 0.8), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), rng.uniform(-0.3, 0.3))
                        for _ in range(E)])
         tp = rng.uniform(-0.05, 0.05, E).astype(f32)
@@ -49,13 +51,14 @@ for it in range(args.n):
         S, G = eng.rollout_cost_grad(s0, Q, tp, np.full(E, te, f32), L=Lv, previous_input=prev)
         S, G = S.cpu().numpy(), G.cpu().numpy()
         for e in range(E):
-            J, g = OT.cost_and_grad(cost_id, s0[e], Q[e], tp[e], te, L=Lv[e], horizon_reduce=reduce, previous_input=prev[e], qbg_weights=QBG_W)
-            traj = O.predict_core(s0[e], np.clip(Q[e], -1, 1), L=Lv[e])
+            J, g = OT.cost_and_grad(cost_id, s0[e], Q[e], tp[e], te, L=Lv[e], horizon_reduce=reduce, previous_input=prev[e], qbg_weights=QBG_W,
+                                    integrator=args.predictor_type)
+            traj = O.predict_core(s0[e], np.clip(Q[e], -1, 1), L=Lv[e], integrator=args.predictor_type)
             assert np.all(np.abs(S[e] - J) <= 5e-4 * np.abs(J) + 1e-4), f"env {e}: forward value"
             assert np.all(G[e][np.abs(Q[e]) > 1.0] == 0.0), f"env {e}: gradient through a clipped control"
             scale = np.abs(g).max(axis=1, keepdims=True) + 1e-6
             err = (np.abs(G[e] - g) / scale).max(axis=1)
-            flagged = PU.flag_discontinuities(traj) | PU.flag_indicators(traj, {O.COST_QBGM: "qbgm", O.COST_DEFAULT: "default"}.get(cost_id, "qbg"), tp[e])
+            flagged = (PU.flag_discontinuities(traj) if args.predictor_type == "ODE_v0" else np.zeros(N, bool)) | PU.flag_indicators(traj, {O.COST_QBGM: "qbgm", O.COST_DEFAULT: "default"}.get(cost_id, "qbg"), tp[e])
             flagged |= (np.abs(np.abs(Q[e]) - 1.0) < 1e-3).any(axis=1)
             off = (err >= 2e-3) & ~flagged
             worst = max(worst, float(err[~flagged].max()) if np.any(~flagged) else 0.0)
@@ -68,4 +71,5 @@ for it in range(args.n):
     except Exception as ex:  # noqa: BLE001
         fails += 1
         print("ERROR", json.dumps(desc), type(ex).__name__, str(ex)[:300], flush=True)
-print(json.dumps({"configurations": args.n, "passed": done, "failed": fails, "seed": args.seed, "worst_clear_error_over_scale": worst}))
+print(json.dumps({"configurations": args.n, "passed": done, "failed": fails, "seed": args.seed, "worst_clear_error_over_scale": worst,
+                  "predictor_type": args.predictor_type}))
