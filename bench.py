@@ -454,13 +454,18 @@ def main():
             and args.noise == "philox" and args.math == "fast"):
         side = [("C4", PRESETS["C4"], "ode", 200, 20)]
         if world == 1:
-            side = [("C3", PRESETS["C3"], "ode", 100, 10)] + side + [("C5_gru", (256, 1024, 50), "gru", 20, 3)]
+            # ... and the headline shape on the reference's OTHER in-tree ODE predictor, the one its shipped config_controllers.yml
+            # names (predictor_specification "ODE": Euler-Cromer substeps, no edge bounce)
+            side = [("C3", PRESETS["C3"], "ode", 100, 10)] + side + [("C5_gru", (256, 1024, 50), "gru", 20, 3),
+                                                                      ("C2_predictor_ODE", (E, N, H), "ode:ODE", 20, 3)]
         for name, (e_, n_, h_), pred, steps_, warm_ in side:
-            w = Workload(ctx, e_, n_, h_, predictor=pred)
+            pred, ptype = (pred.split(":") + ["ODE_v0"])[:2]
+            w = Workload(ctx, e_, n_, h_, predictor=pred, predictor_type=ptype)
             rr = w.run(steps_, warm_)
             impl = w.collective_impl
             w.close()
-            obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}",
+            obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}"
+                               + ("" if ptype == "ODE_v0" else ", predictor_ODE (Euler-Cromer, no edge bounce)"),
                    "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
                    "kernel_ms": rr["kernel_ms"], "kernel_ms_min": rr["kernel_ms_min"],
                    "kernel_launches_timed": rr["kernel_launches_timed"], "kernel_event_group": rr["kernel_event_group"]}
