@@ -64,6 +64,8 @@ class MPPIEngine:
             return None
         if not torch.is_tensor(x):
             x = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
+        elif x.dtype == torch.float32 and x.device == self.device and x.is_contiguous():
+            return x if shape is None else x.reshape(shape)      # (the common case inside optimizer loops: nothing to convert)
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         if shape is not None:
             x = x.reshape(shape)
