@@ -34,6 +34,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_EVENTFUL_UNROLL
 #define CPMPPI_EVENTFUL_UNROLL 1
 #endif
+#ifndef CPMPPI_ODE_TRACK_NEAR
+#define CPMPPI_ODE_TRACK_NEAR 1     // predictor_ODE: boundary-cost flag from one pair of compares per control step (A/B switch)
+#endif
 #ifndef CPMPPI_WAVE_PRIORITY
 #define CPMPPI_WAVE_PRIORITY 1
 #endif
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const QbgmFolded qf = make_qbgm_folded(p, te);
   // (not in the latency build: there the flag's compare -> scalar branch hand-over sits on the lone wave's critical path
   // once per control step - measured 56 -> 66 us for a single env - while the eight instructions it saves are hidden)
-  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0 && INTEG == PREDICTOR_ODE_V0;
+  constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0 && (INTEG == PREDICTOR_ODE_V0 || CPMPPI_ODE_TRACK_NEAR != 0);
   const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
   bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
 
@@ -387,6 +390,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     if constexpr (INTEG == PREDICTOR_ODE) {
       if constexpr (FAST) {
         control_step_cromer_fast<F, (VARIANT == 0 || LONE_WAVE)>(st, ur * splat<F>(ec.uK_scale), p.S, p.t_step, p, ec);
+        if constexpr (TRACK_NEAR) {             // (no edge test in this predictor to piggyback on: one pair of compares per control step)
+          uint64_t m = 0;
+#pragma unroll
+          for (int i = 0; i < R; ++i) m |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(st.x, i)), nearlim, 11);   // unordered or >=
+          near = m != 0;
+        }
       } else {
         for (uint32_t sub = 0; sub < p.S; ++sub) substep_precise_cromer(st, u, p.t_step, p, ec);
       }
