@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane: 0 auto, 1, 2 (tuning knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-env", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of the timed configurations (the `verified` objects; it runs after the timed "
+                         "regions, on rank 0)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the C3 / C4 / GRU side measurements")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only (CPU, gloo): no kernel runs and `value` is null; what the "
@@ -200,8 +203,9 @@ class Workload:
         if predictor == "gru":
             rng = np.random.Generator(np.random.SFC64(5))
             u = lambda *s: rng.uniform(-1, 1, s).astype(np.float32) / np.sqrt(32.0, dtype=np.float32)
-            self.eng.set_gru(dict(w_ih0=u(96, 6), w_hh0=u(96, 32), b_ih0=u(96), b_hh0=u(96), w_ih1=u(96, 32),
-                                  w_hh1=u(96, 32), b_ih1=u(96), b_hh1=u(96), w_out=u(5, 32), b_out=u(5)))
+            self.gru_model = dict(w_ih0=u(96, 6), w_hh0=u(96, 32), b_ih0=u(96), b_hh0=u(96), w_ih1=u(96, 32),
+                                  w_hh1=u(96, 32), b_ih1=u(96), b_hh1=u(96), w_out=u(5, 32), b_out=u(5))
+            self.eng.set_gru(self.gru_model)
             self.pred_kw = dict(predictor="GRU")
         # the one collective of the path: all-gather of the updated nominal sequences.  Envs are
         # independent, so step i+1 does not need step i's gathered result: the gather of step i runs on a side stream under
@@ -333,6 +337,8 @@ class Workload:
         elapsed = time.perf_counter() - t0
         rollout_ms, finalize_ms = self.eng.get_profile()
         self.eng.set_profiling(False)
+        self.timed_kernel = self.eng.last_launch()["kernel"] if self.predictor == "ode" else "gru_rollout_cost_kernel"
+        self.next_step = warmup + steps
         W, rank = self.ctx["world"], self.ctx["rank"]
         if self.ctx["collective"]:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.ctx["device"])
@@ -351,6 +357,71 @@ class Workload:
                 "kernel_launches_timed": int(len(rollout_ms)) * self.profile_group, "kernel_event_group": self.profile_group,
                 "valu_tflops": algorithmic_flops_per_rollout(H) * E * N / (k_ms * 1e-3) / 1e12,
                 "alg_gbs": algorithmic_bytes_per_rollout(N, H) * E * N / (k_ms * 1e-3) / 1e9}
+
+    def verify(self, n_envs=8):
+        """The timed configuration checked against the oracle - OUTSIDE the timed region, the checker only: one more step of
+        the SAME launch (same engine, same shape, same noise source, hence the same kernel instantiation: asserted), from the
+        nominal sequences the timed steps left, with the per-rollout costs written out; `n_envs` envs spread over the launch
+        are then re-computed by the plain-C oracle (modes A and B + the rounding probes; oracle/parity.py rule ODE_V0, or
+        PREDICTOR_ODE for that predictor) from their regenerated perturbations (cpmppi_sample with the launch's seed, step
+        counter and global env index), the GRU side configuration by the numpy GRU oracle.  -> the `verified` object."""
+        import numpy as np
+        from oracle import oracle_np as O
+        from oracle import parity as PR
+        e, E, N, H, rank = self.eng, self.E, self.N, self.H, self.ctx["rank"]
+        i = self.next_step
+        u_before = self.final_u_nom(i - 1).clone()
+        u_work, S, Q = u_before.clone(), e.empty(E, N), e.empty(E)
+        envs = sorted({int(round(x)) for x in np.linspace(0, E - 1, min(n_envs, E))})
+        if self.predictor == "gru":
+            envs = envs[:2]                                         # (the numpy GRU oracle: ~1 s per env at 1024 x 50)
+        du_envs = kn_envs = None
+        if self.noise == "buffer-ref":
+            e._check(e.lib.cpmppi_sample(e._h, E, self.seed, i, rank * E, None, self.du.data_ptr(), e._stream()))
+            e.step(self.s0, u_work, self.tp, self.te, L=self.L, delta_u=self.du, Q_out=Q, S_out=S, **self.pred_kw)
+            du_envs = self.du[envs].cpu().numpy()
+        elif self.noise == "buffer":
+            e.sample_tiled(self.seed, i, rank * E, E=E, out=self.du)
+            e.step(self.s0, u_work, self.tp, self.te, L=self.L, delta_u_tiled=self.du, Q_out=Q, S_out=S)
+            du_envs = e.untile(self.du, E)[envs].cpu().numpy()
+        else:
+            e.step(self.s0, u_work, self.tp, self.te, L=self.L, seed=self.seed, offset=i, env_offset=rank * E, Q_out=Q, S_out=S,
+                   **self.pred_kw)
+            kn_envs = np.concatenate([e.sample(self.seed, offset=i, env_offset=rank * E + x, E=1)[0].cpu().numpy() for x in envs])
+        kernel = e.last_launch()["kernel"] if self.predictor == "ode" else "gru_rollout_cost_kernel"
+        host = lambda t: t[envs].cpu().numpy()
+        s0, tp, te, L = host(self.s0), host(self.tp), host(self.te), host(self.L)
+        ub, ua, Sg = host(u_before), host(u_work), host(S)
+        ptype = self.cfg.predictor_type
+        if self.predictor == "gru":
+            cfg = O.MPPIConfig(N=N, H=H)
+            rep = dict(envs=len(envs), rollouts=len(envs) * N, clear=0, flagged=0, clear_off=0, flagged_off=0, worst_cost_rel=0.0,
+                       worst_u_abs=0.0, rule="1e-4 band; flagged = rollouts the numpy GRU oracle cannot pin to a quarter band in "
+                                             "float32 (float32 vs float64 evaluation)", oracle="oracle_np.gru_mppi_step")
+            ident = dict(in_scale=np.ones(6, np.float32), in_shift=np.zeros(6, np.float32), out_scale=np.ones(5, np.float32),
+                         out_shift=np.zeros(5, np.float32))
+            model = dict(ident, **self.gru_model)                  # (the bench's synthetic model has no normalisation vectors)
+            for j in range(len(envs)):
+                du = O.interpolate_knots(kn_envs[j], H)
+                r32 = O.gru_mppi_step(model, s0[j], ub[j], du, tp[j], te[j], cfg)
+                r64 = O.gru_mppi_step(model, s0[j], ub[j], du, tp[j], te[j], cfg, dtype=np.float64)
+                b = PR.cost_buckets(Sg[j], r32["S"], r64["S"], PR.flag_rounding_sensitive(r32["S"], r64["S"]))
+                clear = ~b["flagged"]
+                rep["clear"] += int(clear.sum()); rep["flagged"] += int(b["flagged"].sum())
+                rep["clear_off"] += int((b["off"] & clear).sum()); rep["flagged_off"] += int((b["off"] & b["flagged"]).sum())
+                rep["worst_cost_rel"] = max(rep["worst_cost_rel"], float(b["rel"][clear].max()))
+                rep["worst_u_abs"] = max(rep["worst_u_abs"], float(np.abs(ua[j] - r32["u_new"]).max()))
+            rep["ok"] = bool(rep["clear_off"] == 0 and rep["flagged_off"] <= int(np.ceil(PR.FLAGGED_CAP * rep["flagged"]))
+                             and rep["worst_u_abs"] <= 1e-4)
+        else:
+            ocfg = O.MPPIConfig(N=N, H=H, integrator=ptype)
+            rep = PR.verify_envs(ocfg, s0, ub, kn_envs, tp, te, L, Sg, ua, rule=PR.ODE_V0 if ptype == "ODE_v0" else PR.PREDICTOR_ODE,
+                                 delta_u=du_envs)
+            rep["oracle"] = "oracle/cpmppi_oracle.c: modes A (float32) and B (float64 substeps) + rounding probes"
+        rep.update(env_indices=envs, step=int(i), kernel=kernel, same_kernel_as_timed=bool(kernel == self.timed_kernel),
+                   math=self.cfg.math_mode)
+        rep["ok"] = bool(rep["ok"] and rep["same_kernel_as_timed"] and np.isfinite(Sg).all())
+        return rep
 
     def close(self):
         if self.native is not None:
@@ -447,6 +518,9 @@ def main():
                        predictor_type=args.predictor_type)
     r = main_wl.run(args.steps, args.warmup)
     cfg = main_wl.cfg
+    verified = {}                                         # (rank 0 only, after - never inside - the timed regions)
+    if rank == 0 and not args.no_verify:
+        verified["main"] = main_wl.verify()
 
     # BASELINE's other configurations, measured by EVERY rank (the collective is part of them), reported by rank 0
     extras = {}
@@ -463,6 +537,8 @@ def main():
             w = Workload(ctx, e_, n_, h_, predictor=pred, predictor_type=ptype)
             rr = w.run(steps_, warm_)
             impl = w.collective_impl
+            if rank == 0 and not args.no_verify:
+                verified[name] = w.verify()
             w.close()
             obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}"
                                + ("" if ptype == "ODE_v0" else ", predictor_ODE (Euler-Cromer, no edge bounce)"),
@@ -471,6 +547,8 @@ def main():
                    "kernel_launches_timed": rr["kernel_launches_timed"], "kernel_event_group": rr["kernel_event_group"]}
             if impl:
                 obj["collective"] = impl
+            if name in verified:
+                obj["verified"] = verified[name]
             if pred == "ode":
                 obj["roofline_valu"] = roofline_valu(rr, e_, n_, h_)
             else:
@@ -537,6 +615,8 @@ def main():
             # the same peak with every substep's sincos costed at ~30 flop-equivalents
             rv["survey_ceiling_rollouts_per_s"] = FP32_VALU_PEAK_TFLOPS * 1e12 / (algorithmic_flops_per_rollout(H) + 2.0 * 10 * H * 30.0)
             out["roofline_valu"] = rv
+        if "main" in verified:
+            out["verified"] = verified["main"]
         if extras:
             out["configs"] = extras
         if not args.no_single_env and world == 1:
@@ -557,10 +637,14 @@ def main():
                 w1.step(400 + i)
             r1, f1 = e1.get_profile()
             e1.set_profiling(False)
+            w1.timed_kernel = e1.last_launch()["kernel"] if args.predictor == "ode" else "gru_rollout_cost_kernel"
+            w1.next_step = 450
             k1 = float(np.median(r1))
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": k1 * 1e3, "finalize_kernel_us": float(np.median(f1)) * 1e3,
                                  "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time = HIP events around groups of 10 launches / 10"}
+            if not args.no_verify:
+                verified["single_env"] = out["single_env"]["verified"] = w1.verify()
             if args.predictor == "ode" and args.math == "fast":
                 # the simulator's own call: state and attributes on the HOST, the control back on the host
                 # (CartPole/__init__.py:509-520) through cpmppi_step_host - PCIe-inclusive, never `value`
@@ -591,6 +675,10 @@ def main():
     if in_rank:
         dist.barrier()
         dist.destroy_process_group()
+    bad = [k for k, v in verified.items() if not v["ok"]]
+    if bad:                                               # a timed configuration whose results the oracle does not confirm
+        print(f"bench.py: verification FAILED for {bad}: " + json.dumps({k: verified[k] for k in bad}), file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
-           "cpmppi_step_gather")
+           "cpmppi_step_gather", "cpmppi_last_launch")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -54,6 +54,11 @@ class cpmppi_gru_model(C.Structure):
     _fields_ = [("inputs", C.c_uint32), ("hidden", C.c_uint32), ("layers", C.c_uint32), ("outputs", C.c_uint32),
                 ("w_ih", _FP * 2), ("w_hh", _FP * 2), ("b_ih", _FP * 2), ("b_hh", _FP * 2), ("w_out", _FP), ("b_out", _FP),
                 ("in_scale", _FP), ("in_shift", _FP), ("out_scale", _FP), ("out_shift", _FP)]
+
+
+class cpmppi_launch_info(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("cost_id", "math_mode", "noise_kind", "rollouts_per_lane", "build_variant",
+                                          "ode_predictor", "blocks")]
 
 
 PREDICTOR_ODE_V0, PREDICTOR_GRU = 0, 1
@@ -122,6 +127,7 @@ def load():
     lib.cpmppi_comm_sync.argtypes = [vp]
     lib.cpmppi_comm_destroy.argtypes = [vp]
     lib.cpmppi_step_gather.argtypes = [vp, C.POINTER(cpmppi_step_args), vp, vp]
+    lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares

@@ -195,10 +195,17 @@ def mppi_config_from_yaml(cfgs, **overrides):
               cost_function_specification=name, cost_weights=weights)
     # config_controllers.yml:3 predictor_specification: a predictor_type, or the name of an entry of config_predictors.yml
     spec = str(ctrl.get("predictor_specification") or "ODE_v0").split(":")[0]
-    ptype = cfgs["predictors"]["predictors"].get(spec, {}).get("predictor_type", spec)
+    entries = cfgs["predictors"]["predictors"]
+    entry = entries.get(spec) or {}
+    ptype = entry.get("predictor_type", spec)
     if ptype in ODE_PREDICTORS:                      # (a neural / GP specification is the caller's to resolve: gru_model=...)
         kw["predictor_type"] = ptype
-        kw["intermediate_steps"] = cfgs["predictors"]["predictors"].get(f"{ptype}_default", {}).get("intermediate_steps", kw["intermediate_steps"])
+        # the named entry's own substep count first (a custom entry such as `I_love_control_too: {predictor_type: ODE,
+        # intermediate_steps: 2}`), "<type>_default" only when the entry has none
+        steps = entry.get("intermediate_steps")
+        if steps is None:
+            steps = (entries.get(f"{ptype}_default") or {}).get("intermediate_steps", kw["intermediate_steps"])
+        kw["intermediate_steps"] = steps
     kw.update(overrides)
     return MPPIConfig(**kw)
 

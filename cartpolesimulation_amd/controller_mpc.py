@@ -103,7 +103,10 @@ class controller_mpc(template_controller):
                                              cost_function_specification=cost_name,
                                              weights=cfg.get("cost_weights"), phys=self.phys, device=self.device)
         spec = predictor_specification or cfg.pop("predictor_specification", None)
-        if spec is None and cfg.get("predictor_type") == "ODE":      # (a checkout's config_controllers.yml:3 read by config_root)
+        # a checkout's config_controllers.yml:3 read by config_root names the ODE predictor - but only as the DEFAULT: a
+        # gru_model handed over explicitly (config={"gru_model": ...}) wins over the YAML's predictor, as it did before
+        # config_root learnt to read that line
+        if spec is None and cfg.get("predictor_type") == "ODE" and cfg.get("gru_model") is None:
             spec = "ODE"
         neural = spec is not None and str(spec).startswith("GRU-6IN-32H1-32H2-5OUT")
         if cfg.get("gru_model") is not None and spec is not None and not neural:

@@ -844,6 +844,7 @@ struct cpmppi_handle {
   std::vector<uint8_t> ev_tail;        // per triple: was the third event recorded (a separate finalize / counter kernel ran)
   size_t ev_used = 0;
   cpmppi_comm::CommState* comm = nullptr;   // RCCL communicator + side stream of cpmppi_comm_* (cpmppi_comm.hip)
+  cpmppi_launch_info last_launch = {0, 0, 0, 0, 0, 0, 0};   // cpmppi_last_launch: the instantiation the last rollout launch used
 };
 
 cpmppi_comm::CommState*& cpmppi_internal_comm(cpmppi_handle* h) { return h->comm; }
@@ -941,41 +942,44 @@ constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D overr
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
-                               const Params& p, const StepPtrs& a) {
+                               const Params& p, const StepPtrs& a, uint32_t* variant_out) {
+  // (the build VARIANT of the instantiation launched: 0 latency, 1 throughput, 2 mid-size phased, 3 its lone-wave form)
+#define CPMPPI_LAUNCH_V(FAST, R, V, ...) (*variant_out = (V), launch_rollout_noise<COST, FAST, R, V, ##__VA_ARGS__>(noise, grid, lds, s, p, a))
   if (ode == CPMPPI_ODE_CROMER) {
     // predictor_ODE has no events, hence no mid-size (phased) build: latency build up to one wave per SIMD with one rollout
     // per lane, the throughput build otherwise
-    if (math != CPMPPI_MATH_FAST) return launch_rollout_noise<COST, false, 1, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
+    if (math != CPMPPI_MATH_FAST) return CPMPPI_LAUNCH_V(false, 1, 1, PREDICTOR_ODE);
     if (rpl == 2)
-      return ((uint64_t)grid.x * WAVES <= 1024ull) ? launch_rollout_noise<COST, true, 2, 3, PREDICTOR_ODE>(noise, grid, lds, s, p, a)
-                                                   : launch_rollout_noise<COST, true, 2, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
-    return ((uint64_t)grid.x * BLOCK <= 65536ull) ? launch_rollout_noise<COST, true, 1, 0, PREDICTOR_ODE>(noise, grid, lds, s, p, a)
-                                                  : launch_rollout_noise<COST, true, 1, 1, PREDICTOR_ODE>(noise, grid, lds, s, p, a);
+      return ((uint64_t)grid.x * WAVES <= 1024ull) ? CPMPPI_LAUNCH_V(true, 2, 3, PREDICTOR_ODE) : CPMPPI_LAUNCH_V(true, 2, 1, PREDICTOR_ODE);
+    return ((uint64_t)grid.x * BLOCK <= 65536ull) ? CPMPPI_LAUNCH_V(true, 1, 0, PREDICTOR_ODE) : CPMPPI_LAUNCH_V(true, 1, 1, PREDICTOR_ODE);
   }
   if (math == CPMPPI_MATH_FAST) {
     if (rpl == 2) {
       const bool mid = (uint64_t)grid.x * BLOCK * 2 <= MID_SIZE_MAX_ROLLOUTS;
       // at most one wave per SIMD (256 CUs x 4): the phased build with the quiet control step unrolled
-      if ((uint64_t)grid.x * WAVES <= 1024ull) return launch_rollout_noise<COST, true, 2, 3>(noise, grid, lds, s, p, a);
-      return mid ? launch_rollout_noise<COST, true, 2, 2>(noise, grid, lds, s, p, a)
-                 : launch_rollout_noise<COST, true, 2, 1>(noise, grid, lds, s, p, a);
+      if ((uint64_t)grid.x * WAVES <= 1024ull) return CPMPPI_LAUNCH_V(true, 2, 3);
+      return mid ? CPMPPI_LAUNCH_V(true, 2, 2) : CPMPPI_LAUNCH_V(true, 2, 1);
     }
     const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
-    return small ? launch_rollout_noise<COST, true, 1, 0>(noise, grid, lds, s, p, a)
-                 : launch_rollout_noise<COST, true, 1, 1>(noise, grid, lds, s, p, a);
+    return small ? CPMPPI_LAUNCH_V(true, 1, 0) : CPMPPI_LAUNCH_V(true, 1, 1);
   }
-  return launch_rollout_noise<COST, false, 1, 1>(noise, grid, lds, s, p, a);
+  return CPMPPI_LAUNCH_V(false, 1, 1);
+#undef CPMPPI_LAUNCH_V
 }
 
 // `prm`: the kernel-argument block of THIS launch (the handle's, or a modified copy: cost-only launches)
-hipError_t launch_rollout(const cpmppi_handle* h, const Params& prm, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds,
+hipError_t launch_rollout(cpmppi_handle* h, const Params& prm, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds,
                           hipStream_t s, const StepPtrs& a) {
+  uint32_t variant = 0;
+  hipError_t e;
   switch (prm.cost_id) {
-    case CPMPPI_COST_QBGM: return launch_rollout_math<COST_QBGM>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
-    case CPMPPI_COST_DEFAULT: return launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
-    case CPMPPI_COST_QBG: return launch_rollout_math<COST_QBG>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
-    default: return launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a);
+    case CPMPPI_COST_QBGM: e = launch_rollout_math<COST_QBGM>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
+    case CPMPPI_COST_DEFAULT: e = launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
+    case CPMPPI_COST_QBG: e = launch_rollout_math<COST_QBG>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
+    default: e = launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
   }
+  h->last_launch = cpmppi_launch_info{prm.cost_id, h->cfg.math_mode, noise, rpl, variant, h->cfg.ode_predictor, grid.x};
+  return e;
 }
 
 }  // namespace
@@ -985,6 +989,12 @@ extern "C" {
 const char* cpmppi_version(void) { return "cpmppi 1 gfx950 hip"; }
 
 const char* cpmppi_last_error(const cpmppi_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int cpmppi_last_launch(const cpmppi_handle* h, cpmppi_launch_info* out) {
+  if (!h || !out) return CPMPPI_ERR_BAD_ARG;
+  *out = h->last_launch;
+  return CPMPPI_OK;
+}
 
 int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   if (!cfg || !out) return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: null argument");

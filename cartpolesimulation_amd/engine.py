@@ -368,6 +368,17 @@ class MPPIEngine:
                                                _ptr(stdev), _ptr(elites), self._stream()))
         return (mean, stdev, elites) if return_elites else (mean, stdev)
 
+    def last_launch(self):
+        """The rollout-kernel instantiation the most recent step launched (cpmppi_last_launch): dict of the template
+        arguments plus `kernel`, its name as rocprofv3 prints it."""
+        info = _L.cpmppi_launch_info()
+        self._check(self.lib.cpmppi_last_launch(self._h, C.byref(info)))
+        d = {n: int(getattr(info, n)) for n, _ in info._fields_}
+        d["kernel"] = ("rollout_cost_kernel<%d, %s, %d, %d, %d%s>" % (
+            d["cost_id"], "true" if d["math_mode"] == _L.MATH_FAST else "false", (0, 1, 2, 3)[d["noise_kind"]],
+            d["rollouts_per_lane"], d["build_variant"], ", PREDICTOR_ODE" if d["ode_predictor"] else ""))
+        return d
+
     def set_profiling(self, enable=True, group=1):
         """HIP-event timing on the launch stream.  ``group`` = 1: every rollout kernel is bracketed; ``group`` = n > 1: one
         bracket around every n consecutive steps, reported as the average per step (an event costs ~5 us on the stream;

@@ -181,6 +181,16 @@ void cpmppi_destroy(cpmppi_handle* h);
 const char* cpmppi_last_error(const cpmppi_handle* h);  /* h may be NULL: error of the last failed cpmppi_create */
 int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out);
 
+/* Which instantiation of the rollout kernel the handle's most recent cpmppi_step / cpmppi_step_host / cpmppi_step_gather /
+ * cpmppi_rollout_cost launch used (all zero before the first one) - so that a caller that verifies or times a launch can
+ * name the kernel it ran: rollout_cost_kernel<cost_id, math_mode == FAST, noise_kind, rollouts_per_lane, build_variant>.
+ * build_variant: 0 = latency build (one rollout per lane, at most one wave per SIMD), 1 = throughput build, 2 = mid-size
+ * build (phased horizon loop), 3 = its form for launches of at most one wave per SIMD. */
+typedef struct {
+  uint32_t cost_id, math_mode, noise_kind, rollouts_per_lane, build_variant, ode_predictor, blocks;
+} cpmppi_launch_info;
+int cpmppi_last_launch(const cpmppi_handle* h, cpmppi_launch_info* out);
+
 /* Mutable per-call knobs (GUI sliders / attribute updates in the reference mutate these between steps). */
 int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cost_w, uint32_t n);
 /* The pole mass every later call of this handle computes with (config.m_pole until then): predictor_ODE takes it from

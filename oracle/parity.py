@@ -1,0 +1,307 @@
+"""Parity rules: how an output of the HIP path is compared with the oracle.  TEST INFRASTRUCTURE (checker side) - used by
+tests/, by __graft_entry__.smoke() and by bench.py's `verified` leg (outside the timed region), never by the product path.
+
+BASELINE.json north_star: "within 1e-4 on identical noise seeds"; SURVEY.md H1 / H2.  Every bound is FIXED or derived from
+the ORACLE - never from the kernel's own error.  The complete list of knobs, and who uses them:
+
+  band               1e-4 + 1e-4 |ref| for states, 1e-4 relative for costs, 1e-4 absolute for controls      every test
+  A / B gap          the reference's own arithmetic ambiguity (H1): numpy >= 2 keeps the substeps in float32 (mode A),
+                     numba carries them in float64 (mode B); a result inside the band around [A, B] conforms    every test
+  H2 flags           rollouts whose ORACLE trajectory comes within reach of a discontinuity (edge bounce, +-pi wrap, a
+                     cost-indicator threshold): counted, at most `flagged_cap` of them (and `total_cap` of all rollouts)
+                     may sit outside; `strict` = no allowance at all                                           random-instance
+                                                                                                               tests; strict on
+                                                                                                               every golden fixture
+  envelope           further realisations of the REFERENCE one rounding away from mode A (mode C = float32 FMA build,
+                     initial state / perturbations / pole length one ulp up): their scatter around mode A widens the
+                     allowance of the element, and a rollout on which they disagree among themselves by more than
+                     `sens_rtol` (a quarter of the band) is rounding-sensitive and joins the flagged bucket     full-width C3 / C4,
+                                                                                                               bench `verified`,
+                                                                                                               headline test
+  soft-min allowance Jacobian bound of the update for a FIXED 1e-5 relative cost perturbation (softmin_allowance)  controls of
+                                                                                                               ill-conditioned updates
+  sensitive_gap_scale  widening of the sampled scatter of oracle-marked sensitive rollouts: 1 in ODE_V0 (the north-star
+                     path: NOT widened), 2 in PREDICTOR_ODE only                                                 test_gpu_ode_predictor
+
+The two rule objects keep the paths apart: the north-star path (predictor_ODE_v0) is graded with ODE_V0 and cannot inherit
+the wider scatter rule of the other in-tree predictor (`rule=` is the only way to select it).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import oracle_np as O
+
+f32 = np.float32
+THL = float(O.DEFAULT_PARAMS.TrackHalfLength)
+FLAGGED_CAP = 0.02            # fraction of the FLAGGED rollouts that may sit outside their allowance
+TOTAL_CAP = 0.005             # ... and never more than this fraction of all rollouts
+
+
+@dataclass(frozen=True)
+class ParityRule:
+    name: str
+    rtol: float = 1e-4                    # the band (north_star)
+    sens_rtol: float = 0.25e-4            # realisations of the reference disagreeing by more than this: rounding-sensitive
+    sensitive_gap_scale: float = 1.0      # scatter of the oracle-marked sensitive rollouts widened by this factor
+    flagged_cap: float = FLAGGED_CAP
+    total_cap: float = TOTAL_CAP
+
+
+# predictor_ODE_v0 (the north-star path): band + envelope of the reference's realisations, nothing widened
+ODE_V0 = ParityRule("predictor_ODE_v0")
+# predictor_ODE (Euler-Cromer, atan2 wrap; not a SURVEY 8 row): it re-derives the angle from float32 sin / cos on every
+# substep, so any float32 evaluation is noisier; `gap` is the LARGEST of k sampled realisations of a chaotic rollout's cost,
+# and one more realisation - the kernel's - exceeds the largest of k with probability 1 / (k + 1), far above the flagged
+# bucket's 2 % cap: the sampled scatter of the rollouts the ORACLE marks sensitive is doubled.  This predictor only.
+PREDICTOR_ODE = ParityRule("predictor_ODE", sensitive_gap_scale=2.0)
+
+
+def band(ref, scale=1.0):
+    return scale * (1e-4 + 1e-4 * np.abs(ref))
+
+
+def flag_discontinuities(traj, dt=0.02, x_margin=2e-3, th_margin=2e-3):
+    """traj[N, H+1, 6] from the ORACLE (control-step granularity).  A rollout is flagged if between two samples its cart
+    can have reached the track edge (|x| + |v| dt within x_margin of THL) or its angle sits within th_margin of +-pi."""
+    x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
+    near_edge = (np.abs(x) + np.abs(v) * dt > THL - x_margin).any(axis=1)
+    near_wrap = (np.abs(np.abs(th) - np.pi) < th_margin).any(axis=1)
+    return near_edge | near_wrap
+
+
+def flag_indicators(traj, cost, target_position, margin=2e-4):
+    """Rollouts whose oracle trajectory passes within `margin` of a cost INDICATOR threshold (default.py:41-88: 1e7 at
+    |x| > 0.9 THL, terminal 1e4 at |angle| > 0.2 or |x - x*| > 0.1 THL; legacy q/phi: 1e6 at 0.95 THL, same terminal)."""
+    x = traj[:, :, O.POSITION_IDX]
+    flagged = np.zeros(traj.shape[0], dtype=bool)
+    if cost in ("default", "legacy"):
+        thr = (0.90 if cost == "default" else 0.95) * THL
+        flagged |= (np.abs(np.abs(x[:, :-1]) - thr) < margin).any(axis=1)
+        flagged |= np.abs(np.abs(traj[:, -1, O.ANGLE_IDX]) - 0.2) < margin
+        flagged |= np.abs(np.abs(x[:, -1] - target_position) - 0.1 * THL) < margin
+    return flagged
+
+
+def _check(off, flagged, what, strict=False, rule=ODE_V0):
+    """strict: the flagged bucket gets NO allowance either (the golden fixtures and the reference's own step traces:
+    measured on MI355X, no rollout of theirs is outside band + gap, flagged or not - so none may be)."""
+    n = off.size
+    clear_off = int((off & ~flagged).sum())
+    assert clear_off == 0, f"{what}: {clear_off} of {int((~flagged).sum())} rollouts clear of every discontinuity are outside the band"
+    fl_off, fl = int((off & flagged).sum()), int(flagged.sum())
+    cap = 0 if strict else min(int(np.ceil(rule.flagged_cap * fl)), int(np.ceil(rule.total_cap * n)))
+    assert fl_off <= cap, f"{what}: {fl_off} of {fl} flagged rollouts outside the band (cap {cap})"
+
+
+def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0, strict=False):
+    """out, ref_a, ref_b [N, 6] (or [N, k, 6]): inside band(ref_a) + |ref_a - ref_b| element-wise."""
+    off = np.abs(out - ref_a) > band(ref_a, scale) + np.abs(ref_a - ref_b)
+    off = off.reshape(off.shape[0], -1).any(axis=1)
+    _check(off, flagged, what, strict)
+
+
+def envelope(ref_a, *others):
+    """max_k |ref_a - other_k|: how far the reference's own realisations (mode B float64 substeps, mode C float32 with
+    FMA + float trig, mode A from an initial state one ulp away) sit from mode A, element-wise.  None entries are skipped."""
+    a = np.asarray(ref_a, np.float64)
+    gap = np.zeros(a.shape)
+    for o in others:
+        if o is not None:
+            gap = np.maximum(gap, np.abs(a - np.asarray(o, np.float64)))
+    return gap
+
+
+def cost_buckets(S, S_a, S_b=None, flagged=None, S_alt=(), rtol=None, flag_sensitive=False, sens_rtol=None, rule=ODE_V0):
+    """The per-rollout verdict behind assert_costs, as arrays: -> dict(off, flagged, sensitive, excess) with
+    excess = |S - S_a| / allowance (<= 1 inside)."""
+    rtol = rule.rtol if rtol is None else rtol
+    S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
+    gap = envelope(S_a, S_b, *S_alt) if (S_b is not None or len(S_alt)) else np.zeros(S_a.shape)
+    flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
+    sensitive = np.zeros(S.shape, bool)
+    if flag_sensitive and (S_b is not None or len(S_alt)):
+        sensitive = gap > (rule.sens_rtol if sens_rtol is None else sens_rtol) * np.abs(S_a)
+        flagged = flagged | sensitive
+    allowance = rtol * np.abs(S_a) + gap * np.where(sensitive, rule.sensitive_gap_scale, 1.0)
+    dev = np.abs(S - S_a)
+    return dict(off=dev > allowance, flagged=flagged, sensitive=sensitive,
+                excess=dev / np.maximum(allowance, np.finfo(np.float64).tiny), rel=dev / np.maximum(np.abs(S_a), 1e-30))
+
+
+def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=None, flag_sensitive=False, strict=False, S_alt=(),
+                 sens_rtol=None, rule=ODE_V0):
+    """Per-rollout costs: |S - S_a| <= rtol |S_a| + gap for every unflagged rollout, gap = the envelope of the reference's
+    own realisations around mode A (S_b and any S_alt).  flag_sensitive: a rollout on which those realisations disagree
+    among THEMSELVES by more than sens_rtol |S_a| (the rule's quarter band: a chaotic trajectory that amplifies 1e-7
+    roundings to a visible fraction of the tolerance) joins the flagged bucket - no evaluation in float32, the reference's
+    included, pins it to the band.
+    Measured on MI355X (tools/dev/cfg_parity_diag.py, C3 = 64 x 4096 rollouts of 1000 substeps from random states up to 21
+    rad/s): with the seven realisations of c_oracle_step_with_flags(probes=True) and the quarter-band rule NO clear
+    rollout is outside its allowance in FAST (both lane mappings) or PRECISE (worst: 0.95 of it); with modes A / B alone
+    25 of 199 887 are - PRECISE, the reference's own operand order, among them."""
+    b = cost_buckets(S, S_a, S_b, flagged, S_alt, rtol, flag_sensitive, sens_rtol, rule)
+    _check(b["off"], b["flagged"], what, strict, rule)
+    return b
+
+
+def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None, u_alt=(), rule=ODE_V0):
+    """Updated control sequence / Q: 1e-4 absolute (north_star) around the reference's own [A, B] interval.  The soft-min
+    update amplifies cost differences by |S| / LBD (costs of ~5e4 at LBD = 100 turn a 1e-5 relative cost difference into
+    a 0.5 % weight change), so where the reference's two arithmetic modes themselves disagree on u by more than the
+    band, the allowance widens by exactly that disagreement (max over the horizon) - an oracle quantity.  `allowance`
+    (optional, per control): softmin_allowance(...) of the oracle's costs, for ill-conditioned updates."""
+    u, u_a = np.asarray(u, np.float64), np.asarray(u_a, np.float64)
+    gap = float(envelope(u_a, u_b, *u_alt).max()) if (u_b is not None or len(u_alt)) else 0.0
+    if gap > atol:          # an update the reference's own realisations disagree on by more than the band
+        gap *= rule.sensitive_gap_scale          # (1.0 on the north-star path)
+    extra = 0.0 if allowance is None else np.asarray(allowance, np.float64)
+    d = np.abs(u - u_a)
+    assert np.all(d <= atol + np.maximum(gap, extra)), (f"{what}: max |u - u_ref| = {d.max():.3e} > {atol:g} + oracle allowance "
+                                                      f"(A/B gap {gap:.3e}, soft-min conditioning {np.max(extra):.3e})")
+
+
+def softmin_allowance(S_a, S_b, du, LBD=100.0, cost_rtol=1e-5):
+    """How far a cost perturbation |dS_n| <= cost_rtol |S_n| + |S_a,n - S_b,n| can move the soft-min update, by its
+    Jacobian on the ORACLE's values:  u_k = sum_n w_n du[n,k],  w_n ~ exp(-S_n / LBD)  =>
+        |d u_k| <= (1 / LBD) sum_n w_n |du[n,k] - u_k| |dS_n|.
+    cost_rtol is FIXED at a tenth of the cost band: for costs of O(100) the term vanishes (the plain 1e-4 applies), for the
+    boundary-penalty regimes with costs of ~5e4 at LBD = 100 it is the honest conditioning of the reference's own update
+    (its float32 and float64-substep evaluations already differ by more than 1e-4 in u there)."""
+    S_a = np.asarray(S_a, np.float64)
+    eps = cost_rtol * np.abs(S_a) + (np.abs(S_a - np.asarray(S_b, np.float64)) if S_b is not None else 0.0)
+    w = np.exp(-(S_a - S_a.min()) / LBD)
+    w /= w.sum()
+    du = np.asarray(du, np.float64)
+    ubar = w @ du
+    return (w * eps) @ np.abs(du - ubar[None, :]) / LBD
+
+
+def reference_spread_ratio(u, u_a, u_b, floor=1e-4):
+    """max_k |u - u_A| / max(floor, max_k |u_A - u_B|): how far an updated control sequence sits from the reference's
+    float32 result, in units of the reference's OWN two-mode spread on that env (never below the 1e-4 band)."""
+    u, u_a, u_b = (np.asarray(x, np.float64) for x in (u, u_a, u_b))
+    return float(np.abs(u - u_a).max() / max(floor, float(np.abs(u_a - u_b).max())))
+
+
+def flag_rounding_sensitive(S_f32, S_f64, thresh=0.25e-4):
+    """Rollouts whose cost the ORACLE itself cannot pin to a quarter of the band in float32 (its float32 and float64
+    evaluations differ by more than `thresh` relative): ill-conditioned, e.g. saturating random GRU weights."""
+    S_f32, S_f64 = np.asarray(S_f32, np.float64), np.asarray(S_f64, np.float64)
+    return np.abs(S_f32 - S_f64) > thresh * np.abs(S_f64)
+
+
+def oracle_step_both_modes(s0, u_nom, du, target_position, target_equilibrium, cfg, **kw):
+    """The oracle's MPPI step in both reference arithmetic modes (A: float32 substeps, B: float64 substeps)."""
+    a = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f32", **kw)
+    b = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f64sub", **kw)
+    return a, b
+
+
+def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None, cost=None, probes=False):
+    """The plain-C oracle's MPPI step for E envs in BOTH reference arithmetic modes, plus the H2 flags of every rollout
+    from the oracle's own trajectories (default glue: shift repeat-last, clip); with ``cost`` ("default" / "legacy") also
+    the rollouts within reach of that plugin's indicator thresholds.  -> dict(S_a, S_b, u_a, u_b, Q_a, flags) and, with
+    ``probes``, S_alt / u_alt: lists of further realisations of the REFERENCE for the rounding-sensitivity envelope -
+    mode C (float32 with FMA contraction and libm float trig, what a fastmath float32 build computes; absent on a host
+    without FMA) and mode A re-run one float32 ulp away in the angular velocity, the cart velocity, the position, the
+    perturbations and the pole length.  Per rollout, in each list entry [E, N] (costs) / [E, H] (controls)."""
+    from . import oracle_c as OC
+    E, N, H = du.shape
+    ca, cb = OC.make_config(ocfg, params), OC.make_config(ocfg, params, mode="f64sub")
+    u_a, Q_a, S_a = OC.step(ca, s0, u0, du, tp, te, L=L)
+    u_b, _, S_b = OC.step(cb, s0, u0, du, tp, te, L=L)
+    extra = {}
+    if probes:
+        # more realisations of the REFERENCE, each one rounding-level away from mode A: how far they scatter is what "the
+        # reference's result" means for a rollout (a chaotic one amplifies 1e-7 to 1e-3 within a hundred control steps)
+        fma = OC.fma_lib()
+        alt_S, alt_u = [], []
+        if fma is not None:                                     # mode C: float32 with FMA contraction + libm float trig
+            u_c, _, S_c = OC.step(ca, s0, u0, du, tp, te, L=L, use_lib=fma)
+            alt_S.append(S_c); alt_u.append(u_c)
+        s0a = np.array(s0, f32).reshape(E, 6)
+        one_up = lambda a: np.nextafter(a, f32(np.inf)).astype(f32)  # noqa: E731
+        for col in (O.ANGLED_IDX, O.POSITIOND_IDX, O.POSITION_IDX):  # mode A from an initial state one float32 ulp away
+            s0p = s0a.copy()
+            s0p[:, col] = one_up(s0p[:, col])
+            u_p, _, S_p = OC.step(ca, s0p, u0, du, tp, te, L=L)
+            alt_S.append(S_p); alt_u.append(u_p)
+        u_p, _, S_p = OC.step(ca, s0, u0, one_up(np.asarray(du, f32)), tp, te, L=L)     # every perturbation one ulp up
+        alt_S.append(S_p); alt_u.append(u_p)
+        if L is not None:                                       # the pole length one ulp longer
+            u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=one_up(np.asarray(L, f32)))
+            alt_S.append(S_p); alt_u.append(u_p)
+        if getattr(ocfg, "integrator", "ODE_v0") == "ODE":
+            # predictor_ODE: three more, each with every sin / cos result moved to a neighbouring float32 at random - all the
+            # realisations above but mode C share ONE sin / cos implementation, and this predictor feeds sin / cos back into the
+            # ANGLE (atan2) on every substep: found at full-width C3, where four rollouts in 262 144 sat 1.5e-4 from mode A in
+            # FAST and PRECISE alike (3e-5 from each other) while the realisations above scattered by 1e-5
+            try:
+                for seed in (1, 2, 3):
+                    OC.set_trig_jitter(seed)
+                    u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=L)
+                    alt_S.append(S_p); alt_u.append(u_p)
+            finally:
+                OC.set_trig_jitter(0)
+        extra = {"S_alt": alt_S, "u_alt": alt_u}
+    if ocfg.shift_mode == "repeat_last":
+        u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1)
+    elif ocfg.shift_mode == "append_zero":
+        u_shift = np.concatenate([u0[:, 1:], np.zeros_like(u0[:, :1])], axis=1)
+    else:
+        u_shift = u0
+    u_run = u_shift[:, None, :] + du
+    if ocfg.control_mode == "clip":
+        u_run = np.clip(u_run, -1, 1)
+    u_run = u_run.astype(f32).reshape(E * N, H)
+    Lr = None if L is None else np.repeat(np.asarray(L, f32), N)
+    traj = OC.predict(ca, np.repeat(np.asarray(s0, f32), N, axis=0), u_run, L=Lr)
+    thl = float((params or O.DEFAULT_PARAMS).TrackHalfLength)
+    x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
+    step = float(ocfg.dt if dt is None else dt)
+    flags = ((np.abs(x) + np.abs(v) * step > thl - 2e-3).any(axis=1) | (np.abs(np.abs(th) - np.pi) < 2e-3).any(axis=1))
+    flags = flags.reshape(E, N)
+    if cost in ("default", "legacy"):
+        tr = traj.reshape(E, N, H + 1, 6)
+        for e in range(E):
+            flags[e] |= flag_indicators(tr[e], cost, float(np.asarray(tp).reshape(-1)[e]))
+    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags, **extra)
+
+
+def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0, chunk=8, delta_u=None):
+    """A launch's outputs for a few envs against the C oracle DIRECTLY, under `rule` (full-width form: modes A / B + the
+    probes' envelope, quarter-band sensitivity flag): the check of bench.py's `verified` object and of the headline-kernel
+    test.  Inputs are numpy, per env: s0[E,6], u_before[E,H] (the nominal sequence the step read), knots[E,N,P] (regenerated
+    with cpmppi_sample from the launch's seed / offset / env index; or ``delta_u``[E,N,H] read back from the launch's own
+    perturbation buffer), tp, te, L[E]; S_gpu[E,N], u_gpu[E,H] from the launch.
+    -> report dict (counts, worst excess, worst relative cost deviation, worst |u - u_A|, per-env spread ratios, `ok`)."""
+    E, N = (knots if delta_u is None else delta_u).shape[:2]
+    H = ocfg.H
+    rep = dict(envs=int(E), rollouts=int(E * N), clear=0, flagged=0, clear_off=0, flagged_off=0, worst_clear_excess=0.0,
+               worst_cost_rel=0.0, worst_u_abs=0.0, worst_u_vs_reference_spread=0.0, u_off_envs=0, rule=rule.name)
+    for e0 in range(0, E, chunk):
+        sl = slice(e0, min(E, e0 + chunk))
+        du = (np.stack([O.interpolate_knots(knots[e], H) for e in range(sl.start, sl.stop)]) if delta_u is None
+              else np.ascontiguousarray(delta_u[sl], f32))
+        ref = c_oracle_step_with_flags(ocfg, s0[sl], u_before[sl], du, tp[sl], te[sl], L=L[sl], probes=True)
+        for i, e in enumerate(range(sl.start, sl.stop)):
+            b = cost_buckets(S_gpu[e], ref["S_a"][i], ref["S_b"][i], ref["flags"][i], [a[i] for a in ref["S_alt"]],
+                             flag_sensitive=True, rule=rule)
+            clear = ~b["flagged"]
+            rep["clear"] += int(clear.sum()); rep["flagged"] += int(b["flagged"].sum())
+            rep["clear_off"] += int((b["off"] & clear).sum()); rep["flagged_off"] += int((b["off"] & b["flagged"]).sum())
+            if clear.any():
+                rep["worst_clear_excess"] = max(rep["worst_clear_excess"], float(b["excess"][clear].max()))
+                rep["worst_cost_rel"] = max(rep["worst_cost_rel"], float(b["rel"][clear].max()))
+            d = np.abs(np.asarray(u_gpu[e], np.float64) - ref["u_a"][i])
+            rep["worst_u_abs"] = max(rep["worst_u_abs"], float(d.max()))
+            rep["worst_u_vs_reference_spread"] = max(rep["worst_u_vs_reference_spread"],
+                                                     reference_spread_ratio(u_gpu[e], ref["u_a"][i], ref["u_b"][i]))
+            allow = softmin_allowance(ref["S_a"][i], ref["S_b"][i], du[i])
+            gap = float(envelope(ref["u_a"][i], ref["u_b"][i]).max())
+            rep["u_off_envs"] += int((d > 1e-4 + np.maximum(gap, allow)).any())
+    cap = min(int(np.ceil(rule.flagged_cap * rep["flagged"])), int(np.ceil(rule.total_cap * rep["rollouts"])))
+    rep["flagged_cap"] = cap
+    rep["ok"] = bool(rep["clear_off"] == 0 and rep["flagged_off"] <= cap and rep["u_off_envs"] == 0)
+    return rep

@@ -1,224 +1,12 @@
-"""Shared parity assertions of the GPU tests (BASELINE.json north_star: "within 1e-4").
+"""Shared parity assertions of the GPU tests: a re-export of oracle/parity.py (the rules live with the oracle, so that
+bench.py's `verified` leg applies exactly what the tests apply).  See that module's docstring for the complete list of
+tolerance knobs and which tests use each; in short:
 
-Every bound here is FIXED or derived from the ORACLE — never from the kernel's own error:
-
-  * the 1e-4 band itself: |d| <= 1e-4 + 1e-4 |ref| for states, 1e-4 relative for costs, 1e-4 absolute for controls;
-  * the reference's own arithmetic ambiguity (H1): numpy >= 2 keeps the substeps in float32 (mode A), numba carries them
-    in float64 (mode B).  A result inside the band around the interval [A, B] is a reference-conformant result, so the
-    per-element allowance is band + |A - B|, both computed by the oracle;
-  * H2 buckets: rollouts that the ORACLE's trajectory shows near a discontinuity (edge bounce, +-pi wrap, a cost
-    indicator threshold) are `flagged`; every unflagged rollout must be inside its allowance (100 %), flagged rollouts
-    are counted and at most `FLAGGED_CAP` of them (never more than 0.5 % of all rollouts) may sit outside — a bounce or an
-    indicator that fires one substep apart in two float32 evaluations is a legitimate, rare outcome of either one.
-    That allowance is for the RANDOM-instance tests only: on the reference-generated golden fixtures and step traces the
-    assertions run `strict` (cap 0: no rollout outside band + gap, flagged or not).
-
-Measured on MI355X (tools/dev/parity_buckets.py, all 8 x 1024 golden rollouts, both math modes and lane mappings): no
-rollout outside band + gap at all, flagged or not; worst clear rollout 0.32 bands; worst cost 2.9e-5 relative.
+  * rule ODE_V0 (default; every test of the north-star path): 1e-4 band + the oracle's A / B gap (+ the envelope of the
+    oracle's further realisations where a test passes probes); flagged bucket capped at 2 % of itself / 0.5 % of all,
+    `strict` (cap 0) on every reference-generated fixture; sensitive scatter NOT widened;
+  * rule PREDICTOR_ODE (tests/test_gpu_ode_predictor.py, tools/dev/shape_fuzz.py --predictor-type ODE only): the same with the
+    scatter of oracle-marked sensitive rollouts doubled.
 """
-import numpy as np
-
-from oracle import oracle_np as O
-
-f32 = np.float32
-THL = float(O.DEFAULT_PARAMS.TrackHalfLength)
-FLAGGED_CAP = 0.02            # fraction of the FLAGGED rollouts that may sit outside their allowance
-TOTAL_CAP = 0.005             # ... and never more than this fraction of all rollouts
-
-
-def band(ref, scale=1.0):
-    return scale * (1e-4 + 1e-4 * np.abs(ref))
-
-
-def flag_discontinuities(traj, dt=0.02, x_margin=2e-3, th_margin=2e-3):
-    """traj[N, H+1, 6] from the ORACLE (control-step granularity).  A rollout is flagged if between two samples its cart
-    can have reached the track edge (|x| + |v| dt within x_margin of THL) or its angle sits within th_margin of +-pi."""
-    x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
-    near_edge = (np.abs(x) + np.abs(v) * dt > THL - x_margin).any(axis=1)
-    near_wrap = (np.abs(np.abs(th) - np.pi) < th_margin).any(axis=1)
-    return near_edge | near_wrap
-
-
-def flag_indicators(traj, cost, target_position, margin=2e-4):
-    """Rollouts whose oracle trajectory passes within `margin` of a cost INDICATOR threshold (default.py:41-88: 1e7 at
-    |x| > 0.9 THL, terminal 1e4 at |angle| > 0.2 or |x - x*| > 0.1 THL; legacy q/phi: 1e6 at 0.95 THL, same terminal)."""
-    x = traj[:, :, O.POSITION_IDX]
-    flagged = np.zeros(traj.shape[0], dtype=bool)
-    if cost in ("default", "legacy"):
-        thr = (0.90 if cost == "default" else 0.95) * THL
-        flagged |= (np.abs(np.abs(x[:, :-1]) - thr) < margin).any(axis=1)
-        flagged |= np.abs(np.abs(traj[:, -1, O.ANGLE_IDX]) - 0.2) < margin
-        flagged |= np.abs(np.abs(x[:, -1] - target_position) - 0.1 * THL) < margin
-    return flagged
-
-
-def _check(off, flagged, what, strict=False):
-    """strict: the flagged bucket gets NO allowance either (the golden fixtures and the reference's own step traces:
-    measured on MI355X, no rollout of theirs is outside band + gap, flagged or not — so none may be)."""
-    n = off.size
-    clear_off = int((off & ~flagged).sum())
-    assert clear_off == 0, f"{what}: {clear_off} of {int((~flagged).sum())} rollouts clear of every discontinuity are outside the band"
-    fl_off, fl = int((off & flagged).sum()), int(flagged.sum())
-    cap = 0 if strict else min(int(np.ceil(FLAGGED_CAP * fl)), int(np.ceil(TOTAL_CAP * n)))
-    assert fl_off <= cap, f"{what}: {fl_off} of {fl} flagged rollouts outside the band (cap {cap})"
-
-
-def assert_states(out, ref_a, ref_b, flagged, what="states", scale=1.0, strict=False):
-    """out, ref_a, ref_b [N, 6] (or [N, k, 6]): inside band(ref_a) + |ref_a - ref_b| element-wise."""
-    off = np.abs(out - ref_a) > band(ref_a, scale) + np.abs(ref_a - ref_b)
-    off = off.reshape(off.shape[0], -1).any(axis=1)
-    _check(off, flagged, what, strict)
-
-
-def envelope(ref_a, *others):
-    """max_k |ref_a - other_k|: how far the reference's own realisations (mode B float64 substeps, mode C float32 with
-    FMA + float trig, mode A from an initial state one ulp away) sit from mode A, element-wise.  None entries are skipped."""
-    a = np.asarray(ref_a, np.float64)
-    gap = np.zeros(a.shape)
-    for o in others:
-        if o is not None:
-            gap = np.maximum(gap, np.abs(a - np.asarray(o, np.float64)))
-    return gap
-
-
-def assert_costs(S, S_a, S_b=None, flagged=None, what="costs", rtol=1e-4, flag_sensitive=False, strict=False, S_alt=(),
-                 sens_rtol=None, sensitive_gap_scale=1.0):
-    """Per-rollout costs: |S - S_a| <= rtol |S_a| + gap for every unflagged rollout, gap = the envelope of the reference's
-    own realisations around mode A (S_b and any S_alt).  flag_sensitive: a rollout on which those realisations disagree
-    among THEMSELVES by more than sens_rtol |S_a| (default: the band; the full-size C3 / C4 tests use a QUARTER of it, as
-    flag_rounding_sensitive does: a chaotic trajectory that amplifies 1e-7 roundings to a visible fraction of the
-    tolerance) joins the flagged bucket - no evaluation in float32, the reference's included, pins it to the band.
-    Measured on MI355X (tools/dev/cfg_parity_diag.py, C3 = 64 x 4096 rollouts of 1000 substeps from random states up to 21
-    rad/s): with the seven realisations of c_oracle_step_with_flags(probes=True) and the quarter-band rule NO clear
-    rollout is outside its allowance in FAST (both lane mappings) or PRECISE (worst: 0.95 of it); with modes A / B alone
-    25 of 199 887 are - PRECISE, the reference's own operand order, among them."""
-    S, S_a = np.asarray(S, np.float64), np.asarray(S_a, np.float64)
-    gap = envelope(S_a, S_b, *S_alt) if (S_b is not None or len(S_alt)) else 0.0
-    flagged = np.zeros(S.shape, bool) if flagged is None else np.asarray(flagged, bool)
-    sensitive = np.zeros(S.shape, bool)
-    if flag_sensitive and (S_b is not None or len(S_alt)):
-        sensitive = gap > (rtol if sens_rtol is None else sens_rtol) * np.abs(S_a)
-        flagged = flagged | sensitive
-    # sensitive_gap_scale (predictor_ODE tests): `gap` is the LARGEST of k sampled realisations of a chaotic rollout's cost; one
-    # more realisation - the kernel's - exceeds the largest of k with probability 1 / (k + 1) (an eighth with the seven of
-    # c_oracle_step_with_flags), far above the flagged bucket's 2 % cap, so for the rollouts the oracle itself marks sensitive the
-    # sampled scatter is widened by this factor (2 in the predictor_ODE tests); every other rollout keeps the plain allowance
-    off = np.abs(S - S_a) > rtol * np.abs(S_a) + gap * np.where(sensitive, sensitive_gap_scale, 1.0)
-    _check(off, flagged, what, strict)
-
-
-def assert_controls(u, u_a, u_b=None, what="controls", atol=1e-4, allowance=None, u_alt=(), sensitive_gap_scale=1.0):
-    """Updated control sequence / Q: 1e-4 absolute (north_star) around the reference's own [A, B] interval.  The soft-min
-    update amplifies cost differences by |S| / LBD (costs of ~5e4 at LBD = 100 turn a 1e-5 relative cost difference into
-    a 0.5 % weight change), so where the reference's two arithmetic modes themselves disagree on u by more than the
-    band, the allowance widens by exactly that disagreement (max over the horizon) — an oracle quantity.  `allowance`
-    (optional, per control): softmin_allowance(...) of the oracle's costs, for ill-conditioned updates."""
-    u, u_a = np.asarray(u, np.float64), np.asarray(u_a, np.float64)
-    gap = float(envelope(u_a, u_b, *u_alt).max()) if (u_b is not None or len(u_alt)) else 0.0
-    if gap > atol:          # an update the reference's own realisations disagree on by more than the band: see assert_costs on
-        gap *= sensitive_gap_scale      # why the largest of k samples is widened (predictor_ODE tests; 1.0 elsewhere)
-    extra = 0.0 if allowance is None else np.asarray(allowance, np.float64)
-    d = np.abs(u - u_a)
-    assert np.all(d <= atol + np.maximum(gap, extra)), (f"{what}: max |u - u_ref| = {d.max():.3e} > {atol:g} + oracle allowance "
-                                                      f"(A/B gap {gap:.3e}, soft-min conditioning {np.max(extra):.3e})")
-
-
-def softmin_allowance(S_a, S_b, du, LBD=100.0, cost_rtol=1e-5):
-    """How far a cost perturbation |dS_n| <= cost_rtol |S_n| + |S_a,n - S_b,n| can move the soft-min update, by its
-    Jacobian on the ORACLE's values:  u_k = sum_n w_n du[n,k],  w_n ~ exp(-S_n / LBD)  =>
-        |d u_k| <= (1 / LBD) sum_n w_n |du[n,k] - u_k| |dS_n|.
-    cost_rtol is FIXED at a tenth of the cost band: for costs of O(100) the term vanishes (the plain 1e-4 applies), for the
-    boundary-penalty regimes with costs of ~5e4 at LBD = 100 it is the honest conditioning of the reference's own update
-    (its float32 and float64-substep evaluations already differ by more than 1e-4 in u there)."""
-    S_a = np.asarray(S_a, np.float64)
-    eps = cost_rtol * np.abs(S_a) + (np.abs(S_a - np.asarray(S_b, np.float64)) if S_b is not None else 0.0)
-    w = np.exp(-(S_a - S_a.min()) / LBD)
-    w /= w.sum()
-    du = np.asarray(du, np.float64)
-    ubar = w @ du
-    return (w * eps) @ np.abs(du - ubar[None, :]) / LBD
-
-
-def flag_rounding_sensitive(S_f32, S_f64, thresh=0.25e-4):
-    """Rollouts whose cost the ORACLE itself cannot pin to a quarter of the band in float32 (its float32 and float64
-    evaluations differ by more than `thresh` relative): ill-conditioned, e.g. saturating random GRU weights."""
-    S_f32, S_f64 = np.asarray(S_f32, np.float64), np.asarray(S_f64, np.float64)
-    return np.abs(S_f32 - S_f64) > thresh * np.abs(S_f64)
-
-
-def oracle_step_both_modes(s0, u_nom, du, target_position, target_equilibrium, cfg, **kw):
-    """The oracle's MPPI step in both reference arithmetic modes (A: float32 substeps, B: float64 substeps)."""
-    a = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f32", **kw)
-    b = O.mppi_step(s0, u_nom, du, target_position, target_equilibrium, cfg, mode="f64sub", **kw)
-    return a, b
-
-
-def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=None, cost=None, probes=False):
-    """The plain-C oracle's MPPI step for E envs in BOTH reference arithmetic modes, plus the H2 flags of every rollout
-    from the oracle's own trajectories (default glue: shift repeat-last, clip); with ``cost`` ("default" / "legacy") also
-    the rollouts within reach of that plugin's indicator thresholds.  -> dict(S_a, S_b, u_a, u_b, Q_a, flags) and, with
-    ``probes``, S_alt / u_alt: lists of further realisations of the REFERENCE for the rounding-sensitivity envelope -
-    mode C (float32 with FMA contraction and libm float trig, what a fastmath float32 build computes; absent on a host
-    without FMA) and mode A re-run one float32 ulp away in the angular velocity, the cart velocity, the position, the
-    perturbations and the pole length.  Per rollout, in each list entry [E, N] (costs) / [E, H] (controls)."""
-    from oracle import oracle_c as OC
-    E, N, H = du.shape
-    ca, cb = OC.make_config(ocfg, params), OC.make_config(ocfg, params, mode="f64sub")
-    u_a, Q_a, S_a = OC.step(ca, s0, u0, du, tp, te, L=L)
-    u_b, _, S_b = OC.step(cb, s0, u0, du, tp, te, L=L)
-    extra = {}
-    if probes:
-        # more realisations of the REFERENCE, each one rounding-level away from mode A: how far they scatter is what "the
-        # reference's result" means for a rollout (a chaotic one amplifies 1e-7 to 1e-3 within a hundred control steps)
-        fma = OC.fma_lib()
-        alt_S, alt_u = [], []
-        if fma is not None:                                     # mode C: float32 with FMA contraction + libm float trig
-            u_c, _, S_c = OC.step(ca, s0, u0, du, tp, te, L=L, use_lib=fma)
-            alt_S.append(S_c); alt_u.append(u_c)
-        s0a = np.array(s0, f32).reshape(E, 6)
-        one_up = lambda a: np.nextafter(a, f32(np.inf)).astype(f32)  # noqa: E731
-        for col in (O.ANGLED_IDX, O.POSITIOND_IDX, O.POSITION_IDX):  # mode A from an initial state one float32 ulp away
-            s0p = s0a.copy()
-            s0p[:, col] = one_up(s0p[:, col])
-            u_p, _, S_p = OC.step(ca, s0p, u0, du, tp, te, L=L)
-            alt_S.append(S_p); alt_u.append(u_p)
-        u_p, _, S_p = OC.step(ca, s0, u0, one_up(np.asarray(du, f32)), tp, te, L=L)     # every perturbation one ulp up
-        alt_S.append(S_p); alt_u.append(u_p)
-        if L is not None:                                       # the pole length one ulp longer
-            u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=one_up(np.asarray(L, f32)))
-            alt_S.append(S_p); alt_u.append(u_p)
-        if getattr(ocfg, "integrator", "ODE_v0") == "ODE":
-            # predictor_ODE: three more, each with every sin / cos result moved to a neighbouring float32 at random - all the
-            # realisations above but mode C share ONE sin / cos implementation, and this predictor feeds sin / cos back into the
-            # ANGLE (atan2) on every substep: found at full-width C3, where four rollouts in 262 144 sat 1.5e-4 from mode A in
-            # FAST and PRECISE alike (3e-5 from each other) while the realisations above scattered by 1e-5
-            try:
-                for seed in (1, 2, 3):
-                    OC.set_trig_jitter(seed)
-                    u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=L)
-                    alt_S.append(S_p); alt_u.append(u_p)
-            finally:
-                OC.set_trig_jitter(0)
-        extra = {"S_alt": alt_S, "u_alt": alt_u}
-    if ocfg.shift_mode == "repeat_last":
-        u_shift = np.concatenate([u0[:, 1:], u0[:, -1:]], axis=1)
-    elif ocfg.shift_mode == "append_zero":
-        u_shift = np.concatenate([u0[:, 1:], np.zeros_like(u0[:, :1])], axis=1)
-    else:
-        u_shift = u0
-    u_run = u_shift[:, None, :] + du
-    if ocfg.control_mode == "clip":
-        u_run = np.clip(u_run, -1, 1)
-    u_run = u_run.astype(f32).reshape(E * N, H)
-    Lr = None if L is None else np.repeat(np.asarray(L, f32), N)
-    traj = OC.predict(ca, np.repeat(np.asarray(s0, f32), N, axis=0), u_run, L=Lr)
-    thl = float((params or O.DEFAULT_PARAMS).TrackHalfLength)
-    x, v, th = traj[:, :, O.POSITION_IDX], traj[:, :, O.POSITIOND_IDX], traj[:, :, O.ANGLE_IDX]
-    step = float(ocfg.dt if dt is None else dt)
-    flags = ((np.abs(x) + np.abs(v) * step > thl - 2e-3).any(axis=1) | (np.abs(np.abs(th) - np.pi) < 2e-3).any(axis=1))
-    flags = flags.reshape(E, N)
-    if cost in ("default", "legacy"):
-        tr = traj.reshape(E, N, H + 1, 6)
-        for e in range(E):
-            flags[e] |= flag_indicators(tr[e], cost, float(np.asarray(tp).reshape(-1)[e]))
-    return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags, **extra)
+from oracle.parity import *  # noqa: F401,F403
+from oracle.parity import _check  # noqa: F401

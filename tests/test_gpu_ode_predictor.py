@@ -158,7 +158,7 @@ def test_fused_step_vs_oracle(math_mode, rpl, flags):
     r = PU.c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=Lv, cost=("default" if cid == O.COST_DEFAULT else None), probes=True)
     # float32 realisations only (no float64-substep mode for this predictor, see the module docstring)
     PU.assert_costs(S, r["S_a"], None, r["flags"] & (cid == O.COST_DEFAULT), "costs", S_alt=r["S_alt"], flag_sensitive=True,
-                    sens_rtol=0.25e-4, sensitive_gap_scale=2.0)
+                    rule=PU.PREDICTOR_ODE)
     PU.assert_controls(un, r["u_a"], None, "u_new", u_alt=r["u_alt"])
     np.testing.assert_allclose(Q, r["Q_a"], atol=1e-4 + float(PU.envelope(r["u_a"], *r["u_alt"]).max()))
     # the numpy oracle (pinned to the reference's class) agrees with the C one on env 0
@@ -318,12 +318,12 @@ def test_baseline_configs_full_width(name, E, N, H):
             for i, e in enumerate(range(e0, e0 + CH)):
                 alts = [a[i] for a in ref["S_alt"]] + [ref["S_b"][i]]           # (float64 substeps: a probe here, not a target)
                 PU.assert_costs(S_m[e], ref["S_a"][i], None, None, f"{name} {mode} env {e} costs", S_alt=alts,
-                                flag_sensitive=True, sens_rtol=0.25e-4, sensitive_gap_scale=2.0)
+                                flag_sensitive=True, rule=PU.PREDICTOR_ODE)
                 allow = PU.softmin_allowance(ref["S_a"][i], ref["S_b"][i], du[i])
                 PU.assert_controls(u_m[e], ref["u_a"][i], ref["u_b"][i], f"{name} {mode} env {e} u_nom", allowance=allow,
-                                   u_alt=[a[i] for a in ref["u_alt"]], sensitive_gap_scale=2.0)
+                                   u_alt=[a[i] for a in ref["u_alt"]], rule=PU.PREDICTOR_ODE)
                 PU.assert_controls(Q_m[e], ref["u_a"][i][0], ref["u_b"][i][0], f"{name} {mode} env {e} Q", allowance=allow[0],
-                                   u_alt=[a[i][0] for a in ref["u_alt"]], sensitive_gap_scale=2.0)
+                                   u_alt=[a[i][0] for a in ref["u_alt"]], rule=PU.PREDICTOR_ODE)
         gap = PU.envelope(ref["S_a"], ref["S_b"], *ref["S_alt"])
         sens = gap > 0.25e-4 * np.abs(ref["S_a"])
         sensitive += int(sens.sum()); clear += int((~sens).sum())

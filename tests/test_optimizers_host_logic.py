@@ -27,6 +27,9 @@ class FakeEngine:
     def apply_pole_mass_of(self, variable_parameters):
         pass
 
+    def set_gru(self, model):
+        self.gru = model
+
     def tensor(self, x, shape=None):
         t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float32))
         return t.to(torch.float32).reshape(shape).contiguous() if shape is not None else t.to(torch.float32).contiguous()
@@ -279,3 +282,36 @@ def test_a_checkout_is_configured_as_shipped(fake_engine):
     c3 = controller_mpc("CartPole", {"target_position": 0.0}, config_root="/root/reference", config=dict(seed=5))
     c3.configure("cem-tf")
     assert c3.optimizer.num_rollouts == 200 and c3.optimizer.cfg.predictor_type == "ODE"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Control_Toolkit_ASF"), reason="reference checkout not mounted")
+def test_a_checkout_with_an_explicit_gru_model_runs_the_gru(fake_engine, monkeypatch):
+    """config_root reads the checkout's `predictor_specification: "ODE"` as the DEFAULT predictor only: a gru_model handed over
+    explicitly wins (it did before config_root learnt to read that line), and naming an ODE specification next to a model is
+    still an error."""
+    import cartpolesimulation_amd.optimizer_mppi as OM
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    monkeypatch.setattr(OM, "MPPIEngine", fake_engine, raising=False)
+    model = {"w_ih0": np.zeros((96, 6), np.float32)}
+    c = controller_mpc("CartPole", {"target_position": 0.0}, config_root="/root/reference", config=dict(seed=5, gru_model=model))
+    c.configure("mppi")
+    assert c.predictor is None and c.optimizer.gru_model is model and c.optimizer.h is not None
+    assert c.optimizer.engine.gru is model
+    with pytest.raises(ValueError):
+        c.configure("mppi", predictor_specification="ODE")
+
+
+def test_a_named_predictor_entry_keeps_its_own_substeps():
+    """config_controllers.yml:3 may name an ENTRY of config_predictors.yml (e.g. `I_love_control_too`): its own
+    intermediate_steps apply, "<type>_default" only when the entry has none."""
+    from cartpolesimulation_amd.configs import mppi_config_from_yaml
+    opt = dict(seed=1, mpc_horizon=10, mpc_timestep=0.02, num_rollouts=32, cc_weight=1.0, R=1.0, LBD=100.0, NU=1000.0,
+               SQRTRHOINV=0.03, period_interpolation_inducing_points=10)
+    base = dict(optimizers={"mppi": opt}, cost={"cost_function_name_default": "default", "CartPole": {"default": {}}})
+    preds = {"ODE_v0_default": {"predictor_type": "ODE_v0", "intermediate_steps": 10},
+             "ODE_default": {"predictor_type": "ODE", "intermediate_steps": 10},
+             "custom": {"predictor_type": "ODE", "intermediate_steps": 2}, "bare": {"predictor_type": "ODE"}}
+    for spec, (ptype, steps) in {"custom": ("ODE", 2), "bare": ("ODE", 10), "ODE": ("ODE", 10), "ODE_v0": ("ODE_v0", 10)}.items():
+        cfgs = dict(base, controllers={"mpc": {"predictor_specification": spec}}, predictors={"predictors": preds})
+        cfg = mppi_config_from_yaml(cfgs)
+        assert (cfg.predictor_type, cfg.intermediate_steps) == (ptype, steps), spec

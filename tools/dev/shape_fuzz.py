@@ -26,7 +26,6 @@ ap.add_argument("--probes", action="store_true", help="allowance from the envelo
                 "--predictor-type ODE the sampled scatter of the rollouts the oracle marks sensitive is widened 2 x (that "
                 "predictor re-derives the angle from float32 sin / cos with atan2 on every substep: rounding noise of a few "
                 "1e-7 enters 500 times per rollout, and an eighth realisation exceeds the largest of seven one time in eight)")
-ap.add_argument("--sens-scale", type=float, default=2.0, help="the widening factor above (1 = the plain envelope)")
 ap.add_argument("--predictor-type", default="ODE_v0", choices=["ODE_v0", "ODE"], help="which in-tree ODE predictor (ODE: Euler-Cromer, no bounce)")
 args = ap.parse_args()
 rng = np.random.Generator(np.random.SFC64(args.seed))
@@ -89,8 +88,8 @@ for it in range(args.n):
                 assert not np.any((dS > bound) & ~ref["flags"][e]), f"env {e} costs (hanging target): {int(((dS > bound) & ~ref['flags'][e]).sum())} outside"
                 continue
             PU.assert_costs(Sh[e], ref["S_a"][e], ref["S_b"][e], ref["flags"][e], f"env {e} costs", flag_sensitive=True,
-                            S_alt=[a[e] for a in S_alt], sens_rtol=(0.25e-4 if args.probes else None),
-                            sensitive_gap_scale=(args.sens_scale if args.probes and args.predictor_type == "ODE" else 1.0))
+                            S_alt=[a[e] for a in S_alt], sens_rtol=(0.25e-4 if args.probes else 1e-4),
+                            rule=(PU.PREDICTOR_ODE if args.probes and args.predictor_type == "ODE" else PU.ODE_V0))
             PU.assert_controls(uh[e], ref["u_a"][e], ref["u_b"][e], f"env {e} u_nom", u_alt=[a[e] for a in u_alt],
                                allowance=PU.softmin_allowance(ref["S_a"][e], ref["S_b"][e], duh[e], LBD=cfg.LBD))
             # and the update GIVEN the kernel's own costs (float64 soft-min of S_gpu over the same perturbations): exact to
