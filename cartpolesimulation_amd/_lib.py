@@ -22,7 +22,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
-           "cpmppi_step_gather", "cpmppi_last_launch")
+           "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -125,6 +125,7 @@ def load():
     lib.cpmppi_comm_gather.argtypes = [vp, u32, vp, vp, C.c_size_t, vp]
     lib.cpmppi_comm_wait.argtypes = [vp, u32, vp]
     lib.cpmppi_comm_sync.argtypes = [vp]
+    lib.cpmppi_comm_set_timeout.argtypes = [vp, C.c_double]
     lib.cpmppi_comm_destroy.argtypes = [vp]
     lib.cpmppi_step_gather.argtypes = [vp, C.POINTER(cpmppi_step_args), vp, vp]
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]

@@ -1234,6 +1234,11 @@ int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* a, float* recv_
   if (!a || !recv_all) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: null argument");
   if (!h->comm) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: no communicator (cpmppi_comm_init)");
   if (a->E == 0 || a->E > h->cfg.E || !a->u_nom) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: bad step arguments");
+  // a wait on the device gave up (a peer rank stalled beyond cpmppi_comm_set_timeout): the steps since then have dropped their
+  // results and the gathered blocks are not to be used - say so NOW, not at a cpmppi_comm_sync the caller may never make
+  if (cpmppi_comm::comm_error_pending(h))
+    return fail(h, CPMPPI_ERR_COMM, "cpmppi_step_gather: an earlier step's device-side wait for an all-gather timed out; "
+                                    "cpmppi_comm_sync reports and clears the condition");
   const bool in_place = !a->u_nom_out || a->u_nom_out == a->u_nom;
   cpmppi_comm::GatherTicket t;
   cpmppi_comm::begin_step_gather(h->comm, in_place ? a->u_nom : a->u_nom_out, &t);

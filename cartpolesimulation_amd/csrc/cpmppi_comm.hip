@@ -12,13 +12,23 @@
 //
 // Two ways to order the two streams:
 //   * cpmppi_step_gather (the production path): through DEVICE MEMORY.  The env-finalizing blocks of the rollout kernel
-//     count themselves; the last one publishes the step number (agent-scope release).  On the side stream a one-lane
-//     kernel waits for that number, the all-gather follows in stream order, a second one-lane kernel posts the number
-//     of completed gathers, which the finalize of the step that overwrites the gathered buffer (two steps later) checks
-//     before its stores.  The launch stream carries the rollout kernels and NOTHING else: an event record or a
-//     cross-stream wait is a barrier packet the next dispatch has to queue behind - measured 4-5 us each next to a 91 us
-//     kernel at BASELINE configs[3] (torch.distributed's snapshot copy + Work object + two waits per step: 33 us).
-//     Every device-side wait gives up after ~2 s and raises an error flag (cpmppi_comm_sync reports it).
+//     count themselves; the last one publishes the step number (system-scope release) into 8 bytes of SIGNAL MEMORY.  The
+//     side stream carries, per step, hipStreamWaitValue32(published >= step) -> ncclAllGather -> hipStreamWriteValue32(
+//     gathers completed = step): the two stream-memory operations are packets of the command processor, which polls and
+//     writes memory itself - no guest wave on the rollout kernel's SIMDs, no kernel launch beside RCCL's own (round 3: two
+//     one-lane kernels per step).  The finalize of the step that overwrites a gathered buffer (two steps later) checks the
+//     completed count before its stores.  The launch stream carries the rollout kernels and NOTHING else: an event record
+//     or a cross-stream wait is a barrier packet the next dispatch has to queue behind - measured 4-5 us each next to a
+//     91 us kernel at BASELINE configs[3] (torch.distributed's snapshot copy + Work object + two waits per step: 33 us).
+//     Where stream memory operations are unavailable (hipDeviceAttributeCanUseStreamWaitValue = 0; CPMPPI_COMM_WAITER=kernel
+//     forces it) ONE one-lane kernel per step does both jobs: it posts the previous gather's completion and waits for this
+//     step (post_wait_kernel).
+//     The only device-side wait left that depends on OTHER ranks is the finalize's: it gives up after
+//     cpmppi_comm_set_timeout seconds (default 10; a peer may legitimately stall in a first-launch module load or a
+//     checkpoint), and a wait that gives up does NOT proceed - the stores it guards are skipped (the buffer a gather is
+//     still reading stays intact), the error is raised in device memory (every later wait and store of the handle is
+//     skipped at once: the queue drains, nothing is overwritten) and in a pinned host word that the next
+//     cpmppi_step_gather returns as CPMPPI_ERR_COMM; cpmppi_comm_sync reports and clears it.
 //   * cpmppi_comm_gather / cpmppi_comm_wait: HIP events, for buffers that are not produced by cpmppi_step.
 //
 // RCCL is bound at run time (dlopen) so that libcpmppi.so loads on hosts without it and, inside a PyTorch process,
@@ -90,29 +100,47 @@ struct CommState {
   hipEvent_t done[SLOTS] = {};          // side stream -> launch stream: the gather of this slot has completed
   bool pending[SLOTS] = {};
   // cpmppi_step_gather: ordering through device memory instead of events (no packet on the launch stream)
-  unsigned* flags = nullptr;            // [0] envs finalized, [1] steps published, [2] gathers completed, [3] error
+  unsigned* flags = nullptr;            // [0] envs finalized, [1] steps published (fallback waiter), [2] gathers completed, [3] error
+  unsigned* published = nullptr;        // 8 bytes of signal memory: steps published, watched by hipStreamWaitValue32 (NULL = fallback)
+  unsigned* err_host = nullptr;         // pinned, device-mapped host word: the error flag as the host reads it
   unsigned gather_index = 0;            // step_gathers enqueued so far
+  unsigned pending_post = 0;            // fallback waiter: the completion count the next post_wait_kernel has to post (0 = none)
+  unsigned long long timeout_ticks = 1000000000ull;   // 10 s of the 100 MHz device clock (cpmppi_comm_set_timeout)
+  unsigned debug_delay_us = 0;          // tests: a spin of this length on the side stream in front of every all-gather
   const float* last_send = nullptr;     // the buffer the previous step_gather's all-gather reads
 };
 
-// side stream, one lane: hold the stream until the rollout kernel's last finalizing block has published step `need`
-// (finalize_env, cpmppi_rollout.hpp).  Gives up after ~2 s and raises the error flag: a launch that never comes must not
-// wedge the queue.
-__global__ void wait_published_kernel(unsigned* flags, unsigned need) {
+// Fallback waiter (no stream memory operations), side stream, one lane: posts "gathers completed = post" (the all-gather in
+// front of it on the stream has finished) and then holds the stream until the rollout kernel's last finalizing block has
+// published step `need` (finalize_env, cpmppi_rollout.hpp).  A wait that gives up raises the error for device and host; the
+// all-gather behind it then sends whatever the buffer holds - the error tells every consumer not to use it.
+__global__ void post_wait_kernel(unsigned* flags, unsigned post, unsigned need, unsigned* err_host, unsigned long long timeout_ticks) {
+  if (post != 0u) __hip_atomic_store(flags + 2, post, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (need == 0u) return;
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   while ((int)(__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
     __builtin_amdgcn_s_sleep(64);      // (~4096 cycles between polls: the wave shares a SIMD with a rollout wave)
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+    if (__hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
       __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
 }
 
-// side stream, after the all-gather: gathers completed = value (read by the finalize of the step that overwrites the
-// gathered buffer next)
-__global__ void post_gathered_kernel(unsigned* flags, unsigned value) {
-  __hip_atomic_store(flags + 2, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// tests only (cpmppi_debug_comm_delay): keeps the side stream busy for `ticks` of the 100 MHz clock - a slow peer
+__global__ void delay_kernel(unsigned long long ticks) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// words [4..9] of the flag block: what only the kernels' slow paths read (GatherSync in cpmppi_rollout.hpp) - the signal
+// memory's address (0 = fallback waiter), the pinned error word's address, the timeout in 100 MHz ticks
+constexpr int FLAG_WORDS = 16;
+hipError_t upload_slow_path_words(CommState* c) {
+  unsigned long long w[3] = {(unsigned long long)(uintptr_t)c->published, (unsigned long long)(uintptr_t)c->err_host, c->timeout_ticks};
+  return hipMemcpy(c->flags + 4, w, sizeof(w), hipMemcpyHostToDevice);
 }
 
 void destroy(CommState* c) {
@@ -123,6 +151,8 @@ void destroy(CommState* c) {
   for (hipEvent_t e : c->done)
     if (e) (void)hipEventDestroy(e);
   if (c->flags) (void)hipFree(c->flags);
+  if (c->published) (void)hipFree(c->published);
+  if (c->err_host) (void)hipHostFree(c->err_host);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
@@ -202,8 +232,25 @@ int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, cons
   if (const char* ev = getenv("CPMPPI_COMM_READY_FENCE")) if (ev[0] == '1') ready_flags = hipEventDisableTiming;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, ready_flags);
   for (int i = 0; i < SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->flags, 4 * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMemset(c->flags, 0, 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->flags, FLAG_WORDS * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(c->flags, 0, FLAG_WORDS * sizeof(unsigned));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) memset(c->err_host, 0, 64);
+  if (e == hipSuccess) {
+    // stream memory operations: the side stream waits for a published step / posts a completed gather without a kernel
+    int can = 0;
+    const char* w = getenv("CPMPPI_COMM_WAITER");
+    const bool force_kernel = w && strcmp(w, "kernel") == 0;
+    if (!force_kernel && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, cpmppi_internal_device(h)) == hipSuccess && can == 1) {
+      if (hipExtMallocWithFlags((void**)&c->published, 8, hipMallocSignalMemory) == hipSuccess) {
+        *reinterpret_cast<volatile unsigned long long*>(c->published) = 0ull;
+      } else {
+        (void)hipGetLastError();
+        c->published = nullptr;
+      }
+    }
+  }
+  if (e == hipSuccess) e = upload_slow_path_words(c);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     destroy(c);
@@ -244,15 +291,47 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
   CommState* c = cpmppi_internal_comm(h);
   if (!c) return CPMPPI_OK;
   OnDevice guard(cpmppi_internal_device(h));
+  if (c->pending_post != 0u) {          // fallback waiter: the last gather's completion has not been posted yet
+    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, c->pending_post, 0u, c->err_host, c->timeout_ticks);
+    COMM_HIP(h, hipGetLastError());
+    c->pending_post = 0u;
+  }
   COMM_HIP(h, hipStreamSynchronize(c->side));
   for (bool& p : c->pending) p = false;
-  unsigned f[4] = {0, 0, 0, 0};
-  COMM_HIP(h, hipMemcpy(f, c->flags, sizeof(f), hipMemcpyDeviceToHost));
-  if (f[3] != 0u) {
+  if (__atomic_load_n(c->err_host, __ATOMIC_ACQUIRE) != 0u) {
+    // reported once; cleared for device and host so that the handle can go on (the steps since the error left their
+    // nominal sequences unwritten)
     (void)hipMemset(c->flags + 3, 0, sizeof(unsigned));
-    return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, "cpmppi_comm_sync: a device-side wait between a step and its all-gather timed out");
+    (void)hipDeviceSynchronize();
+    __atomic_store_n(c->err_host, 0u, __ATOMIC_RELEASE);
+    return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, "cpmppi_comm_sync: a device-side wait between a step and an all-gather timed out "
+                                                    "(cpmppi_comm_set_timeout); the steps since then did not write their nominal sequences");
   }
   return CPMPPI_OK;
+}
+
+int cpmppi_comm_set_timeout(cpmppi_handle* h, double seconds) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_set_timeout: no communicator (cpmppi_comm_init)");
+  if (!(seconds == seconds)) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_set_timeout: not a number");
+  c->timeout_ticks = (seconds <= 0.0 || seconds > 1.0e9) ? ~0ull : (unsigned long long)(seconds * 1.0e8 + 0.5);
+  OnDevice guard(cpmppi_internal_device(h));
+  COMM_HIP(h, upload_slow_path_words(c));          // (a synchronous copy: launches already enqueued keep the old value)
+  return CPMPPI_OK;
+}
+
+// tests only (not in cpmppi.h): every later all-gather of cpmppi_step_gather is preceded by a spin of `microseconds` on the side
+// stream - a peer that joins the collective late
+int cpmppi_debug_comm_delay(cpmppi_handle* h, unsigned microseconds) {
+  if (!h || !cpmppi_internal_comm(h)) return CPMPPI_ERR_BAD_ARG;
+  cpmppi_internal_comm(h)->debug_delay_us = microseconds;
+  return CPMPPI_OK;
+}
+// tests only: 1 = stream memory operations order the side stream, 0 = the fallback waiter kernel
+int cpmppi_debug_comm_mode(cpmppi_handle* h) {
+  if (!h || !cpmppi_internal_comm(h)) return CPMPPI_ERR_BAD_ARG;
+  return cpmppi_internal_comm(h)->published ? 1 : 0;
 }
 
 int cpmppi_comm_destroy(cpmppi_handle* h) {
@@ -270,15 +349,29 @@ int cpmppi_comm_destroy(cpmppi_handle* h) {
 
 namespace cpmppi_comm {
 
+int comm_error_pending(cpmppi_handle* h) {
+  CommState* c = cpmppi_internal_comm(h);
+  return (c && __atomic_load_n(c->err_host, __ATOMIC_ACQUIRE) != 0u) ? 1 : 0;
+}
+
 int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t count) {
   CommState* c = cpmppi_internal_comm(h);
   OnDevice guard(cpmppi_internal_device(h));
   const unsigned g = c->gather_index;
-  hipLaunchKernelGGL(wait_published_kernel, dim3(1), dim3(1), 0, c->side, c->flags, g + 1u);
-  COMM_HIP(h, hipGetLastError());
+  if (c->published) {
+    COMM_HIP(h, hipStreamWaitValue32(c->side, c->published, g + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  } else {
+    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, c->pending_post, g + 1u, c->err_host, c->timeout_ticks);
+    COMM_HIP(h, hipGetLastError());
+    c->pending_post = 0u;
+  }
+  if (c->debug_delay_us) {
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, c->side, (unsigned long long)c->debug_delay_us * 100ull);
+    COMM_HIP(h, hipGetLastError());
+  }
   COMM_NCCL(h, g_rccl.AllGather(send, recv_all, count, ncclFloat, c->comm, c->side));
-  hipLaunchKernelGGL(post_gathered_kernel, dim3(1), dim3(1), 0, c->side, c->flags, g + 1u);
-  COMM_HIP(h, hipGetLastError());
+  if (c->published) COMM_HIP(h, hipStreamWriteValue32(c->side, c->flags + 2, g + 1u, 0));
+  else c->pending_post = g + 1u;          // posted by the next step's post_wait_kernel, or by cpmppi_comm_sync
   c->gather_index = g + 1u;
   c->last_send = send;
   return CPMPPI_OK;

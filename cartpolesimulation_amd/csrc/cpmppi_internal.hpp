@@ -11,12 +11,14 @@ void destroy(CommState* c);                              // called by cpmppi_des
 // cpmppi_step_gather = begin_step_gather (numbers the gather, says what the step's finalize must publish / await) ->
 // the step launch -> enqueue_gather (side stream: wait for the published step, ncclAllGather, post completion)
 struct GatherTicket {
-  unsigned* flags;        // device words: [0] envs finalized, [1] steps published, [2] gathers completed, [3] error
+  unsigned* flags;        // device words: [0] envs finalized, [1] steps published, [2] gathers completed, [3] error, [4..9] the
+                          // slow paths' pointers and the timeout (GatherSync, cpmppi_rollout.hpp)
   unsigned publish, need;
 };
 void begin_step_gather(CommState* c, const float* out_buffer, GatherTicket* out);
 void abort_step_gather(CommState* c);
 int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t count);
+int comm_error_pending(cpmppi_handle* h);    // a device-side wait of this handle has timed out (sticky until cpmppi_comm_sync)
 }  // namespace cpmppi_comm
 
 cpmppi_comm::CommState*& cpmppi_internal_comm(cpmppi_handle* h);

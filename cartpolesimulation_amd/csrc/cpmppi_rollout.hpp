@@ -43,23 +43,41 @@ constexpr int WAVES = BLOCK / 64;
 constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
 
 // Device-side ordering between a step and the all-gather of its result (cpmppi_step_gather, cpmppi_comm.hip) without any
-// packet on the launch stream: flags[0] envs finalized by this launch, flags[1] steps published, flags[2] gathers
-// completed (written by the side stream), flags[3] a spin gave up (error).
+// packet on the launch stream: flags[0] envs finalized by this launch, flags[1] steps published (read by the fallback
+// waiter kernel), flags[2] gathers completed (written by the side stream), flags[3] a wait gave up (sticky until
+// cpmppi_comm_sync: while it is set nothing waits and nothing is stored).
 struct GatherSync {
-  uint32_t* flags;      // NULL = no gather follows this step
-  uint32_t publish;     // value of flags[1] once every env of this launch has written its nominal sequence
-  uint32_t need;        // flags[2] must have reached this before the output buffer may be overwritten (0 = no wait)
-  uint32_t envs;        // envs in this launch
+  uint32_t* flags;          // NULL = no gather follows this step.  The block also holds what only the slow paths need, so that
+                            // the kernel argument stays four words: [4,5] pointer to the signal memory the side stream's
+                            // hipStreamWaitValue32 watches (0: the waiter kernel polls flags[1]), [6,7] pointer to the pinned
+                            // host word that mirrors the error, [8,9] the 100 MHz ticks a wait may last (~0 = for ever)
+  uint32_t publish;         // the step number every env of this launch publishes once its nominal sequence is written
+  uint32_t need;            // flags[2] must have reached this before the output buffer may be overwritten (0 = no wait)
+  uint32_t envs;            // envs in this launch
 };
+constexpr int GS_PUBLISHED = 4, GS_ERR_HOST = 6, GS_TIMEOUT = 8, GS_WORDS = 16;
+__device__ __forceinline__ uint64_t gs_word64(const uint32_t* flags, int i) {
+  return (uint64_t)flags[i] | ((uint64_t)flags[i + 1] << 32);
+}
 
-// flag >= need (wrap-safe), polling at agent scope; gives up after ~2 s (100 MHz counter) and raises the error flag
-__device__ __forceinline__ void spin_until_reached(uint32_t* flag, uint32_t need, uint32_t* err) {
+// flag >= need (wrap-safe), polled with system-scope loads (the side stream's hipStreamWriteValue32 is a write of the command
+// processor: not through this XCD's L2).  Returns false - after raising the error for device and host - when the wait
+// outlasts `timeout_ticks` or the error is already up: the caller then does NOT proceed to the stores the wait guards.
+__device__ __forceinline__ bool spin_until_reached(uint32_t* flag, uint32_t need, const GatherSync& gs) {
+  uint32_t* err = gs.flags + 3;
+  if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - need) >= 0)
+    return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-  while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+  for (;;) {
     __builtin_amdgcn_s_sleep(4);
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+    if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - need) >= 0)
+      return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > gs_word64(gs.flags, GS_TIMEOUT)) {
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
+      uint32_t* err_host = reinterpret_cast<uint32_t*>(gs_word64(gs.flags, GS_ERR_HOST));
+      if (err_host) __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
     }
   }
 }
@@ -197,14 +215,22 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
     u_new[k] = v;
   }
   __syncthreads();                          // every read of the old nominal sequence is done
+  bool store = true;
   if (gs.flags && gs.need) {
     // the all-gather that still reads the buffer written next (two steps back with alternating buffers) must be complete:
-    // by now it has had a whole step to run, so this practically never spins
-    if (tid == 0) spin_until_reached(gs.flags + 2, gs.need, gs.flags + 3);
+    // by now it has had a whole step to run, so this practically never spins.  A wait that gives up (a peer rank stalled
+    // beyond cpmppi_comm_set_timeout) must NOT fall through to the stores - the gather would send a half-overwritten
+    // buffer to every rank: this step's result is dropped instead, the error is raised for the host, and the launch still
+    // publishes so that nothing behind it wedges.
+    __shared__ uint32_t may_store;
+    if (tid == 0) may_store = spin_until_reached(gs.flags + 2, gs.need, gs) ? 1u : 0u;
     __syncthreads();
+    store = may_store != 0u;
   }
-  for (uint32_t k = tid; k < H; k += BLOCK) uo[k] = u_new[k];
-  if (tid == 0 && Q_out) Q_out[env] = u_new[0];
+  if (store) {
+    for (uint32_t k = tid; k < H; k += BLOCK) uo[k] = u_new[k];
+    if (tid == 0 && Q_out) Q_out[env] = u_new[0];
+  }
   if (tid == 0 && host_ticket) {
     // the simulator's host thread spins on this counter instead of waiting on the stream (cpmppi_step_host): Q_out lives
     // in the same pinned, fine-grained block; system-scope release so that the control is visible before the ticket
@@ -220,7 +246,11 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
       const uint32_t arrived = __hip_atomic_fetch_add(gs.flags, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (arrived == gs.envs - 1u) {
         __hip_atomic_store(gs.flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(gs.flags + 1, gs.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // the side stream waits for this number: hipStreamWaitValue32 on signal memory (the command processor polls it: no
+        // wave of another kernel on our SIMDs), or - where that is unavailable - a one-lane kernel polling flags[1]
+        uint32_t* published = reinterpret_cast<uint32_t*>(gs_word64(gs.flags, GS_PUBLISHED));
+        if (published) __hip_atomic_store(published, gs.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(gs.flags + 1, gs.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }

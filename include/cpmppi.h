@@ -350,7 +350,10 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
  *   cpmppi_comm_wait       `stream` waits (on the device) for the gather of `slot` - call it before the step that overwrites
  *                          that gather's send buffer (with the two u_nom buffers of cpmppi_step_args.u_nom_out: two steps later)
  *                          or before reading recv_all on `stream`
- *   cpmppi_comm_sync       host wait for every gather enqueued so far
+ *   cpmppi_comm_sync       host wait for every gather enqueued so far; reports (once) and clears a device-side timeout
+ *   cpmppi_comm_set_timeout  how long a device-side wait of cpmppi_step_gather may last, in seconds (default 10; <= 0: for
+ *                          ever): the finalize of a step that is about to overwrite a buffer an all-gather still reads
+ *                          waits for that gather, which completes only when EVERY rank has joined it
  * Errors: CPMPPI_ERR_COMM.  RCCL is bound at run time: the library loads without it. */
 #define CPMPPI_COMM_ID_BYTES 128
 #define CPMPPI_COMM_SLOTS 4
@@ -359,17 +362,21 @@ int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, cons
 int cpmppi_comm_gather(cpmppi_handle* h, uint32_t slot, const float* send, float* recv_all, size_t count, void* stream);
 int cpmppi_comm_wait(cpmppi_handle* h, uint32_t slot, void* stream);
 int cpmppi_comm_sync(cpmppi_handle* h);
+int cpmppi_comm_set_timeout(cpmppi_handle* h, double seconds);
 int cpmppi_comm_destroy(cpmppi_handle* h);
 
 /* cpmppi_step + the all-gather of its result in ONE call - the production form of the per-step collective:
  * recv_all[world][E*H] <- all-gather of the nominal sequences this step writes (args->u_nom_out, or args->u_nom when the
  * step runs in place).  The launch stream receives the rollout kernel and nothing else; step and gather are ordered
- * through device memory (the kernel's finalizing blocks publish the step, a one-lane kernel on the side stream waits
- * for it; the finalize of a later step that overwrites a buffer still being gathered waits for that gather).  Use two
+ * through device memory (the kernel's finalizing blocks publish the step into signal memory, the side stream waits for
+ * it with hipStreamWaitValue32 - a one-lane kernel where the device has no stream memory operations; the finalize of a
+ * later step that overwrites a buffer still being gathered waits for that gather).  Use two
  * u_nom buffers alternately (step i: u_nom = B[i & 1], u_nom_out = B[(i + 1) & 1]) so that the gather of step i runs
  * under step i + 1; in place is correct too, but then step i + 1's finalize waits for gather i.  recv_all must stay
  * untouched until cpmppi_comm_sync (host) returns or a later cpmppi_comm_gather/wait pair orders the reader.
- * cpmppi_comm_sync returns CPMPPI_ERR_COMM if a device-side wait timed out (~2 s). */
+ * A device-side wait that outlasts cpmppi_comm_set_timeout does NOT proceed: the step drops its result (the buffer being
+ * gathered is not overwritten), so does every later step of the handle, and the next cpmppi_step_gather - or
+ * cpmppi_comm_sync, which also clears the condition - returns CPMPPI_ERR_COMM. */
 int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* args, float* recv_all, void* stream);
 
 /* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */

@@ -505,6 +505,104 @@ def test_native_gather_one_rank():
     eng.close(); ref.close()
 
 
+def _gather_setup(E=6, N=512, H=16, seed=61):
+    import ctypes as C
+    from cartpolesimulation_amd import _lib as L
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.shard import NativeGather
+    eng, ref = (MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H)) for _ in range(2))
+    uid = C.create_string_buffer(L.COMM_ID_BYTES)
+    assert eng.lib.cpmppi_comm_unique_id(uid, None) == 0, eng.lib.cpmppi_last_error(None)
+    g = NativeGather(eng, uid.raw, 1, 0)
+    rng = Generator(SFC64(seed))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.1) for _ in range(E)])
+    tp, te = rng.uniform(-0.05, 0.05, E).astype(f32), np.ones(E, f32)
+    return eng, ref, g, s0, tp, te
+
+
+@pytest.mark.parametrize("waiter", ["stream-ops", "kernel"])
+def test_step_gather_protocol_with_a_slow_collective(waiter, monkeypatch):
+    """The device-side ordering of cpmppi_step_gather against a gather that joins LATE (a spin on the side stream in front
+    of every all-gather: a slow peer), the host enqueueing far ahead, with one receive buffer per step so that every gather
+    can be checked afterwards against the loop without any collective, bit for bit:
+      (a) in place: step i + 1 must not overwrite the sequence gather i still has to read;
+      (b) alternating buffers: step i + 2 must not, and gather i never sees a half-written buffer;
+    in both forms of the side-stream waiter (hipStreamWaitValue32 / the one-lane kernel of devices without it)."""
+    if waiter == "kernel":
+        monkeypatch.setenv("CPMPPI_COMM_WAITER", "kernel")
+    eng, ref, g, s0, tp, te = _gather_setup()
+    E, H = eng.E, eng.H
+    assert eng.lib.cpmppi_debug_comm_mode(eng._h) == (1 if waiter == "stream-ops" else 0)
+    K = 12
+    eng.lib.cpmppi_debug_comm_delay(eng._h, 400)                     # 400 us per gather; a step of this size takes ~30 us
+    u_ref = ref.zeros(E, H)
+    want = []
+    # (b) alternating buffers
+    recv = [torch.zeros(1, E * H, device=u_ref.device) for _ in range(K)]
+    for i in range(K):
+        eng.step(s0, g.u_in(i), tp, te, seed=4, offset=i, u_nom_out=g.u_out(i), gather_into=recv[i])
+        ref.step(s0, u_ref, tp, te, seed=4, offset=i)
+        want.append(u_ref.clone())
+    g.sync()
+    torch.cuda.synchronize()
+    for i in range(K):
+        assert torch.equal(recv[i].view(E, H), want[i]), f"alternating buffers: gather {i} is not step {i}'s result"
+    assert torch.equal(g.u_out(K - 1), u_ref)
+    # (a) in place
+    inplace = g.u_out(K - 1).clone()
+    recv = [torch.zeros(1, E * H, device=u_ref.device) for _ in range(K)]
+    want = []
+    for i in range(K, 2 * K):
+        eng.step(s0, inplace, tp, te, seed=4, offset=i, gather_into=recv[i - K])
+        ref.step(s0, u_ref, tp, te, seed=4, offset=i)
+        want.append(u_ref.clone())
+    g.sync()
+    torch.cuda.synchronize()
+    for i in range(K):
+        assert torch.equal(recv[i].view(E, H), want[i]), f"in place: gather {i} read a sequence step {i + 1} had already overwritten"
+    assert torch.equal(inplace, u_ref)
+    g.close(); eng.close(); ref.close()
+
+
+@pytest.mark.parametrize("waiter", ["stream-ops", "kernel"])
+def test_step_gather_timeout_drops_the_step_and_reaches_the_host(waiter, monkeypatch):
+    """(c) a device-side wait that outlasts cpmppi_comm_set_timeout does NOT proceed: the buffer the late gather still reads
+    is left alone (its gather delivers the right sequence), the NEXT cpmppi_step_gather returns CPMPPI_ERR_COMM without a
+    cpmppi_comm_sync in between, cpmppi_comm_sync reports it once and clears it, and the handle works again afterwards."""
+    from cartpolesimulation_amd import _lib as L
+    if waiter == "kernel":
+        monkeypatch.setenv("CPMPPI_COMM_WAITER", "kernel")
+    eng, ref, g, s0, tp, te = _gather_setup(seed=62)
+    E, H = eng.E, eng.H
+    assert eng.lib.cpmppi_comm_set_timeout(eng._h, 0.002) == 0       # 2 ms
+    inplace, u_ref = eng.zeros(E, H), ref.zeros(E, H)
+    r0, r1 = (torch.zeros(1, E * H, device=u_ref.device) for _ in range(2))
+    eng.lib.cpmppi_debug_comm_delay(eng._h, 60000)                   # the gather joins 60 ms late
+    eng.step(s0, inplace, tp, te, seed=5, offset=0, gather_into=r0)  # step 0: fine; its gather is the late one
+    ref.step(s0, u_ref, tp, te, seed=5, offset=0)
+    eng.lib.cpmppi_debug_comm_delay(eng._h, 0)
+    eng.step(s0, inplace, tp, te, seed=5, offset=1, gather_into=r1)  # step 1 (in place): waits for gather 0, gives up after 2 ms
+    torch.cuda.synchronize()                                         # (the launch stream: the rollout kernels are done)
+    with pytest.raises(L.CpmppiError) as ei:                         # no sync in between: the next call already says so
+        eng.step(s0, inplace, tp, te, seed=5, offset=2, gather_into=r1)
+    assert ei.value.code == -6
+    with pytest.raises(L.CpmppiError) as ei:
+        g.sync()
+    assert ei.value.code == -6
+    assert torch.equal(r0.view(E, H), u_ref), "the late gather did not deliver step 0's sequence"
+    assert torch.equal(inplace, u_ref), "the step whose wait timed out overwrote the buffer all the same"
+    g.sync()                                                         # reported once, cleared
+    eng.lib.cpmppi_comm_set_timeout(eng._h, 10.0)
+    for i in (1, 2, 3):                                              # the dropped step 1 is simply taken again
+        eng.step(s0, inplace, tp, te, seed=5, offset=i, gather_into=r1)
+        ref.step(s0, u_ref, tp, te, seed=5, offset=i)
+    g.sync()
+    assert torch.equal(inplace, u_ref) and torch.equal(r1.view(E, H), u_ref)
+    assert eng.lib.cpmppi_comm_set_timeout(ref._h, 1.0) == -1        # no communicator on that handle
+    g.close(); eng.close(); ref.close()
+
+
 def test_failed_step_leaves_the_event_recorder_intact():
     """A step that fails validation while profiling is on (GRU requested without a model) must not leave a half-recorded
     bracket: the steps before and after it are still reported."""
