@@ -22,7 +22,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
-           "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout")
+           "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -128,6 +128,8 @@ def load():
     lib.cpmppi_comm_set_timeout.argtypes = [vp, C.c_double]
     lib.cpmppi_comm_destroy.argtypes = [vp]
     lib.cpmppi_step_gather.argtypes = [vp, C.POINTER(cpmppi_step_args), vp, vp]
+    lib.cpmppi_write_recordings.argtypes = [C.POINTER(C.c_char_p), u32, u32, C.c_char_p, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp,
+                                            C.c_double, C.c_double, C.c_int]
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:

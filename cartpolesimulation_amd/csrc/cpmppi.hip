@@ -844,6 +844,7 @@ struct cpmppi_handle {
   std::vector<uint8_t> ev_tail;        // per triple: was the third event recorded (a separate finalize / counter kernel ran)
   size_t ev_used = 0;
   cpmppi_comm::CommState* comm = nullptr;   // RCCL communicator + side stream of cpmppi_comm_* (cpmppi_comm.hip)
+  float plant_m_pole = 0.0f;           // the pole mass of the simulated PLANT (cfg.m_pole at creation; cpmppi_set_pole_mass does not touch it)
   cpmppi_launch_info last_launch = {0, 0, 0, 0, 0, 0, 0};   // cpmppi_last_launch: the instantiation the last rollout launch used
 };
 
@@ -1021,6 +1022,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   h->cfg = *cfg;
   h->device = device;
   fill_params(*cfg, h->prm);
+  h->plant_m_pole = cfg->m_pole;
   h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
   if (const char* ev = getenv("CPMPPI_FUSE_FINALIZE")) h->fuse_finalize = ev[0] != '0';
   if (const char* ev = getenv("CPMPPI_HOST_ZERO_COPY_MAX")) h->host_zero_copy_max = (uint32_t)strtoul(ev, nullptr, 10);
@@ -1099,6 +1101,9 @@ int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cos
 
 int cpmppi_set_pole_mass(cpmppi_handle* h, float m_pole) {
   if (!h || !(m_pole > 0.0f) || !(m_pole < INFINITY)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_pole_mass: m_pole must be a positive number");
+  // the CONTROLLER's belief (CartPole/__init__.py:516 sends m_pole_for_controller): the predictor / cost kernels compute with it.
+  // The PLANT of cpmppi_plant_advance* is the simulated system itself and keeps the mass the handle was created with
+  // (plant_m_pole): a handle that serves as both must not change the plant by updating the controller's attribute.
   h->cfg.m_pole = m_pole;
   h->prm.m_pole = m_pole;
   return CPMPPI_OK;
@@ -1779,7 +1784,9 @@ int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q,
   if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance: bad argument");
   if (misaligned(s) || misaligned(Q) || misaligned(L)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance: misaligned");
   CPMPPI_ON_DEVICE(h);
-  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
+  Params plant = h->prm;                  // the simulated system's own pole mass (see cpmppi_set_pole_mass)
+  plant.m_pole = h->plant_m_pole;
+  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, E, s, Q,
                      L, n_substeps, dt_sim, (float*)nullptr, (float*)nullptr, (uint64_t)0, (const unsigned long long*)nullptr,
                      (uint64_t)0);
   CPMPPI_HIP(h, hipGetLastError());
@@ -1797,7 +1804,9 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
       (row_dev && ((uintptr_t)row_dev & 7u)))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance_record: misaligned");
   CPMPPI_ON_DEVICE(h);
-  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, h->prm, E, s, Q,
+  Params plant = h->prm;
+  plant.m_pole = h->plant_m_pole;
+  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, E, s, Q,
                      L, n_substeps, dt_sim, states_log, Q_log, row, (const unsigned long long*)row_dev, log_rows);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;

@@ -205,10 +205,14 @@ class optimizer_mppi:
         vp, last = self.variable_parameters, f["last"]
         for i, (name, key) in enumerate((("target_position", "tp"), ("target_equilibrium", "te"), ("L", "L"))):
             x = getattr(vp, name, None)
-            if x is not last[i]:                                # (the same object as last time: nothing to convert)
+            if isinstance(x, (float, int, np.floating)):        # immutable: the same object as last time = the same value
+                if x is last[i]:
+                    continue
                 last[i] = x
-                if x is not None:
-                    f[key][0] = np.asarray(x.cpu() if hasattr(x, "cpu") else x, dtype=np.float32).reshape(-1)[0]
+                f[key][0] = x
+            elif x is not None:                                 # arrays / tensors may be assigned in place: converted every time
+                last[i] = None
+                f[key][0] = np.asarray(x.cpu() if hasattr(x, "cpu") else x, dtype=np.float32).reshape(-1)[0]
         rc = f["call"](f["h"], 1, f["p_s"], f["p_tp"], f["p_te"], f["p_L"], f["u"], self.seed, self.step_counter, 0, f["p_q"],
                        f["stream"]())
         if rc != 0:

@@ -71,6 +71,45 @@ def write_recording(path, columns, title=None, header=(), revision="cartpolesimu
     return path
 
 
+def preamble_bytes(header, columns=None, title=None, revision="cartpolesimulation_amd"):
+    """The comment block and the column-name row exactly as write_recording's csv.writer emits them, as bytes (what
+    cpmppi_write_recordings puts at the top of every file)."""
+    import io
+    title = title or (f"This is CartPole simulation from {datetime.now().strftime('%d.%m.%Y')}"
+                      f" at time {datetime.now().strftime('%H:%M:%S')}")
+    f = io.StringIO(newline="")
+    w = csv.writer(f)
+    w.writerow(["# " + title])
+    w.writerow(["# Done with git-revision: {}".format(revision)])
+    w.writerow(["#"])
+    for line in header:
+        w.writerow(["# " + line])
+    w.writerow(list(columns or COLUMNS))
+    return f.getvalue().encode()
+
+
+def write_recordings_native(paths, block, dt_control, target_position, target_equilibrium, L, phys, header, title=None,
+                            n_threads=0):
+    """All recordings of a batched run through libcpmppi's native writer (cpmppi_write_recordings: one thread per file, Python's
+    float repr and csv.writer's row format reproduced byte for byte - tests/test_recording.py).  `block` = _host_block(...)."""
+    import ctypes as C
+    from . import _lib as _L
+    lib = _L.load()
+    T, E = block["Q"].shape
+    f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))        # noqa: E731
+    per_env = lambda a: f32(np.broadcast_to(np.asarray(a, dtype=np.float32), (E,)))  # noqa: E731
+    arrs = [f32(block["s"]), f32(block["Q"]), f32(block["aDD"]), f32(block["xDD"]), f32(block["u"]), per_env(target_position),
+            per_env(target_equilibrium), per_env(L)]
+    assert arrs[0].shape == (T, E, 6) and len(paths) == E
+    pre = preamble_bytes(header, title=title)
+    cpaths = (C.c_char_p * E)(*[os.fsencode(p) for p in paths])
+    rc = lib.cpmppi_write_recordings(cpaths, E, T, pre, len(pre), *[a.ctypes.data for a in arrs], float(phys.m_pole),
+                                     float(dt_control), int(n_threads))
+    if rc != 0:
+        raise _L.CpmppiError(rc, lib.cpmppi_last_error(None).decode())
+    return list(paths)
+
+
 def second_derivatives(states, Q, L, phys):
     """angleDD, positionDD of the logged states under the logged control (CartPole/cartpole_equations.py:44-105), as
     torch ops on whatever device the tensors live on."""
@@ -120,8 +159,9 @@ def experiment_columns(result, env, dt_control, target_position, target_equilibr
 
 
 def generate_dataset(engine, num_envs, length_of_experiment, out_dir, seed=0, target_position=None, L=None,
-                     dt_simulation=0.002, dt_control=0.02, init_limits=None, prefix="CPS"):
-    """Batched run_data_generator: ``num_envs`` experiments of ``length_of_experiment`` seconds -> one CSV each."""
+                     dt_simulation=0.002, dt_control=0.02, init_limits=None, prefix="CPS", native=True):
+    """Batched run_data_generator: ``num_envs`` experiments of ``length_of_experiment`` seconds -> one CSV each, written by
+    the library's native writer (``native=False``: through Python's csv module, the same bytes, ~10 x slower)."""
     from .harness import BatchedCartPoleExperiment, generate_random_initial_states
     rng = np.random.Generator(np.random.SFC64(seed))
     phys = engine.phys
@@ -133,12 +173,16 @@ def generate_dataset(engine, num_envs, length_of_experiment, out_dir, seed=0, ta
     exp = BatchedCartPoleExperiment(engine, dt_simulation, dt_control, seed=seed)
     res = exp.run(s0, steps, target_position=tp, target_equilibrium=1.0, L=Lv, record=True)
     header = create_csv_header(length_of_experiment, dt_simulation, dt_control, dt_control, "mpc", "mppi", phys)
-    paths = []
     block = _host_block(res, Lv, phys)                      # (one device pass and one copy for all envs)
+    paths = []
+    for e in range(num_envs):                               # (names made unique one after the other, as csv_logger.py:61-91 does)
+        name = create_csv_file_name("mpc", "mppi", prefix=prefix, with_date=False, title=f"env{e:05d}")
+        paths.append(_unique_path(out_dir, name))
+    if native:
+        return write_recordings_native(paths, block, dt_control, tp, np.ones(num_envs, np.float32), Lv, phys, header)
     for e in range(num_envs):
         cols = _columns_of(block, e, dt_control, tp[e], 1.0, Lv[e], phys)
-        name = create_csv_file_name("mpc", "mppi", prefix=prefix, with_date=False, title=f"env{e:05d}")
-        paths.append(write_recording(_unique_path(out_dir, name), cols, header=header))
+        write_recording(paths[e], cols, header=header)
     return paths
 
 

@@ -196,7 +196,8 @@ int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cos
 /* The pole mass every later call of this handle computes with (config.m_pole until then): predictor_ODE takes it from
  * variable_parameters.m_pole at every step (predictors_customization.py:55-58; the simulator sends 'm_pole' with every
  * controller.step, CartPole/__init__.py:509-520).  Handle-wide (one value for all envs; the pole LENGTH is the per-env
- * attribute); launches already enqueued - and captured graphs - keep the value they were enqueued with. */
+ * attribute); launches already enqueued - and captured graphs - keep the value they were enqueued with.  This is the
+ * CONTROLLER's belief (the simulator sends m_pole_for_controller): the plant of cpmppi_plant_advance* keeps config.m_pole. */
 int cpmppi_set_pole_mass(cpmppi_handle* h, float m_pole);
 
 /* a17 — device sampler: knots ~ sigma * N(0,1) from Philox4x32-10 keyed by (seed), counter (rollout, env, knot pair,
@@ -378,6 +379,22 @@ int cpmppi_comm_destroy(cpmppi_handle* h);
  * gathered is not overwritten), so does every later step of the handle, and the next cpmppi_step_gather - or
  * cpmppi_comm_sync, which also clears the condition - returns CPMPPI_ERR_COMM. */
 int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* args, float* recv_all, void* stream);
+
+/* Recording writer (HOST pointers, no GPU involved): E experiment recordings in the reference's CSV layout
+ * (CartPole/csv_logger.py:10-33,125-159; column set and order CartPole/__init__.py:221-259), byte for byte what the
+ * reference's csv.writer produces for the same values (Python float repr, "\r\n" rows) - one thread per file.
+ *   paths[E]            one file per experiment, opened for appending (the caller has made the names unique, csv_logger.py:61-91)
+ *   preamble            the comment block and the column-name row as ready-made bytes, the same for every file
+ *   states[T,E,6]       the state at the time each control was computed; Q[T,E] that control (written as Q_calculated and
+ *                       Q_applied; Q_ccrc = the control of the previous row, 0 in the first)
+ *   angleDD, positionDD, u [T,E]   the logged second derivatives and motor input
+ *   target_position, target_equilibrium, L [E], m_pole   constant columns (L and m_pole also as the controller's copies);
+ *                       time = row * dt_control; the vertical-angle-offset columns are 0 / 1 / 0, Q_update_time 0
+ *   n_threads           0 = one per hardware thread (at most 32) */
+int cpmppi_write_recordings(const char* const* paths, uint32_t E, uint32_t T, const char* preamble, size_t preamble_len,
+                            const float* states, const float* Q, const float* angleDD, const float* positionDD, const float* u,
+                            const float* target_position, const float* target_equilibrium, const float* L, double m_pole,
+                            double dt_control, int n_threads);
 
 /* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */
 const char* cpmppi_version(void);

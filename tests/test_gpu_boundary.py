@@ -387,6 +387,31 @@ def test_host_seam_staging_equals_device_inputs():
         assert torch.equal(ctrls[0].optimizer.u_nom, ctrls[1].optimizer.u_nom)
 
 
+def test_host_seam_reads_attribute_arrays_by_value():
+    """The single-env host path keeps its staging arrays between calls and skips the conversion of an attribute that is the
+    SAME OBJECT as last time - which is only safe for immutable scalars: an array (or tensor) attribute updated in place
+    between two controller steps must reach the kernel with its new value."""
+    from types import SimpleNamespace
+    from cartpolesimulation_amd.optimizer_mppi import optimizer_mppi
+    N, H = 256, 12
+    s = O.create_cartpole_state(0.3, -0.5, 0.02, 0.1)
+    tp = np.array([0.03], f32)
+    vp = SimpleNamespace(target_position=tp, target_equilibrium=f32(1.0), L=np.array(0.3, f32))
+    a = optimizer_mppi(seed=8, num_rollouts=N, mpc_horizon=H, variable_parameters=vp)
+    a.configure()
+    a.step(s)
+    tp[0] = -0.06                                   # in place: the same object, a new value
+    vp.L[...] = 0.45
+    q_a = a.step(s)
+    vp2 = SimpleNamespace(target_position=f32(0.03), target_equilibrium=f32(1.0), L=f32(0.3))
+    b = optimizer_mppi(seed=8, num_rollouts=N, mpc_horizon=H, variable_parameters=vp2)
+    b.configure()
+    b.step(s)
+    vp2.target_position, vp2.L = f32(-0.06), f32(0.45)
+    q_b = b.step(s)
+    assert np.array_equal(q_a, q_b) and torch.equal(a.u_nom, b.u_nom)
+
+
 def test_step_host_equals_step():
     """cpmppi_step_host (host state / attributes in, host Q out, one call) == cpmppi_step on device copies of the same
     inputs with the same Philox (seed, offset, env_offset), with and without per-env pole lengths; bad arrays raise."""

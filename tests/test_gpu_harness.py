@@ -30,6 +30,13 @@ def test_plant_matches_oracle():
             r = O.plant_substep(r, add, pdd, 0.002, Lv[e])
             add, pdd = O.plant_ode(r, Q[e], Lv[e])
         assert np.all(np.abs(out[e] - r) <= 2e-5 + 2e-5 * np.abs(r)), (e, out[e], r)
+    # the controller's belief about the pole mass (variable_parameters.m_pole -> cpmppi_set_pole_mass, CartPole/__init__.py:516
+    # sends m_pole_for_controller) is NOT the plant's: a handle that serves as both keeps simulating the system it was created for
+    eng.set_pole_mass(0.2)
+    s2 = eng.tensor(s0.copy())
+    eng.plant_advance(s2, Q, L=Lv, n_substeps=10, dt_sim=0.002)
+    assert torch.equal(s2, s)
+    eng.close()
 
 
 @pytest.mark.parametrize("cost", ["legacy", "default"])

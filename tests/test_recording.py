@@ -61,3 +61,37 @@ def test_generate_dataset_on_device(tmp_path):
     add, pdd = O.cartpole_ode(np.float32(r.angle_cos), np.float32(r.angle_sin), np.float32(r.angleD),
                               np.float32(r.positionD), np.float32(1.77 * r.Q_applied), np.float32(r.L))
     assert abs(add - r.angleDD) < 1e-3 * max(1, abs(add)) and abs(pdd - r.positionDD) < 1e-3 * max(1, abs(pdd))
+
+
+def test_native_writer_is_byte_identical_to_the_csv_module(tmp_path):
+    """cpmppi_write_recordings (host code of libcpmppi.so, no GPU involved) against write_recording (Python's csv module, as
+    the reference writes its files) on the same block of E experiments: the files must be equal byte for byte - Python's float
+    repr of every value (incl. exponent notation, integers, negative zero), "\\r\\n" rows, the comment block."""
+    rng = np.random.Generator(np.random.SFC64(7))
+    T, E = 57, 5
+    s = (rng.standard_normal((T, E, 6)) * 10.0 ** rng.integers(-7, 3, (T, E, 6))).astype(np.float32)
+    s[3, 1, 0], s[4, 1, 1], s[5, 2, 4], s[6, 2, 5] = 0.0, -0.0, 1.0, 123456.0
+    Q = rng.uniform(-1, 1, (T, E)).astype(np.float32)
+    block = dict(s=s, Q=Q, aDD=(1e3 * rng.standard_normal((T, E))).astype(np.float32),
+                 xDD=(1e-6 * rng.standard_normal((T, E))).astype(np.float32), u=(np.float32(1.77) * Q).astype(np.float32))
+    phys = PhysicalParameters()
+    tp = rng.uniform(-0.1, 0.1, E).astype(np.float32)
+    te = np.array([1, -1, 1, 1, -1], np.float32)
+    Lv = rng.uniform(0.2, 0.5, E).astype(np.float32)
+    header = R.create_csv_header(1.14, 0.002, 0.02, 0.02, "mpc", "mppi", phys)
+    title = "This is CartPole simulation from 01.01.2026 at time 00:00:00"
+    a = [str(tmp_path / f"py_{e}.csv") for e in range(E)]
+    b = [str(tmp_path / f"native_{e}.csv") for e in range(E)]
+    for e in range(E):
+        R.write_recording(a[e], R._columns_of(block, e, 0.02, tp[e], te[e], Lv[e], phys), title=title, header=header)
+    for threads in (1, 3):
+        for p in b:
+            if os.path.exists(p):
+                os.remove(p)
+        R.write_recordings_native(b, block, 0.02, tp, te, Lv, phys, header, title=title, n_threads=threads)
+        for e in range(E):
+            assert open(a[e], "rb").read() == open(b[e], "rb").read(), (e, threads)
+    df = pd.read_csv(b[1], comment="#")
+    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == T
+    with pytest.raises(Exception):
+        R.write_recordings_native([str(tmp_path / "no_such_dir" / "x.csv")] * E, block, 0.02, tp, te, Lv, phys, header)
