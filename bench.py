@@ -518,9 +518,10 @@ def main():
                        predictor_type=args.predictor_type)
     r = main_wl.run(args.steps, args.warmup)
     cfg = main_wl.cfg
-    verified = {}                                         # (rank 0 only, after - never inside - the timed regions)
-    if rank == 0 and not args.no_verify:
-        verified["main"] = main_wl.verify()
+    # Verification against the oracle happens AFTER every timed region of the run (rank 0 only): the workloads are kept until
+    # then.  (Not only a matter of principle: the C oracle's OpenMP pool, once started in this process, slows the host-paced
+    # single-env loop below by an order of magnitude.)
+    verified, to_verify = {}, [("main", main_wl)]
 
     # BASELINE's other configurations, measured by EVERY rank (the collective is part of them), reported by rank 0
     extras = {}
@@ -538,8 +539,9 @@ def main():
             rr = w.run(steps_, warm_)
             impl = w.collective_impl
             if rank == 0 and not args.no_verify:
-                verified[name] = w.verify()
-            w.close()
+                to_verify.append((name, w))                # (closed after its verification)
+            else:
+                w.close()
             obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}"
                                + ("" if ptype == "ODE_v0" else ", predictor_ODE (Euler-Cromer, no edge bounce)"),
                    "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
@@ -547,8 +549,6 @@ def main():
                    "kernel_launches_timed": rr["kernel_launches_timed"], "kernel_event_group": rr["kernel_event_group"]}
             if impl:
                 obj["collective"] = impl
-            if name in verified:
-                obj["verified"] = verified[name]
             if pred == "ode":
                 obj["roofline_valu"] = roofline_valu(rr, e_, n_, h_)
             else:
@@ -615,8 +615,6 @@ def main():
             # the same peak with every substep's sincos costed at ~30 flop-equivalents
             rv["survey_ceiling_rollouts_per_s"] = FP32_VALU_PEAK_TFLOPS * 1e12 / (algorithmic_flops_per_rollout(H) + 2.0 * 10 * H * 30.0)
             out["roofline_valu"] = rv
-        if "main" in verified:
-            out["verified"] = verified["main"]
         if extras:
             out["configs"] = extras
         if not args.no_single_env and world == 1:
@@ -643,8 +641,6 @@ def main():
             out["single_env"] = {"us_per_step": dt1 * 1e6, "rollouts_per_s": N / dt1, "noise": "philox",
                                  "rollout_kernel_us": k1 * 1e3, "finalize_kernel_us": float(np.median(f1)) * 1e3,
                                  "note": "host-paced python loop, one launch per step (finalize fused into the rollout kernel); kernel time = HIP events around groups of 10 launches / 10"}
-            if not args.no_verify:
-                verified["single_env"] = out["single_env"]["verified"] = w1.verify()
             if args.predictor == "ode" and args.math == "fast":
                 # the simulator's own call: state and attributes on the HOST, the control back on the host
                 # (CartPole/__init__.py:509-520) through cpmppi_step_host - PCIe-inclusive, never `value`
@@ -668,7 +664,22 @@ def main():
                     "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": algorithmic_flops_per_rollout(H) * N / (k1 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
                     "note": f"{N} rollouts = {N // 64} waves on 1024 SIMDs: latency of one wave's dependency chain, not throughput"}
-            w1.close()
+            if not args.no_verify:
+                to_verify.append(("single_env", w1))
+            else:
+                w1.close()
+        # ---- every timed region is over: the checker's turn
+        if not args.no_verify:
+            for name, w in to_verify:
+                verified[name] = w.verify()
+                if w is not main_wl:
+                    w.close()
+            out["verified"] = verified["main"]
+            for name, v in verified.items():
+                if name == "single_env":
+                    out["single_env"]["verified"] = v
+                elif name != "main":
+                    out["configs"][name]["verified"] = v
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             out["cpu_baseline"] = cpu_baseline(N, H, integrator=args.predictor_type)
         print(json.dumps(out), flush=True)

@@ -178,6 +178,19 @@ __device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ f2 abs_(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
 __device__ __forceinline__ float clamp_(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
 __device__ __forceinline__ f2 clamp_(f2 a, float lo, float hi) { return f2{clamp_(a.x, lo, hi), clamp_(a.y, lo, hi)}; }
+// max(|a|, b) / max(|a|, |b|) as ONE v_max_f32 with source modifiers (fmaxf(fabsf(a), ...) comes out as three instructions: in
+// IEEE mode the compiler canonicalises each operand of a maximum with a v_max x, x of its own; the operands here are results of
+// arithmetic, never signalling NaNs)
+__device__ __forceinline__ float max_abs_(float a, float b) {
+  float r;
+  asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_abs2_(float a, float b) {
+  float r;
+  asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float cos_(float a) { return cosf(a); }
 __device__ __forceinline__ f2 cos_(f2 a) { return f2{cosf(a.x), cosf(a.y)}; }
 
@@ -415,6 +428,13 @@ __device__ __forceinline__ F wrap_rint(F th) {
 // wrap + sincos on every substep (it practically never happens: a pole released from rest tops out near 20 rad/s).
 constexpr float ROT_LIMIT_LO = 0.125f;
 constexpr float ROT_LIMIT = 0.25f;
+#ifndef CPMPPI_SEED_LO
+#define CPMPPI_SEED_LO 1        // packed path: the carried pair is seeded from the degree-5/4 polynomials (|w t| <= 0.125)
+#endif
+// Packed path: the range of |w t| within which a control step runs on the carried rotation pair.  Seeded from rot_pair_lo
+// (two instructions fewer per control step than the degree-7/6 pair; truncation below 1e-9 up to 0.125 rad per substep =
+// 62 rad/s at t = 2 ms - a pole released from rest tops out near 20), lanes beyond take the exact sincos on every substep.
+constexpr float ROT_LIMIT_SEED = CPMPPI_SEED_LO ? ROT_LIMIT_LO : ROT_LIMIT;
 
 template <class F>
 __device__ __forceinline__ void rot_pair_lo(F d, F& cd, F& sd) {
@@ -719,7 +739,11 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
 // One control step of S substeps under a held control (FAST).
 // Returns whether any lane of the wave ends the step with |x| >= nearlim (wave-uniform; always true where it is
 // not tracked): the caller's next stage evaluates the boundary cost only then.
-template <class F, bool QUIET_UNROLL = false>
+// SPIN_BRANCH (packed mapping, launches with several waves per SIMD): the once-per-control-step test "does a lane spin beyond
+// the rotation range?" is ONE v_max of the lane's two |w| and one compare behind which a practically never taken wave-uniform
+// branch flags the lanes, instead of a compare + select per rollout (two vector instructions per control step fewer).  Not for
+// launches of one wave per SIMD: there the compare -> scalar-branch hand-over sits on the lone wave's critical path.
+template <class F, bool QUIET_UNROLL = false, bool SPIN_BRANCH = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e, float nearlim, unsigned* sec = nullptr,
                                                   bool* at_edge = nullptr) {
@@ -760,15 +784,22 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     if (sec) CPMPPI_SEC(sec, 4, st);
     return near_one;
   }
-  // The seed needs |w t| <= ROT_LIMIT.  Tested once per control step: without a bounce w cannot leave the range within
+  // The seed needs |w t| <= ROT_LIMIT_SEED.  Tested once per control step: without a bounce w cannot leave the range within
   // one control step by more than the polynomials' margin, and a lane that bounces is re-tested.  Lanes beyond the
   // range are flagged and take the exact sincos on every substep.
 #if CPMPPI_INCR_ROT
   bool check = true;
   F xlim = splat<F>(p.THL);
-  const float wlim = ROT_LIMIT / t;             // |w t| > ROT_LIMIT as one compare with a free abs modifier per lane
+  const float wlim = ROT_LIMIT_SEED / t;        // |w t| > the seed's range as one compare with a free abs modifier per lane
   uint64_t spinning = 0;      // wave mask of lanes beyond the rotation range: the same compare as the select's (one v_cmp)
-  if (check) {
+  if constexpr (SPIN_BRANCH && Width<F>::value == 2) {
+    const float wmax = max_abs2_(get(st.w, 0), get(st.w, 1));
+    spinning = __builtin_amdgcn_fcmpf(wmax, wlim, 2);              // 2 = ordered >  (a NaN counts as within, as in the select form)
+    if (__builtin_expect(spinning != 0, 0)) {
+#pragma unroll
+      for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, !(__builtin_fabsf(get(st.w, i)) > wlim) ? p.THL : -1.0f);
+    }
+  } else if (check) {
 #pragma unroll
     for (int i = 0; i < Width<F>::value; ++i) {
       const bool within = !(__builtin_fabsf(get(st.w, i)) > wlim);
@@ -778,7 +809,8 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
     }
   }
   F cd, sd;
-  rot_pair<F>(st.w * splat<F>(t), cd, sd);
+  if constexpr (CPMPPI_SEED_LO != 0) rot_pair_lo<F>(st.w * splat<F>(t), cd, sd);
+  else rot_pair<F>(st.w * splat<F>(t), cd, sd);
   // (Rounds 2 and 3 ran the packed mid-size build on three substeps at a time without event handling, under a rollback -
   // one v_max3 test per triple, the discarded triple redone substep by substep with the event arithmetic inline - until
   // section stamps showed that build's median wave 17 % slower per control step than this plain loop, in every section:
@@ -832,7 +864,7 @@ template <class F, bool UNROLL = false>
 __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                            const EnvConst& e, float nearlim, bool* at_edge) {
   F xlim = splat<F>(p.THL);
-  const float wlim = ROT_LIMIT / t;
+  const float wlim = ROT_LIMIT_SEED / t;
   uint64_t spinning = 0;
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) {
@@ -841,7 +873,8 @@ __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, u
     spinning |= ~__builtin_amdgcn_ballot_w64(within) & __builtin_amdgcn_ballot_w64(true);
   }
   F cd, sd;
-  rot_pair<F>(st.w * splat<F>(t), cd, sd);
+  if constexpr (CPMPPI_SEED_LO != 0) rot_pair_lo<F>(st.w * splat<F>(t), cd, sd);
+  else rot_pair<F>(st.w * splat<F>(t), cd, sd);
   if (UNROLL && S == 10u) {                      // (launches of one wave per SIMD: no taken branch between the substeps)
 #pragma unroll
     for (int sub = 0; sub < 9; ++sub) substep_fast_rot_carried<F, true>(st, uK, t, p, e, cd, sd, xlim);
@@ -986,6 +1019,12 @@ __device__ __forceinline__ F div_uniform(F x, float c) {
 // 2 ulp of the reference's grouping (PRECISE keeps that grouping operation for operation).
 struct QbgmFolded {
   float c_dd, c_cc, neg_te;
+  // stage_qbgm_acc (FAST, the rollout kernel): every term's weight with the horizon aggregation's scale (1 for sum, 1/(H+1)
+  // for mean) folded in, and the MPPI correction's coefficients (controller_mppi_cartpole.py:261-263: cc_weight (0.5 (1 - 1/NU) R du^2 + R u du + 0.5 R u^2))
+  float a_dd, a_ep, a_ekp, a_db, db_lim;   // db: b^2 w_db = (|x| - lim)^2 a_db for |x| > lim = permissible_track_fraction THL
+  float a_u2;                              // u_run^2: w_cc R scale, + 0.5 cc_weight R when the correction takes u_run
+  float k_a, k_b_run, k_b_nom;             // du (k_a du + k_b_run u_run + k_b_nom u_nom): one of the two k_b is zero
+  float k_c_nom;                           // 0.5 cc_weight R when the correction takes u_nom: the (rollout-independent) term u_nom^2
 };
 __device__ __forceinline__ QbgmFolded make_qbgm_folded(const Params& p, float te) {
   QbgmFolded f;
@@ -993,7 +1032,55 @@ __device__ __forceinline__ QbgmFolded make_qbgm_folded(const Params& p, float te
   f.c_dd = uniform_((float)((double)p.w[0] / (two_thl * two_thl)));
   f.c_cc = uniform_((float)((double)p.w[5] * (double)p.w[4]));
   f.neg_te = uniform_(-te);
+  const double scale = (p.horizon_reduce == 0u) ? 1.0 : 1.0 / (double)(p.H + 1u);      // CPMPPI_REDUCE_SUM = 0
+  const double ptf = (double)p.w[6], span = (1.0 - ptf) * (double)p.THL;
+  f.a_dd = uniform_((float)(scale * (double)p.w[0] / (two_thl * two_thl)));
+  f.a_ep = uniform_((float)(scale * (double)p.w[2]));
+  f.a_ekp = uniform_((float)(scale * (double)p.w[3]));
+  f.a_db = uniform_((float)(scale * (double)p.w[1] / (span * span)));
+  f.db_lim = uniform_((float)(ptf * (double)p.THL));
+  const bool run = p.correction_u == 0u;                                                // CPMPPI_CORRECTION_U_RUN = 0
+  const double half_r = (double)p.cc_weight * 0.5 * (double)p.R;
+  f.a_u2 = uniform_((float)(scale * (double)p.w[5] * (double)p.w[4] + (run ? half_r : 0.0)));
+  f.k_a = uniform_((float)((double)p.cc_weight * 0.5 * (1.0 - 1.0 / (double)p.NU) * (double)p.R));
+  f.k_b_run = uniform_(run ? (float)((double)p.cc_weight * (double)p.R) : 0.0f);
+  f.k_b_nom = uniform_(run ? 0.0f : (float)((double)p.cc_weight * (double)p.R));
+  f.k_c_nom = uniform_(run ? 0.0f : (float)half_r);
   return f;
+}
+
+// quadratic_boundary_grad_minimal's stage cost AND the MPPI correction term of one stage added to two running sums (FAST path of
+// the rollout kernel).  Same terms as stage_qbgm + mppi_correction; what differs is the grouping: every term is accumulated
+// with one FMA (weight folded into the constant) instead of formed, weighted, summed into the stage cost and added to the
+// horizon's sum - 13 vector instructions instead of 20 per stage, each term within 2 ulp of the reference's grouping (PRECISE
+// keeps that grouping operation for operation).  Two sums (`acc_a`: position and angle terms, `acc_b`: speed, control and
+// correction terms) keep the dependent chain of a stage at two FMAs.  `b_nom` = k_b_nom * u_nom of this stage (wave-uniform; zero unless the correction takes
+// u_nom); the rollout-independent term k_c_nom u_nom^2 of that mode is added by the caller once per rollout.
+// near = false: |x| < permissible_track_fraction * THL for every lane, the boundary term is exactly zero and left out.
+template <class F>
+__device__ __forceinline__ void stage_qbgm_acc(const QbgmFolded& f, F x, F cosang, F w, F ur, F du, bool nom_mode, float b_nom,
+                                               float x_t, bool near, F& acc_a, F& acc_b) {
+  const F dx = x - splat<F>(x_t);
+  acc_a = fma_(dx * dx, splat<F>(f.a_dd), acc_a);
+  const F e1 = fma_(cosang, splat<F>(f.neg_te), splat<F>(1.0f));
+  acc_a = fma_(e1 * e1, splat<F>(f.a_ep), acc_a);
+  acc_b = fma_(w * w, splat<F>(f.a_ekp), acc_b);
+  acc_b = fma_(ur * ur, splat<F>(f.a_u2), acc_b);
+  const F lin = fma_(du, splat<F>(f.k_a), ur * splat<F>(f.k_b_run));
+  acc_b = fma_(du, lin, acc_b);
+  if (__builtin_expect(nom_mode, 0)) {
+    asm volatile("; correction term on u_nom");    // (keeps this a branch: the common path carries no operand for it)
+    acc_b = fma_(du, splat<F>(b_nom), acc_b);
+  }
+  if (__builtin_expect(near, 0)) {
+    // (the asm statement keeps this a BRANCH: if-converted, the term's eight instructions would run on every stage)
+    asm volatile("; quadratic_boundary_grad_minimal: boundary term");
+    F over;
+#pragma unroll
+    for (int i = 0; i < Width<F>::value; ++i) put(over, i, max_abs_(get(x, i), f.db_lim));
+    over = over - splat<F>(f.db_lim);
+    acc_a = fma_(over * over, splat<F>(f.a_db), acc_a);
+  }
 }
 
 template <class F, bool FAST = false>
@@ -1132,8 +1219,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
                                               uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // (the full 64-bit products: one v_mad_u64_u32 each instead of a v_mul_hi_u32 + v_mul_lo_u32 pair)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -40,6 +40,15 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_WAVE_PRIORITY
 #define CPMPPI_WAVE_PRIORITY 1
 #endif
+#ifndef CPMPPI_KNOT_SEGMENTS
+#define CPMPPI_KNOT_SEGMENTS 1      // throughput build, in-kernel interpolation: knot segments as an outer loop (A/B switch)
+#endif
+#ifndef CPMPPI_QBGM_ACC
+#define CPMPPI_QBGM_ACC 1           // FAST quadratic_boundary_grad_minimal: stage cost + correction accumulated with FMAs (A/B switch)
+#endif
+#ifndef CPMPPI_SPIN_BRANCH
+#define CPMPPI_SPIN_BRANCH 1        // throughput build, two rollouts per lane: the spin test as one v_max + compare + branch (A/B switch)
+#endif
 constexpr size_t SAMPLER_LDS_MAX = 159 * 1024;   // gfx950: 160 KB of LDS per workgroup (sampler: [256][P+1] floats)
 
 // Device-side ordering between a step and the all-gather of its result (cpmppi_step_gather, cpmppi_comm.hip) without any
@@ -330,6 +339,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   State<F> st{splat<F>(s0[0]), splat<F>(s0[1]), splat<F>(s0[2]), splat<F>(s0[3]), splat<F>(s0[4]), splat<F>(s0[5])};
 
   F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
+  const bool nom_mode = p.correction_u != CPMPPI_CORRECTION_U_RUN;
+  float u_nom_sq = 0.0f;                     // QBGM_ACC with the correction on u_nom: sum of u_nom^2 over the stages (wave-uniform)
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
   // `near` (wave-uniform): may any rollout of this wave sit at or beyond permissible_track_fraction * THL at the current
@@ -338,6 +349,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // against this coarser limit (substep_fast); stage 0 is the initial state all rollouts share.  Other costs: the limit
   // is the edge itself and the flag is unused.
   const QbgmFolded qf = make_qbgm_folded(p, te);
+  // quadratic_boundary_grad_minimal, FAST: stage cost and correction term accumulated term by term with FMAs (stage_qbgm_acc)
+  constexpr bool QBGM_ACC = FAST && COST == COST_QBGM && CPMPPI_QBGM_FOLD != 0 && CPMPPI_QBGM_ACC != 0;
   // (not in the latency build: there the flag's compare -> scalar branch hand-over sits on the lone wave's critical path
   // once per control step - measured 56 -> 66 us for a single env - while the eight instructions it saves are hidden)
   constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0 && (INTEG == PREDICTOR_ODE_V0 || CPMPPI_ODE_TRACK_NEAR != 0);
@@ -374,6 +387,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // phased build: does a rollout of this wave sit at or beyond the track edge (or spin beyond the rotation range) as the
   // next control step starts?  (wave-uniform)
   bool at_edge = false;
+  float run_hi_v = p.run_hi;
+  if constexpr (FAST && VARIANT == 1) asm volatile("v_mov_b32 %0, %1" : "=v"(run_hi_v) : "s"(p.run_hi));
   auto control_step = [&](uint32_t k, F du, auto eventful) __attribute__((always_inline)) {
     if (secp) { asm volatile("" : "+v"(du)); CPMPPI_SEC(secp, 5, st); CPMPPI_SEC(secp, 0, st); }
     float uk, upk = 0.0f;
@@ -402,8 +417,23 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       if constexpr (COST == COST_LEGACY) upk = up[k];
     }
     F ur = splat<F>(uk) + du;
-    ur = clamp_(ur, p.run_lo, p.run_hi);
-    if constexpr (COST == COST_QBGM) {
+    if constexpr (FAST && VARIANT == 1) {
+      // (v_med3_f32 takes ONE scalar operand: as plain kernel arguments the upper limit is copied into a vector register on
+      // every control step; `run_hi_v` is that copy made once, behind an opaque asm so that it is not re-materialised)
+#pragma unroll
+      for (int i = 0; i < R; ++i) put(ur, i, __builtin_amdgcn_fmed3f(get(ur, i), p.run_lo, run_hi_v));
+    } else {
+      ur = clamp_(ur, p.run_lo, p.run_hi);
+    }
+    if constexpr (QBGM_ACC) {
+      float b_nom = 0.0f;
+      if (__builtin_expect(nom_mode, 0)) {             // (wave-uniform; the correction takes u_nom: non-default glue)
+        asm volatile("; correction term on u_nom");    // (keeps this a branch: if-converted it costs five instructions per stage)
+        b_nom = uniform_(qf.k_b_nom * uk);
+        u_nom_sq = __builtin_fmaf(uk, uk, u_nom_sq);
+      }
+      stage_qbgm_acc<F>(qf, st.x, cosang, st.w, ur, du, nom_mode, b_nom, x_t, near, cost, corr);
+    } else if constexpr (COST == COST_QBGM) {
       cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near, (FAST && CPMPPI_QBGM_FOLD != 0) ? &qf : nullptr);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
@@ -437,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F, (LONE_WAVE && CPMPPI_EVENTFUL_UNROLL != 0)>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
         else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, &at_edge);
       } else {
-        near_next = control_step_fast<F>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp);
+        near_next = control_step_fast<F, false, (VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0)>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp);
       }
       near = !TRACK_NEAR || near_next;
     } else {
@@ -690,6 +720,42 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     };
     if constexpr (PHASED) {
       run_phased(horizon_step);
+    } else if constexpr (FAST && VARIANT == 1 && CPMPPI_KNOT_SEGMENTS != 0 && !(COST == COST_DEFAULT && NOISE == NOISE_PHILOX && R == 2)) {
+      // throughput build: the horizon as NESTED loops - knot segments outside, the `period` control steps between two knots
+      // inside, where the segment's knot and slope are loop invariants.  The flat loop above refreshes the knots behind a
+      // branch inside the loop body, and the register allocator lines the hot path up with that branch's assignment by
+      // shuffling (z_lo, z_hi, slope) through four v_mov_b64 on EVERY control step; here the refresh sits between two inner
+      // loops.  Same knots in the same order, same interpolation (bit-identical).  (Not the `default`-cost Philox kernel with two
+      // rollouts per lane: there this form costs two more scalar registers than the file has - a 20-byte scratch slot, which
+      // tests/test_abi_and_host.py refuses.)
+      uint32_t k = 0;
+      for (uint32_t seg = 0; k < H; ++seg) {
+        const uint32_t kend = (H - k < p.period) ? H : k + p.period;
+        for (uint32_t i2 = 0; k < kend; ++k, ++i2) {
+          F du;
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            if constexpr (F32_INTERP) put(du, i, interp_from_slope32(slope32[i], z_lo[i], i2));
+            else put(du, i, interp_from_slope(slope[i], z_lo[i], i2));
+          }
+          control_step(k, du, std::false_type{});
+        }
+        if (k < H) {                                 // the next segment's knots (seg + 1, seg + 2)
+          const uint32_t jn = seg + 1u;
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            z_lo[i] = z_hi[i];
+            if constexpr (KNOT_AHEAD) {
+              if (jn + 1 < p.P) z_hi[i] = z_ahead[i];
+              if (jn + 2 < p.P) z_ahead[i] = knot(i, jn + 2);
+            } else {
+              if (jn + 1 < p.P) z_hi[i] = knot(i, jn + 1);
+            }
+            if constexpr (F32_INTERP) slope32[i] = knot_slope32(z_lo[i], z_hi[i], inv_period);
+            else slope[i] = knot_slope(z_lo[i], z_hi[i], p.period);
+          }
+        }
+      }
     } else {
       for (uint32_t k = 0; k < H; ++k) horizon_step(k, std::false_type{});
     }
@@ -716,9 +782,14 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   if constexpr (COST == COST_LEGACY) {
     S_total = cost + terminal_indicator<F>(p, st.th, st.x, x_t);     // sum_k q + phi  (:197-199)
   } else {
-    const F term = (COST == COST_DEFAULT) ? terminal_indicator<F>(p, st.th, st.x, x_t) : splat<F>(0.0f);
-    S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / splat<F>((float)(H + 1));
-    S_total += corr;
+    if constexpr (QBGM_ACC) {
+      // (the two running sums of stage_qbgm_acc: the horizon aggregation's scale is in their weights; terminal cost zero)
+      S_total = (cost + corr) + splat<F>(qf.k_c_nom * u_nom_sq);
+    } else {
+      const F term = (COST == COST_DEFAULT) ? terminal_indicator<F>(p, st.th, st.x, x_t) : splat<F>(0.0f);
+      S_total = (p.horizon_reduce == CPMPPI_REDUCE_SUM) ? (cost + term) : (cost + term) / splat<F>((float)(H + 1));
+      S_total += corr;
+    }
   }
 #pragma unroll
   for (int i = 0; i < R; ++i)
