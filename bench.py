@@ -415,8 +415,12 @@ class Workload:
                              and rep["worst_u_abs"] <= 1e-4)
         else:
             ocfg = O.MPPIConfig(N=N, H=H, integrator=ptype)
+            params = None
+            if os.environ.get("CPMPPI_BENCH_TEST_PERTURB_ORACLE") == "1":      # test hook: the checker must be able to say no
+                import dataclasses
+                params = dataclasses.replace(O.DEFAULT_PARAMS, m_pole=np.float32(0.09))
             rep = PR.verify_envs(ocfg, s0, ub, kn_envs, tp, te, L, Sg, ua, rule=PR.ODE_V0 if ptype == "ODE_v0" else PR.PREDICTOR_ODE,
-                                 delta_u=du_envs)
+                                 delta_u=du_envs, params=params)
             rep["oracle"] = "oracle/cpmppi_oracle.c: modes A (float32) and B (float64 substeps) + rounding probes"
         rep.update(env_indices=envs, step=int(i), kernel=kernel, same_kernel_as_timed=bool(kernel == self.timed_kernel),
                    math=self.cfg.math_mode)

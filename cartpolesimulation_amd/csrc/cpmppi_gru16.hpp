@@ -124,6 +124,59 @@ __device__ __forceinline__ void gru16_gates(const f16v& ar, const f16v& az, cons
   }
 }
 
+// The gates of one layer (ar, az, anx, anh -> h in place) with the 18 MFMAs of ANOTHER layer's / step's hidden products
+// pr / pz / pn += W[fh ...] hs placed BETWEEN them in program order, one MFMA per gate element.
+// Why in program order: a wave issues in order, and a v_mfma_f32_32x32x16_f16 occupies the SIMD's matrix pipe for 32 cycles -
+// the NEXT MFMA of the same wave cannot issue before that, so 18 MFMAs written back to back hold the wave for 18 x 32 cycles
+// whatever follows them; only the instructions placed between two MFMAs run in that gap (MI355X_MICROARCH.md, per-instruction
+// constants: an MFMA takes 8 cycles of the SIMD's vector issue, a plain VALU instruction 4, a transcendental 8; issue costs up
+// to 24 cycles per gap are hidden).  A gate element is 7 plain + 6 transcendental instructions = 76 cycles of issue: the phase
+// is bound by the gate math and the products disappear under it (round 3 issued the 18 MFMAs in front of the gates behind a
+// scheduling barrier: 576 + ~1220 cycles per phase; now ~1220 + 18 x 8).  Accumulation order per accumulator is unchanged
+// (block 0: hi hi, hi lo, lo hi; block 1 likewise), so the results are bit-identical.  Fragments are fetched two MFMAs ahead.
+#ifndef CPMPPI_GRU_INTERLEAVE
+#define CPMPPI_GRU_INTERLEAVE 1
+#endif
+__device__ __forceinline__ void gru16_gates_overlapped(const f16v& ar, const f16v& az, const f16v& anx, const f16v& anh, f16v& h,
+                                                       const char* __restrict__ lds, int fh, const HSplit hs[2], f16v& pr,
+                                                       f16v& pz, f16v& pn, uint32_t lane) {
+  // MFMA m = 0..17: block b = m / 9, term = (m % 9) / 3 (0: Whi Xhi, 1: Whi Xlo, 2: Wlo Xhi), gate g = m % 3 (r, z, n)
+  auto frag_of = [&](int m) -> const h8* {
+    const int b = m / 9, term = (m % 9) / 3, g = m % 3;
+    return gru16_frag(lds, fh + (g * 2 + b) * 2 + (term == 2 ? 1 : 0), lane);
+  };
+  auto issue = [&](int m, const h8& w) __attribute__((always_inline)) {
+    const int b = m / 9, term = (m % 9) / 3, g = m % 3;
+    const h8& x = (term == 1) ? hs[b].lo : hs[b].hi;
+    if (g == 0) pr = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, pr, 0, 0, 0);
+    else if (g == 1) pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, pz, 0, 0, 0);
+    else pn = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, pn, 0, 0, 0);
+  };
+  h8 w0 = *frag_of(0), w1 = *frag_of(1);
+  // the two MFMAs that have no gate element of their own go first
+  {
+    const h8 w2 = *frag_of(2), w3 = *frag_of(3);
+    issue(0, w0);
+    issue(1, w1);
+    w0 = w2; w1 = w3;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int m = v + 2;
+    h8 wn = w1;
+    if (m + 2 < 18) wn = *frag_of(m + 2);
+    issue(m, w0);
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ar[v]));
+    const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(az[v]));
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(r, anh[v], anx[v]));
+    const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    h[v] = __builtin_fmaf(z, h[v] - n, n);                    // (1-z)*n + z*h
+    w0 = w1; w1 = wn;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __device__ __forceinline__ void gru16_carry_init(const char* __restrict__ lds, Gru16State& s, uint32_t lane, Gru16Carry& c) {
   gru16_resplit(s.h1, s.h1s);
   gru16_resplit(s.h2, s.h2s);
@@ -154,9 +207,13 @@ __device__ __forceinline__ f16v gru16_step(const char* __restrict__ lds, const f
   __builtin_amdgcn_sched_barrier(0);
   GRU_STAMP(1);
   f16v br = gru16_bias(lds, 4, lane), bz = gru16_bias(lds, 5, lane), bnh = gru16_bias(lds, 7, lane);
+#if CPMPPI_GRU_INTERLEAVE
+  gru16_gates_overlapped(ar, az, anx, anh, s.h1, lds, HF_L2H, s.h2s, br, bz, bnh, lane);   // gates 1 || W_hh2 h2(t-1)
+#else
   gru16_hidden_products(lds, HF_L2H, s.h2s, br, bz, bnh, lane);        // W_hh2 h2(t-1): independent of the gates below
   __builtin_amdgcn_sched_barrier(0);
   gru16_gates(ar, az, anx, anh, s.h1);
+#endif
   gru16_resplit(s.h1, s.h1s);
   __builtin_amdgcn_sched_barrier(0);
   GRU_STAMP(2);
@@ -171,9 +228,13 @@ __device__ __forceinline__ f16v gru16_step(const char* __restrict__ lds, const f
   __builtin_amdgcn_sched_barrier(0);
   GRU_STAMP(3);
   c.ar = gru16_bias(lds, 0, lane); c.az = gru16_bias(lds, 1, lane); c.anh = gru16_bias(lds, 3, lane);
+#if CPMPPI_GRU_INTERLEAVE
+  gru16_gates_overlapped(br, bz, bnx, bnh, s.h2, lds, HF_L1H, s.h1s, c.ar, c.az, c.anh, lane);   // gates 2 || W_hh1 h1(t) for step t+1
+#else
   gru16_hidden_products(lds, HF_L1H, s.h1s, c.ar, c.az, c.anh, lane);  // W_hh1 h1(t) for step t+1
   __builtin_amdgcn_sched_barrier(0);
   gru16_gates(br, bz, bnx, bnh, s.h2);
+#endif
   gru16_resplit(s.h2, s.h2s);
   __builtin_amdgcn_sched_barrier(0);
   GRU_STAMP(4);

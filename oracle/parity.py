@@ -269,7 +269,7 @@ def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=N
     return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags, **extra)
 
 
-def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0, chunk=8, delta_u=None):
+def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0, chunk=8, delta_u=None, params=None):
     """A launch's outputs for a few envs against the C oracle DIRECTLY, under `rule` (full-width form: modes A / B + the
     probes' envelope, quarter-band sensitivity flag): the check of bench.py's `verified` object and of the headline-kernel
     test.  Inputs are numpy, per env: s0[E,6], u_before[E,H] (the nominal sequence the step read), knots[E,N,P] (regenerated
@@ -284,7 +284,7 @@ def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0,
         sl = slice(e0, min(E, e0 + chunk))
         du = (np.stack([O.interpolate_knots(knots[e], H) for e in range(sl.start, sl.stop)]) if delta_u is None
               else np.ascontiguousarray(delta_u[sl], f32))
-        ref = c_oracle_step_with_flags(ocfg, s0[sl], u_before[sl], du, tp[sl], te[sl], L=L[sl], probes=True)
+        ref = c_oracle_step_with_flags(ocfg, s0[sl], u_before[sl], du, tp[sl], te[sl], L=L[sl], probes=True, params=params)
         for i, e in enumerate(range(sl.start, sl.stop)):
             b = cost_buckets(S_gpu[e], ref["S_a"][i], ref["S_b"][i], ref["flags"][i], [a[i] for a in ref["S_alt"]],
                              flag_sensitive=True, rule=rule)

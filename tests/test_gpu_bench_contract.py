@@ -45,6 +45,27 @@ def test_bench_line_contract_small_shape():
     assert out["value"] > cb["value"]
     se = out["single_env"]
     assert se["rollouts_per_s"] == pytest.approx(N / (se["us_per_step"] * 1e-6), rel=1e-6)
+    # the timed configuration was checked against the oracle after timing: the same kernel instantiation, envs of the launch
+    # re-computed by the C oracle, every clear rollout inside the ODE_v0 rule
+    for v in (out["verified"], se["verified"]):
+        assert v["ok"] is True and v["same_kernel_as_timed"] is True and v["clear_off"] == 0 and v["u_off_envs"] == 0
+        assert v["rule"] == "predictor_ODE_v0" and v["kernel"].startswith("rollout_cost_kernel<") and v["envs"] >= 1
+    assert out["verified"]["envs"] == 8 and out["verified"]["rollouts"] == 8 * N
+
+
+def test_bench_exits_nonzero_when_the_oracle_disagrees(monkeypatch):
+    """A timed configuration whose results the oracle does not confirm must not pass as a bench line: with the oracle's pole
+    mass changed behind the bench's back (CPMPPI_BENCH_TEST_PERTURB_ORACLE, test hook of bench.py's verify leg) the run prints
+    its line, reports the miss on stderr and exits with code 3."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CPMPPI_BENCH_TEST_PERTURB_ORACLE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", "16", "--rollouts", "256", "--horizon", "20", "--steps", "3",
+                        "--warmup", "1", "--no-extra-configs", "--no-cpu-baseline", "--no-single-env"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "verification FAILED" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["verified"]["ok"] is False and line["verified"]["clear_off"] > 0
 
 
 def test_bench_gru_line_names_the_mfma_roof():

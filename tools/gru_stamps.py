@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib_path = sys.argv[1]
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-shutil.copy(lib_path, os.path.join(ROOT, "cartpolesimulation_amd", "libcpmppi.so"))
+os.environ["CPMPPI_LIB"] = os.path.abspath(lib_path)          # (the stamped build is loaded instead of the product library)
 import numpy as np
 import torch
 from cartpolesimulation_amd.engine import MPPIEngine
