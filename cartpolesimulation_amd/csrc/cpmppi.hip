@@ -312,7 +312,9 @@ __device__ __forceinline__ void gru_load_image(float* __restrict__ lds, const fl
 }
 
 // predictor seam with the neural predictor: s0[B,6], Q[B,H], h0[2,B,32] or NULL -> traj[B,H+1,6], h_out[2,B,32] or NULL
-__global__ __launch_bounds__(BLOCK, CPMPPI_GRU_MIN_WAVES) void gru_predict_kernel(const GruNorm nm, const float* __restrict__ image, uint32_t B,
+// (one wave per SIMD: the exact-f32 MFMA chain of gru_step with all its fragment loads in flight wants more than 256 registers -
+// compiled for two waves per SIMD it spilled 38 of them to a 156-byte scratch slot; the seam is bound by the matrix pipe either way)
+__global__ __launch_bounds__(BLOCK, 1) void gru_predict_kernel(const GruNorm nm, const float* __restrict__ image, uint32_t B,
                                                             uint32_t H, const float* __restrict__ s0,
                                                             const float* __restrict__ Q, const float* __restrict__ h0,
                                                             float* __restrict__ traj, float* __restrict__ h_out) {

@@ -199,7 +199,7 @@ def test_rollout_kernels_have_no_scratch_and_no_vgpr_spills():
     if not os.path.exists(os.path.join(code_objects.LLVM_BIN, "llvm-readelf")):
         pytest.skip("no llvm-readelf")
     from cartpolesimulation_amd import _lib
-    ks = [k for k in code_objects.kernels(_lib.LIB_PATH) if "rollout_cost_kernel" in k["name"]]
+    ks = [k for k in code_objects.kernels(_lib.LIB_PATH) if "rollout_cost_kernel" in k["name"] or "gru_predict_kernel" in k["name"]]
     hot = [k for k in ks if "19rollout_cost_kernel" in k["name"]]
     # 4 costs x 4 noise sources x (latency R1, throughput R1 fast + precise, throughput R2, mid R2, mid R2 for launches of one
     # wave per SIMD) for predictor_ODE_v0 + (latency R1, throughput R1 fast + precise, throughput R2, its form for launches of
