@@ -542,9 +542,13 @@ def main():
             w = Workload(ctx, e_, n_, h_, predictor=pred, predictor_type=ptype)
             rr = w.run(steps_, warm_)
             impl = w.collective_impl
-            if rank == 0 and not args.no_verify:
+            if rank == 0 and not args.no_verify and world == 1:
                 to_verify.append((name, w))                # (closed after its verification)
             else:
+                # several ranks: every rank tears its communicator down at the same point of the run (rank 0 checks its side
+                # configuration first; no host-paced single-env loop follows in that case)
+                if rank == 0 and not args.no_verify:
+                    verified[name] = w.verify()
                 w.close()
             obj = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon, {steps_} steps after {warm_}"
                                + ("" if ptype == "ODE_v0" else ", predictor_ODE (Euler-Cromer, no edge bounce)"),
@@ -682,7 +686,7 @@ def main():
             for name, v in verified.items():
                 if name == "single_env":
                     out["single_env"]["verified"] = v
-                elif name != "main":
+                elif name != "main" and name in out.get("configs", {}):
                     out["configs"][name]["verified"] = v
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             out["cpu_baseline"] = cpu_baseline(N, H, integrator=args.predictor_type)
