@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPMPPI_LIB") or os.path.join(_HERE, "libcpmppi.so")   # CPMPPI_LIB: development builds (tools/)
 
 ABI_VERSION = 3
-COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG = 0, 1, 2, 3
+COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG, COST_QB, COST_QB_NONCONVEX = 0, 1, 2, 3, 4, 5
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 CONTROL_CLIP, CONTROL_PENALISE = 0, 1
 SHIFT_REPEAT_LAST, SHIFT_APPEND_ZERO, SHIFT_NONE = 0, 1, 2

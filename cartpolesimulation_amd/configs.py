@@ -61,6 +61,12 @@ COST_WEIGHTS = {
                                      target_angular_speed_sqr_max_correction_down=100.0, ekp_weight_down=30.0,
                                      db_weight_down=10000.0, cc_weight_down=5.0, ccrc_weight_down=0.0,
                                      permissible_track_fraction=0.85, admissible_angle=0.0, R=1.0)),
+    # config_cost_function.yml:53-58 / :47-52 (the nonconvex module reads `cem_ccrc_weight`, which the shipped YAML lacks: here
+    # the key is ccrc_weight for both)
+    "quadratic_boundary": (L.COST_QB, ["dd_weight", "ep_weight", "cc_weight", "R", "ccrc_weight"],
+                           dict(dd_weight=600.0, ep_weight=20000.0, cc_weight=1.0, R=1.0, ccrc_weight=1.0)),
+    "quadratic_boundary_nonconvex": (L.COST_QB_NONCONVEX, ["dd_weight", "ep_weight", "cc_weight", "R", "ccrc_weight"],
+                                     dict(dd_weight=600.0, ep_weight=20000.0, cc_weight=1.0, R=1.0, ccrc_weight=1.0)),
     "legacy_mppi_cartpole": (L.COST_LEGACY,
                              ["dd_weight", "ep_weight", "ekp_weight", "ekc_weight", "cc_weight", "ccrc_weight"],
                              dict(dd_weight=120.0, ep_weight=50000.0, ekp_weight=0.01, ekc_weight=5.0, cc_weight=1.0,

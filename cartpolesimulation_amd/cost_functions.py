@@ -105,8 +105,25 @@ class quadratic_boundary_grad(cost_function_base):
     cost_name = "quadratic_boundary_grad"
 
 
+class quadratic_boundary(cost_function_base):
+    """Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary.py:26-87: `default` with a quadratic track-edge term beyond
+    0.95 THL and a control-change-rate term against ``previous_input`` (added only when one is given)."""
+    cost_name = "quadratic_boundary"
+    MAX_COST = 600.0 * 1.0e7 + 20000.0 + 1.0 * 1.0 * (1.77 ** 2) + 1.0 * 4 * (1.77 ** 2)      # quadratic_boundary.py:24
+
+    def _get_stage_cost(self, states, inputs, previous_input):          # (the stale name the reference's class still carries, :79)
+        return self.get_stage_cost(states, inputs, previous_input)
+
+
+class quadratic_boundary_nonconvex(quadratic_boundary):
+    """.../quadratic_boundary_nonconvex.py:27-105: the same plus a cosine ripple on the position term.  The reference cannot
+    import its own module (KeyError 'cem_ccrc_weight'), so this plugin is restated from the source text and unpinned."""
+    cost_name = "quadratic_boundary_nonconvex"
+
+
 COST_FUNCTIONS = {"quadratic_boundary_grad_minimal": quadratic_boundary_grad_minimal, "default": default,
-                  "quadratic_boundary_grad": quadratic_boundary_grad}
+                  "quadratic_boundary_grad": quadratic_boundary_grad, "quadratic_boundary": quadratic_boundary,
+                  "quadratic_boundary_nonconvex": quadratic_boundary_nonconvex}
 
 
 class CostFunctionWrapper:

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(BLOCK) void trajectory_cost_kernel(const Params p, 
         const float in = inputs[b * H + k];
         const float cosang = cosf(t[0]);
         if (p.cost_id == CPMPPI_COST_QBGM) c = stage_qbgm<float>(p, t[4], cosang, t[1], in, x_t, te);
-        else if (p.cost_id == CPMPPI_COST_DEFAULT) c = stage_default<float>(p, t[4], cosang, in, x_t, te);
+        else if (p.cost_id == CPMPPI_COST_DEFAULT)      // (default.py and, by p.qb_mode, quadratic_boundary / _nonconvex: ccrc only with a previous input)
+          c = stage_default<float>(p, t[4], cosang, in, x_t, te, k == 0 ? (u_prev ? u_prev[0] : 0.0f) : inputs[b * H + k - 1],
+                                   p.qb_mode != 0u && u_prev != nullptr);
         else if (p.cost_id == CPMPPI_COST_QBG)
           c = stage_qbg<float>(p, t[4], cosang, t[1], in, k == 0 ? (u_prev ? u_prev[0] : 0.0f) : inputs[b * H + k - 1], x_t, te);
         else c = stage_legacy<float>(p, t[4], cosang, t[1], t[5], u_nom[k], in, u_prev ? u_prev[k] : 0.0f, x_t);
@@ -881,6 +883,11 @@ void fill_params(const cpmppi_config& c, Params& p) {
   p.k = c.k; p.m_cart = c.m_cart; p.m_pole = c.m_pole; p.g = c.g; p.J_fric = c.J_fric; p.M_fric = c.M_fric;
   p.u_max = c.u_max; p.THL = c.track_half_length; p.L_default = c.L_default;
   p.cost_id = c.cost_id;
+  p.qb_mode = 0;
+  if (c.cost_id == CPMPPI_COST_QB || c.cost_id == CPMPPI_COST_QB_NONCONVEX) {     // default.py's kernels, sub-mode in qb_mode
+    p.qb_mode = (c.cost_id == CPMPPI_COST_QB) ? 1u : 2u;
+    p.cost_id = CPMPPI_COST_DEFAULT;
+  }
   memcpy(p.w, c.cost_w, sizeof(p.w));
   p.R = c.R; p.LBD = c.LBD; p.NU = c.NU; p.cc_weight = c.cc_weight; p.sigma = c.sigma;
   p.lo = c.action_low; p.hi = c.action_high;
@@ -1008,9 +1015,11 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: E, N, H, S, period must be > 0 and H <= 1024");
   if (!(cfg->dt > 0.0f) || !(cfg->LBD > 0.0f) || !(cfg->NU > 0.0f) || !(cfg->L_default > 0.0f))
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: dt, LBD, NU, L_default must be > 0");
-  if (cfg->cost_id > CPMPPI_COST_QBG || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
+  if (cfg->cost_id > CPMPPI_COST_QB_NONCONVEX || cfg->horizon_reduce > 1 || cfg->control_mode > 1 || cfg->shift_mode > 2 ||
       cfg->correction_u > 1 || cfg->math_mode > 1 || cfg->rollouts_per_lane > 2 || cfg->ode_predictor > CPMPPI_ODE_CROMER)
     return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: unknown enum value");
+  if ((cfg->cost_id == CPMPPI_COST_QB || cfg->cost_id == CPMPPI_COST_QB_NONCONVEX) && cfg->ode_predictor != CPMPPI_ODE_V0)
+    return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: quadratic_boundary / _nonconvex are built for predictor_ODE_v0");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
     return fail(nullptr, CPMPPI_ERR_NO_DEVICE, "cpmppi_create: no HIP device (this library has no CPU fallback)");
@@ -1093,10 +1102,14 @@ int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out) {
 }
 
 int cpmppi_set_cost_weights(cpmppi_handle* h, uint32_t cost_id, const float* cost_w, uint32_t n) {
-  if (!h || !cost_w || n > 24 || cost_id > CPMPPI_COST_QBG)
+  if (!h || !cost_w || n > 24 || cost_id > CPMPPI_COST_QB_NONCONVEX)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_cost_weights: bad argument");
+  const bool qb = cost_id == CPMPPI_COST_QB || cost_id == CPMPPI_COST_QB_NONCONVEX;   // default.py's kernels + sub-mode (fill_params)
+  if (qb && h->cfg.ode_predictor != CPMPPI_ODE_V0)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_cost_weights: quadratic_boundary / _nonconvex are built for predictor_ODE_v0");
   h->cfg.cost_id = cost_id;
-  h->prm.cost_id = cost_id;
+  h->prm.cost_id = qb ? (uint32_t)CPMPPI_COST_DEFAULT : cost_id;
+  h->prm.qb_mode = qb ? (cost_id == CPMPPI_COST_QB ? 1u : 2u) : 0u;
   for (uint32_t i = 0; i < n; ++i) h->cfg.cost_w[i] = h->prm.w[i] = cost_w[i];
   return CPMPPI_OK;
 }
@@ -1279,7 +1292,7 @@ static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, 
   if (a->predictor > CPMPPI_PREDICTOR_GRU) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: unknown predictor");
   if (a->predictor == CPMPPI_PREDICTOR_GRU) {
     if (!h->gru_image) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: predictor GRU requested but no model set (cpmppi_set_gru)");
-    if (h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT)
+    if ((h->prm.cost_id != CPMPPI_COST_QBGM && h->prm.cost_id != CPMPPI_COST_DEFAULT) || h->prm.qb_mode != 0u)
       return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step: the GRU predictor supports quadratic_boundary_grad_minimal and default");
   }
   CPMPPI_ON_DEVICE(h);
@@ -1669,6 +1682,9 @@ int cpmppi_rollout_cost_grad(cpmppi_handle* h, uint32_t E, const float* s0, cons
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: bad argument");
   if (h->prm.cost_id == CPMPPI_COST_LEGACY)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: plugin costs only");
+  if (h->prm.qb_mode != 0u)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: no adjoint for quadratic_boundary / quadratic_boundary_nonconvex "
+                                       "(built: quadratic_boundary_grad_minimal, default, quadratic_boundary_grad)");
   if (h->cfg.math_mode != CPMPPI_MATH_FAST)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_rollout_cost_grad: the adjoint is written for the FAST arithmetic");
   const size_t lds = (size_t)h->cfg.S * 6 * BLOCK * sizeof(float);

@@ -85,6 +85,8 @@ struct Params {
   uint32_t horizon_reduce, control_mode, shift_mode, correction_u;
   uint32_t interp_f32;               // FAST + device-generated knots: interpolate with one float32 FMA (<= 1 ulp of the
                                      // float64 scipy form, which stays in force for caller-provided knots)
+  uint32_t qb_mode;                  // cost_id == COST_DEFAULT only: 0 = default.py, 1 = quadratic_boundary.py, 2 = its
+                                     // _nonconvex sibling (the public ids CPMPPI_COST_QB / _QB_NONCONVEX; same kernels)
 };
 
 // Per-env constants.  PRECISE keeps the reference's operands; FAST folds them (all wave-uniform).
@@ -1150,19 +1152,43 @@ __device__ __forceinline__ F stage_qbg(const Params& p, F x, F cosang, F w_ang, 
   return dd_linear + dd_quadratic + db + ep + ekp + cc + ccrc;
 }
 
-// default.py:23-88; w = {dd, ep, cc, R}
-template <class F, bool FAST = false>
-__device__ __forceinline__ F stage_default(const Params& p, F x, F cosang, F u, float x_t, float te) {
+// default.py:23-88; w = {dd, ep, cc, R}.
+// The same function serves the plugin's two siblings (p.qb_mode, wave-uniform; w = {dd, ep, cc, R, ccrc}):
+//   1  quadratic_boundary.py:26-87 - the track-edge term is 1[|x| > 0.95 THL] 1e9 ((|x| - 0.95 THL) / (0.05 THL))^2 instead of
+//      the 1e7 indicator at 0.9 THL, and a control-change-rate term ccrc_weight (u - u_before)^2 joins when the caller hands a
+//      previous input over (`with_ccrc`; the reference adds the term only `if previous_input is not None`, :83-85);
+//   2  quadratic_boundary_nonconvex.py:27-105 - the same plus the ripple -0.15 (cos(4 2 pi (x - x*) / (2 THL)) - 1) on the
+//      position term (restated from the source text: the reference cannot import that module, oracle_np.qb_stage_cost).
+// QB = false: compiled without the siblings (the predictor_ODE kernels: the plugins are built for predictor_ODE_v0 only).
+template <class F, bool FAST = false, bool QB = true>
+__device__ __forceinline__ F stage_default(const Params& p, F x, F cosang, F u, float x_t, float te, F u_before = splat<F>(0.0f),
+                                           bool with_ccrc = false) {
 #pragma clang fp contract(off)     // every product and sum rounds once, wherever the function is inlined
   const float THL = p.THL;
   const F d = div_uniform<FAST, F>(x - splat<F>(x_t), 2.0f * THL);
-  F ind;
+  F pos = d * d, edge;
+  if (!QB || p.qb_mode == 0u) {
 #pragma unroll
-  for (int i = 0; i < Width<F>::value; ++i) put(ind, i, (__builtin_fabsf(get(x, i)) > 0.90f * THL) ? 1.0e7f : 0.0f);
-  const F dd = (d * d + ind) * splat<F>(p.w[0]);
+    for (int i = 0; i < Width<F>::value; ++i) put(edge, i, (__builtin_fabsf(get(x, i)) > 0.90f * THL) ? 1.0e7f : 0.0f);
+  } else {
+    const F b = div_uniform<FAST, F>(abs_(x) - splat<F>(0.95f * THL), 0.05f * THL);
+    F ind;
+#pragma unroll
+    for (int i = 0; i < Width<F>::value; ++i) put(ind, i, (__builtin_fabsf(get(x, i)) > 0.95f * THL) ? 1.0e9f : 0.0f);
+    edge = ind * (b * b);
+    if (p.qb_mode == 2u) {
+      const F arg = div_uniform<FAST, F>(splat<F>(25.132741228718345f) * (x - splat<F>(x_t)), 2.0f * THL);
+      pos = pos - splat<F>(0.15f) * (cos_(arg) - splat<F>(1.0f));
+    }
+  }
+  const F dd = (pos + edge) * splat<F>(p.w[0]);
   const F e1 = splat<F>(1.0f) - cosang;
   const F ep = ((e1 * e1) * splat<F>(0.25f) * splat<F>(te)) * splat<F>(p.w[1]);
   const F cc = ((u * u) * splat<F>(p.w[3])) * splat<F>(p.w[2]);
+  if (QB && with_ccrc) {
+    const F dc = u - u_before;
+    return dd + ep + cc + (dc * dc) * splat<F>(p.w[4]);
+  }
   return dd + ep + cc;
 }
 

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const bool nom_mode = p.correction_u != CPMPPI_CORRECTION_U_RUN;
   float u_nom_sq = 0.0f;                     // QBGM_ACC with the correction on u_nom: sum of u_nom^2 over the stages (wave-uniform)
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
+  const bool qb_ccrc = COST == COST_DEFAULT && INTEG == PREDICTOR_ODE_V0 && p.qb_mode != 0u && a.prev_in != nullptr;   // quadratic_boundary.py:83-85
   F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
   // `near` (wave-uniform): may any rollout of this wave sit at or beyond permissible_track_fraction * THL at the current
   // stage?  Only then does quadratic_boundary_grad_minimal's boundary term need evaluating (it is exactly zero below the
@@ -437,8 +438,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       cost += stage_qbgm<F, FAST>(p, st.x, cosang, st.w, ur, x_t, te, near, (FAST && CPMPPI_QBGM_FOLD != 0) ? &qf : nullptr);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
     } else if constexpr (COST == COST_DEFAULT) {
-      cost += stage_default<F, FAST>(p, st.x, cosang, ur, x_t, te);
+      cost += stage_default<F, FAST, (INTEG == PREDICTOR_ODE_V0)>(p, st.x, cosang, ur, x_t, te, u_before, qb_ccrc);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);
+      if (qb_ccrc) u_before = ur;               // (quadratic_boundary's control-change-rate term; wave-uniform)
     } else if constexpr (COST == COST_QBG) {
       cost += stage_qbg<F, FAST>(p, st.x, cosang, st.w, ur, u_before, x_t, te);
       corr += mppi_correction<F>(p, p.correction_u == CPMPPI_CORRECTION_U_RUN ? ur : splat<F>(uk), du);

@@ -18,6 +18,9 @@ import torch
 
 from .configs import MPPIConfig, PhysicalParameters
 
+# cost plugins with a control-change-rate term against the control applied last (Q_ccrc, CartPole/__init__.py:517-518)
+PREVIOUS_INPUT_COSTS = ("quadratic_boundary_grad", "quadratic_boundary", "quadratic_boundary_nonconvex")
+
 
 def _vec(x, E, default):
     if x is None:
@@ -232,7 +235,7 @@ class optimizer_mppi:
         host_state = not hasattr(s, "is_cuda")
         if (host_state and self.u_nom.is_cuda and self.noise == "philox" and self.h is None and not as_tensor
                 and not self.optimizer_logging and not self.calculate_optimal_trajectory
-                and self.cfg.cost_function_specification != "quadratic_boundary_grad"):
+                and self.cfg.cost_function_specification not in PREVIOUS_INPUT_COSTS):
             # the simulator's call (CartPole/__init__.py:509-520) in its plain form: host state in, host Q out, in-kernel
             # noise - ONE library call (cpmppi_step_host: staging, launch, the controls delivered into pinned memory)
             if self.num_envs == 1:
@@ -286,7 +289,7 @@ class optimizer_mppi:
         prev = getattr(vp, "Q_applied_-1", None)
         if prev is None:
             prev = getattr(vp, "Q_ccrc", None)
-        if prev is not None and self.cfg.cost_function_specification == "quadratic_boundary_grad":
+        if prev is not None and self.cfg.cost_function_specification in PREVIOUS_INPUT_COSTS:
             kw["previous_input"] = _vec(prev, E, 0.0)
         if host_state and self.u_nom.is_cuda and set(kw) == {"seed", "offset"}:
             # the simulator's call with in-kernel noise: every pointer is the same from call to call (staging block, u_nom,

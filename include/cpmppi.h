@@ -63,10 +63,17 @@ enum {
   CPMPPI_COST_DEFAULT = 1, /* default.py:23-88 ; cost_w = {dd_weight, ep_weight, cc_weight, R} */
   CPMPPI_COST_LEGACY = 2,  /* controller_mppi_cartpole.py:119-161,227-303 (q + phi); cost_w = {dd_weight, ep_weight,
                               ekp_weight, ekc_weight, cc_weight, ccrc_weight}; the MPPI correction term is part of q */
-  CPMPPI_COST_QBG = 3      /* quadratic_boundary_grad.py:64-232; cost_w = {up: dd_quadratic, dd_linear, db, ep, ekp, cc,
+  CPMPPI_COST_QBG = 3,     /* quadratic_boundary_grad.py:64-232; cost_w = {up: dd_quadratic, dd_linear, db, ep, ekp, cc,
                               ccrc | down: the same seven | target_angular_speed_sqr_max_correction up, down |
                               permissible_track_fraction | cos(admissible_angle) | R}; the set is chosen per env by
                               target_equilibrium == 1 */
+  CPMPPI_COST_QB = 4,      /* quadratic_boundary.py:26-87 ; cost_w = {dd_weight, ep_weight, cc_weight, R, ccrc_weight}: default.py
+                              with a quadratic track-edge term beyond 0.95 THL and a control-change-rate term against
+                              previous_input (added only when a previous input is given, :83-85); default.py's terminal
+                              cost.  Runs on default.py's kernels (one more wave-uniform switch); no adjoint, no GRU */
+  CPMPPI_COST_QB_NONCONVEX = 5 /* quadratic_boundary_nonconvex.py:27-105: the same plus the cosine ripple on the position term.
+                              The reference itself cannot import this module (it reads `cem_ccrc_weight`, absent from
+                              the shipped config_cost_function.yml:47-52): restated from its source text, PARITY UNPINNED */
 };
 
 enum { CPMPPI_REDUCE_SUM = 0, CPMPPI_REDUCE_MEAN = 1 };            /* horizon aggregation of the plugin costs */

@@ -296,6 +296,10 @@ def trajectory_cost(cost_id, traj, inputs, target_position, target_equilibrium, 
     elif cost_id == COST_DEFAULT:
         stage = default_stage_cost(traj[:, :-1], inputs, target_position, target_equilibrium, p, c)
         term = default_terminal_cost(traj[:, -1], target_position, p)
+    elif cost_id in (4, 5):              # COST_QB / COST_QB_NONCONVEX (defined further down); terminal = default.py's (:46-67)
+        stage = qb_stage_cost(traj[:, :-1], inputs, getattr(c, "qb_previous_input", None), target_position, target_equilibrium,
+                              getattr(c, "qb_weights", None), p, nonconvex=(cost_id == 5))
+        term = default_terminal_cost(traj[:, -1], target_position, p)
     elif cost_id == 3:                   # COST_QBG (defined further down)
         stage = qbg_stage_cost(traj[:, :-1], inputs, getattr(c, "qbg_previous_input", f32(0.0)), target_position,
                                target_equilibrium, getattr(c, "qbg_weights", None), p)
@@ -660,3 +664,35 @@ def qbg_stage_cost(states, inputs, previous_input, target_position, target_equil
     u_before = np.concatenate([np.full((inputs.shape[0], 1), previous_input, dtype=f32), inputs[:, :-1]], axis=1)
     ccrc = g("ccrc_weight") * (inputs - u_before) ** 2                                      # :178-183
     return (dd_linear + dd_quadratic + db + ep + ekp + cc + ccrc).astype(f32)               # :232
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# SURVEY 8f N4 "the remaining cost plugins": quadratic_boundary (Control_Toolkit_ASF/Cost_Functions/CartPole/
+# quadratic_boundary.py:26-87; weights config_cost_function.yml:53-58) - pinned to the reference's own class
+# (tests/golden/qb_costs.npz, oracle/gen_golden_qb.py) - and quadratic_boundary_nonconvex (.../quadratic_boundary_nonconvex.py:
+# 27-105), which adds a cosine ripple to the position term.  The second CANNOT be imported in the reference (its module reads
+# `cem_ccrc_weight`, which the shipped config_cost_function.yml:47-52 does not have: KeyError), so it is restated from its
+# source text only: PARITY UNPINNED for the ripple term; every other term is the pinned sibling's.
+COST_QB, COST_QB_NONCONVEX = 4, 5
+QB_DEFAULT_WEIGHTS = dict(dd_weight=600.0, ep_weight=20000.0, cc_weight=1.0, R=1.0, ccrc_weight=1.0)
+
+
+def qb_stage_cost(states, inputs, previous_input, target_position, target_equilibrium, w=None, p=DEFAULT_PARAMS,
+                  nonconvex=False):
+    """states[N,H,6], inputs[N,H], previous_input scalar or None -> [N,H] float32 (quadratic_boundary.py:79-87)."""
+    w = dict(QB_DEFAULT_WEIGHTS, **(w or {}))
+    THL = p.TrackHalfLength
+    x = states[:, :, POSITION_IDX]
+    d = (x - target_position) / (2.0 * THL)
+    pos = d ** 2                                                                                           # :29-31
+    if nonconvex:                                                                                          # nonconvex.py:31-41
+        pos = pos - 0.15 * (np.cos(4 * 2 * np.pi * (x - target_position) / (2.0 * THL)) - 1.0)
+    bnd = (np.abs(x) > 0.95 * THL).astype(f32) * 1e9 * ((np.abs(x) - 0.95 * THL) / (0.05 * THL)) ** 2      # :31-35
+    dd = w["dd_weight"] * (pos + bnd)                                                                      # :80
+    ep = w["ep_weight"] * (target_equilibrium * 0.25 * (1.0 - np.cos(states[:, :, ANGLE_IDX])) ** 2)      # :38-40,:81
+    cc = w["cc_weight"] * (w["R"] * inputs ** 2)                                                          # :43-44,:82
+    ccrc = 0
+    if previous_input is not None:                                                                         # :83-85
+        u_before = np.concatenate([np.ones((inputs.shape[0], 1), dtype=f32) * previous_input, inputs[:, :-1]], axis=1)
+        ccrc = w["ccrc_weight"] * (inputs - u_before) ** 2                                                 # :70-76
+    return (dd + ep + cc + ccrc).astype(f32)                                                               # :86

@@ -137,8 +137,10 @@ def test_config_defaults_match_reference_yaml_values():
     assert (lg.control_mode, lg.shift_mode, lg.correction_u, lg.SQRTRHOINV) == ("penalise", "append_zero", "u_nom", 0.02)
     with pytest.raises(ValueError):
         build_c_config(1, MPPIConfig(shift_mode="rotate"))
+    assert cost_vector("quadratic_boundary") == (4, [600.0, 20000.0, 1.0, 1.0, 1.0])          # config_cost_function.yml:53-58
+    assert cost_vector("quadratic_boundary_nonconvex", dict(ccrc_weight=2.0)) == (5, [600.0, 20000.0, 1.0, 1.0, 2.0])
     with pytest.raises(ValueError):
-        cost_vector("quadratic_boundary_nonconvex")
+        cost_vector("no_such_cost")
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Control_Toolkit_ASF"), reason="reference checkout not mounted")

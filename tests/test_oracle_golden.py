@@ -218,6 +218,28 @@ def test_qbg_cost_oracle_matches_reference(golden_dir, case):
     np.testing.assert_allclose(stage.sum(1), g[f"{case}/total"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("case", ["up_centre", "up_edge", "down_edge", "up_no_previous"])
+def test_quadratic_boundary_cost_oracle_matches_reference(golden_dir, case):
+    """quadratic_boundary (in-tree plugin; the reference class's `_get_stage_cost` and `get_terminal_cost` run under the import
+    stand-ins, oracle/gen_golden_qb.py): stage cost bit for bit - centre of the track, beyond 0.95 THL (costs up to 6e11), the
+    hanging target (negative stage costs), with and without a previous input - and the terminal indicator.  The fixture also
+    records that the reference cannot import quadratic_boundary_nonconvex at all: that sibling stays unpinned."""
+    g = load(golden_dir, "qb_costs.npz")
+    prev = g[f"{case}/previous_input"]
+    prev = None if np.isnan(prev) else f32(prev)
+    traj, Q = g[f"{case}/traj"], g[f"{case}/Q"]
+    stage = O.qb_stage_cost(traj[:, :-1], Q, prev, g[f"{case}/target_position"], g[f"{case}/target_equilibrium"])
+    assert stage.dtype == np.float32 and np.array_equal(stage, g[f"{case}/stage"])
+    assert np.array_equal(O.default_terminal_cost(traj[:, -1], g[f"{case}/target_position"]).reshape(-1, 1), g[f"{case}/terminal"])
+    assert list(g["weights"]) == [O.QB_DEFAULT_WEIGHTS[k] for k in ("dd_weight", "ep_weight", "cc_weight", "R", "ccrc_weight")]
+    assert "cem_ccrc_weight" in str(g["nonconvex_import"])
+    # the nonconvex sibling = the same terms + 0.15 dd_weight (1 - cos(8 pi d)) >= 0 on top, zero where d is a multiple of 1/4
+    nc = O.qb_stage_cost(traj[:, :-1], Q, prev, g[f"{case}/target_position"], g[f"{case}/target_equilibrium"], nonconvex=True)
+    small = np.abs(stage) < 1e6
+    extra = (nc.astype(np.float64) - stage)[small]
+    assert extra.min() > -0.05 and extra.max() <= 600.0 * 0.30 + 0.05
+
+
 @pytest.mark.parametrize("mode", ["random_walk", "uniform", "repeated", "iid", "interpolated"])
 def test_sampler_modes_match_the_reference(golden_dir, mode):
     """controller_mppi_cartpole.py:414-450: every sampling_type of `initialize_perturbations`, bit for bit on the same
