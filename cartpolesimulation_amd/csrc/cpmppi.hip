@@ -829,6 +829,7 @@ struct cpmppi_handle {
   std::string err;
   // optional per-kernel timing with HIP events recorded on the launch stream (cpmppi_set_profiling)
   uint32_t* counters = nullptr;        // [cfg.E] block-arrival tickets of the fused finalize
+  EnvFold* env_fold = nullptr;         // [cfg.E] per-env constants of the throughput build (fold_env_kernel, rewritten before every such launch)
   float* zeros_H = nullptr;            // [cfg.E, cfg.H] zeros: the nominal sequence of a cost-only launch
   float* host_stage = nullptr;         // pinned [cfg.E * 10 + 16]: staging of cpmppi_step_host (state 6, target, equilibrium, L | Q | ticket)
   uint32_t host_ticket_value = 0;      // what the ticket in that block reads once every launch so far has delivered
@@ -922,6 +923,22 @@ struct DeviceGuard {
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
+// Per-env constants of the throughput build (EnvFold, cpmppi_device.hpp): one lane per env, the very device functions the
+// other builds call in their prologues.  Runs in front of every throughput-build launch on the same stream (L, the targets and
+// s0 are the caller's device arrays and may change between any two steps): ~2 us against launches of a millisecond and more.
+__global__ __launch_bounds__(BLOCK) void fold_env_kernel(const Params p, const float* __restrict__ L, const float* __restrict__ te,
+                                                         const float* __restrict__ s0, EnvFold* __restrict__ out, uint32_t envs) {
+  const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
+  if (env >= envs) return;
+  EnvFold f;
+  f.ec = make_env_const(p, L ? L[env] : p.L_default);
+  f.qf = make_qbgm_folded_lane(p, te[env]);
+  f.cos0 = cosf(s0[(size_t)env * 6]);
+  f.inv_period = 1.0f / (float)p.period;
+  f.nearlim = __builtin_fminf(p.w[6], 1.0f) * p.THL;
+  out[env] = f;
+}
+
 template <int COST, bool FAST, int R, int V, int INTEG = PREDICTOR_ODE_V0>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                 const StepPtrs& a) {
@@ -964,14 +981,29 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32
     return ((uint64_t)grid.x * BLOCK <= 65536ull) ? CPMPPI_LAUNCH_V(true, 1, 0, PREDICTOR_ODE) : CPMPPI_LAUNCH_V(true, 1, 1, PREDICTOR_ODE);
   }
   if (math == CPMPPI_MATH_FAST) {
+    // the throughput build reads its per-env constants from a.env_fold: written here, on the same stream, first
+    auto fold_first = [&]() -> hipError_t {
+#if CPMPPI_ENV_FOLD
+      const uint32_t envs = grid.x / a.nb;
+      hipLaunchKernelGGL(fold_env_kernel, dim3((envs + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p, a.L, a.te, a.s0,
+                         const_cast<EnvFold*>(a.env_fold), envs);
+      return hipGetLastError();
+#else
+      return hipSuccess;
+#endif
+    };
     if (rpl == 2) {
       const bool mid = (uint64_t)grid.x * BLOCK * 2 <= MID_SIZE_MAX_ROLLOUTS;
       // at most one wave per SIMD (256 CUs x 4): the phased build with the quiet control step unrolled
       if ((uint64_t)grid.x * WAVES <= 1024ull) return CPMPPI_LAUNCH_V(true, 2, 3);
-      return mid ? CPMPPI_LAUNCH_V(true, 2, 2) : CPMPPI_LAUNCH_V(true, 2, 1);
+      if (mid) return CPMPPI_LAUNCH_V(true, 2, 2);
+      if (hipError_t fe = fold_first(); fe != hipSuccess) return fe;
+      return CPMPPI_LAUNCH_V(true, 2, 1);
     }
     const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
-    return small ? CPMPPI_LAUNCH_V(true, 1, 0) : CPMPPI_LAUNCH_V(true, 1, 1);
+    if (small) return CPMPPI_LAUNCH_V(true, 1, 0);
+    if (hipError_t fe = fold_first(); fe != hipSuccess) return fe;
+    return CPMPPI_LAUNCH_V(true, 1, 1);
   }
   return CPMPPI_LAUNCH_V(false, 1, 1);
 #undef CPMPPI_LAUNCH_V
@@ -979,9 +1011,11 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32
 
 // `prm`: the kernel-argument block of THIS launch (the handle's, or a modified copy: cost-only launches)
 hipError_t launch_rollout(cpmppi_handle* h, const Params& prm, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds,
-                          hipStream_t s, const StepPtrs& a) {
+                          hipStream_t s, const StepPtrs& a_in) {
   uint32_t variant = 0;
   hipError_t e;
+  StepPtrs a = a_in;
+  a.env_fold = h->env_fold;
   switch (prm.cost_id) {
     case CPMPPI_COST_QBGM: e = launch_rollout_math<COST_QBGM>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
     case CPMPPI_COST_DEFAULT: e = launch_rollout_math<COST_DEFAULT>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
@@ -1068,6 +1102,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   hipError_t e = hipMalloc(&h->workspace, h->workspace_floats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->counters, (size_t)cfg->E * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(h->counters, 0, (size_t)cfg->E * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&h->env_fold, (size_t)cfg->E * sizeof(EnvFold));
   if (e == hipSuccess) e = hipMalloc(&h->zeros_H, (size_t)cfg->E * cfg->H * sizeof(float));
   if (e == hipSuccess) e = hipMemset(h->zeros_H, 0, (size_t)cfg->E * cfg->H * sizeof(float));
   if (e != hipSuccess) {
@@ -1088,6 +1123,7 @@ void cpmppi_destroy(cpmppi_handle* h) {
   if (h->gru16_image) (void)hipFree(h->gru16_image);
   if (h->grad_ckpt) (void)hipFree(h->grad_ckpt);
   if (h->counters) (void)hipFree(h->counters);
+  if (h->env_fold) (void)hipFree(h->env_fold);
   if (h->zeros_H) (void)hipFree(h->zeros_H);
   if (h->host_stage) (void)hipHostFree(h->host_stage);
   if (h->dev_stage) (void)hipFree(h->dev_stage);

@@ -90,6 +90,13 @@ struct Params {
 };
 
 // Per-env constants.  PRECISE keeps the reference's operands; FAST folds them (all wave-uniform).
+constexpr float ROT_LIMIT_LO = 0.125f;
+constexpr float ROT_LIMIT = 0.25f;
+#ifndef CPMPPI_SEED_LO
+#define CPMPPI_SEED_LO 1        // packed path: the carried pair is seeded from the degree-5/4 polynomials (|w t| <= 0.125)
+#endif
+constexpr float ROT_LIMIT_SEED = CPMPPI_SEED_LO ? ROT_LIMIT_LO : ROT_LIMIT;     // (see rot_pair_lo / rot_pair below)
+
 struct EnvConst {
   float L, Lh;
   float kp1, kp1_mt;                 // (k+1), (k+1)*(m_cart+m_pole)
@@ -97,6 +104,7 @@ struct EnvConst {
   float uK_scale;                    // (k+1) u_max: FAST forms (k+1) u = (k+1) u_max Q with one product
   float t1_i;                        // inv_kLh / m_pole: g_i s - cT_i w = t1_i (m_p g s - J/Lh w), the bracket xDD's numerator forms anyway
   float tg_i, tcT_i, tinv_kLh;       // the same three angleDD coefficients times the substep length t
+  float wlim;                        // ROT_LIMIT_SEED / t: |w| beyond it leaves the carried rotation pair's seed range (packed path)
 };
 
 __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
@@ -122,6 +130,7 @@ __device__ __forceinline__ EnvConst make_env_const(const Params& p, float L) {
   c.tg_i = (float)(t * (double)p.g * inv_kLh);
   c.tcT_i = (float)(t * ((double)p.J_fric / ((double)p.m_pole * Lh) * inv_kLh));
   c.tinv_kLh = (float)(t * inv_kLh);
+  c.wlim = ROT_LIMIT_SEED / p.t_step;
   return c;
 }
 
@@ -136,7 +145,7 @@ __device__ __forceinline__ EnvConst make_env_const_uniform(const Params& p, floa
   u.mg = uniform_(c.mg); u.JinvLh = uniform_(c.JinvLh); u.kmLh = uniform_(c.kmLh); u.kM = uniform_(c.kM);
   u.g_i = uniform_(c.g_i); u.cT_i = uniform_(c.cT_i); u.inv_kLh = uniform_(c.inv_kLh); u.inv_halfL = uniform_(c.inv_halfL);
   u.tg_i = uniform_(c.tg_i); u.tcT_i = uniform_(c.tcT_i); u.tinv_kLh = uniform_(c.tinv_kLh); u.t1_i = uniform_(c.t1_i);
-  u.uK_scale = uniform_(c.uK_scale);
+  u.uK_scale = uniform_(c.uK_scale); u.wlim = uniform_(c.wlim);
   return u;
 }
 
@@ -428,15 +437,11 @@ __device__ __forceinline__ F wrap_rint(F th) {
 //                path once per control step and serves every rare event (bounce, fast-spinning lane) of both paths
 // |d| = |w t| > 0.25 means an angular velocity beyond 125 rad/s at t = 2 ms; such a lane is evaluated with the exact
 // wrap + sincos on every substep (it practically never happens: a pole released from rest tops out near 20 rad/s).
-constexpr float ROT_LIMIT_LO = 0.125f;
-constexpr float ROT_LIMIT = 0.25f;
-#ifndef CPMPPI_SEED_LO
-#define CPMPPI_SEED_LO 1        // packed path: the carried pair is seeded from the degree-5/4 polynomials (|w t| <= 0.125)
-#endif
-// Packed path: the range of |w t| within which a control step runs on the carried rotation pair.  Seeded from rot_pair_lo
-// (two instructions fewer per control step than the degree-7/6 pair; truncation below 1e-9 up to 0.125 rad per substep =
-// 62 rad/s at t = 2 ms - a pole released from rest tops out near 20), lanes beyond take the exact sincos on every substep.
-constexpr float ROT_LIMIT_SEED = CPMPPI_SEED_LO ? ROT_LIMIT_LO : ROT_LIMIT;
+// (ROT_LIMIT_LO = 0.125, ROT_LIMIT = 0.25: defined ahead of EnvConst, which carries the seed's limit as an angular velocity)
+// Packed path: the range of |w t| within which a control step runs on the carried rotation pair, ROT_LIMIT_SEED.  Seeded from
+// rot_pair_lo (CPMPPI_SEED_LO; two instructions fewer per control step than the degree-7/6 pair; truncation below 1e-9 up to
+// 0.125 rad per substep = 62 rad/s at t = 2 ms - a pole released from rest tops out near 20), lanes beyond take the exact sincos
+// on every substep.
 
 template <class F>
 __device__ __forceinline__ void rot_pair_lo(F d, F& cd, F& sd) {
@@ -792,7 +797,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
 #if CPMPPI_INCR_ROT
   bool check = true;
   F xlim = splat<F>(p.THL);
-  const float wlim = ROT_LIMIT_SEED / t;        // |w t| > the seed's range as one compare with a free abs modifier per lane
+  const float wlim = e.wlim;                    // = ROT_LIMIT_SEED / t: |w t| > the seed's range as one compare with a free abs modifier per lane
   uint64_t spinning = 0;      // wave mask of lanes beyond the rotation range: the same compare as the select's (one v_cmp)
   if constexpr (SPIN_BRANCH && Width<F>::value == 2) {
     const float wmax = max_abs2_(get(st.w, 0), get(st.w, 1));
@@ -866,7 +871,7 @@ template <class F, bool UNROLL = false>
 __device__ __forceinline__ bool control_step_fast_eventful(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                            const EnvConst& e, float nearlim, bool* at_edge) {
   F xlim = splat<F>(p.THL);
-  const float wlim = ROT_LIMIT_SEED / t;
+  const float wlim = e.wlim;
   uint64_t spinning = 0;
 #pragma unroll
   for (int i = 0; i < Width<F>::value; ++i) {
@@ -1028,28 +1033,51 @@ struct QbgmFolded {
   float k_a, k_b_run, k_b_nom;             // du (k_a du + k_b_run u_run + k_b_nom u_nom): one of the two k_b is zero
   float k_c_nom;                           // 0.5 cc_weight R when the correction takes u_nom: the (rollout-independent) term u_nom^2
 };
-__device__ __forceinline__ QbgmFolded make_qbgm_folded(const Params& p, float te) {
+// (`_lane`: every lane its own `te` - the per-env fold kernel; the rollout kernel's in-kernel form pins the fields to SGPRs)
+__device__ __forceinline__ QbgmFolded make_qbgm_folded_lane(const Params& p, float te) {
   QbgmFolded f;
   const double two_thl = 2.0 * (double)p.THL;
-  f.c_dd = uniform_((float)((double)p.w[0] / (two_thl * two_thl)));
-  f.c_cc = uniform_((float)((double)p.w[5] * (double)p.w[4]));
-  f.neg_te = uniform_(-te);
+  f.c_dd = (float)((double)p.w[0] / (two_thl * two_thl));
+  f.c_cc = (float)((double)p.w[5] * (double)p.w[4]);
+  f.neg_te = -te;
   const double scale = (p.horizon_reduce == 0u) ? 1.0 : 1.0 / (double)(p.H + 1u);      // CPMPPI_REDUCE_SUM = 0
   const double ptf = (double)p.w[6], span = (1.0 - ptf) * (double)p.THL;
-  f.a_dd = uniform_((float)(scale * (double)p.w[0] / (two_thl * two_thl)));
-  f.a_ep = uniform_((float)(scale * (double)p.w[2]));
-  f.a_ekp = uniform_((float)(scale * (double)p.w[3]));
-  f.a_db = uniform_((float)(scale * (double)p.w[1] / (span * span)));
-  f.db_lim = uniform_((float)(ptf * (double)p.THL));
+  f.a_dd = (float)(scale * (double)p.w[0] / (two_thl * two_thl));
+  f.a_ep = (float)(scale * (double)p.w[2]);
+  f.a_ekp = (float)(scale * (double)p.w[3]);
+  f.a_db = (float)(scale * (double)p.w[1] / (span * span));
+  f.db_lim = (float)(ptf * (double)p.THL);
   const bool run = p.correction_u == 0u;                                                // CPMPPI_CORRECTION_U_RUN = 0
   const double half_r = (double)p.cc_weight * 0.5 * (double)p.R;
-  f.a_u2 = uniform_((float)(scale * (double)p.w[5] * (double)p.w[4] + (run ? half_r : 0.0)));
-  f.k_a = uniform_((float)((double)p.cc_weight * 0.5 * (1.0 - 1.0 / (double)p.NU) * (double)p.R));
-  f.k_b_run = uniform_(run ? (float)((double)p.cc_weight * (double)p.R) : 0.0f);
-  f.k_b_nom = uniform_(run ? 0.0f : (float)((double)p.cc_weight * (double)p.R));
-  f.k_c_nom = uniform_(run ? 0.0f : (float)half_r);
+  f.a_u2 = (float)(scale * (double)p.w[5] * (double)p.w[4] + (run ? half_r : 0.0));
+  f.k_a = (float)((double)p.cc_weight * 0.5 * (1.0 - 1.0 / (double)p.NU) * (double)p.R);
+  f.k_b_run = run ? (float)((double)p.cc_weight * (double)p.R) : 0.0f;
+  f.k_b_nom = run ? 0.0f : (float)((double)p.cc_weight * (double)p.R);
+  f.k_c_nom = run ? 0.0f : (float)half_r;
   return f;
 }
+__device__ __forceinline__ QbgmFolded make_qbgm_folded(const Params& p, float te) {
+  const QbgmFolded c = make_qbgm_folded_lane(p, te);
+  QbgmFolded f;
+  f.c_dd = uniform_(c.c_dd); f.c_cc = uniform_(c.c_cc); f.neg_te = uniform_(c.neg_te);
+  f.a_dd = uniform_(c.a_dd); f.a_ep = uniform_(c.a_ep); f.a_ekp = uniform_(c.a_ekp); f.a_db = uniform_(c.a_db);
+  f.db_lim = uniform_(c.db_lim); f.a_u2 = uniform_(c.a_u2); f.k_a = uniform_(c.k_a); f.k_b_run = uniform_(c.k_b_run);
+  f.k_b_nom = uniform_(c.k_b_nom); f.k_c_nom = uniform_(c.k_c_nom);
+  return f;
+}
+
+// Everything the throughput build's rollout kernel derives from (Params, L[env], target_equilibrium[env], s0[env]) alone, formed
+// ONCE per env by fold_env_kernel (cpmppi.hip) instead of once per WAVE in the rollout kernel's prologue: ~300 vector instructions
+// (double-precision folds, two IEEE divides, libm cosf) per wave of 128 rollouts = 1.5 % of the launch, read back with scalar loads.
+// Same device functions, same values.  136 bytes per env.
+struct EnvFold {
+  EnvConst ec;          // 18 words
+  QbgmFolded qf;        // 13 words
+  float cos0;           // cosf(s0[0]): the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+  float inv_period;     // 1 / period_interpolation_inducing_points (the in-kernel interpolation's slope factor)
+  float nearlim;        // min(permissible_track_fraction, 1) * THL: below it quadratic_boundary_grad_minimal's boundary term is zero
+};
+static_assert(sizeof(EnvFold) == 136, "EnvFold: 34 words per env");
 
 // quadratic_boundary_grad_minimal's stage cost AND the MPPI correction term of one stage added to two running sums (FAST path of
 // the rollout kernel).  Same terms as stage_qbgm + mppi_correction; what differs is the grouping: every term is accumulated

@@ -46,6 +46,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_QBGM_ACC
 #define CPMPPI_QBGM_ACC 1           // FAST quadratic_boundary_grad_minimal: stage cost + correction accumulated with FMAs (A/B switch)
 #endif
+#ifndef CPMPPI_ENV_FOLD
+#define CPMPPI_ENV_FOLD 1           // throughput build: per-env constants from fold_env_kernel's block instead of each wave's prologue (A/B switch)
+#endif
 #ifndef CPMPPI_SPIN_BRANCH
 #define CPMPPI_SPIN_BRANCH 1        // throughput build, two rollouts per lane: the spin test as one v_max + compare + branch (A/B switch)
 #endif
@@ -100,6 +103,7 @@ struct StepPtrs {
   const float* L;
   const float* noise;
   const float* prev_in; // [E] control applied before this step (quadratic_boundary_grad ccrc) or NULL
+  const EnvFold* env_fold;   // [envs of this launch] per-env constants (throughput build, FAST, predictor_ODE_v0: launch_rollout_math fills it first)
   uint64_t seed, offset;
   const unsigned long long* offset_dev;   // if set: the Philox step counter lives in device memory (graph replay)
   uint32_t stash;       // NOISE_PHILOX: the generated knots are parked in LDS ([P][R][BLOCK] after the weighted sums) for the reduction
@@ -316,8 +320,37 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   const uint64_t step_offset = a.offset_dev ? (uint64_t)*a.offset_dev : a.offset;
 
   // ---- per-env, wave-uniform -------------------------------------------------------------------------------------
-  const float L = a.L ? a.L[env] : p.L_default;
-  const EnvConst ec = make_env_const_uniform(p, L);
+  // throughput build: the per-env constants come from the block fold_env_kernel wrote just before this launch (scalar loads
+  // through the constant address space: the block is read-only for this kernel), everywhere else each wave forms them itself
+  // (not default.py's cost fed with knots from memory, two rollouts per lane: with the block's 31 scalars live from the first
+  // instruction that one instantiation runs out of SGPRs and spill lanes - 20 bytes of scratch; it keeps the in-kernel fold)
+  constexpr bool ENV_FOLD = CPMPPI_ENV_FOLD != 0 && FAST && VARIANT_ == 1 && INTEG == PREDICTOR_ODE_V0 &&
+                            !(COST == COST_DEFAULT && NOISE == NOISE_KNOTS && R == 2);
+  typedef const __attribute__((address_space(4))) float* env_fold_ptr;
+  const float te = a.te[env];
+  EnvConst ec_;
+  QbgmFolded qf_;
+  float cos0_, inv_period_ = 0.0f, nearlim_ = 0.0f;
+  if constexpr (ENV_FOLD) {
+    env_fold_ptr ef = (env_fold_ptr)(uintptr_t)(a.env_fold + env);
+#define CPMPPI_EF(field) ef[offsetof(EnvFold, field) / sizeof(float)]
+    ec_.L = CPMPPI_EF(ec.L); ec_.Lh = CPMPPI_EF(ec.Lh); ec_.kp1 = CPMPPI_EF(ec.kp1); ec_.kp1_mt = CPMPPI_EF(ec.kp1_mt);
+    ec_.mg = CPMPPI_EF(ec.mg); ec_.JinvLh = CPMPPI_EF(ec.JinvLh); ec_.kmLh = CPMPPI_EF(ec.kmLh); ec_.kM = CPMPPI_EF(ec.kM);
+    ec_.g_i = CPMPPI_EF(ec.g_i); ec_.cT_i = CPMPPI_EF(ec.cT_i); ec_.inv_kLh = CPMPPI_EF(ec.inv_kLh);
+    ec_.inv_halfL = CPMPPI_EF(ec.inv_halfL); ec_.uK_scale = CPMPPI_EF(ec.uK_scale); ec_.t1_i = CPMPPI_EF(ec.t1_i);
+    ec_.tg_i = CPMPPI_EF(ec.tg_i); ec_.tcT_i = CPMPPI_EF(ec.tcT_i); ec_.tinv_kLh = CPMPPI_EF(ec.tinv_kLh); ec_.wlim = CPMPPI_EF(ec.wlim);
+    qf_.c_dd = CPMPPI_EF(qf.c_dd); qf_.c_cc = CPMPPI_EF(qf.c_cc); qf_.neg_te = CPMPPI_EF(qf.neg_te);
+    qf_.a_dd = CPMPPI_EF(qf.a_dd); qf_.a_ep = CPMPPI_EF(qf.a_ep); qf_.a_ekp = CPMPPI_EF(qf.a_ekp); qf_.a_db = CPMPPI_EF(qf.a_db);
+    qf_.db_lim = CPMPPI_EF(qf.db_lim); qf_.a_u2 = CPMPPI_EF(qf.a_u2); qf_.k_a = CPMPPI_EF(qf.k_a);
+    qf_.k_b_run = CPMPPI_EF(qf.k_b_run); qf_.k_b_nom = CPMPPI_EF(qf.k_b_nom); qf_.k_c_nom = CPMPPI_EF(qf.k_c_nom);
+    cos0_ = CPMPPI_EF(cos0); inv_period_ = CPMPPI_EF(inv_period); nearlim_ = CPMPPI_EF(nearlim);
+#undef CPMPPI_EF
+  } else {
+    ec_ = make_env_const_uniform(p, a.L ? a.L[env] : p.L_default);
+    qf_ = make_qbgm_folded(p, te);
+    cos0_ = cosf(a.s0[(size_t)env * 6]);
+  }
+  const EnvConst ec = ec_;
   // Mid-size build (VARIANT 2 / 3, two rollouts per lane), phased horizon loop: quiet control steps and eventful ones - a
   // rollout of the wave ended the previous step at or beyond the track edge, or its pole spins beyond the rotation range -
   // run in SEPARATE loops over k (run_phased below).  The quiet loop is the throughput build's control step, untouched
@@ -332,7 +365,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   constexpr bool PHASED = FAST && VARIANT == 2 && R == 2;
   const Params& ph = p;
   const EnvConst& eh = ec;
-  const float x_t = a.x_t[env], te = a.te[env];
+  const float x_t = a.x_t[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
   const float* __restrict__ up = (a.u_prev ? a.u_prev : a.u_nom) + (size_t)env * H;
@@ -343,19 +376,19 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   float u_nom_sq = 0.0f;                     // QBGM_ACC with the correction on u_nom: sum of u_nom^2 over the stages (wave-uniform)
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   const bool qb_ccrc = COST == COST_DEFAULT && INTEG == PREDICTOR_ODE_V0 && p.qb_mode != 0u && a.prev_in != nullptr;   // quadratic_boundary.py:83-85
-  F cosang = splat<F>(cosf(s0[0]));         // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+  F cosang = splat<F>(cos0_);               // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
   // `near` (wave-uniform): may any rollout of this wave sit at or beyond permissible_track_fraction * THL at the current
   // stage?  Only then does quadratic_boundary_grad_minimal's boundary term need evaluating (it is exactly zero below the
   // threshold).  The flag comes out of the previous control step's last substep, whose one pair of edge compares tests
   // against this coarser limit (substep_fast); stage 0 is the initial state all rollouts share.  Other costs: the limit
   // is the edge itself and the flag is unused.
-  const QbgmFolded qf = make_qbgm_folded(p, te);
+  const QbgmFolded qf = qf_;
   // quadratic_boundary_grad_minimal, FAST: stage cost and correction term accumulated term by term with FMAs (stage_qbgm_acc)
   constexpr bool QBGM_ACC = FAST && COST == COST_QBGM && CPMPPI_QBGM_FOLD != 0 && CPMPPI_QBGM_ACC != 0;
   // (not in the latency build: there the flag's compare -> scalar branch hand-over sits on the lone wave's critical path
   // once per control step - measured 56 -> 66 us for a single env - while the eight instructions it saves are hidden)
   constexpr bool TRACK_NEAR = FAST && COST == COST_QBGM && VARIANT != 0 && (INTEG == PREDICTOR_ODE_V0 || CPMPPI_ODE_TRACK_NEAR != 0);
-  const float nearlim = uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
+  const float nearlim = (ENV_FOLD && TRACK_NEAR) ? nearlim_ : uniform_(TRACK_NEAR ? __builtin_fminf(p.w[6], 1.0f) * p.THL : p.THL);
   bool near = !TRACK_NEAR || !(__builtin_fabsf(s0[4]) < nearlim);
 
   // Latency build: the nominal control (and the legacy cost's previous sequence) of step k + 1 is requested while step k
@@ -679,7 +712,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       }
     };
     constexpr bool F32_INTERP = FAST && NOISE == NOISE_PHILOX;       // our own noise: one FMA instead of the f64 form
-    const float inv_period = 1.0f / (float)p.period;
+    const float inv_period = ENV_FOLD ? inv_period_ : 1.0f / (float)p.period;
     float z_lo[R], z_hi[R], slope32[R];
     double slope[R];
     // knots from memory (the reference's own noise stream): the one after next is requested a whole knot period before it
