@@ -202,6 +202,12 @@ __device__ __forceinline__ float max_abs2_(float a, float b) {
   asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// max(m, |a|, |b|) as ONE v_max3_f32 (m >= 0; a NaN operand is ignored, as by an ordered compare)
+__device__ __forceinline__ float max3_abs2_(float m, float a, float b) {
+  float r;
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float cos_(float a) { return cosf(a); }
 __device__ __forceinline__ f2 cos_(f2 a) { return f2{cosf(a.x), cosf(a.y)}; }
 
@@ -658,6 +664,9 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
 #ifndef CPMPPI_LATENCY_UNROLL
 #define CPMPPI_LATENCY_UNROLL 1
 #endif
+#ifndef CPMPPI_ROLLBACK
+#define CPMPPI_ROLLBACK 2       // throughput build, two rollouts per lane (control_step_fast): 0 = an edge test per substep, 1 = one per
+#endif                          // control step, the step redone on an event, 2 = one per three substeps (A/B switch)
 #ifndef CPMPPI_INCR_ROT
 #define CPMPPI_INCR_ROT 1       // packed path: (cos d, sin d) of d = w t advanced by d' - d = angleDD t^2 instead of re-evaluated
 #endif
@@ -687,7 +696,7 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
 // passes false at present: proving a control step clear of the edge beforehand was measured slower).
 template <class F, bool BOUNCY, bool MASK_ONLY = false>
 __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK, float t, const Params& p, const EnvConst& e,
-                                                             F& cd, F& sd, F& xlim, bool check = true) {
+                                                             F& cd, F& sd, F& xlim, bool check = true, float* xmax = nullptr) {
   constexpr int W = Width<F>::value;
   F th1, w1, x1, v1, aDD;
   ode_euler_fast<F>(st, uK, t, p, e, th1, w1, x1, v1, &aDD);
@@ -697,7 +706,10 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
   F cd1 = fma_(-eps, fma_(eps, splat<F>(0.5f), sd), cd);            // cd - eps sd - eps^2/2  (cd ~ 1: the eps^2 term matters)
   F sd1 = fma_(cd, eps, sd);                                         // sd + eps cd
   uint64_t fired = 0;                                               // wave mask (a scalar register pair; the loops' exit tests read it)
-  if (check) {
+  if (xmax != nullptr) {
+    // (MASK_ONLY callers that test once per control step: the lane's largest |x| so far, one v_max3 instead of two compares)
+    if constexpr (W == 2) *xmax = max3_abs2_(*xmax, get(x1, 0), get(x1, 1));
+  } else if (check) {
 #pragma unroll
     for (int i = 0; i < W; ++i)                                     // edge, or a lane flagged `beyond`  (3 = ordered >=)
       fired |= __builtin_amdgcn_fcmpf(__builtin_fabsf(get(x1, i)), get(xlim, i), 3);
@@ -750,7 +762,15 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
 // the rotation range?" is ONE v_max of the lane's two |w| and one compare behind which a practically never taken wave-uniform
 // branch flags the lanes, instead of a compare + select per rollout (two vector instructions per control step fewer).  Not for
 // launches of one wave per SIMD: there the compare -> scalar-branch hand-over sits on the lone wave's critical path.
-template <class F, bool QUIET_UNROLL = false, bool SPIN_BRANCH = false>
+// ROLLBACK (with SPIN_BRANCH; the throughput build): the nine intermediate substeps run WITHOUT an event test - each only folds
+// its two |x| into the lane's running maximum (one v_max3 instead of two compares) - on a working copy of the state, and ONE
+// compare per control step decides: no rollout of the wave reached the edge -> the copy is the state (the common case, eight
+// vector instructions fewer per control step); otherwise the control step is integrated again from its entry state by the loop
+// with the per-substep test and the event arithmetic behind it.  A rollout's arithmetic is the same on both routes.
+// `at_edge` (in/out, required): a wave one of whose rollouts ENDED the previous control step at or beyond the edge does not
+// speculate - a rollout caught there bounces on every substep, for tens of control steps (see bounce_masked), and each of
+// those would be integrated twice.
+template <class F, bool QUIET_UNROLL = false, bool SPIN_BRANCH = false, bool ROLLBACK = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e, float nearlim, unsigned* sec = nullptr,
                                                   bool* at_edge = nullptr) {
@@ -818,6 +838,60 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   F cd, sd;
   if constexpr (CPMPPI_SEED_LO != 0) rot_pair_lo<F>(st.w * splat<F>(t), cd, sd);
   else rot_pair<F>(st.w * splat<F>(t), cd, sd);
+  uint32_t left = S - 1u;                         // intermediate substeps the loop below still has to integrate
+  if constexpr (ROLLBACK && SPIN_BRANCH && Width<F>::value == 2) {
+#if CPMPPI_ROLLBACK == 2
+    // three tests per control step (after substeps 3, 6, 9; the reference's intermediate_steps = 10 only): an event discards at
+    // most one triple, and the loop below takes over from that triple's entry state
+    if (__builtin_expect(spinning == 0 && S == 10u && !*at_edge, 1)) {
+      float xmax = 0.0f;
+      State<F> a = st;
+      F cda = cd, sda = sd;
+#pragma unroll
+      for (int sub = 0; sub < 3; ++sub) substep_fast_rot_carried<F, false, true>(a, uK, t, p, e, cda, sda, xlim, true, &xmax);
+      if (__builtin_expect(__builtin_amdgcn_fcmpf(xmax, p.THL, 3) == 0, 1)) {         // 3 = ordered >=
+        State<F> b = a;
+        F cdb = cda, sdb = sda;
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) substep_fast_rot_carried<F, false, true>(b, uK, t, p, e, cdb, sdb, xlim, true, &xmax);
+        if (__builtin_expect(__builtin_amdgcn_fcmpf(xmax, p.THL, 3) == 0, 1)) {
+          State<F> c = b;
+          F cdc = cdb, sdc = sdb;
+#pragma unroll
+          for (int sub = 0; sub < 3; ++sub) substep_fast_rot_carried<F, false, true>(c, uK, t, p, e, cdc, sdc, xlim, true, &xmax);
+          if (__builtin_expect(__builtin_amdgcn_fcmpf(xmax, p.THL, 3) == 0, 1)) {
+            st = c;
+            return substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
+          }
+          st = b; cd = cdb; sd = sdb; left = 3u;
+        } else {
+          st = a; cd = cda; sd = sda; left = 6u;
+        }
+      }
+      asm volatile("; rollback: a rollout of this wave reached the track edge within the last three substeps");
+    }
+#else
+    if (__builtin_expect(spinning == 0 && S >= 2u && !*at_edge, 1)) {
+      State<F> wk = st;                           // (the first substep reads the entry state and writes the copy: no register moves)
+      F cdw = cd, sdw = sd;
+      float xmax = 0.0f;
+      substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
+      if (S == 10u) {
+        // the reference's intermediate_steps = 10 as straight-line code: without an event branch a substep is 28 instructions,
+        // and as a loop the register allocator closes it with two v_mov_b64 per iteration (more than the test saves)
+#pragma unroll
+        for (int sub = 1; sub < 9; ++sub) substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
+      } else {
+        for (uint32_t sub = 1; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
+      }
+      if (__builtin_expect(__builtin_amdgcn_fcmpf(xmax, p.THL, 3) == 0, 1)) {       // 3 = ordered >=
+        st = wk;
+        return substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
+      }
+      asm volatile("; rollback: a rollout of this wave reached the track edge within the control step");
+    }
+#endif
+  }
   // (Rounds 2 and 3 ran the packed mid-size build on three substeps at a time without event handling, under a rollback -
   // one v_max3 test per triple, the discarded triple redone substep by substep with the event arithmetic inline - until
   // section stamps showed that build's median wave 17 % slower per control step than this plain loop, in every section:
@@ -831,7 +905,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
 #pragma unroll
       for (int sub = 0; sub < 9; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
     } else {
-      for (uint32_t sub = 0; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+      for (; left != 0u; --left) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
     }
     if (sec) CPMPPI_SEC(sec, 3, st);
   }

@@ -363,8 +363,20 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // Measured: C4 84 -> 78 us, C3 243 -> 235, 256 envs 121 -> 117, 1024 envs 379 -> 353 us; buffer-fed kernels alike
   // (C4 reference layout 87.5 -> 82.9 us).
   constexpr bool PHASED = FAST && VARIANT == 2 && R == 2;
+  // throughput build, two rollouts per lane: ONE edge test per quiet control step, the step redone from its entry state on an
+  // event (control_step_fast).  The entry state stays live through the step - 12 registers: within the 128 of four waves per
+  // SIMD for quadratic_boundary_grad_minimal (113-122), beyond it for the other costs (130-157), which keep the per-substep test.
+  constexpr bool ROLLBACK = VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0 && CPMPPI_ROLLBACK != 0 && COST == COST_QBGM;
   const Params& ph = p;
-  const EnvConst& eh = ec;
+  // (ROLLBACK kernels: three of the substep's wave-uniform constants are parked in vector registers - these kernels have twenty
+  // to spare, while the scalar file is what they run out of: the Philox one was 20 bytes of scratch short)
+  EnvConst eh_ = ec;
+  if constexpr (ROLLBACK) {
+    asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.kp1_mt) : "s"(ec.kp1_mt));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.mg) : "s"(ec.mg));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.inv_kLh) : "s"(ec.inv_kLh));
+  }
+  const EnvConst& eh = eh_;
   const float x_t = a.x_t[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
         if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F, (LONE_WAVE && CPMPPI_EVENTFUL_UNROLL != 0)>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
         else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, &at_edge);
       } else {
-        near_next = control_step_fast<F, false, (VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0)>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp);
+        near_next = control_step_fast<F, false, (VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0), ROLLBACK>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, ROLLBACK ? &at_edge : nullptr);
       }
       near = !TRACK_NEAR || near_next;
     } else {
