@@ -817,6 +817,7 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
 #if CPMPPI_INCR_ROT
   bool check = true;
   F xlim = splat<F>(p.THL);
+  float xmax = 0.0f;                            // ROLLBACK: the lane's largest |x| over the substeps not yet tested
   const float wlim = e.wlim;                    // = ROT_LIMIT_SEED / t: |w t| > the seed's range as one compare with a free abs modifier per lane
   uint64_t spinning = 0;      // wave mask of lanes beyond the rotation range: the same compare as the select's (one v_cmp)
   if constexpr (SPIN_BRANCH && Width<F>::value == 2) {
@@ -833,18 +834,20 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       put(xlim, i, within ? p.THL : -1.0f);
       // (the select's own compare, in the sense the compiler emits it - v_cmp_ngt - so that no second compare is needed)
       if (at_edge != nullptr) spinning |= ~__builtin_amdgcn_ballot_w64(within) & __builtin_amdgcn_ballot_w64(true);
+      if constexpr (ROLLBACK) xmax = within ? xmax : INFINITY;     // (no branch on the spin test here: such a lane fails the first edge test)
     }
   }
   F cd, sd;
   if constexpr (CPMPPI_SEED_LO != 0) rot_pair_lo<F>(st.w * splat<F>(t), cd, sd);
   else rot_pair<F>(st.w * splat<F>(t), cd, sd);
   uint32_t left = S - 1u;                         // intermediate substeps the loop below still has to integrate
-  if constexpr (ROLLBACK && SPIN_BRANCH && Width<F>::value == 2) {
+  if constexpr (ROLLBACK && Width<F>::value == 2) {
 #if CPMPPI_ROLLBACK == 2
     // three tests per control step (after substeps 3, 6, 9; the reference's intermediate_steps = 10 only): an event discards at
     // most one triple, and the loop below takes over from that triple's entry state
-    if (__builtin_expect(spinning == 0 && S == 10u && !*at_edge, 1)) {
-      float xmax = 0.0f;
+    // (the phased mid-size build's quiet loop - no SPIN_BRANCH - enters with *at_edge false; a lane beyond the rotation range
+    // carries xmax = inf into the first test)
+    if (__builtin_expect(S == 10u && (!SPIN_BRANCH || (spinning == 0 && !*at_edge)), 1)) {
       State<F> a = st;
       F cda = cd, sda = sd;
 #pragma unroll
@@ -871,10 +874,9 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       asm volatile("; rollback: a rollout of this wave reached the track edge within the last three substeps");
     }
 #else
-    if (__builtin_expect(spinning == 0 && S >= 2u && !*at_edge, 1)) {
+    if (__builtin_expect(S >= 2u && (!SPIN_BRANCH || (spinning == 0 && !*at_edge)), 1)) {
       State<F> wk = st;                           // (the first substep reads the entry state and writes the copy: no register moves)
       F cdw = cd, sdw = sd;
-      float xmax = 0.0f;
       substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
       if (S == 10u) {
         // the reference's intermediate_steps = 10 as straight-line code: without an event branch a substep is 28 instructions,
@@ -898,12 +900,18 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   // DESIGN.md §4.  The phased horizon loop replaced it; the code is in the history.)
   {
     if (sec) { asm volatile("" : "+v"(cd), "+v"(sd), "+v"(xlim)); CPMPPI_SEC(sec, 2, st); }
-    if (QUIET_UNROLL && S == 10u) {
+    if (QUIET_UNROLL && !ROLLBACK && S == 10u) {
       // the quiet control step of the phased mid-size build in a launch of one wave per SIMD, the reference's
       // intermediate_steps = 10: the nine substeps as straight-line code - a lone wave pays ~50 cycles per taken branch
       // (see the one-rollout-per-lane mapping above), and the loop's back edge is one per substep
 #pragma unroll
       for (int sub = 0; sub < 9; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+    } else if (QUIET_UNROLL && ROLLBACK && S == 10u) {
+      // (the lone-wave build after a discarded triple: 9, 6 or 3 substeps left, whole triples as straight-line code)
+      for (; left != 0u; left -= 3u) {
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
+      }
     } else {
       for (; left != 0u; --left) substep_fast_rot_carried<F, false>(st, uK, t, p, e, cd, sd, xlim, check);
     }

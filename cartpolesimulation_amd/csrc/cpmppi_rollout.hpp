@@ -49,6 +49,9 @@ constexpr int WAVES = BLOCK / 64;
 #ifndef CPMPPI_ENV_FOLD
 #define CPMPPI_ENV_FOLD 1           // throughput build: per-env constants from fold_env_kernel's block instead of each wave's prologue (A/B switch)
 #endif
+#ifndef CPMPPI_ROLLBACK_PHASED
+#define CPMPPI_ROLLBACK_PHASED 1    // phased mid-size build: the quiet control step with one edge test per three substeps too (A/B switch)
+#endif
 #ifndef CPMPPI_SPIN_BRANCH
 #define CPMPPI_SPIN_BRANCH 1        // throughput build, two rollouts per lane: the spin test as one v_max + compare + branch (A/B switch)
 #endif
@@ -366,12 +369,16 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   // throughput build, two rollouts per lane: ONE edge test per quiet control step, the step redone from its entry state on an
   // event (control_step_fast).  The entry state stays live through the step - 12 registers: within the 128 of four waves per
   // SIMD for quadratic_boundary_grad_minimal (113-122), beyond it for the other costs (130-157), which keep the per-substep test.
-  constexpr bool ROLLBACK = VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0 && CPMPPI_ROLLBACK != 0 && COST == COST_QBGM;
+  // The phased mid-size build's quiet loop does the same (same cost only: the other costs' kernels grow by 10-25 registers,
+  // past the 168 of three waves per SIMD) - there the compare -> scalar-branch hand-over a test costs a lone wave is paid three
+  // times per control step instead of nine.
+  constexpr bool ROLLBACK_TP = VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0 && CPMPPI_ROLLBACK != 0 && COST == COST_QBGM;
+  constexpr bool ROLLBACK = ROLLBACK_TP || (PHASED && CPMPPI_ROLLBACK != 0 && CPMPPI_ROLLBACK_PHASED != 0 && COST == COST_QBGM);
   const Params& ph = p;
   // (ROLLBACK kernels: three of the substep's wave-uniform constants are parked in vector registers - these kernels have twenty
   // to spare, while the scalar file is what they run out of: the Philox one was 20 bytes of scratch short)
   EnvConst eh_ = ec;
-  if constexpr (ROLLBACK) {
+  if constexpr (ROLLBACK_TP) {
     asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.kp1_mt) : "s"(ec.kp1_mt));
     asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.mg) : "s"(ec.mg));
     asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.inv_kLh) : "s"(ec.inv_kLh));
@@ -512,9 +519,9 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
       bool near_next;
       if constexpr (PHASED) {
         if constexpr (decltype(eventful)::value) near_next = control_step_fast_eventful<F, (LONE_WAVE && CPMPPI_EVENTFUL_UNROLL != 0)>(st, uK, p.S, p.t_step, ph, eh, nearlim, &at_edge);
-        else near_next = control_step_fast<F, LONE_WAVE>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, &at_edge);
+        else near_next = control_step_fast<F, LONE_WAVE, false, ROLLBACK>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, &at_edge);
       } else {
-        near_next = control_step_fast<F, false, (VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0), ROLLBACK>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, ROLLBACK ? &at_edge : nullptr);
+        near_next = control_step_fast<F, false, (VARIANT == 1 && R == 2 && CPMPPI_SPIN_BRANCH != 0), ROLLBACK_TP>(st, uK, p.S, p.t_step, ph, eh, nearlim, secp, ROLLBACK_TP ? &at_edge : nullptr);
       }
       near = !TRACK_NEAR || near_next;
     } else {
