@@ -106,7 +106,6 @@ struct StepPtrs {
   const float* L;
   const float* noise;
   const float* prev_in; // [E] control applied before this step (quadratic_boundary_grad ccrc) or NULL
-  const EnvFold* env_fold;   // [envs of this launch] per-env constants (throughput build, FAST, predictor_ODE_v0: launch_rollout_math fills it first)
   uint64_t seed, offset;
   const unsigned long long* offset_dev;   // if set: the Philox step counter lives in device memory (graph replay)
   uint32_t stash;       // NOISE_PHILOX: the generated knots are parked in LDS ([P][R][BLOCK] after the weighted sums) for the reduction
@@ -120,6 +119,8 @@ struct StepPtrs {
   float* Q_out;
   uint32_t* host_ticket; // cpmppi_step_host: counter in pinned host memory, +1 (system scope) per finalized env; NULL otherwise
   GatherSync gs;
+  const EnvFold* env_fold;   // [envs of this launch] per-env constants (throughput build, FAST, predictor_ODE_v0: launch_rollout_math fills it first;
+                             // last: every other field keeps the kernarg offset the latency builds were tuned with)
 };
 
 // 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform `lds`) + 16 * lane - gfx950's
@@ -330,10 +331,11 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   constexpr bool ENV_FOLD = CPMPPI_ENV_FOLD != 0 && FAST && VARIANT_ == 1 && INTEG == PREDICTOR_ODE_V0 &&
                             !(COST == COST_DEFAULT && NOISE == NOISE_KNOTS && R == 2);
   typedef const __attribute__((address_space(4))) float* env_fold_ptr;
-  const float te = a.te[env];
+  // (the builds that fold in-kernel do so where they always did - further down for te, cos and the cost's constants: the latency
+  // build's time moves by 3 % with the order of this prologue)
   EnvConst ec_;
-  QbgmFolded qf_;
-  float cos0_, inv_period_ = 0.0f, nearlim_ = 0.0f;
+  QbgmFolded qf_{};
+  float cos0_ = 0.0f, inv_period_ = 0.0f, nearlim_ = 0.0f;
   if constexpr (ENV_FOLD) {
     env_fold_ptr ef = (env_fold_ptr)(uintptr_t)(a.env_fold + env);
 #define CPMPPI_EF(field) ef[offsetof(EnvFold, field) / sizeof(float)]
@@ -349,9 +351,8 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     cos0_ = CPMPPI_EF(cos0); inv_period_ = CPMPPI_EF(inv_period); nearlim_ = CPMPPI_EF(nearlim);
 #undef CPMPPI_EF
   } else {
-    ec_ = make_env_const_uniform(p, a.L ? a.L[env] : p.L_default);
-    qf_ = make_qbgm_folded(p, te);
-    cos0_ = cosf(a.s0[(size_t)env * 6]);
+    const float L = a.L ? a.L[env] : p.L_default;
+    ec_ = make_env_const_uniform(p, L);
   }
   const EnvConst ec = ec_;
   // Mid-size build (VARIANT 2 / 3, two rollouts per lane), phased horizon loop: quiet control steps and eventful ones - a
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     asm volatile("v_mov_b32 %0, %1" : "=v"(eh_.inv_kLh) : "s"(ec.inv_kLh));
   }
   const EnvConst& eh = eh_;
-  const float x_t = a.x_t[env];
+  const float x_t = a.x_t[env], te = a.te[env];
   const float* __restrict__ s0 = a.s0 + (size_t)env * 6;
   const float* __restrict__ un = a.u_nom + (size_t)env * H;
   const float* __restrict__ up = (a.u_prev ? a.u_prev : a.u_nom) + (size_t)env * H;
@@ -395,13 +396,13 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   float u_nom_sq = 0.0f;                     // QBGM_ACC with the correction on u_nom: sum of u_nom^2 over the stages (wave-uniform)
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   const bool qb_ccrc = COST == COST_DEFAULT && INTEG == PREDICTOR_ODE_V0 && p.qb_mode != 0u && a.prev_in != nullptr;   // quadratic_boundary.py:83-85
-  F cosang = splat<F>(cos0_);               // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
+  F cosang = splat<F>(ENV_FOLD ? cos0_ : cosf(s0[0]));     // the cost plugins take cos(angle), not the stored angle_cos, at stage 0
   // `near` (wave-uniform): may any rollout of this wave sit at or beyond permissible_track_fraction * THL at the current
   // stage?  Only then does quadratic_boundary_grad_minimal's boundary term need evaluating (it is exactly zero below the
   // threshold).  The flag comes out of the previous control step's last substep, whose one pair of edge compares tests
   // against this coarser limit (substep_fast); stage 0 is the initial state all rollouts share.  Other costs: the limit
   // is the edge itself and the flag is unused.
-  const QbgmFolded qf = qf_;
+  const QbgmFolded qf = ENV_FOLD ? qf_ : make_qbgm_folded(p, te);
   // quadratic_boundary_grad_minimal, FAST: stage cost and correction term accumulated term by term with FMAs (stage_qbgm_acc)
   constexpr bool QBGM_ACC = FAST && COST == COST_QBGM && CPMPPI_QBGM_FOLD != 0 && CPMPPI_QBGM_ACC != 0;
   // (not in the latency build: there the flag's compare -> scalar branch hand-over sits on the lone wave's critical path
