@@ -42,7 +42,8 @@ extern "C" {
 #endif
 
 #define CPMPPI_ABI_VERSION 3u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_*;
-                                   3: cpmppi_config.ode_predictor */
+                                   3: cpmppi_config.ode_predictor.  Added since without a layout change (still 3): cost ids 4 / 5,
+                                   cpmppi_last_launch, cpmppi_comm_set_timeout, cpmppi_write_recordings */
 #define CPMPPI_STATE_DIM 6u
 #define CPMPPI_MAX_HORIZON 1024u
 
