@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development soak (GPU): 256 cartpoles x 5000 control steps (100 s of simulated time) with target switches and
-per-env pole lengths; everything must stay finite and on the track.   python tools/dev/soak.py [ODE_v0|ODE]  (the predictor)"""
+per-env pole lengths; everything must stay finite and on the track.   python tools/dev/soak.py [ODE_v0|ODE] [cost plugin]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,8 @@ from cartpolesimulation_amd.configs import MPPIConfig
 E = 256
 rng = np.random.Generator(np.random.SFC64(9))
 ptype = sys.argv[1] if len(sys.argv) > 1 else "ODE_v0"
-eng = MPPIEngine(E, MPPIConfig(num_rollouts=2048, mpc_horizon=50, cost_function_specification="default", predictor_type=ptype))
+cost = sys.argv[2] if len(sys.argv) > 2 else "default"
+eng = MPPIEngine(E, MPPIConfig(num_rollouts=2048, mpc_horizon=50, cost_function_specification=cost, predictor_type=ptype))
 ang = rng.uniform(-np.pi, np.pi, E)
 s = np.zeros((E, 6), np.float32); s[:, 0] = ang; s[:, 2] = np.cos(ang); s[:, 3] = np.sin(ang); s[:, 4] = rng.uniform(-0.1, 0.1, E)
 s = eng.tensor(s)
