@@ -17,16 +17,16 @@ from cartpolesimulation_amd.engine import MPPIEngine  # noqa: E402
 from cartpolesimulation_amd.configs import MPPIConfig  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "bench"
-E, N, H = 8192, 1024, 50
+E, N, H = (int(sys.argv[2]) if len(sys.argv) > 2 else 8192), 1024, 50
 dev = torch.device("cuda", 0)
 kw = dict(SQRTRHOINV=0.03e-3) if mode == "quiet" else {}
-eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=2, **kw), device=0)
+eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=(2 if E * N >= 131072 else 0), **kw), device=0)
 s0, tp, te, Lt = synthetic_inputs(E, H, 2, dev)
 if mode == "quiet":
     s0[:, 4] = 0.0
     s0[:, 5] = 0.0
 u_nom = eng.zeros(E, H)
-for i in range(3):
+for i in range(3 if E > 64 else 30):
     eng.step(s0, u_nom, tp, te, L=Lt, seed=1234, offset=i)
 torch.cuda.synchronize()
 print(mode, eng.last_launch())
