@@ -798,7 +798,9 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       // loop's back edge is one per 190-cycle substep.  Unrolled, the nine substeps fall through their untaken event
       // branches: single env 56.3 -> 50.0 us, 256 x 20 27.9 -> 25.4 us, 3500 x 35 44.7 -> 39.1 us, 64 envs 62 -> 56 us.
       // (In this straight-line form too, one test per three substeps - rollback as in the mid-size build - is slower:
-      // 49.9 -> 51.2 us.  The untaken event branch costs less than the rollback's copies.)
+      // 49.9 -> 51.2 us.  The untaken event branch costs less than the rollback's copies.  Round 4 repeated it in the copy-free
+      // form the packed builds now use - fresh State per triple, two running maxima instead of the two compares, one compare pair
+      // and branch per triple: 48.9 -> 51.8 us, 256 x 20 24.7 -> 25.9, 64 envs 52.6 -> 56.5.  Not for one rollout per lane.)
 #pragma unroll
       for (int sub = 0; sub < 9; ++sub) substep_fast_rot<F>(st, uK, t, p, e);
     } else
