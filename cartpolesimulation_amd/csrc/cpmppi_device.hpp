@@ -665,8 +665,8 @@ __device__ __forceinline__ uint64_t substep_fast_rot(State<F>& st, F uK, float t
 #define CPMPPI_LATENCY_UNROLL 1
 #endif
 #ifndef CPMPPI_ROLLBACK
-#define CPMPPI_ROLLBACK 2       // throughput build, two rollouts per lane (control_step_fast): 0 = an edge test per substep, 1 = one per
-#endif                          // control step, the step redone on an event, 2 = one per three substeps (A/B switch)
+#define CPMPPI_ROLLBACK 1       // packed builds, quadratic_boundary_grad_minimal (control_step_fast): 0 = an edge test per substep,
+#endif                          // 1 = one per three substeps, the triple redone on an event (A/B switch)
 #ifndef CPMPPI_INCR_ROT
 #define CPMPPI_INCR_ROT 1       // packed path: (cos d, sin d) of d = w t advanced by d' - d = angleDD t^2 instead of re-evaluated
 #endif
@@ -762,14 +762,16 @@ __device__ __forceinline__ uint64_t substep_fast_rot_carried(State<F>& st, F uK,
 // the rotation range?" is ONE v_max of the lane's two |w| and one compare behind which a practically never taken wave-uniform
 // branch flags the lanes, instead of a compare + select per rollout (two vector instructions per control step fewer).  Not for
 // launches of one wave per SIMD: there the compare -> scalar-branch hand-over sits on the lone wave's critical path.
-// ROLLBACK (with SPIN_BRANCH; the throughput build): the nine intermediate substeps run WITHOUT an event test - each only folds
-// its two |x| into the lane's running maximum (one v_max3 instead of two compares) - on a working copy of the state, and ONE
-// compare per control step decides: no rollout of the wave reached the edge -> the copy is the state (the common case, eight
-// vector instructions fewer per control step); otherwise the control step is integrated again from its entry state by the loop
-// with the per-substep test and the event arithmetic behind it.  A rollout's arithmetic is the same on both routes.
-// `at_edge` (in/out, required): a wave one of whose rollouts ENDED the previous control step at or beyond the edge does not
-// speculate - a rollout caught there bounces on every substep, for tens of control steps (see bounce_masked), and each of
-// those would be integrated twice.
+// ROLLBACK (packed builds, the reference's intermediate_steps = 10): the nine intermediate substeps run WITHOUT an event test of
+// their own - each folds its two |x| into the lane's running maximum with one v_max3 instead of two compares, an s_or and a branch
+// - as three straight-line triples, each on a fresh copy of the state (SSA renaming: no register moves), and ONE compare after
+// substeps 3, 6 and 9 decides: no rollout of the wave reached the edge -> the copy is the state (the common case: 9 x 27 + 3
+// vector instructions instead of 9 x 29); otherwise the triple is discarded and the loop with the per-substep test and the event
+// arithmetic integrates from that triple's entry state to the end of the control step.  A rollout's arithmetic is the same on
+// both routes (bit-identical results with the switch off).  Measured first with one test per control step: an event then wastes
+// the whole step and SQ_INSTS_VALU did not move (profiles/HISTORY.md).
+// `at_edge` (in/out; required with SPIN_BRANCH): a wave one of whose rollouts ENDED the previous control step at or beyond the edge
+// does not speculate - a rollout caught there bounces on every substep, for tens of control steps (see bounce_masked).
 template <class F, bool QUIET_UNROLL = false, bool SPIN_BRANCH = false, bool ROLLBACK = false>
 __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S, float t, const Params& p,
                                                   const EnvConst& e, float nearlim, unsigned* sec = nullptr,
@@ -844,7 +846,6 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   else rot_pair<F>(st.w * splat<F>(t), cd, sd);
   uint32_t left = S - 1u;                         // intermediate substeps the loop below still has to integrate
   if constexpr (ROLLBACK && Width<F>::value == 2) {
-#if CPMPPI_ROLLBACK == 2
     // three tests per control step (after substeps 3, 6, 9; the reference's intermediate_steps = 10 only): an event discards at
     // most one triple, and the loop below takes over from that triple's entry state
     // (the phased mid-size build's quiet loop - no SPIN_BRANCH - enters with *at_edge false; a lane beyond the rotation range
@@ -875,26 +876,6 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
       }
       asm volatile("; rollback: a rollout of this wave reached the track edge within the last three substeps");
     }
-#else
-    if (__builtin_expect(S >= 2u && (!SPIN_BRANCH || (spinning == 0 && !*at_edge)), 1)) {
-      State<F> wk = st;                           // (the first substep reads the entry state and writes the copy: no register moves)
-      F cdw = cd, sdw = sd;
-      substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
-      if (S == 10u) {
-        // the reference's intermediate_steps = 10 as straight-line code: without an event branch a substep is 28 instructions,
-        // and as a loop the register allocator closes it with two v_mov_b64 per iteration (more than the test saves)
-#pragma unroll
-        for (int sub = 1; sub < 9; ++sub) substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
-      } else {
-        for (uint32_t sub = 1; sub + 1 < S; ++sub) substep_fast_rot_carried<F, false, true>(wk, uK, t, p, e, cdw, sdw, xlim, true, &xmax);
-      }
-      if (__builtin_expect(__builtin_amdgcn_fcmpf(xmax, p.THL, 3) == 0, 1)) {       // 3 = ordered >=
-        st = wk;
-        return substep_fast<F>(st, uK, t, p, e, nearlim, true, at_edge);
-      }
-      asm volatile("; rollback: a rollout of this wave reached the track edge within the control step");
-    }
-#endif
   }
   // (Rounds 2 and 3 ran the packed mid-size build on three substeps at a time without event handling, under a rollback -
   // one v_max3 test per triple, the discarded triple redone substep by substep with the event arithmetic inline - until

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 4 A/B of the throughput build edge test: build_variants/rb0.so (-DCPMPPI_ROLLBACK=0: per substep), rb1.so (once per control
 # step), the library (once per three substeps) - parity tests of the throughput shapes, same-process kernel times, SQ counters.
-# (variants: python __graft_entry__.py --variant rb0 -DCPMPPI_ROLLBACK=0; --variant rb1 -DCPMPPI_ROLLBACK=1; for the per-env fold: -DCPMPPI_ENV_FOLD=0)
+# (variants: python __graft_entry__.py --variant rb0 -DCPMPPI_ROLLBACK=0; rb1 = the one-test-per-control-step form, removed from the
+# source after this measurement - git show 65f3aaf; for the per-env fold: -DCPMPPI_ENV_FOLD=0)
 O=gpurun_out/r4; mkdir -p $O
 python -m pytest tests/test_gpu_configs.py tests/test_gpu_boundary.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -5 > $O/rb_tests.txt
 tail -3 $O/rb_tests.txt
