@@ -827,7 +827,10 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
   if constexpr (SPIN_BRANCH && Width<F>::value == 2) {
     const float wmax = max_abs2_(get(st.w, 0), get(st.w, 1));
     spinning = __builtin_amdgcn_fcmpf(wmax, wlim, 2);              // 2 = ordered >  (a NaN counts as within, as in the select form)
-    if (__builtin_expect(spinning != 0, 0)) {
+    // (ROLLBACK: the lanes are flagged BEHIND the triples - only the loop with the per-substep test reads xlim, and a wave with a
+    // spinning lane never enters the triples, so st.w there is still the entry value: the common path no longer carries the
+    // v_mov_b64 that formed xlim ahead of the branch)
+    if (!ROLLBACK && __builtin_expect(spinning != 0, 0)) {
 #pragma unroll
       for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, !(__builtin_fabsf(get(st.w, i)) > wlim) ? p.THL : -1.0f);
     }
@@ -875,6 +878,12 @@ __device__ __forceinline__ bool control_step_fast(State<F>& st, F uK, uint32_t S
         }
       }
       asm volatile("; rollback: a rollout of this wave reached the track edge within the last three substeps");
+    }
+    if constexpr (SPIN_BRANCH) {
+      if (__builtin_expect(spinning != 0, 0)) {
+#pragma unroll
+        for (int i = 0; i < Width<F>::value; ++i) put(xlim, i, !(__builtin_fabsf(get(st.w, i)) > wlim) ? p.THL : -1.0f);
+      }
     }
   }
   // (Rounds 2 and 3 ran the packed mid-size build on three substeps at a time without event handling, under a rollback -

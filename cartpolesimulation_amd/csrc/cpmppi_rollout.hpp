@@ -392,7 +392,6 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
   State<F> st{splat<F>(s0[0]), splat<F>(s0[1]), splat<F>(s0[2]), splat<F>(s0[3]), splat<F>(s0[4]), splat<F>(s0[5])};
 
   F cost = splat<F>(0.0f), corr = splat<F>(0.0f);
-  const bool nom_mode = p.correction_u != CPMPPI_CORRECTION_U_RUN;
   float u_nom_sq = 0.0f;                     // QBGM_ACC with the correction on u_nom: sum of u_nom^2 over the stages (wave-uniform)
   F u_before = splat<F>(a.prev_in ? a.prev_in[env] : 0.0f);
   const bool qb_ccrc = COST == COST_DEFAULT && INTEG == PREDICTOR_ODE_V0 && p.qb_mode != 0u && a.prev_in != nullptr;   // quadratic_boundary.py:83-85
@@ -481,6 +480,12 @@ __global__ __launch_bounds__(BLOCK, CPMPPI_MIN_WAVES) void rollout_cost_kernel(c
     }
     if constexpr (QBGM_ACC) {
       float b_nom = 0.0f;
+      // (packed builds: the flag is re-formed from the kernel argument on every stage, behind an opaque copy - as a loop-invariant
+      // bool the compiler keeps ONE lane mask for it and derives the negated one through a v_cndmask + v_cmp pair on every control
+      // step; the latency build keeps the hoisted flag: there the three scalar instructions cost what vector ones do)
+      uint32_t correction_u_now = p.correction_u;
+      if constexpr (VARIANT != 0) asm volatile("" : "+s"(correction_u_now));
+      const bool nom_mode = correction_u_now != CPMPPI_CORRECTION_U_RUN;
       if (__builtin_expect(nom_mode, 0)) {             // (wave-uniform; the correction takes u_nom: non-default glue)
         asm volatile("; correction term on u_nom");    // (keeps this a branch: if-converted it costs five instructions per stage)
         b_nom = uniform_(qf.k_b_nom * uk);
