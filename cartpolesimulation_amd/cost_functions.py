@@ -117,7 +117,8 @@ class quadratic_boundary(cost_function_base):
 
 class quadratic_boundary_nonconvex(quadratic_boundary):
     """.../quadratic_boundary_nonconvex.py:27-105: the same plus a cosine ripple on the position term.  The reference cannot
-    import its own module (KeyError 'cem_ccrc_weight'), so this plugin is restated from the source text and unpinned."""
+    import its own module as shipped (KeyError 'cem_ccrc_weight'); it is pinned to the outputs of that module's class with the one
+    missing configuration key supplied (tests/golden/qb_costs.npz, "nc/...")."""
     cost_name = "quadratic_boundary_nonconvex"
 
 

@@ -73,8 +73,9 @@ enum {
                               previous_input (added only when a previous input is given, :83-85); default.py's terminal
                               cost.  Runs on default.py's kernels (one more wave-uniform switch); no adjoint, no GRU */
   CPMPPI_COST_QB_NONCONVEX = 5 /* quadratic_boundary_nonconvex.py:27-105: the same plus the cosine ripple on the position term.
-                              The reference itself cannot import this module (it reads `cem_ccrc_weight`, absent from
-                              the shipped config_cost_function.yml:47-52): restated from its source text, PARITY UNPINNED */
+                              The reference cannot import this module as shipped (it reads `cem_ccrc_weight`, absent from
+                              config_cost_function.yml:47-52); pinned to the outputs of its own class with that one key supplied
+                              (:= the section's ccrc_weight; tests/golden/qb_costs.npz "nc/...") */
 };
 
 enum { CPMPPI_REDUCE_SUM = 0, CPMPPI_REDUCE_MEAN = 1 };            /* horizon aggregation of the plugin costs */

@@ -2,7 +2,10 @@
 reference's own class (Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary.py) under the import stand-ins.  The
 class still implements the stale `_get_stage_cost` name, which is called directly (:79-87); `get_terminal_cost` :43-67.
 Its sibling quadratic_boundary_nonconvex cannot be imported at all in the reference (KeyError 'cem_ccrc_weight' against the
-shipped config_cost_function.yml:47-52): the script records that fact and no vectors for it.
+shipped config_cost_function.yml:47-52): the script records that fact.  It then imports the module a second time with ONE key added
+to what yaml.safe_load returns for that section - cem_ccrc_weight := the section's own ccrc_weight (the key the module asks for was
+renamed in the YAML) - and records the outputs of the reference's class under that augmented configuration ("nc/..." arrays): the
+module's code is the reference's, unmodified; the augmentation is stated in the fixture.
 TEST INFRASTRUCTURE; usage:  cd /root/reference && python -B /root/repo/oracle/gen_golden_qb.py"""
 import os
 import sys
@@ -51,6 +54,35 @@ for name, (te, x0, prev) in cases.items():
     out[f"{name}/previous_input"] = np.array(np.nan if prev is None else prev, dtype=f32)
     print(name, "stage range", float(np.min(stage)), float(np.max(stage)), "dtype", np.asarray(stage).dtype, "beyond 0.95 THL:",
           int((np.abs(traj[:, :-1, 4]) > 0.95 * 0.198).sum()))
+# ---- quadratic_boundary_nonconvex under the one-key augmentation of the configuration
+import yaml  # noqa: E402
+
+_safe_load = yaml.safe_load
+
+
+def _augmented(stream):
+    cfg = _safe_load(stream)
+    sec = cfg.get("CartPole", {}).get("quadratic_boundary_nonconvex") if isinstance(cfg, dict) else None
+    if isinstance(sec, dict) and "cem_ccrc_weight" not in sec:
+        sec["cem_ccrc_weight"] = sec["ccrc_weight"]
+    return cfg
+
+
+yaml.safe_load = _augmented
+sys.modules.pop("Control_Toolkit_ASF.Cost_Functions.CartPole.quadratic_boundary_nonconvex", None)
+import Control_Toolkit_ASF.Cost_Functions.CartPole.quadratic_boundary_nonconvex as NC  # noqa: E402
+yaml.safe_load = _safe_load
+out["nc/augmentation"] = np.array("CartPole.quadratic_boundary_nonconvex.cem_ccrc_weight := ccrc_weight (%r)" % NC.ccrc_weight)
+for name in cases:
+    traj, Q = out[f"{name}/traj"], out[f"{name}/Q"]
+    vp = SimpleNamespace(target_position=out[f"{name}/target_position"], target_equilibrium=out[f"{name}/target_equilibrium"])
+    c = NC.quadratic_boundary_nonconvex(vp, lib)
+    prev = out[f"{name}/previous_input"]
+    prev_in = None if np.isnan(prev) else f32(prev)
+    out[f"nc/{name}/stage"] = np.asarray(c._get_stage_cost(traj[:, :-1], Q[..., None], prev_in))
+    out[f"nc/{name}/terminal"] = np.asarray(c.get_terminal_cost(traj[:, -1]))
+    print("nonconvex", name, "stage range", float(out[f"nc/{name}/stage"].min()), float(out[f"nc/{name}/stage"].max()))
+out["nc/weights"] = np.array([NC.dd_weight, NC.ep_weight, NC.cc_weight, NC.R, NC.ccrc_weight], dtype=np.float64)
 out["weights"] = np.array([QB.dd_weight, QB.ep_weight, QB.cc_weight, QB.R, QB.ccrc_weight], dtype=np.float64)
 out["names"] = np.array(list(cases))
 np.savez_compressed(os.path.join(OUT, "qb_costs.npz"), **out)

@@ -670,9 +670,10 @@ def qbg_stage_cost(states, inputs, previous_input, target_position, target_equil
 # SURVEY 8f N4 "the remaining cost plugins": quadratic_boundary (Control_Toolkit_ASF/Cost_Functions/CartPole/
 # quadratic_boundary.py:26-87; weights config_cost_function.yml:53-58) - pinned to the reference's own class
 # (tests/golden/qb_costs.npz, oracle/gen_golden_qb.py) - and quadratic_boundary_nonconvex (.../quadratic_boundary_nonconvex.py:
-# 27-105), which adds a cosine ripple to the position term.  The second CANNOT be imported in the reference (its module reads
-# `cem_ccrc_weight`, which the shipped config_cost_function.yml:47-52 does not have: KeyError), so it is restated from its
-# source text only: PARITY UNPINNED for the ripple term; every other term is the pinned sibling's.
+# 27-105), which adds a cosine ripple to the position term.  The second CANNOT be imported in the reference as shipped (its
+# module reads `cem_ccrc_weight`, which config_cost_function.yml:47-52 does not have: KeyError); the fixture therefore holds the
+# outputs of that module's own class with the ONE missing key supplied (cem_ccrc_weight := the section's ccrc_weight; "nc/..."),
+# and the restatement below reproduces them bit for bit: pinned under that stated augmentation of the configuration.
 COST_QB, COST_QB_NONCONVEX = 4, 5
 QB_DEFAULT_WEIGHTS = dict(dd_weight=600.0, ep_weight=20000.0, cc_weight=1.0, R=1.0, ccrc_weight=1.0)
 

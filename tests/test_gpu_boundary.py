@@ -170,7 +170,8 @@ def test_quadratic_boundary_seam_and_fused(golden_dir, case):
     """The in-tree plugin quadratic_boundary (cost_id 4: default.py's kernels with a sub-mode): the cost seam against the
     reference's own outputs (stage under the class's stale `_get_stage_cost` name too, terminal indicator), then the fused
     step against the oracle in both math modes and lane mappings, with and without a previous input; the nonconvex sibling
-    (cost_id 5, unpinned in the reference) against the oracle's restatement; what is not built for them is refused."""
+    (cost_id 5; the reference imports it only with the one missing configuration key supplied: "nc/..." in the fixture) against
+    those outputs of the reference's class and against the oracle's restatement; what is not built for them is refused."""
     import os
     from cartpolesimulation_amd import _lib as L
     from cartpolesimulation_amd.cost_functions import quadratic_boundary, quadratic_boundary_nonconvex
@@ -190,6 +191,8 @@ def test_quadratic_boundary_seam_and_fused(golden_dir, case):
     nc = quadratic_boundary_nonconvex(vp, None).get_stage_cost(traj[:, :-1], Qin[..., None], prev)
     np.testing.assert_allclose(nc, O.qb_stage_cost(traj[:, :-1], Qin, prev, vp.target_position, vp.target_equilibrium, nonconvex=True),
                                rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(nc, g[f"nc/{case}/stage"], rtol=1e-4, atol=2e-2)        # the reference's own class (augmented config)
+    np.testing.assert_array_equal(quadratic_boundary_nonconvex(vp, None).get_terminal_cost(traj[:, -1]), g[f"nc/{case}/terminal"])
     # fused step
     N, H = Qin.shape
     for name, cid in (("quadratic_boundary", O.COST_QB), ("quadratic_boundary_nonconvex", O.COST_QB_NONCONVEX)):

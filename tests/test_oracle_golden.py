@@ -223,7 +223,9 @@ def test_quadratic_boundary_cost_oracle_matches_reference(golden_dir, case):
     """quadratic_boundary (in-tree plugin; the reference class's `_get_stage_cost` and `get_terminal_cost` run under the import
     stand-ins, oracle/gen_golden_qb.py): stage cost bit for bit - centre of the track, beyond 0.95 THL (costs up to 6e11), the
     hanging target (negative stage costs), with and without a previous input - and the terminal indicator.  The fixture also
-    records that the reference cannot import quadratic_boundary_nonconvex at all: that sibling stays unpinned."""
+    records that the reference cannot import quadratic_boundary_nonconvex as shipped (KeyError 'cem_ccrc_weight'), and holds the
+    outputs of that module's own class with the ONE missing key supplied (cem_ccrc_weight := the section's ccrc_weight, "nc/..."):
+    the restatement of the sibling is pinned to those."""
     g = load(golden_dir, "qb_costs.npz")
     prev = g[f"{case}/previous_input"]
     prev = None if np.isnan(prev) else f32(prev)
@@ -238,6 +240,11 @@ def test_quadratic_boundary_cost_oracle_matches_reference(golden_dir, case):
     small = np.abs(stage) < 1e6
     extra = (nc.astype(np.float64) - stage)[small]
     assert extra.min() > -0.05 and extra.max() <= 600.0 * 0.30 + 0.05
+    # ... and against the reference's own class under the one-key augmentation of its configuration
+    assert "cem_ccrc_weight := ccrc_weight" in str(g["nc/augmentation"])
+    assert list(g["nc/weights"]) == list(g["weights"])
+    assert nc.dtype == np.float32 and np.array_equal(nc, g[f"nc/{case}/stage"])
+    assert np.array_equal(g[f"nc/{case}/terminal"], g[f"{case}/terminal"])
 
 
 @pytest.mark.parametrize("mode", ["random_walk", "uniform", "repeated", "iid", "interpolated"])
