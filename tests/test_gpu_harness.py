@@ -101,21 +101,27 @@ def test_swing_up_from_hanging_with_the_shipped_sizes(cost, H):
     assert held.mean() >= 0.9, f"{cost}: {held.mean():.2f} of the poles are up"
 
 
-def test_graph_replayed_loop_equals_the_launched_loop():
+@pytest.mark.parametrize("E,N,H,cost,steps", [(3, 512, 30, "default", 43),
+                                               # the throughput build (above 1.5 M rollouts): its launch is two kernels - the
+                                               # per-env constants block is written by fold_env_kernel first - both captured
+                                               (1600, 1024, 20, "quadratic_boundary_grad_minimal", 11)])
+def test_graph_replayed_loop_equals_the_launched_loop(E, N, H, cost, steps):
     """The closed loop captured once as a HIP graph (device-resident Philox counter, cpmppi_step_args.offset_dev) and
     replayed per control step gives the same trajectories, bit for bit, as the loop launched step by step."""
     from cartpolesimulation_amd.engine import MPPIEngine
     from cartpolesimulation_amd.configs import MPPIConfig
     from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
-    E = 3
     rng = np.random.Generator(np.random.SFC64(4))
     s0 = np.stack([O.create_cartpole_state(rng.uniform(-0.3, 0.3), rng.uniform(-1, 1), rng.uniform(-0.05, 0.05), 0.0) for _ in range(E)])
     Lv = rng.uniform(0.3, 0.45, E).astype(np.float32)
     outs = []
     for graph in (False, True):
-        eng = MPPIEngine(E, MPPIConfig(num_rollouts=512, mpc_horizon=30, cost_function_specification="default"))
-        out = BatchedCartPoleExperiment(eng, seed=7).run(s0, 43, target_position=0.02, L=Lv, graph=graph, steps_per_graph=8)
+        eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, cost_function_specification=cost))
+        out = BatchedCartPoleExperiment(eng, seed=7).run(s0, steps, target_position=0.02, L=Lv, graph=graph, steps_per_graph=8)
+        if E >= 1600:
+            assert eng.last_launch()["build_variant"] == 1, eng.last_launch()
         outs.append((out["states"].cpu().numpy(), out["Q"].cpu().numpy(), out["u_nom"].cpu().numpy()))
+        eng.close()
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
     assert np.abs(outs[0][1]).max() > 0.01
