@@ -295,3 +295,72 @@ def install():
     ct.__path__ = []
     _module("Control_Toolkit.Cost_Functions", cost_function_base=cost_function_base)
     _module("Control_Toolkit.Controllers", template_controller=template_controller)
+
+
+# --------------------------------------------------------------------------- the simulator class itself (CartPole/__init__.py)
+class EnvironmentBatched:
+    """Base class of CartPole.CartPole in the absent Control_Toolkit (only inherited from, CartPole/__init__.py:76)."""
+
+
+class FunctionalDict(dict):
+    """SI_Toolkit.Functions.FunctionalDict as CartPole/__init__.py:221-259, 413-433 uses it: a dict of zero-argument
+    callables whose VALUES are what item access / items() / values() yield."""
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, k)()
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
+class HistoryClass(dict):
+    """... and its HistoryClass: name -> list of logged values (add_keys, update_history; read as a plain dict of lists)."""
+
+    def add_keys(self, keys):
+        for k in keys:
+            self.setdefault(k, [])
+
+    def update_history(self, d):
+        for k, v in d.items():
+            self[k].append(v)
+
+
+class _Repo:
+    """git.Repo(search_parent_directories=True).head.object.hexsha (CartPole/csv_logger.py:21-22)."""
+
+    def __init__(self, *a, **k):
+        self.head = SimpleNamespace(object=SimpleNamespace(hexsha="ref_shims"))
+
+
+def install_app(controllers):
+    """After install(): make the simulator class itself importable - the experiment loop of CartPole/__init__.py
+    (update_state :283-324, update_target_position :360-378, update_target_equilibrium :380-388, Update_Q :475-527,
+    save_csv_routine :403-433, setup / run_cartpole_random_experiment :570-735) and CartPole/data_generator.py's
+    random_experiment_setter run as the reference's OWN code objects.  `controllers`: name -> class, what the absent
+    Control_Toolkit's import_controller_by_name would find.  Returns the module object of CartPole/__init__.py."""
+    import importlib.util
+    import matplotlib
+    matplotlib.use("Agg")
+    template_controller.has_optimizer = False          # (class attribute of the absent template_controller; the legacy controller has none)
+    o = _module("Control_Toolkit.others")
+    o.__path__ = []
+    _module("Control_Toolkit.others.environment", EnvironmentBatched=EnvironmentBatched)
+    _module("Control_Toolkit.others.globals_and_utils",
+            get_available_controller_names=lambda: ["manual-stabilization"] + list(controllers),
+            get_available_optimizer_names=lambda: [],
+            get_controller_name=lambda controller_name=None, controller_idx=None: (controller_name, 0),
+            get_optimizer_name=lambda optimizer_name=None, optimizer_idx=None: (optimizer_name, 0),
+            import_controller_by_name=lambda name: controllers[name])
+    fn = _module("SI_Toolkit.Functions")
+    fn.__path__ = []
+    _module("SI_Toolkit.Functions.FunctionalDict", FunctionalDict=FunctionalDict, HistoryClass=HistoryClass)
+    _module("git", Repo=_Repo)
+    spec = importlib.util.spec_from_file_location("CartPole_app", f"{REFERENCE_ROOT}/CartPole/__init__.py")
+    app = importlib.util.module_from_spec(spec)
+    sys.modules["CartPole_app"] = app
+    spec.loader.exec_module(app)
+    sys.modules["CartPole"].CartPole = app.CartPole    # `from CartPole import CartPole` (CartPole/data_generator.py:8)
+    return app

@@ -1,0 +1,259 @@
+"""CPU restatement of the reference's EXPERIMENT SCHEDULE - what the data generator's simulator does around the controller
+(SURVEY.md §8f N1 / N2): the random target-position trace, the target-equilibrium flips, the experiment setter and the order of
+events inside one simulation step, down to the rows of the recording.
+
+TEST INFRASTRUCTURE (like everything under oracle/): only tests/ may import it; the product's counterpart is
+cartpolesimulation_amd/schedule.py + harness.py + the plant kernel.  Plain numpy, one experiment at a time, line by line after:
+  * CartPole/random_target_generator.py:9-89          Generate_Random_Trace_Function      -> random_trace
+  * CartPole/data_generator.py:95-218, 221-256         random_experiment_setter, generate_random_initial_state
+  * CartPole/__init__.py:283-324 (update_state), :360-378 (update_target_position), :380-388 (update_target_equilibrium),
+    :403-433 (save_csv_routine), :475-527 (Update_Q), :570-657 / :659-735 (setup / run_cartpole_random_experiment),
+    :796-880 (set_cartpole_state_at_t0)                                                   -> run_experiment
+Pinned by tests/golden/schedule.npz, which oracle/gen_golden_schedule.py produced by running those very code objects - the
+simulator class itself with the in-tree legacy MPPI controller in the loop (tests/test_oracle_schedule.py).
+scipy is NOT used: interp1d (kinds 'linear' and 'previous', fill_value='extrapolate') and BPoly.from_derivatives with zero
+slopes are restated from their published algorithms (scipy 1.15: interpolate/_interpolate.py interp1d._call_linear /
+_call_previousnext; _ppoly.pyx evaluate_bpoly1; BPoly._construct_from_derivatives gives c = [ya, ya, yb, yb] exactly when both
+slopes are zero) and reproduce scipy's doubles bit for bit on the fixture.
+"""
+import numpy as np
+
+from . import oracle_np as O
+
+f32 = np.float32
+THL32 = f32((44.0e-2 - 4.4e-2) / 2.0)             # CartPole/cartpole_parameters.py:31 (a 0-d float32 array there)
+
+
+def _weak_times_thl(x):
+    """python-float * TrackHalfLength: the 0-d float32 array wins (NEP 50), the product is formed in float32."""
+    return f32(x) * THL32
+
+
+# ------------------------------------------------------------------------------------------------ random_target_generator.py
+def random_trace(length_of_experiment, rtf_rng, track_relative_complexity, interpolation_type, turning_points,
+                 turning_points_period, start_random_target_position_at, end_random_target_position_at, used_track_fraction):
+    """-> f(time) (scalar or array, float64), CartPole/random_target_generator.py:9-89."""
+    if (turning_points is None) or (len(turning_points) == 0):                                # :24
+        n = int(np.floor(length_of_experiment * track_relative_complexity))                   # :26
+        y = rtf_rng.uniform(-1.0, 1.0, n)                                                     # :28
+        y = y * used_track_fraction * np.float64(THL32)                                       # :29 (float64 array x float32 0-d)
+        if n == 0:
+            y = np.append(np.append(y, 0.0), 0.0)                                             # :31-33
+        elif n == 1:
+            if start_random_target_position_at is not None:                                   # :35-40
+                y[0] = start_random_target_position_at
+            elif end_random_target_position_at is not None:
+                y[0] = end_random_target_position_at
+            y = np.append(y, y[0])                                                            # :41
+        else:
+            if start_random_target_position_at is not None:                                   # :43-46
+                y[0] = start_random_target_position_at
+            if end_random_target_position_at is not None:
+                y[-1] = end_random_target_position_at
+    else:
+        n = len(turning_points)                                                               # :49
+        y = np.array([turning_points[0], turning_points[0]]) if n == 1 else np.array(turning_points)   # :52-55
+        y = y.astype(np.float64)
+    random_samples = n - 2 if n - 2 >= 0 else 0                                               # :57
+    if turning_points_period == "random":
+        t_init = np.sort(rtf_rng.uniform(0.0, 1.0, random_samples))                           # :60-62
+        t_init = np.append(np.insert(t_init, 0, 0.0), 1.0)
+    elif turning_points_period == "regular":
+        t_init = np.linspace(0, 1.0, num=random_samples + 2, endpoint=True)                   # :64
+    else:
+        raise NotImplementedError("There is no mode corresponding to this value of turning_points_period variable")
+    t_init = t_init * length_of_experiment                                                    # :68
+    if interpolation_type == "0-derivative-smooth":
+        inner = lambda t: _bpoly_zero_slopes(t_init, y, t)                                    # noqa: E731  (:71-73)
+    elif interpolation_type == "linear":
+        inner = lambda t: _interp_linear(t_init, y, t)                                        # noqa: E731  (:75)
+    elif interpolation_type == "previous":
+        inner = lambda t: _interp_previous(t_init, y, t)                                      # noqa: E731  (:77)
+    else:
+        raise ValueError("Unknown interpolation type.")
+    # :82-87: the bounds are python-float x float32 0-d array -> float32, compared as doubles
+    hi = np.float64(f32(used_track_fraction) * THL32)
+
+    def truncated(time):
+        scalar = np.ndim(time) == 0
+        v = np.clip(inner(np.atleast_1d(np.asarray(time, dtype=np.float64))), -hi, hi)
+        return float(v[0]) if scalar else v
+
+    return truncated
+
+
+def _interp_linear(x, y, t):
+    """scipy interp1d(kind='linear', fill_value='extrapolate')._call_linear."""
+    i = np.searchsorted(x, t).clip(1, len(x) - 1)
+    lo, hi = i - 1, i
+    slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
+    return slope * (t - x[lo]) + y[lo]
+
+
+def _interp_previous(x, y, t):
+    """scipy interp1d(kind='previous', fill_value='extrapolate')._call_previousnext: _ind = 0, side 'left',
+    _x_shift = nextafter(x, -inf); below x[0] scipy fills nan (never evaluated there: time >= 0 = x[0])."""
+    i = np.searchsorted(np.nextafter(x, -np.inf), t, side="left").clip(1, len(x))
+    return y[i - 1]                                           # (_y[i + _ind - 1])
+
+
+def _bpoly_zero_slopes(x, y, t):
+    """BPoly.from_derivatives(x, [[y_i, 0]], extrapolate='periodic')(t): per interval the cubic with Bernstein coefficients
+    [y_i, y_i, y_i+1, y_i+1]; periodic mapping t -> x0 + (t - x0) % (xN - x0) for every t (_PPolyBase.__call__)."""
+    t = x[0] + (t - x[0]) % (x[-1] - x[0])
+    i = (np.searchsorted(x, t, side="right") - 1).clip(0, len(x) - 2)          # x[i] <= t < x[i+1]; the last interval is closed
+    s = (t - x[i]) / (x[i + 1] - x[i])
+    s1 = 1.0 - s
+    c0, c3 = y[i], y[i + 1]
+    return c0 * s1 * s1 * s1 + c0 * 3.0 * s1 * s1 * s + c3 * 3.0 * s1 * s * s + c3 * s * s * s   # evaluate_bpoly1, k == 3
+
+
+# ------------------------------------------------------------------------------------------------ data_generator.py
+def generate_random_initial_state(stub, init_limits, rng):
+    """CartPole/data_generator.py:221-256; `stub`: (position, positionD, angle, angleD) with None = draw it."""
+    position_lim, positionD_lim, angle_lim, angleD_lim = init_limits
+    position, positionD, angle, angleD = stub
+    s = np.zeros(6, dtype=f32)
+    s[O.POSITION_IDX] = _weak_times_thl(rng.uniform(low=-1.0, high=1.0)) * f32(position_lim) if position is None else position
+    s[O.POSITIOND_IDX] = _weak_times_thl(rng.uniform(low=-1.0, high=1.0)) * f32(positionD_lim) if positionD is None else positionD
+    if angle is None:
+        if rng.uniform() > 0.5:
+            s[O.ANGLE_IDX] = rng.uniform(low=angle_lim[0], high=angle_lim[1]) * (np.pi / 180.0)
+        else:
+            s[O.ANGLE_IDX] = rng.uniform(low=-angle_lim[1], high=-angle_lim[0]) * (np.pi / 180.0)
+    else:
+        s[O.ANGLE_IDX] = angle
+    s[O.ANGLED_IDX] = rng.uniform(low=-1.0, high=1.0) * angleD_lim * (np.pi / 180.0) if angleD is None else angleD
+    s[O.ANGLE_COS_IDX], s[O.ANGLE_SIN_IDX] = np.cos(s[O.ANGLE_IDX]), np.sin(s[O.ANGLE_IDX])     # float32 cos / sin of the stored angle
+    return s
+
+
+class ExperimentSetter:
+    """CartPole/data_generator.py:93-218: one instance serves all experiments of a run (its rng and the alternation of the
+    interpolation types carry over from one experiment to the next)."""
+
+    def __init__(self, config):
+        c = config
+        self.c = c
+        ris = c["random_initial_state"]
+        self.stub = (ris["position"], ris["positionD"], ris["angle"], ris["angleD"])
+        lim = ris["init_limits"]
+        self.init_limits = [lim["position"], lim["positionD"], lim["angle"], lim["angleD"]]
+        self.interpolation_type_idx = 0
+        inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                     # noqa: E731
+        self.keep_up, self.keep_down = inf(c["keep_target_equilibrium_x_seconds_up"]), inf(c["keep_target_equilibrium_x_seconds_down"])
+        self.rng = np.random.Generator(np.random.SFC64(c["seed"]))                              # create_rng, others/globals_and_utils.py:198-214
+
+    def set(self, cartpole_rng):
+        """-> dict(s0, trace f(t), target_equilibrium, interpolation_type, start, end); `cartpole_rng` = the CartPole
+        instance's own generator, which draws the turning points (CartPole/__init__.py:631-646)."""
+        c = self.c
+        s0 = generate_random_initial_state(self.stub, self.init_limits, self.rng)               # :155
+        frac = c["track_fraction_usable_for_target_position"]
+        if c["start_at_target"]:
+            start = s0[O.POSITION_IDX]                                                          # :157-158
+        elif c["random_initial_state"]["target_position"] is None:
+            start = f32(frac) * THL32 * f32(self.rng.uniform(-1.0, 1.0))                        # :160-162 (float32 products)
+        else:
+            start = c["random_initial_state"]["target_position"]
+        if c["target_position_end"] is None:
+            end = f32(frac) * THL32 * f32(self.rng.uniform(-1.0, 1.0))                          # :166-168
+        else:
+            end = c["target_position_end"]
+        ite = c["initial_target_equilibrium"]
+        if ite == "up" or ite == 1:
+            te = 1
+        elif ite == "down" or ite == -1:
+            te = -1
+        else:
+            raise NotImplementedError("initial_target_equilibrium 'random' draws from numpy's global generator (:177)")
+        it = c["turning_points"]["interpolation_type"]
+        if isinstance(it, list):                                                                # :181-185
+            interpolation_type = it[self.interpolation_type_idx]
+            self.interpolation_type_idx = (self.interpolation_type_idx + 1) % len(it)
+        else:
+            interpolation_type = it
+        f = random_trace(c["length_of_experiment"], cartpole_rng, c["turning_points"]["track_relative_complexity"],
+                         interpolation_type, c["turning_points"]["turning_points"], c["turning_points"]["turning_points_period"],
+                         start, end, frac)
+        return dict(s0=s0, trace=f, target_equilibrium=te, interpolation_type=interpolation_type, start=start, end=end)
+
+
+# ------------------------------------------------------------------------------------------------ the experiment loop
+def accumulated_times(n, dt):
+    """time after g calls of step_time (CartPole/__init__.py:326-327), g = 0..n."""
+    t, out = 0.0, [0.0]
+    for _ in range(n):
+        t = t + dt
+        out.append(t)
+    return np.array(out)
+
+
+def schedule_tables(trace, te0, length, dt_sim, keep_up, keep_down):
+    """target_position and target_equilibrium as the simulator holds them AFTER each simulation step g = 0..n
+    (update_target_position :360-378 - not updated once time >= length -, update_target_equilibrium :380-388)."""
+    n = int(np.ceil(length / dt_sim))                                                           # :648
+    times = accumulated_times(n, dt_sim)
+    tp = np.empty(n + 1)
+    te = np.empty(n + 1, dtype=np.int64)
+    tp[0], te[0] = trace(0.0), te0                                                              # :651 (time 0)
+    last = None
+    for g in range(1, n + 1):
+        t = times[g]
+        tp[g] = trace(t) if not (t >= length) else tp[g - 1]
+        cur = te[g - 1]
+        if last is None:
+            last = t
+        elif cur == -1 and (t - last) > keep_down:
+            last, cur = t, -cur
+        elif cur == 1 and (t - last) > keep_up:
+            last, cur = t, -cur
+        te[g] = cur
+    return times, tp, te
+
+
+def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS):
+    """One experiment as CartPole.run_cartpole_random_experiment runs it (noise, latency, disturbance OFF as shipped).
+    controller_step(s, time, target_position, target_equilibrium, L) -> Q.  Returns dict(rows: column -> list, calls)."""
+    c = config
+    dt_sim = c["dt"]["simulation"]
+    n_ctrl = max(1, int(np.rint(c["dt"]["control"] / dt_sim)))                                  # :909-916
+    n_save = max(1, int(np.rint(c["dt"]["saving"] / dt_sim)))                                   # :925-933
+    Lf = float(p.L if L is None else L)
+    inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                          # noqa: E731
+    times, tp_g, te_g = schedule_tables(setup["trace"], setup["target_equilibrium"], c["length_of_experiment"], dt_sim,
+                                        inf(c["keep_target_equilibrium_x_seconds_up"]), inf(c["keep_target_equilibrium_x_seconds_down"]))
+    s = np.array(setup["s0"], dtype=f32)
+    calls = []
+
+    def control(g):
+        Q = controller_step(s.copy(), times[g], tp_g[g], te_g[g], Lf)
+        calls.append(dict(s=s.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q)))
+        return f32(Q)
+
+    rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium")}
+    Q_ccrc = f32(0.0)                                                                           # :838
+    Q = control(0)                                                                              # set_cartpole_state_at_t0 :842-852
+    aDD, xDD = O.plant_ode(s, Q, Lf, p)                                                         # :859-860
+
+    def save(g):
+        rows["time"].append(times[g]); rows["s"].append(s.copy()); rows["angleDD"].append(aDD); rows["positionDD"].append(xDD)
+        rows["Q"].append(Q); rows["Q_ccrc"].append(Q_ccrc); rows["u"].append(O.Q2u(Q, p))
+        rows["target_position"].append(tp_g[g]); rows["target_equilibrium"].append(te_g[g])
+
+    save(0)                                                                                     # :875 (the t = 0 row)
+    ctrl_counter = save_counter = 0
+    for g in range(1, len(times)):                                                              # update_state, :283-324
+        s = O.plant_substep(s, aDD, xDD, dt_sim, Lf, p)                                         # integration, bounce, cos/sin, wrap
+        ctrl_counter += 1
+        if ctrl_counter == n_ctrl:                                                              # Update_Q :475-527
+            Q_ccrc = Q
+            Q = control(g)
+            ctrl_counter = 0
+        aDD, xDD = O.plant_ode(s, Q, Lf, p)                                                     # :319-320
+        save_counter += 1
+        if save_counter == n_save:                                                              # save_csv_routine :403-433
+            save(g)
+            save_counter = 0
+    return dict(rows={k: np.array(v) for k, v in rows.items()}, calls=calls, n_ctrl=n_ctrl, n_save=n_save, times=times,
+                target_position=tp_g, target_equilibrium=te_g)

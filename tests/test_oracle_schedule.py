@@ -1,0 +1,121 @@
+"""CPU: the oracle's restatement of the reference's EXPERIMENT SCHEDULE (oracle/schedule_np.py) against tests/golden/schedule.npz,
+which oracle/gen_golden_schedule.py made by running the reference's own code objects - Generate_Random_Trace_Function,
+random_experiment_setter.set and the simulator class CartPole itself (update_state with its target-position / target-equilibrium
+updates, controller calls and save routine) with the in-tree legacy MPPI controller in the loop."""
+import json
+
+import numpy as np
+import pytest
+from numpy.random import SFC64, Generator
+
+from oracle import oracle_np as O
+from oracle import schedule_np as S
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    import os
+    return np.load(os.path.join(golden_dir, "schedule.npz"))
+
+
+def test_random_trace_is_bit_equal_for_every_interpolation_type(g):
+    """'previous' / 'linear' (scipy interp1d) and '0-derivative-smooth' (BPoly.from_derivatives, periodic), regular and random
+    turning-point times, 0 / 1 / n / given turning points, clipping to the usable track: the doubles the reference returns."""
+    cases = json.loads(g["trace/cases"].item())
+    assert {c["interpolation"] for c in cases} == {"previous", "linear", "0-derivative-smooth"}
+    for c in cases:
+        f = S.random_trace(c["length"], Generator(SFC64(c["seed"])), c["complexity"], c["interpolation"], c["turning_points"],
+                           c["period"], c["start"], c["end"], c["used_fraction"])
+        t, y = g[f"trace/{c['name']}/t"], g[f"trace/{c['name']}/y"]
+        assert np.array_equal(f(t), y), c["name"]
+        assert np.array_equal(np.array([f(float(x)) for x in t[::37]]), y[::37]), c["name"]     # scalar calls, as the simulator makes them
+        hi = float(f32(c["used_fraction"]) * S.THL32)
+        assert np.abs(y).max() <= hi
+    y = g["trace/clipped/y"]
+    assert (np.abs(y) == float(f32(0.5) * S.THL32)).any()            # the clip is exercised
+
+
+@pytest.mark.parametrize("tag", ["setter_shipped", "setter_alt"])
+def test_experiment_setter_draws_what_the_reference_draws(g, tag):
+    """random_experiment_setter.set for consecutive experiments: initial state (float32, bit for bit), alternating interpolation
+    type, initial target equilibrium, and the whole target trace each experiment then follows."""
+    cfg = json.loads(g[f"{tag}/config"].item())
+    es = S.ExperimentSetter(cfg)
+    K = g[f"{tag}/s0"].shape[0]
+    n = int(np.ceil(cfg["length_of_experiment"] / cfg["dt"]["simulation"]))
+    t = S.accumulated_times(n, cfg["dt"]["simulation"])
+    t = t[t < cfg["length_of_experiment"]]
+    for i in range(K):
+        st = es.set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]) + i)))
+        assert np.array_equal(st["s0"], g[f"{tag}/s0"][i])
+        assert st["interpolation_type"] == g[f"{tag}/interpolation_type"][i]
+        assert st["target_equilibrium"] == g[f"{tag}/target_equilibrium"][i]
+        assert np.array_equal(st["trace"](t), g[f"{tag}/target_position"][i])
+    if tag == "setter_shipped":
+        assert list(g[f"{tag}/interpolation_type"][:4]) == ["previous", "0-derivative-smooth"] * 2      # config_data_gen.yml:33
+        assert np.array_equal(g[f"{tag}/target_position"][:, 0], g[f"{tag}/s0"][:, O.POSITION_IDX].astype(np.float64))   # start_at_target
+
+
+@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0"])
+def test_experiment_loop_against_the_simulator_class(g, key):
+    """Whole experiments of the REAL CartPole class (moving target, target-equilibrium flips, dt_save != dt_control): the
+    oracle's loop reproduces the schedule the controller saw and the recording's time / target columns bit for bit, and the
+    closed-loop dynamics (state, Q, second derivatives) to 1e-4 while trajectories have not diverged (first 12 controller calls)."""
+    tag, i = key.split("/")
+    i = int(i)
+    cfg = json.loads(g[f"{tag}/config"].item())
+    es = S.ExperimentSetter(cfg)
+    for j in range(i + 1):                                            # (the setter's rng and alternation carry over)
+        st = es.set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]) + j)))
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    ctrl = O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]) + i, N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))
+    cs, ctp = g[f"{key}/call/s"], g[f"{key}/call/tp"]
+    # the simulator steps a freshly set controller once on its placeholder state (set_controller -> set_cartpole_state_at_t0,
+    # CartPole/__init__.py:759-794) before the experiment's own t = 0 call: same rng stream, same warm nominal sequence
+    assert g[f"{key}/call/time"][0] == 0.0 and g[f"{key}/call/time"][1] == 0.0
+    ctrl.step(cs[0], f32(ctp[0]), L=O.DEFAULT_PARAMS.L)
+    out = S.run_experiment(st, cfg, lambda s, t, tp, te, L: ctrl.step(s, f32(tp), L=L))
+    rows, calls = out["rows"], out["calls"]
+    col = lambda name: g[f"{key}/col/{name}"]                         # noqa: E731
+    # --- the schedule: bit-exact
+    assert np.array_equal(rows["time"], col("time"))
+    assert np.array_equal(rows["target_position"], col("target_position"))
+    assert np.array_equal(rows["target_equilibrium"], col("target_equilibrium"))
+    assert np.array_equal(np.array([c["time"] for c in calls]), g[f"{key}/call/time"][1:])
+    assert np.array_equal(np.array([c["tp"] for c in calls]), ctp[1:])
+    assert np.array_equal(np.array([c["te"] for c in calls]), g[f"{key}/call/te"][1:])
+    flips = np.flatnonzero(np.diff(col("target_equilibrium")) != 0)
+    assert len(flips) >= 4 and np.ptp(col("target_position")) > 0.05   # the fixture does exercise a moving target and flips
+    assert len(calls) == out["n_ctrl"] * 0 + len(cs) - 1
+    # --- the dynamics
+    K = 12
+    Qo, Qf = np.array([c["Q"] for c in calls]), g[f"{key}/call/Q"][1:]
+    so, sf = np.array([c["s"] for c in calls]), cs[1:]
+    np.testing.assert_allclose(Qo[:K], Qf[:K], atol=1e-4)
+    np.testing.assert_allclose(so[:K], sf[:K], atol=1e-4, rtol=1e-4)
+    r = (K - 1) * out["n_ctrl"] // out["n_save"]                      # rows recorded before controller call K
+    np.testing.assert_allclose(rows["s"][:r, 0], col("angle")[:r], atol=1e-4)
+    np.testing.assert_allclose(rows["s"][:r, 4], col("position")[:r], atol=1e-4)
+    np.testing.assert_allclose(rows["Q"][:r], col("Q_calculated")[:r], atol=1e-4)
+    np.testing.assert_allclose(rows["Q_ccrc"][:r], col("Q_ccrc")[:r].astype(np.float64), atol=1e-4)
+    np.testing.assert_allclose(rows["u"][:r], col("u")[:r], atol=2e-4)
+    np.testing.assert_allclose(rows["angleDD"][:r], col("angleDD")[:r], atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(rows["positionDD"][:r], col("positionDD")[:r], atol=1e-3, rtol=1e-4)
+    # constant columns of the recording as the reference writes them (shipped physical-parameters YAML)
+    assert set(col("L_for_controller")) == {"true"} and set(col("m_pole_for_controller")) == {"true"}
+    assert np.all(col("L") == float(f32(0.395))) and np.all(col("m_pole") == float(f32(0.087)))
+    assert np.all(col("vertical_angle_offset") == 0.0) and np.all(col("vertical_angle_offset_cos") == 1.0)
+
+
+def test_row_and_call_counts_follow_the_time_scales(g):
+    """dt_save = dt_control / 2 -> two rows per controller call; dt_save = 2 dt_control -> one row per two calls; the last simulation
+    step both calls the controller and saves (n = ceil(length / dt_sim) steps)."""
+    for key, per_call in (("exp_fine/0", 2.0), ("exp_coarse/0", 0.5)):
+        cfg = json.loads(g[f"{key.split('/')[0]}/config"].item())
+        n = int(np.ceil(cfg["length_of_experiment"] / cfg["dt"]["simulation"]))
+        n_ctrl, n_save = int(np.rint(cfg["dt"]["control"] / cfg["dt"]["simulation"])), int(np.rint(cfg["dt"]["saving"] / cfg["dt"]["simulation"]))
+        assert len(g[f"{key}/col/time"]) == n // n_save + 1
+        assert len(g[f"{key}/call/time"]) == 2 + n // n_ctrl
+        assert n_ctrl / n_save == per_call
