@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPMPPI_LIB") or os.path.join(_HERE, "libcpmppi.so")   # CPMPPI_LIB: development builds (tools/)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG, COST_QB, COST_QB_NONCONVEX = 0, 1, 2, 3, 4, 5
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 CONTROL_CLIP, CONTROL_PENALISE = 0, 1
@@ -22,7 +22,8 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_rollout_cost_grad", "cpmppi_adam_step", "cpmppi_sgd_step", "cpmppi_version", "cpmppi_tiled_floats",
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
-           "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings")
+           "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings", "cpmppi_plant_step",
+           "cpmppi_abi_version")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -58,7 +59,25 @@ class cpmppi_gru_model(C.Structure):
 
 class cpmppi_launch_info(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("cost_id", "math_mode", "noise_kind", "rollouts_per_lane", "build_variant",
-                                          "ode_predictor", "blocks")]
+                                          "ode_predictor", "blocks", "cost_plugin")]
+
+
+class cpmppi_plant_args(C.Structure):
+    _fields_ = [("E", C.c_uint32), ("s", C.c_void_p), ("Q", C.c_void_p), ("L", C.c_void_p),
+                ("n_substeps", C.c_uint32), ("period_steps", C.c_uint32), ("dt_sim", C.c_float),
+                ("period", C.c_uint64), ("period_dev", C.c_void_p),
+                ("states_log", C.c_void_p), ("dd_log", C.c_void_p), ("save_rows", C.c_uint64), ("save_every", C.c_uint32),
+                ("Q_log", C.c_void_p), ("ctrl_rows", C.c_uint64),
+                ("target_position_table", C.c_void_p), ("target_equilibrium_table", C.c_void_p), ("L_table", C.c_void_p),
+                ("sched_rows", C.c_uint64), ("sched_stride", C.c_uint32),
+                ("target_position_out", C.c_void_p), ("target_equilibrium_out", C.c_void_p), ("L_out", C.c_void_p)]
+
+
+class cpmppi_recording(C.Structure):
+    _fields_ = [("E", C.c_uint32), ("rows", C.c_uint32), ("time", C.c_void_p), ("states", C.c_void_p), ("dd", C.c_void_p),
+                ("Q", C.c_void_p), ("Q_ccrc", C.c_void_p), ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p),
+                ("L", C.c_void_p), ("m_pole", C.c_double), ("u_max", C.c_float), ("first_update_row", C.c_uint32),
+                ("q_update_time", C.c_double)]
 
 
 PREDICTOR_ODE_V0, PREDICTOR_GRU = 0, 1
@@ -128,11 +147,14 @@ def load():
     lib.cpmppi_comm_set_timeout.argtypes = [vp, C.c_double]
     lib.cpmppi_comm_destroy.argtypes = [vp]
     lib.cpmppi_step_gather.argtypes = [vp, C.POINTER(cpmppi_step_args), vp, vp]
-    lib.cpmppi_write_recordings.argtypes = [C.POINTER(C.c_char_p), u32, u32, C.c_char_p, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp,
-                                            C.c_double, C.c_double, C.c_int]
+    lib.cpmppi_write_recordings.argtypes = [C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t, C.POINTER(cpmppi_recording), C.c_int]
+    lib.cpmppi_plant_step.argtypes = [vp, C.POINTER(cpmppi_plant_args), vp]
+    lib.cpmppi_abi_version.restype = u32
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = the .so does not export what include/cpmppi.h declares
+    if lib.cpmppi_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} was built as ABI {lib.cpmppi_abi_version()}, this binding is ABI {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib

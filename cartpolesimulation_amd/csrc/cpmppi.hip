@@ -268,39 +268,78 @@ __global__ __launch_bounds__(BLOCK) void rwa_kernel(const Params p, const float*
   }
 }
 
-// Plant (caller side): advance E simulated cartpoles n_sub simulation steps under held controls.
-// With logs: Q_log[row][E] = Q, states_log[row + 1][E][6] = the advanced state (the closed loop's recording, in the same
-// launch instead of two copy kernels per control step); row = the caller's, or *row_dev - 1 (the device step counter
-// of cpmppi_step_args.offset_dev, which cpmppi_step has already advanced).
-__global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, uint32_t E, float* __restrict__ s,
-                                                      const float* __restrict__ Q, const float* __restrict__ Lp,
-                                                      uint32_t n_sub, float dt_sim, float* __restrict__ states_log,
-                                                      float* __restrict__ Q_log, uint64_t row,
-                                                      const unsigned long long* __restrict__ row_dev, uint64_t log_rows) {
+// Plant (caller side): one control period of E simulated cartpoles under held controls, with the reference's
+// experiment schedule and the recording in the same launch (include/cpmppi.h, cpmppi_plant_args, lists the order of events; one
+// env per lane).  The pole length may change from one simulation step to the next (CartPole/__init__.py:529-537): its folded
+// constants are re-formed only on a change.
+struct PlantDev {
+  uint32_t E, n_sub, period_steps, save_every, sched_stride;
+  float dt_sim;
+  uint64_t period, save_rows, ctrl_rows, sched_rows;
+  const unsigned long long* period_dev;
+  float* s;
+  const float* Q;
+  const float* L;
+  float *states_log, *dd_log, *Q_log;
+  const float *tp_table, *te_table, *L_table;
+  float *tp_out, *te_out, *L_out;
+};
+
+__global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, const PlantDev a) {
   const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t E = a.E;
   if (env >= E) return;
-  // a row outside the logs (a device counter that is still 0, a graph replayed past the recording's end) is not recorded
-  bool in_log = row < log_rows;
-  if (row_dev) {
-    const uint64_t c = (uint64_t)*row_dev;
-    row = c - 1u;
-    in_log = (c != 0u) && (row < log_rows);
+  // a period the device counter cannot name (still 0) is advanced from the schedule's first row and neither recorded nor published
+  uint64_t c = a.period;
+  bool known = true;
+  if (a.period_dev) {
+    const uint64_t cnt = (uint64_t)*a.period_dev;
+    known = cnt != 0u;
+    c = known ? cnt - 1u : 0u;
   }
-  const EnvConst ec = make_env_const(p, Lp ? Lp[env] : p.L_default);
-  float* se = s + (size_t)env * 6;
+  const uint64_t g0 = c * a.period_steps;                              // simulation step at which this period's control was computed
+  auto sched_row = [&](uint64_t g) -> size_t {
+    const uint64_t r = g / a.sched_stride;
+    return (size_t)(r < a.sched_rows ? r : a.sched_rows - 1u) * E + env;
+  };
+  float Lcur = a.L_table ? a.L_table[sched_row(g0)] : (a.L ? a.L[env] : p.L_default);
+  EnvConst ec = make_env_const(p, Lcur);
+  float* se = a.s + (size_t)env * 6;
   State<float> st{se[0], se[1], se[2], se[3], se[4], se[5]};
-  const float u = p.u_max * Q[env];
+  const float q = a.Q[env];
+  const float u = p.u_max * q;
+  if (a.Q_log && known && c < a.ctrl_rows) a.Q_log[(size_t)c * E + env] = q;
   float aDD, xDD;
-  ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);       // CartPole/__init__.py:342-346
-  for (uint32_t i = 0; i < n_sub; ++i) {
-    plant_substep(st, aDD, xDD, dt_sim, p, ec);
+  ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);             // CartPole/__init__.py:316-320 (Update_Q, Q2u, cartpole_ode)
+  auto log_dd = [&](uint64_t g) {
+    if (!a.dd_log || !known || g % a.save_every) return;
+    const uint64_t r = g / a.save_every;
+    if (r < a.save_rows) { float* d = a.dd_log + ((size_t)r * E + env) * 2u; d[0] = aDD; d[1] = xDD; }
+  };
+  log_dd(g0);
+  for (uint32_t i = 0; i < a.n_sub; ++i) {
+    const uint64_t g = g0 + i + 1u;
+    if (a.L_table) {                                                   // update_parameters (:529-537) comes first in update_state
+      const float Ln = a.L_table[sched_row(g)];
+      if (Ln != Lcur) { Lcur = Ln; ec = make_env_const(p, Lcur); }
+    }
+    plant_substep(st, aDD, xDD, a.dt_sim, p, ec);
     ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);
+    if (known && g % a.save_every == 0u) {
+      const uint64_t r = g / a.save_every;
+      if (a.states_log && r < a.save_rows) {
+        float* lg = a.states_log + ((size_t)r * E + env) * 6u;
+        lg[0] = st.th; lg[1] = st.w; lg[2] = st.c; lg[3] = st.s; lg[4] = st.x; lg[5] = st.v;
+      }
+      if (i + 1u < a.n_sub) log_dd(g);                                 // (the period's last step gets its control from the next call)
+    }
   }
   se[0] = st.th; se[1] = st.w; se[2] = st.c; se[3] = st.s; se[4] = st.x; se[5] = st.v;
-  if (Q_log && in_log) Q_log[row * E + env] = Q[env];
-  if (states_log && in_log) {
-    float* lg = states_log + ((row + 1u) * E + env) * 6u;
-    lg[0] = st.th; lg[1] = st.w; lg[2] = st.c; lg[3] = st.s; lg[4] = st.x; lg[5] = st.v;
+  if (a.n_sub && known) {                                              // what the next controller call is handed (:509-520)
+    const size_t r = sched_row(g0 + a.n_sub);
+    if (a.tp_table && a.tp_out) a.tp_out[env] = a.tp_table[r];
+    if (a.te_table && a.te_out) a.te_out[env] = a.te_table[r];
+    if (a.L_table && a.L_out) a.L_out[env] = a.L_table[r];
   }
 }
 
@@ -1022,7 +1061,8 @@ hipError_t launch_rollout(cpmppi_handle* h, const Params& prm, uint32_t rpl, uin
     case CPMPPI_COST_QBG: e = launch_rollout_math<COST_QBG>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
     default: e = launch_rollout_math<COST_LEGACY>(h->cfg.math_mode, h->cfg.ode_predictor, rpl, noise, grid, lds, s, prm, a, &variant); break;
   }
-  h->last_launch = cpmppi_launch_info{prm.cost_id, h->cfg.math_mode, noise, rpl, variant, h->cfg.ode_predictor, grid.x};
+  h->last_launch = cpmppi_launch_info{prm.cost_id, h->cfg.math_mode, noise, rpl, variant, h->cfg.ode_predictor, grid.x,
+                                      prm.qb_mode == 1u ? (uint32_t)CPMPPI_COST_QB : (prm.qb_mode == 2u ? (uint32_t)CPMPPI_COST_QB_NONCONVEX : prm.cost_id)};
   return e;
 }
 
@@ -1832,38 +1872,71 @@ int cpmppi_reward_weighted_average(cpmppi_handle* h, uint32_t E, const float* S,
   return CPMPPI_OK;
 }
 
-int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
-                         float dt_sim, void* stream) {
+int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
-  if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance: bad argument");
-  if (misaligned(s) || misaligned(Q) || misaligned(L)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance: misaligned");
+  if (!a || a->E == 0 || !a->s || !a->Q || !(a->dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: bad argument");
+  const uint32_t period_steps = a->period_steps ? a->period_steps : a->n_substeps;
+  if (a->n_substeps > period_steps)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: n_substeps must not exceed period_steps");
+  const uint32_t save_every = a->save_every ? a->save_every : period_steps;
+  if ((a->states_log || a->dd_log) && save_every == 0)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: save_every / period_steps missing");
+  const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table;
+  if (tables && a->sched_rows == 0) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: schedule tables need sched_rows > 0");
+  // a host-named period must lie inside the control log it is to be written to (rows of the state logs that fall outside are
+  // skipped by the kernel, as for a device counter)
+  if (!a->period_dev && a->Q_log && a->period >= a->ctrl_rows)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: period outside Q_log (period >= ctrl_rows)");
+  if (misaligned(a->s) || misaligned(a->Q) || misaligned(a->L) || misaligned(a->states_log) || misaligned(a->dd_log) ||
+      misaligned(a->Q_log) || misaligned(a->target_position_table) || misaligned(a->target_equilibrium_table) ||
+      misaligned(a->L_table) || misaligned(a->target_position_out) || misaligned(a->target_equilibrium_out) || misaligned(a->L_out) ||
+      (a->period_dev && ((uintptr_t)a->period_dev & 7u)))
+    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_step: misaligned");
   CPMPPI_ON_DEVICE(h);
   Params plant = h->prm;                  // the simulated system's own pole mass (see cpmppi_set_pole_mass)
   plant.m_pole = h->plant_m_pole;
-  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, E, s, Q,
-                     L, n_substeps, dt_sim, (float*)nullptr, (float*)nullptr, (uint64_t)0, (const unsigned long long*)nullptr,
-                     (uint64_t)0);
+  PlantDev d{};
+  d.E = a->E; d.n_sub = a->n_substeps; d.period_steps = period_steps; d.save_every = save_every ? save_every : 1u;
+  d.sched_stride = a->sched_stride ? a->sched_stride : 1u;
+  d.dt_sim = a->dt_sim;
+  d.period = a->period; d.save_rows = a->save_rows; d.ctrl_rows = a->ctrl_rows; d.sched_rows = a->sched_rows ? a->sched_rows : 1u;
+  d.period_dev = (const unsigned long long*)a->period_dev;
+  d.s = a->s; d.Q = a->Q; d.L = a->L;
+  d.states_log = a->states_log; d.dd_log = a->dd_log; d.Q_log = a->Q_log;
+  d.tp_table = a->target_position_table; d.te_table = a->target_equilibrium_table; d.L_table = a->L_table;
+  d.tp_out = a->target_position_out; d.te_out = a->target_equilibrium_out; d.L_out = a->L_out;
+  hipLaunchKernelGGL(plant_kernel, dim3((a->E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, d);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;
 }
 
+int cpmppi_plant_advance(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
+                         float dt_sim, void* stream) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance: bad argument");
+  cpmppi_plant_args a{};
+  a.E = E; a.s = s; a.Q = Q; a.L = L; a.n_substeps = n_substeps; a.period_steps = n_substeps; a.dt_sim = dt_sim;
+  return cpmppi_plant_step(h, &a, stream);
+}
+
+// (ABI 2's form of the recording plant: states_log[row + 1] = the advanced state, Q_log[row] = Q - cpmppi_plant_step with one saved
+// row per control period)
 int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const float* Q, const float* L, uint32_t n_substeps,
                                 float dt_sim, float* states_log, float* Q_log, uint64_t log_rows, uint64_t row,
                                 const void* row_dev, void* stream) {
   if (!h) return CPMPPI_ERR_BAD_ARG;
-  if (E == 0 || !s || !Q || !(dt_sim > 0.0f)) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance_record: bad argument");
+  if (E == 0 || !s || !Q || !(dt_sim > 0.0f) || n_substeps == 0)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance_record: bad argument");
   if ((states_log || Q_log) && !row_dev && row >= log_rows)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_advance_record: row outside the logs (row >= log_rows)");
-  if (misaligned(s) || misaligned(Q) || misaligned(L) || misaligned(states_log) || misaligned(Q_log) ||
-      (row_dev && ((uintptr_t)row_dev & 7u)))
-    return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_advance_record: misaligned");
-  CPMPPI_ON_DEVICE(h);
-  Params plant = h->prm;
-  plant.m_pole = h->plant_m_pole;
-  hipLaunchKernelGGL(plant_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, E, s, Q,
-                     L, n_substeps, dt_sim, states_log, Q_log, row, (const unsigned long long*)row_dev, log_rows);
-  CPMPPI_HIP(h, hipGetLastError());
-  return CPMPPI_OK;
+  cpmppi_plant_args a{};
+  a.E = E; a.s = s; a.Q = Q; a.L = L; a.n_substeps = n_substeps; a.period_steps = n_substeps; a.dt_sim = dt_sim;
+  a.period = row; a.period_dev = row_dev;
+  a.states_log = states_log; a.save_rows = log_rows + 1u; a.save_every = n_substeps;
+  a.Q_log = Q_log; a.ctrl_rows = log_rows;
+  return cpmppi_plant_step(h, &a, stream);
 }
+
+uint32_t cpmppi_abi_version(void) { return CPMPPI_ABI_VERSION; }
 
 }  // extern "C"

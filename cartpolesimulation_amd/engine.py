@@ -240,6 +240,59 @@ class MPPIEngine:
                                                          _ptr(row_dev), self._stream()))
         return s
 
+    def plant_step(self, s, Q, n_substeps, dt_sim=0.002, period=0, period_dev=None, period_steps=None, L=None, states_log=None,
+                   dd_log=None, save_every=None, Q_log=None, target_position_table=None, target_equilibrium_table=None,
+                   L_table=None, sched_stride=1, target_position_out=None, target_equilibrium_out=None, L_out=None):
+        """cpmppi_plant_step: one control period of the simulated cartpoles with the experiment schedule and the recording in the
+        same launch (include/cpmppi.h).  ``s`` [E,6] in place under held ``Q`` [E]; logs ``states_log`` [rows,E,6], ``dd_log``
+        [rows,E,2], ``Q_log`` [periods,E]; schedule tables [sched_rows,E] sampled every ``sched_stride`` simulation steps; ``*_out``
+        [E] receive the row the NEXT controller call reads.  ``n_substeps`` = 0 records only."""
+        if not (torch.is_tensor(s) and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()):
+            raise ValueError("s must be a contiguous float32 ROCm tensor (it is updated in place)")
+        E = s.shape[0]
+
+        def dev(name, t, tail, dtype=torch.float32):
+            if t is None:
+                return None
+            if not (torch.is_tensor(t) and t.is_cuda and t.dtype == dtype and t.is_contiguous() and tuple(t.shape[1:]) == tail):
+                raise ValueError(f"{name} must be a contiguous {dtype} ROCm tensor [rows{''.join(', ' + str(x) for x in tail)}]")
+            return t
+
+        a = _L.cpmppi_plant_args()
+        Q = self.tensor(Q).reshape(E)
+        Lt = self.tensor(L).reshape(E) if L is not None else None
+        a.E, a.s, a.Q, a.L = E, s.data_ptr(), Q.data_ptr(), (Lt.data_ptr() if Lt is not None else None)
+        a.n_substeps, a.period_steps, a.dt_sim = int(n_substeps), int(period_steps if period_steps is not None else n_substeps), float(dt_sim)
+        a.period = int(period)
+        if period_dev is not None:
+            if not (torch.is_tensor(period_dev) and period_dev.is_cuda and period_dev.dtype == torch.int64):
+                raise ValueError("period_dev must be an int64 ROCm tensor")
+            a.period_dev = period_dev.data_ptr()
+        states_log, dd_log, Q_log = dev("states_log", states_log, (E, 6)), dev("dd_log", dd_log, (E, 2)), dev("Q_log", Q_log, (E,))
+        rows = [t.shape[0] for t in (states_log, dd_log) if t is not None]
+        a.states_log = states_log.data_ptr() if states_log is not None else None
+        a.dd_log = dd_log.data_ptr() if dd_log is not None else None
+        a.save_rows = min(rows) if rows else 0
+        a.save_every = int(save_every) if save_every else 0
+        if Q_log is not None:
+            a.Q_log, a.ctrl_rows = Q_log.data_ptr(), Q_log.shape[0]
+            if period_dev is None and not 0 <= int(period) < Q_log.shape[0]:
+                raise IndexError(f"period {period} outside Q_log")
+        tabs = [dev(n, t, (E,)) for n, t in (("target_position_table", target_position_table),
+                                             ("target_equilibrium_table", target_equilibrium_table), ("L_table", L_table))]
+        sched = [t.shape[0] for t in tabs if t is not None]
+        if sched and min(sched) != max(sched):
+            raise ValueError("the schedule tables must have the same number of rows")
+        a.target_position_table, a.target_equilibrium_table, a.L_table = [t.data_ptr() if t is not None else None for t in tabs]
+        a.sched_rows, a.sched_stride = (sched[0] if sched else 0), int(sched_stride)
+        outs = [dev(n, t.reshape(E, 1) if t is not None else None, (1,)) for n, t in (
+            ("target_position_out", target_position_out), ("target_equilibrium_out", target_equilibrium_out), ("L_out", L_out))]
+        a.target_position_out, a.target_equilibrium_out, a.L_out = [t.data_ptr() if t is not None else None for t in outs]
+        keep = (Q, Lt)                                                   # (alive until the launch is enqueued)
+        self._check(self.lib.cpmppi_plant_step(self._h, C.byref(a), self._stream()))
+        del keep
+        return s
+
     # ------------------------------------------------------------------ GRU predictor (BASELINE configs[4])
     GRU_KEYS = ("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "w_out", "b_out")
 

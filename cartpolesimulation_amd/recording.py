@@ -1,13 +1,22 @@
-"""Experiment recordings in the reference's CSV format and a batched data generator (N1 + N2).
+"""Experiment recordings in the reference's CSV format and the batched data generator (N1 + N2).
 
-Format (CartPole/csv_logger.py:10-33,125-159): comment block of ``# `` lines — title, git revision, ``#``, header with
-the time intervals, controller, optimizer and physical parameters, ``# Data:`` — then one row with the column names and
-one row per saved time step.  Column set and order = ``CartPole.variables_to_log`` (CartPole/__init__.py:221-259).
-Downstream tooling reads these files with ``pandas.read_csv(path, comment='#')``.
+Format (CartPole/csv_logger.py:10-58,125-159): comment block of ``# `` lines — title, git revision, ``#``, header with the time
+intervals, controller, optimizer and physical parameters, ``# Data:`` — then one row with the column names and one row per saved
+time step (every dt_save).  Column set and order = ``CartPole.variables_to_log`` (CartPole/__init__.py:221-259).  Downstream
+tooling reads these files with ``pandas.read_csv(path, comment='#')``.
 
-``generate_dataset`` is the counterpart of ``run_data_generator.py`` -> ``CartPole/data_generator.py:259-367``: instead
-of ``number_of_experiments`` sequential single-env runs it steps E envs at once on the GPU (plant + MPPI in one device
-loop, harness.py) and writes one recording per env.
+What a field looks like in the reference's files depends on the TYPE its simulator holds the value in (csv.writer: repr() for a
+Python float, str() for everything else): Python floats for time, Q_calculated, target_position, L, m_pole; numpy float32 scalars
+for the state, the second derivatives, Q_applied, Q_ccrc, u; an int for target_equilibrium; the controller informer's string
+'true' for L_for_controller / m_pole_for_controller; None (an empty field) for Q_update_time until the first controller update
+inside the loop.  ``typed_columns`` reproduces those types, so that ``write_recording`` (Python's csv module) and the native
+``cpmppi_write_recordings`` both give the reference's bytes - pinned to a file the reference's own CartPole class wrote
+(tests/golden/schedule.npz "csv_rows", tests/test_recording.py).
+
+``generate_dataset`` is the counterpart of ``run_data_generator.py`` -> ``CartPole/data_generator.py:259-367``: instead of
+``number_of_experiments`` sequential single-env runs it runs them all at once on the GPU (schedule.py tabulates every experiment's
+random target trace and equilibrium flips, harness.run_schedule runs plant + MPPI in one device loop) and writes one recording per
+experiment under the reference's file names, with its Train / Validate / Test split in ML_Pipeline_mode.
 """
 import csv
 import os
@@ -19,6 +28,7 @@ COLUMNS = ["time", "angle", "angleD", "angleDD", "angle_cos", "angle_sin", "posi
            "Q_calculated", "Q_applied", "Q_ccrc", "u", "target_position", "target_equilibrium", "L", "L_for_controller",
            "m_pole", "m_pole_for_controller", "vertical_angle_offset", "vertical_angle_offset_cos",
            "vertical_angle_offset_sin", "Q_update_time"]
+f32 = np.float32
 
 
 def create_csv_file_name(controller_name="mpc", optimizer_name="mppi", prefix="CPS", with_date=True, title=""):
@@ -28,14 +38,14 @@ def create_csv_file_name(controller_name="mpc", optimizer_name="mppi", prefix="C
     return prefix + ("_" + title if title else "") + name_controller + date + ".csv"
 
 
-def _unique_path(folder, csv_name):
-    """CartPole/csv_logger.py:61-91: never overwrite, append -1, -2, ..."""
+def _unique_path(folder, csv_name, taken=()):
+    """CartPole/csv_logger.py:61-91: never overwrite, append -1, -2, ... (`taken`: names already given out in this batch)."""
     os.makedirs(folder, exist_ok=True)
     if not csv_name.endswith(".csv"):
         csv_name += ".csv"
     path = os.path.join(folder, csv_name)
     base, idx = path[:-4], 1
-    while os.path.isfile(path):
+    while os.path.isfile(path) or path in taken:
         path = f"{base}-{idx}.csv"
         idx += 1
     return path
@@ -55,19 +65,25 @@ def create_csv_header(length_of_experiment, dt_simulation, dt_controller, dt_sav
     return header
 
 
+def _title(title):
+    return title or (f"This is CartPole simulation from {datetime.now().strftime('%d.%m.%Y')}"
+                     f" at time {datetime.now().strftime('%H:%M:%S')}")
+
+
 def write_recording(path, columns, title=None, header=(), revision="cartpolesimulation_amd"):
-    """columns: dict name -> 1-D array (all the same length), written in dict order."""
-    title = title or (f"This is CartPole simulation from {datetime.now().strftime('%d.%m.%Y')}"
-                      f" at time {datetime.now().strftime('%H:%M:%S')}")
-    with open(path, "a", newline="") as f:
+    """columns: dict name -> sequence (all the same length), written in dict order with Python's csv module exactly as
+    CartPole/csv_logger.py:10-58 does (a Python float is written with repr(), anything else with str(), None as '')."""
+    if os.path.exists(path):
+        raise FileExistsError(path)                             # (the reference never reuses a name: csv_logger.py:76-88)
+    with open(path, "x", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["# " + title])
+        w.writerow(["# " + _title(title)])
         w.writerow(["# Done with git-revision: {}".format(revision)])
         w.writerow(["#"])
         for line in header:
             w.writerow(["# " + line])
         w.writerow(list(columns.keys()))
-        w.writerows(zip(*[np.asarray(v).tolist() for v in columns.values()]))
+        w.writerows(zip(*[v.tolist() if isinstance(v, np.ndarray) and v.dtype == np.float64 else list(v) for v in columns.values()]))
     return path
 
 
@@ -75,11 +91,9 @@ def preamble_bytes(header, columns=None, title=None, revision="cartpolesimulatio
     """The comment block and the column-name row exactly as write_recording's csv.writer emits them, as bytes (what
     cpmppi_write_recordings puts at the top of every file)."""
     import io
-    title = title or (f"This is CartPole simulation from {datetime.now().strftime('%d.%m.%Y')}"
-                      f" at time {datetime.now().strftime('%H:%M:%S')}")
     f = io.StringIO(newline="")
     w = csv.writer(f)
-    w.writerow(["# " + title])
+    w.writerow(["# " + _title(title)])
     w.writerow(["# Done with git-revision: {}".format(revision)])
     w.writerow(["#"])
     for line in header:
@@ -88,124 +102,173 @@ def preamble_bytes(header, columns=None, title=None, revision="cartpolesimulatio
     return f.getvalue().encode()
 
 
-def write_recordings_native(paths, block, dt_control, target_position, target_equilibrium, L, phys, header, title=None,
-                            n_threads=0):
-    """All recordings of a batched run through libcpmppi's native writer (cpmppi_write_recordings: one thread per file, Python's
-    float repr and csv.writer's row format reproduced byte for byte - tests/test_recording.py).  `block` = _host_block(...)."""
+# ------------------------------------------------------------------------------------------------ rows of a run
+def recording_block(result, phys, L_default=None):
+    """A harness.run_schedule result -> the per-row host arrays of ALL its experiments (one copy per log):
+    time [R] float64; states [R,E,6], dd [R,E,2], Q [R,E], Q_ccrc [R,E], L [R,E] float32; target_position [R,E] float64;
+    target_equilibrium [R,E] int32; first_update_row.  Row r is simulation step r * n_save: its control is the one of the last
+    controller update at or before that step (Update_Q precedes save_csv_routine, CartPole/__init__.py:316-324), Q_ccrc the
+    control before that one (:489), 0 before the first update inside the loop."""
+    b = result["batch"]
+    c = lambda t: t.detach().cpu().numpy()                          # noqa: E731
+    states, dd, Qc = c(result["states"]), c(result["dd"]), c(result["Q"])
+    R, E = states.shape[0], states.shape[1]
+    steps = np.arange(R) * b.n_save
+    k = np.minimum(steps // b.n_ctrl, Qc.shape[0] - 1)               # controller call whose control is in force at the row
+    Q = Qc[k]
+    Q_ccrc = np.where((k > 0)[:, None], Qc[np.maximum(k - 1, 0)], f32(0.0)).astype(f32)
+    rows = b.rows_at(steps)
+    if b.L_table is not None:
+        L = np.asarray(b.L_table, f32)[np.minimum(steps, b.L_table.shape[0] - 1)]
+    else:
+        L = np.broadcast_to(np.asarray(b.L if b.L is not None else (phys.L if L_default is None else L_default), f32), (R, E))
+    return dict(time=np.ascontiguousarray(b.times[steps]), states=states, dd=dd, Q=np.ascontiguousarray(Q), Q_ccrc=Q_ccrc,
+                target_position=np.ascontiguousarray(b.target_position[rows]),
+                target_equilibrium=np.ascontiguousarray(b.target_equilibrium[rows].astype(np.int32)),
+                L=np.ascontiguousarray(L, dtype=f32), first_update_row=int(-(-b.n_ctrl // b.n_save)))
+
+
+def typed_columns(block, env, phys, q_update_time=0.0):
+    """One experiment of a recording block as the reference's column dict, every value in the TYPE the reference logs it in."""
+    s, dd, Q = block["states"][:, env], block["dd"][:, env], block["Q"][:, env]
+    R = s.shape[0]
+    py = lambda a: [float(x) for x in a]                            # noqa: E731  (Python floats: written with repr)
+    u_max, m_pole = f32(phys.u_max), float(f32(phys.m_pole))
+    cols = {"time": py(block["time"]), "angle": list(s[:, 0]), "angleD": list(s[:, 1]), "angleDD": list(dd[:, 0]),
+            "angle_cos": list(s[:, 2]), "angle_sin": list(s[:, 3]), "position": list(s[:, 4]), "positionD": list(s[:, 5]),
+            "positionDD": list(dd[:, 1]), "Q_calculated": py(Q), "Q_applied": list(Q), "Q_ccrc": list(block["Q_ccrc"][:, env]),
+            "u": list(u_max * Q), "target_position": py(block["target_position"][:, env]),
+            "target_equilibrium": [int(x) for x in block["target_equilibrium"][:, env]], "L": py(block["L"][:, env]),
+            "L_for_controller": ["true"] * R, "m_pole": [m_pole] * R, "m_pole_for_controller": ["true"] * R,
+            "vertical_angle_offset": [0.0] * R, "vertical_angle_offset_cos": [1.0] * R, "vertical_angle_offset_sin": [0.0] * R,
+            "Q_update_time": [None if r < block["first_update_row"] else float(q_update_time) for r in range(R)]}
+    assert list(cols) == COLUMNS
+    return cols
+
+
+def write_recordings_native(paths, block, phys, header, title=None, q_update_time=0.0, n_threads=0):
+    """All recordings of a batched run through libcpmppi's native writer (cpmppi_write_recordings: one thread per file, the
+    reference's field formats reproduced byte for byte - tests/test_recording.py)."""
     import ctypes as C
     from . import _lib as _L
     lib = _L.load()
-    T, E = block["Q"].shape
-    f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))        # noqa: E731
-    per_env = lambda a: f32(np.broadcast_to(np.asarray(a, dtype=np.float32), (E,)))  # noqa: E731
-    arrs = [f32(block["s"]), f32(block["Q"]), f32(block["aDD"]), f32(block["xDD"]), f32(block["u"]), per_env(target_position),
-            per_env(target_equilibrium), per_env(L)]
-    assert arrs[0].shape == (T, E, 6) and len(paths) == E
+    R, E = block["states"].shape[:2]
+    assert len(paths) == E
+    want = dict(time=((R,), np.float64), states=((R, E, 6), f32), dd=((R, E, 2), f32), Q=((R, E), f32), Q_ccrc=((R, E), f32),
+                target_position=((R, E), np.float64), target_equilibrium=((R, E), np.int32), L=((R, E), f32))
+    arrs = {}
+    for k, (shape, dt) in want.items():
+        arrs[k] = a = np.ascontiguousarray(block[k], dtype=dt)
+        if a.shape != shape:
+            raise ValueError(f"recording block: {k} is {a.shape}, expected {shape}")
+    rec = _L.cpmppi_recording()
+    rec.E, rec.rows = E, R
+    for k, a in arrs.items():
+        setattr(rec, k, a.ctypes.data)
+    rec.m_pole, rec.u_max = float(f32(phys.m_pole)), float(f32(phys.u_max))
+    rec.first_update_row, rec.q_update_time = int(block["first_update_row"]), float(q_update_time)
     pre = preamble_bytes(header, title=title)
     cpaths = (C.c_char_p * E)(*[os.fsencode(p) for p in paths])
-    rc = lib.cpmppi_write_recordings(cpaths, E, T, pre, len(pre), *[a.ctypes.data for a in arrs], float(phys.m_pole),
-                                     float(dt_control), int(n_threads))
+    rc = lib.cpmppi_write_recordings(cpaths, pre, len(pre), C.byref(rec), int(n_threads))
     if rc != 0:
         raise _L.CpmppiError(rc, lib.cpmppi_last_error(None).decode())
     return list(paths)
 
 
-def second_derivatives(states, Q, L, phys):
-    """angleDD, positionDD of the logged states under the logged control (CartPole/cartpole_equations.py:44-105), as
-    torch ops on whatever device the tensors live on."""
+# ------------------------------------------------------------------------------------------------ the data generator
+def dataset_paths(n, out_dir, ml_pipeline=False, split=(0.8, 0.1), secondary_experiment_index=None, digits=3):
+    """The files run_data_generator gives its experiments (CartPole/data_generator.py:290-322 + csv_logger.py:61-91): all are
+    called "Experiment" (or "Experiment-007" with a secondary index) and the logger makes the names unique by appending -1, -2, ...;
+    in ML_Pipeline_mode they go to Train / Validate / Test by their position in the run."""
+    paths, taken = [], set()
+    for i in range(n):
+        if ml_pipeline:
+            sub = "Train" if i < int(split[0] * n) else ("Validate" if i < int((split[0] + split[1]) * n) else "Test")
+            folder, name = os.path.join(out_dir, sub), "Experiment"
+        else:
+            folder = out_dir
+            name = "Experiment" if secondary_experiment_index is None else f"Experiment-{secondary_experiment_index:0{digits}d}"
+        p = _unique_path(folder, name, taken)
+        taken.add(p)
+        paths.append(p)
+    return paths
+
+
+def experiment_folder(root, secondary_experiment_index=None, digits=3):
+    """get_record_path (CartPole/data_generator.py:33-51): the first unused <root>/Experiment-[idx-]k, + "/Recordings"."""
+    base = "Experiment-" + (f"{secondary_experiment_index:0{digits}d}-" if secondary_experiment_index is not None else "")
+    k = 1
+    while os.path.exists(os.path.join(root, base + str(k))):
+        k += 1
+    return os.path.join(root, base + str(k), "Recordings")
+
+
+def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, seed=None, cartpole_seed=None, L=None, native=True,
+                     graph=False, secondary_experiment_index=None, controller_name="mpc", optimizer_name="mppi", title=None):
+    """Batched run_data_generator: ``config`` = config_data_gen.yml as a dict (or overrides of the shipped file, see
+    schedule.merged_config) - length_of_experiment, the three dt, the random initial state, the target trace's turning points
+    and interpolation types, the target-equilibrium dwell times, number_of_experiments, ML_Pipeline_mode / split.  All
+    experiments run at once on ``engine``'s GPU; one CSV each.  -> list of paths.
+    ``seed`` overrides config['seed'] (the shipped file leaves it empty = clock); ``cartpole_seed`` seeds the per-experiment
+    generators of the turning points (default: seed + 1)."""
+    import time
+    from .harness import BatchedCartPoleExperiment
+    from .schedule import RandomExperimentSetter, merged_config
+    cfg = merged_config(config)
+    if seed is not None:
+        cfg["seed"] = int(seed)
+    n = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
+    if n > engine.E:
+        raise ValueError(f"{n} experiments on an engine created for {engine.E} envs")
+    setter = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength)
+    batch = setter.draw(n, cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1, L=L)
+    exp = BatchedCartPoleExperiment(engine, batch.dt_simulation, batch.dt_control, seed=cfg["seed"])
     import torch
-    ca, sa, w, v = states[..., 2], states[..., 3], states[..., 1], states[..., 5]
-    u = phys.u_max * Q
-    kp1, Lh = phys.k + 1.0, L / 2.0
-    A = kp1 * (phys.m_cart + phys.m_pole) - phys.m_pole * ca * ca
-    T = -phys.J_fric * w
-    xDD = (phys.m_pole * phys.g * sa * ca + T * ca / Lh + kp1 * (-(phys.m_pole * Lh * w * w * sa) - phys.M_fric * v + u)) / A
-    aDD = (phys.g * sa + xDD * ca + T / (phys.m_pole * Lh)) / (kp1 * Lh)
-    return aDD, xDD, torch.as_tensor(u)
-
-
-def _host_block(result, L, phys):
-    """The whole recording on the host in ONE pass: derived columns for all envs on the device, one copy each."""
-    import torch
-    states = result["states"][:-1]                          # [T,E,6]: the state at the time each control was computed
-    Q = result["Q"]                                         # [T,E]
-    Lt = torch.as_tensor(np.asarray(L, dtype=np.float32), device=states.device).reshape(1, -1).expand(Q.shape)
-    aDD, xDD, u = second_derivatives(states, Q, Lt, phys)
-    c = lambda t: t.detach().cpu().numpy()                  # noqa: E731
-    return dict(s=c(states), Q=c(Q), aDD=c(aDD), xDD=c(xDD), u=c(u))
-
-
-def _columns_of(block, env, dt_control, target_position, target_equilibrium, L, phys):
-    s, Q = block["s"][:, env], block["Q"][:, env]
-    T = s.shape[0]
-    zeros, ones = np.zeros(T), np.ones(T)
-    cols = {"time": np.arange(T) * dt_control, "angle": s[:, 0], "angleD": s[:, 1], "angleDD": block["aDD"][:, env],
-            "angle_cos": s[:, 2], "angle_sin": s[:, 3], "position": s[:, 4], "positionD": s[:, 5],
-            "positionDD": block["xDD"][:, env], "Q_calculated": Q, "Q_applied": Q, "Q_ccrc": np.concatenate([[0.0], Q[:-1]]),
-            "u": block["u"][:, env],
-            "target_position": ones * float(target_position), "target_equilibrium": ones * float(target_equilibrium),
-            "L": ones * float(L), "L_for_controller": ones * float(L), "m_pole": ones * phys.m_pole,
-            "m_pole_for_controller": ones * phys.m_pole, "vertical_angle_offset": zeros,
-            "vertical_angle_offset_cos": ones, "vertical_angle_offset_sin": zeros, "Q_update_time": zeros}
-    assert list(cols) == COLUMNS
-    return cols
-
-
-def experiment_columns(result, env, dt_control, target_position, target_equilibrium, L, phys):
-    """One env of a harness.BatchedCartPoleExperiment.run(record=True) result -> the reference's column dict."""
-    E = result["Q"].shape[1]
-    block = _host_block(result, np.full(E, float(L), np.float32), phys)
-    return _columns_of(block, env, dt_control, target_position, target_equilibrium, L, phys)
-
-
-def generate_dataset(engine, num_envs, length_of_experiment, out_dir, seed=0, target_position=None, L=None,
-                     dt_simulation=0.002, dt_control=0.02, init_limits=None, prefix="CPS", native=True):
-    """Batched run_data_generator: ``num_envs`` experiments of ``length_of_experiment`` seconds -> one CSV each, written by
-    the library's native writer (``native=False``: through Python's csv module, the same bytes, ~10 x slower)."""
-    from .harness import BatchedCartPoleExperiment, generate_random_initial_states
-    rng = np.random.Generator(np.random.SFC64(seed))
+    t0 = time.perf_counter()
+    res = exp.run_schedule(batch, graph=graph)
+    torch.cuda.synchronize()
+    per_call = (time.perf_counter() - t0) / (batch.n_periods + 1)   # what Q_update_time can honestly say: wall time per controller update of the batch
     phys = engine.phys
-    s0 = generate_random_initial_states(num_envs, rng, phys.TrackHalfLength, init_limits)
-    tp = np.zeros(num_envs, np.float32) if target_position is None else \
-        np.broadcast_to(np.asarray(target_position, np.float32), (num_envs,)).copy()
-    Lv = np.full(num_envs, phys.L, np.float32) if L is None else np.broadcast_to(np.asarray(L, np.float32), (num_envs,)).copy()
-    steps = int(round(length_of_experiment / dt_control))
-    exp = BatchedCartPoleExperiment(engine, dt_simulation, dt_control, seed=seed)
-    res = exp.run(s0, steps, target_position=tp, target_equilibrium=1.0, L=Lv, record=True)
-    header = create_csv_header(length_of_experiment, dt_simulation, dt_control, dt_control, "mpc", "mppi", phys)
-    block = _host_block(res, Lv, phys)                      # (one device pass and one copy for all envs)
-    paths = []
-    for e in range(num_envs):                               # (names made unique one after the other, as csv_logger.py:61-91 does)
-        name = create_csv_file_name("mpc", "mppi", prefix=prefix, with_date=False, title=f"env{e:05d}")
-        paths.append(_unique_path(out_dir, name))
+    header = create_csv_header(cfg["length_of_experiment"], batch.dt_simulation, batch.dt_control, batch.dt_save, controller_name,
+                               optimizer_name, phys)
+    block = recording_block(res, phys)
+    root = out_dir if out_dir is not None else cfg["PATH_TO_EXPERIMENT_RECORDINGS_DEFAULT"]
+    if cfg.get("ML_Pipeline_mode"):
+        root = experiment_folder(root, secondary_experiment_index)
+    paths = dataset_paths(n, root, bool(cfg.get("ML_Pipeline_mode")), cfg["split"], secondary_experiment_index)
     if native:
-        return write_recordings_native(paths, block, dt_control, tp, np.ones(num_envs, np.float32), Lv, phys, header)
-    for e in range(num_envs):
-        cols = _columns_of(block, e, dt_control, tp[e], 1.0, Lv[e], phys)
-        write_recording(paths[e], cols, header=header)
+        return write_recordings_native(paths, block, phys, header, title=title, q_update_time=per_call)
+    for e in range(n):
+        write_recording(paths[e], typed_columns(block, e, phys, per_call), title=title, header=header)
     return paths
 
 
 def main(argv=None):
-    """python -m cartpolesimulation_amd.recording --envs 64 --length 10 --out ./Experiment_Recordings/"""
+    """python -m cartpolesimulation_amd.recording --experiments 64 --length 10 --out ./Experiment_Recordings/ --seed 1"""
     import argparse
     from .configs import MPPIConfig, legacy_mppi_config
     from .engine import MPPIEngine
     ap = argparse.ArgumentParser(description="Batched CartPole data generator on MI355X (reference: run_data_generator.py)")
-    ap.add_argument("--envs", type=int, default=64)
+    ap.add_argument("--experiments", "--envs", type=int, default=64, dest="experiments")
     ap.add_argument("--length", type=float, default=10.0, help="length of each experiment in seconds")
     ap.add_argument("--out", default="./Experiment_Recordings/")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--rollouts", type=int, default=3500)
     ap.add_argument("--horizon", type=int, default=35)
+    ap.add_argument("--dt-save", type=float, default=0.02)
+    ap.add_argument("--ml-pipeline", action="store_true", help="Train / Validate / Test folders (config_data_gen.yml: ML_Pipeline_mode)")
+    ap.add_argument("-i", "--secondary_experiment_index", type=int, default=-1)
     ap.add_argument("--cost", default="legacy_mppi_cartpole",
-                    choices=["legacy_mppi_cartpole", "default", "quadratic_boundary_grad_minimal"])
+                    choices=["legacy_mppi_cartpole", "default", "quadratic_boundary_grad_minimal", "quadratic_boundary_grad"])
     args = ap.parse_args(argv)
     cfg = legacy_mppi_config(num_rollouts=args.rollouts, mpc_horizon=args.horizon) if args.cost == "legacy_mppi_cartpole" \
         else MPPIConfig(num_rollouts=args.rollouts, mpc_horizon=args.horizon, cost_function_specification=args.cost)
-    eng = MPPIEngine(args.envs, cfg)
-    paths = generate_dataset(eng, args.envs, args.length, args.out, seed=args.seed)
-    print(f"wrote {len(paths)} recordings to {args.out}")
+    eng = MPPIEngine(args.experiments, cfg)
+    paths = generate_dataset(eng, args.experiments, args.out, seed=args.seed,
+                             config=dict(length_of_experiment=args.length, ML_Pipeline_mode=args.ml_pipeline,
+                                         dt=dict(saving=args.dt_save)),
+                             secondary_experiment_index=None if args.secondary_experiment_index < 0 else args.secondary_experiment_index)
+    print(f"wrote {len(paths)} recordings under {os.path.dirname(paths[0])}")
 
 
 if __name__ == "__main__":

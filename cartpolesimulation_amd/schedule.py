@@ -1,0 +1,267 @@
+"""The data generator's EXPERIMENT SCHEDULE for a whole batch of experiments.
+
+In the reference every experiment is one CartPole instance that, on EVERY simulation step, moves its target position along a random
+trace and flips its target equilibrium after a dwell time (CartPole/__init__.py:283-293, :360-388), and random_experiment_setter
+(CartPole/data_generator.py:93-218) draws the initial state and the trace's parameters per experiment.  All of it is a function of
+time alone, so here it is tabulated ONCE per batch on the host - `ExperimentBatch`: initial states [E,6] and tables [rows, E] -
+and the device loop (harness.py, cpmppi_plant_step) indexes the tables with its own step counter.
+
+Random streams: the setter's own generator (SFC64(config seed), one for the run, consumed experiment after experiment in the
+reference's order) and one generator per experiment for the turning points (the reference: CartPole.rng_CartPole, clock-seeded by the
+shipped YAML; here SFC64(cartpole_seed + experiment index)).  With the same seeds the tables equal the reference's doubles bit for
+bit (tests/test_schedule_host.py against tests/golden/schedule.npz).
+"""
+from dataclasses import dataclass, field
+from math import gcd
+
+import numpy as np
+
+f32 = np.float32
+INTERPOLATION_TYPES = ("previous", "linear", "0-derivative-smooth")
+
+
+def default_data_gen_config():
+    """config_data_gen.yml as shipped (the keys the experiment setter and the file naming read)."""
+    return dict(controller="mpc", ML_Pipeline_mode=False, split=[0.8, 0.1],
+                PATH_TO_EXPERIMENT_RECORDINGS_DEFAULT="./Experiment_Recordings/", seed=None, length_of_experiment=360,
+                random_initial_state=dict(position=None, positionD=None, angle=None, angleD=None, target_position=None,
+                                          init_limits=dict(angle=[0.0, 180.0], angleD=1200.0, position=0.8, positionD=0.5)),
+                start_at_target=True, track_fraction_usable_for_target_position=1.0, target_position_end=None,
+                initial_target_equilibrium="up", keep_target_equilibrium_x_seconds_up=10,
+                keep_target_equilibrium_x_seconds_down=2.5, dt=dict(simulation=0.002, control=0.02, saving=0.02),
+                turning_points=dict(track_relative_complexity=1, interpolation_type=["previous", "0-derivative-smooth"],
+                                    turning_points=None, turning_points_period="regular"),
+                save_mode="online", number_of_experiments=1)
+
+
+def merged_config(overrides=None, base=None):
+    """The shipped config with `overrides` applied (nested dicts are merged key by key)."""
+    import copy
+    cfg = copy.deepcopy(base if base is not None else default_data_gen_config())
+    for k, v in (overrides or {}).items():
+        if isinstance(v, dict) and isinstance(cfg.get(k), dict):
+            cfg[k].update(v)
+        else:
+            cfg[k] = v
+    return cfg
+
+
+def _inf(v):
+    return np.inf if isinstance(v, str) and v == "inf" else v
+
+
+@dataclass
+class ExperimentBatch:
+    """E experiments' worth of schedule.  Simulation step g = 0 is the initial state; table row j holds the values the simulator
+    has AFTER step j * stride (stride = gcd of the control and saving periods: every step at which anything reads them)."""
+    s0: np.ndarray                      # [E,6] float32
+    times: np.ndarray                   # [n_sim + 1] float64: time after g calls of step_time (accumulated, not g * dt)
+    target_position: np.ndarray         # [rows, E] float64
+    target_equilibrium: np.ndarray      # [rows, E] int32 (+1 / -1)
+    stride: int
+    n_sim: int                          # simulation steps of the experiment: ceil(length / dt_simulation)
+    n_ctrl: int                         # simulation steps per controller update
+    n_save: int                         # simulation steps per saved row
+    dt_simulation: float
+    dt_control: float
+    dt_save: float
+    length_of_experiment: float
+    interpolation_type: list = field(default_factory=list)
+    L: np.ndarray = None                # [E] float32 constant pole length per experiment, or None (the handle's default)
+    L_table: np.ndarray = None          # [rows_L, E] float32 with its own stride 1 (per simulation step), or None
+
+    @property
+    def E(self):
+        return self.s0.shape[0]
+
+    @property
+    def n_periods(self):
+        """control periods the plant is advanced by = controller calls - 1 (the last call only completes the last row)."""
+        return self.n_sim // self.n_ctrl
+
+    def rows_at(self, steps):
+        return np.minimum(np.asarray(steps) // self.stride, self.target_position.shape[0] - 1)
+
+
+class RandomExperimentSetter:
+    """random_experiment_setter (CartPole/data_generator.py:93-218) for any number of consecutive experiments."""
+
+    def __init__(self, config=None, track_half_length=None):
+        self.config = c = merged_config(config)
+        if c["seed"] is None:
+            raise ValueError("config['seed'] is empty: the reference then seeds from the clock; give a seed for a reproducible batch")
+        self.rng = np.random.Generator(np.random.SFC64(c["seed"]))                  # others/globals_and_utils.py:198-214
+        self.thl = f32((44.0e-2 - 4.4e-2) / 2.0) if track_half_length is None else f32(track_half_length)
+        self._interp_idx = 0
+
+    # -- CartPole/data_generator.py:221-256, in the reference's draw order and its float32 / float64 mix
+    def _initial_state(self):
+        ris = self.config["random_initial_state"]
+        lim = ris["init_limits"]
+        rng, thl = self.rng, self.thl
+        s = np.zeros(6, dtype=f32)
+        s[4] = f32(rng.uniform(low=-1.0, high=1.0)) * thl * f32(lim["position"]) if ris["position"] is None else ris["position"]
+        s[5] = f32(rng.uniform(low=-1.0, high=1.0)) * thl * f32(lim["positionD"]) if ris["positionD"] is None else ris["positionD"]
+        if ris["angle"] is None:
+            lo, hi = lim["angle"]
+            s[0] = (rng.uniform(low=lo, high=hi) if rng.uniform() > 0.5 else rng.uniform(low=-hi, high=-lo)) * (np.pi / 180.0)
+        else:
+            s[0] = ris["angle"]
+        s[1] = rng.uniform(low=-1.0, high=1.0) * lim["angleD"] * (np.pi / 180.0) if ris["angleD"] is None else ris["angleD"]
+        s[2], s[3] = np.cos(s[0]), np.sin(s[0])
+        return s
+
+    def _one(self, cartpole_rng):
+        """What one `set` call fixes: initial state, turning points (times, values), interpolation type, initial equilibrium."""
+        c = self.config
+        s0 = self._initial_state()                                                   # :155
+        frac = c["track_fraction_usable_for_target_position"]
+        if c["start_at_target"]:
+            start = s0[4]                                                            # :157-158
+        elif c["random_initial_state"]["target_position"] is None:
+            start = f32(frac) * self.thl * f32(self.rng.uniform(-1.0, 1.0))          # :160-162
+        else:
+            start = c["random_initial_state"]["target_position"]
+        end = f32(frac) * self.thl * f32(self.rng.uniform(-1.0, 1.0)) if c["target_position_end"] is None else c["target_position_end"]
+        ite = c["initial_target_equilibrium"]
+        if ite in ("up", 1):
+            te = 1
+        elif ite in ("down", -1):
+            te = -1
+        elif ite == "random":                                                        # (the reference: numpy's GLOBAL generator, :177)
+            te = int(2 * (self.rng.uniform() > 0.5) - 1)
+        else:
+            raise ValueError(f"{ite!r} is not a valid specification for target equilibrium")
+        it = c["turning_points"]["interpolation_type"]
+        if isinstance(it, (list, tuple)):                                            # :181-185
+            interp = it[self._interp_idx]
+            self._interp_idx = (self._interp_idx + 1) % len(it)
+        else:
+            interp = it
+        if interp not in INTERPOLATION_TYPES:
+            raise ValueError("Unknown interpolation type.")
+        t_knots, y_knots = turning_points(c["length_of_experiment"], cartpole_rng, c["turning_points"]["track_relative_complexity"],
+                                          c["turning_points"]["turning_points"], c["turning_points"]["turning_points_period"],
+                                          start, end, frac, self.thl)
+        return s0, t_knots, y_knots, interp, te
+
+    def draw(self, E, cartpole_seed, L=None):
+        """The next E experiments of the run -> ExperimentBatch."""
+        c = self.config
+        dt_sim, dt_ctrl, dt_save = c["dt"]["simulation"], c["dt"]["control"], c["dt"]["saving"]
+        n_ctrl = max(1, int(np.rint(dt_ctrl / dt_sim)))                              # CartPole/__init__.py:909-916
+        n_save = max(1, int(np.rint(dt_save / dt_sim)))                              # :925-933
+        length = c["length_of_experiment"]
+        n_sim = int(np.ceil(length / dt_sim))                                        # :648
+        times = accumulated_times(n_sim, dt_sim)
+        stride = gcd(n_ctrl, n_save)
+        steps = np.arange(0, n_sim + 1, stride)
+        frac = c["track_fraction_usable_for_target_position"]
+        hi = np.float64(f32(frac) * self.thl)                                        # random_target_generator.py:85 (float32 bounds)
+        s0 = np.empty((E, 6), f32)
+        tp = np.empty((len(steps), E))
+        te0 = np.empty(E, np.int32)
+        interps = []
+        # update_target_position (:360-378) stops updating once time >= length: the value of the last simulation step before that
+        # is kept (the run's final step, whose accumulated time may or may not have reached the length)
+        g_last = int(np.flatnonzero(times < length)[-1])
+        t_eval = times[np.minimum(steps, g_last)]
+        for e in range(E):
+            s0[e], tk, yk, interp, te0[e] = self._one(np.random.Generator(np.random.SFC64(int(cartpole_seed) + e)))
+            interps.append(interp)
+            tp[:, e] = np.clip(evaluate_trace(tk, yk, interp, t_eval), -hi, hi)
+        te = equilibrium_table(times, steps, te0, _inf(c["keep_target_equilibrium_x_seconds_up"]),
+                               _inf(c["keep_target_equilibrium_x_seconds_down"]))
+        Lv = None if L is None else np.broadcast_to(np.asarray(L, f32), (E,)).copy()
+        return ExperimentBatch(s0=s0, times=times, target_position=tp, target_equilibrium=te, stride=stride, n_sim=n_sim, n_ctrl=n_ctrl,
+                               n_save=n_save, dt_simulation=dt_sim, dt_control=dt_ctrl, dt_save=dt_save, length_of_experiment=length,
+                               interpolation_type=interps, L=Lv)
+
+
+def accumulated_times(n, dt):
+    """time after g = 0..n calls of CartPole.step_time (CartPole/__init__.py:326-327: time = time + dt, in float64)."""
+    return np.concatenate([[0.0], np.cumsum(np.full(n, float(dt)))]) if n else np.zeros(1)
+
+
+def turning_points(length, rng, complexity, given, period, start, end, used_fraction, thl):
+    """The knots of Generate_Random_Trace_Function (CartPole/random_target_generator.py:24-68) -> (times[n], values[n])."""
+    if given is None or len(given) == 0:
+        n = int(np.floor(length * complexity))
+        y = rng.uniform(-1.0, 1.0, n) * used_fraction * np.float64(thl)
+        if n == 0:
+            y = np.zeros(2)
+        elif n == 1:
+            if start is not None:
+                y[0] = start
+            elif end is not None:
+                y[0] = end
+            y = np.array([y[0], y[0]])
+        else:
+            if start is not None:
+                y[0] = start
+            if end is not None:
+                y[-1] = end
+    else:
+        n = len(given)
+        y = np.array([given[0], given[0]] if n == 1 else given, dtype=np.float64)
+    inner = max(n - 2, 0)
+    if period == "random":
+        t = np.concatenate([[0.0], np.sort(rng.uniform(0.0, 1.0, inner)), [1.0]])
+    elif period == "regular":
+        t = np.linspace(0, 1.0, num=inner + 2, endpoint=True)
+    else:
+        raise NotImplementedError("There is no mode corresponding to this value of turning_points_period variable")
+    return t * length, y
+
+
+def evaluate_trace(tk, yk, interpolation_type, t):
+    """The interpolant the reference builds over the knots (random_target_generator.py:70-79), evaluated at the times `t`:
+    scipy's interp1d 'previous' / 'linear' with extrapolation, BPoly.from_derivatives with zero slopes and periodic extension -
+    here in closed form (no scipy), the same doubles."""
+    t = np.asarray(t, dtype=np.float64)
+    if interpolation_type == "previous":
+        # the knot at or before t (scipy shifts the knots one ulp down so that t == knot selects that knot)
+        idx = np.searchsorted(np.nextafter(tk, -np.inf), t, side="left")
+        return yk[np.clip(idx, 1, len(tk)) - 1]
+    if interpolation_type == "linear":
+        hi = np.clip(np.searchsorted(tk, t), 1, len(tk) - 1)
+        lo = hi - 1
+        return (yk[hi] - yk[lo]) / (tk[hi] - tk[lo]) * (t - tk[lo]) + yk[lo]
+    if interpolation_type == "0-derivative-smooth":
+        # cubic Hermite with zero end slopes per interval = Bernstein coefficients [a, a, b, b]; periodic in the experiment's length
+        t = tk[0] + (t - tk[0]) % (tk[-1] - tk[0])
+        lo = np.clip(np.searchsorted(tk, t, side="right") - 1, 0, len(tk) - 2)
+        s = (t - tk[lo]) / (tk[lo + 1] - tk[lo])
+        r = 1.0 - s
+        a, b = yk[lo], yk[lo + 1]
+        return a * r * r * r + a * 3.0 * r * r * s + b * 3.0 * r * s * s + b * s * s * s
+    raise ValueError("Unknown interpolation type.")
+
+
+def equilibrium_table(times, steps, te0, keep_up, keep_down):
+    """update_target_equilibrium (CartPole/__init__.py:380-388) over all simulation steps, sampled at `steps`: the first update
+    only starts the dwell clock; afterwards the equilibrium flips when the time since the last change EXCEEDS the dwell time of
+    the side it is on.  It depends on the initial side only: computed once per side, shared by the experiments."""
+    out = np.empty((len(steps), len(te0)), np.int32)
+    want = set(int(g) for g in steps)
+    for side in (1, -1):
+        cols = np.flatnonzero(te0 == side)
+        if not len(cols):
+            continue
+        cur, last = side, None
+        seq = np.empty(len(steps), np.int32)
+        k = 0
+        if 0 in want:
+            seq[k] = cur
+            k += 1
+        for g in range(1, len(times)):
+            t = times[g]
+            if last is None:
+                last = t
+            elif (t - last) > (keep_down if cur == -1 else keep_up):
+                last, cur = t, -cur
+            if g in want:
+                seq[k] = cur
+                k += 1
+        out[:, cols] = seq[:, None]
+    return out

@@ -41,9 +41,11 @@
 extern "C" {
 #endif
 
-#define CPMPPI_ABI_VERSION 3u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_*;
-                                   3: cpmppi_config.ode_predictor.  Added since without a layout change (still 3): cost ids 4 / 5,
-                                   cpmppi_last_launch, cpmppi_comm_set_timeout, cpmppi_write_recordings */
+#define CPMPPI_ABI_VERSION 4u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_*;
+                                   3: cpmppi_config.ode_predictor (+ cost ids 4 / 5, cpmppi_last_launch, cpmppi_comm_set_timeout);
+                                   4: cpmppi_plant_step / cpmppi_plant_args (the experiment schedule), cpmppi_write_recordings takes
+                                      per-row columns (cpmppi_recording), cpmppi_launch_info.cost_plugin, CPMPPI_ERR_IO,
+                                      cpmppi_comm_info.  cpmppi_abi_version() reports what a loaded library was built as. */
 #define CPMPPI_STATE_DIM 6u
 #define CPMPPI_MAX_HORIZON 1024u
 
@@ -54,7 +56,8 @@ typedef enum {
   CPMPPI_ERR_NO_DEVICE = -3,    /* no HIP device / not a gfx950 part */
   CPMPPI_ERR_HIP = -4,          /* a HIP runtime call failed (text in cpmppi_last_error) */
   CPMPPI_ERR_ALIGN = -5,        /* pointer not 4-byte aligned */
-  CPMPPI_ERR_COMM = -6          /* RCCL missing or an RCCL call failed (text in cpmppi_last_error) */
+  CPMPPI_ERR_COMM = -6,         /* RCCL missing or an RCCL call failed (text in cpmppi_last_error) */
+  CPMPPI_ERR_IO = -7            /* a file could not be created or written (cpmppi_write_recordings; errno text in cpmppi_last_error) */
 } cpmppi_status;
 
 /* cost_id: which in-tree cost formulation the rollout kernel evaluates. */
@@ -197,6 +200,8 @@ int cpmppi_get_config(const cpmppi_handle* h, cpmppi_config* out);
  * build (phased horizon loop), 3 = its form for launches of at most one wave per SIMD. */
 typedef struct {
   uint32_t cost_id, math_mode, noise_kind, rollouts_per_lane, build_variant, ode_predictor, blocks;
+  uint32_t cost_plugin;   /* the PUBLIC cost id of the handle (CPMPPI_COST_*): quadratic_boundary (4) and _nonconvex (5) run on
+                             default.py's kernels, so `cost_id` - the kernel's template argument - reads 1 for both */
 } cpmppi_launch_info;
 int cpmppi_last_launch(const cpmppi_handle* h, cpmppi_launch_info* out);
 
@@ -346,6 +351,56 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
                                 float dt_sim, float* states_log, float* Q_log, uint64_t log_rows, uint64_t row,
                                 const void* row_dev, void* stream);
 
+/* The plant with the reference's EXPERIMENT SCHEDULE: what CartPole.update_state does around the controller on
+ * every SIMULATION step (CartPole/__init__.py:283-324) - update_parameters (:529-537: the pole length may change in time),
+ * update_target_position (:360-378: target_position = random_track_f(time)), update_target_equilibrium (:380-388: flips after
+ * keep_target_equilibrium_x_seconds_up / _down), integration + bounce + wrap, the controller every dt_control (Update_Q :475-527),
+ * the second derivatives, save_csv_routine every dt_save (:403-433).  The schedule is a function of TIME only, so the host
+ * tabulates it once per experiment (cartpolesimulation_amd/schedule.py) and the device loop indexes the tables with its own step
+ * counter: a captured graph of control periods still replays without a changing launch argument.
+ *   simulation step g = 0 is the initial state; control period c advances steps c*period_steps + 1 .. (c + 1)*period_steps;
+ *   table row of step g = min(g / sched_stride, sched_rows - 1): the value the simulator holds AFTER step g's updates.
+ * One call = one control period, ONE kernel:
+ *   1. held control q = Q[env]; Q_log[c][E] = q (c < ctrl_rows)
+ *   2. second derivatives of (s, q) with the pole length of step c*period_steps; dd_log[r][E][2] = (angleDD, positionDD) if that
+ *      step is a saved one (r = step / save_every < save_rows) - the row whose state the PREVIOUS period stored, completed with
+ *      the control computed from it (save_csv_routine runs after Update_Q, :316-324)
+ *   3. n_substeps x { pole length of the step (L_table, else L / config.L_default); Euler-Cromer + edge bounce + cos / sin + wrap;
+ *      second derivatives; if step % save_every == 0: states_log[step / save_every][E][6] = state, and dd_log unless the step ends
+ *      the period }
+ *   4. *_out[E] = row ((c + 1)*period_steps) of the tables: what the NEXT controller call is handed (updated_attributes
+ *      target_position / target_equilibrium / L, :509-520) - point cpmppi_step_args.target_position / target_equilibrium / L there.
+ * n_substeps = 0 records only (1. and 2.: the run's last controller call is followed by no plant step, :690-716).
+ * period_dev: c = *period_dev - 1, the device step counter of cpmppi_step_args.offset_dev (already advanced by the step); a
+ * counter that is still 0 advances the plant from table row 0 WITHOUT recording or publishing.  Any log / table / out pointer may
+ * be NULL.  Noise, latency and actuator disturbance: OFF, as in the shipped YAML.  m_pole: config.m_pole (see cpmppi_set_pole_mass). */
+typedef struct {
+  uint32_t E;
+  float* s;                             /* [E,6] in / out */
+  const float* Q;                       /* [E] held controls */
+  const float* L;                       /* [E] pole length when there is no L_table; NULL = config.L_default */
+  uint32_t n_substeps;                  /* simulation steps to advance now: period_steps (fewer: a run's trailing partial period), or 0 (record only) */
+  uint32_t period_steps;                /* simulation steps per control period (dt_control / dt_sim); 0 = n_substeps */
+  float dt_sim;
+  uint64_t period;                      /* c */
+  const void* period_dev;               /* or NULL */
+  float* states_log;                    /* [save_rows][E][6]; row 0 is the caller's (the initial state) */
+  float* dd_log;                        /* [save_rows][E][2] */
+  uint64_t save_rows;
+  uint32_t save_every;                  /* simulation steps per saved row (dt_save / dt_sim); 0 = period_steps */
+  float* Q_log;                         /* [ctrl_rows][E] */
+  uint64_t ctrl_rows;
+  const float* target_position_table;   /* [sched_rows][E] */
+  const float* target_equilibrium_table;/* [sched_rows][E] */
+  const float* L_table;                 /* [sched_rows][E] */
+  uint64_t sched_rows;
+  uint32_t sched_stride;                /* simulation steps per table row; 0 = 1 */
+  float* target_position_out;           /* [E] */
+  float* target_equilibrium_out;        /* [E] */
+  float* L_out;                         /* [E] */
+} cpmppi_plant_args;
+int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* stream);
+
 /* Multi-GPU (no reference counterpart - its only fan-out is share-nothing SLURM job arrays,
  * others/EulerClusterScripts/ParallelDataGeneration.sh:2-17): one process per GPU, each owning a contiguous block of
  * envs, and ONE all-gather of the chosen control sequences per step over RCCL / xGMI, enqueued from C on a high-priority
@@ -390,20 +445,41 @@ int cpmppi_comm_destroy(cpmppi_handle* h);
 int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* args, float* recv_all, void* stream);
 
 /* Recording writer (HOST pointers, no GPU involved): E experiment recordings in the reference's CSV layout
- * (CartPole/csv_logger.py:10-33,125-159; column set and order CartPole/__init__.py:221-259), byte for byte what the
- * reference's csv.writer produces for the same values (Python float repr, "\r\n" rows) - one thread per file.
- *   paths[E]            one file per experiment, opened for appending (the caller has made the names unique, csv_logger.py:61-91)
- *   preamble            the comment block and the column-name row as ready-made bytes, the same for every file
- *   states[T,E,6]       the state at the time each control was computed; Q[T,E] that control (written as Q_calculated and
- *                       Q_applied; Q_ccrc = the control of the previous row, 0 in the first)
- *   angleDD, positionDD, u [T,E]   the logged second derivatives and motor input
- *   target_position, target_equilibrium, L [E], m_pole   constant columns (L and m_pole also as the controller's copies);
- *                       time = row * dt_control; the vertical-angle-offset columns are 0 / 1 / 0, Q_update_time 0
- *   n_threads           0 = one per hardware thread (at most 32) */
-int cpmppi_write_recordings(const char* const* paths, uint32_t E, uint32_t T, const char* preamble, size_t preamble_len,
-                            const float* states, const float* Q, const float* angleDD, const float* positionDD, const float* u,
-                            const float* target_position, const float* target_equilibrium, const float* L, double m_pole,
-                            double dt_control, int n_threads);
+ * (CartPole/csv_logger.py:10-58,125-159; column set and order CartPole/__init__.py:221-259), byte for byte what the reference's
+ * csv.writer produces from the values its simulator logs - pinned to a recording written by the reference itself
+ * (tests/golden/schedule.npz "csv_rows"): every column in the representation of the TYPE the reference holds it in -
+ *   time, Q_calculated, target_position, L, m_pole, the vertical-angle-offset columns: Python floats -> repr(float) of the double
+ *   the state, angleDD / positionDD, Q_applied, Q_ccrc, u: numpy float32 scalars -> str(numpy.float32), shortest float32 digits
+ *   target_equilibrium: an int; L_for_controller / m_pole_for_controller: the controller informer's 'true'
+ *   Q_update_time: empty until the first controller update inside the loop, then `q_update_time` (the reference logs the wall
+ *   clock of its controller call there: not reproducible by construction)
+ * rows end with "\r\n".  One thread per file.
+ *   paths[E]      one file per experiment; a path that already exists is an error (CPMPPI_ERR_IO) - the caller makes the names
+ *                 unique (csv_logger.py:61-91) and nothing is ever appended to or overwritten.  Files are written under a
+ *                 temporary name and renamed when complete; on any failure the files of THIS call are removed again.
+ *   preamble      the comment block and the column-name row as ready-made bytes, the same for every file
+ *   n_threads     0 = one per hardware thread (at most 32) */
+typedef struct {
+  uint32_t E, rows;
+  const double* time;                   /* [rows] */
+  const float* states;                  /* [rows][E][6] */
+  const float* dd;                      /* [rows][E][2] angleDD, positionDD */
+  const float* Q;                       /* [rows][E] the control in force when the row was saved (Q_calculated = Q_applied) */
+  const float* Q_ccrc;                  /* [rows][E] the control before it */
+  const double* target_position;        /* [rows][E] */
+  const int32_t* target_equilibrium;    /* [rows][E] */
+  const float* L;                       /* [rows][E] */
+  double m_pole;
+  float u_max;                          /* u = u_max * Q in float32 (CartPole/cartpole_equations.py:119-127) */
+  uint32_t first_update_row;            /* rows before it have an empty Q_update_time */
+  double q_update_time;
+} cpmppi_recording;
+int cpmppi_write_recordings(const char* const* paths, const char* preamble, size_t preamble_len, const cpmppi_recording* rec,
+                            int n_threads);
+
+/* The ABI version this library was BUILT as (CPMPPI_ABI_VERSION of its header): lets a client that was compiled against another
+ * header notice before it passes a struct of the wrong layout (cpmppi_create refuses a mismatching cpmppi_config.abi_version). */
+uint32_t cpmppi_abi_version(void);
 
 /* Build info, e.g. "cpmppi 1 gfx950 hip-7.2". */
 const char* cpmppi_version(void);

@@ -159,8 +159,10 @@ class CallLog:
         return Q
 
 
-def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234):
+def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None):
     DG.load_config = lambda name: copy.deepcopy(cfg)
+    if p_Q is not None:                                            # (cartpole_physical_parameters.yml `actuator_noise`, read at :83)
+        LEG.p_Q = p_Q
     RES = DG.random_experiment_setter()
     out[f"{tag}/config"] = np.array(json.dumps(cfg))
     out[f"{tag}/N"], out[f"{tag}/H"], out[f"{tag}/ctrl_seed"] = np.int64(N), np.int64(H), np.int64(ctrl_seed)
@@ -243,5 +245,9 @@ if __name__ == "__main__":
     gen_experiments(out, "exp_coarse", data_gen_config(dt=dict(saving=0.04), **dict(
         fast, seed=78, initial_target_equilibrium="down", length_of_experiment=0.6,
         turning_points=dict(track_relative_complexity=10, interpolation_type="linear"))), 1, 800)
+    # the same kind of experiment with the legacy controller's multiplicative output noise (actuator_noise) switched off: nothing
+    # but the controller's own update stands between its nominal sequence and the plant - what a device-resident loop computes
+    gen_experiments(out, "exp_device", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=79, length_of_experiment=0.5)), 2, 900,
+                    ctrl_seed=4321, p_Q=0.0)
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
     print("wrote", os.path.join(OUT, "schedule.npz"), len(out), "arrays")

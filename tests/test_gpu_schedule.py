@@ -1,0 +1,231 @@
+"""GPU: the data generator's experiment schedule in the device loop: cpmppi_plant_step reading the schedule
+tables and recording at the saving period, harness.run_schedule, against the oracle's experiment loop and against whole experiments
+the reference's own simulator class ran (tests/golden/schedule.npz: moving target, target-equilibrium flips, dt_save != dt_control)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from numpy.random import SFC64, Generator
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O  # noqa: E402
+from oracle import schedule_np as S  # noqa: E402
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "schedule.npz"))
+
+
+def test_plant_step_follows_the_oracle_loop_row_by_row():
+    """cpmppi_plant_step under a GIVEN control sequence (no controller): states and second derivatives at every saved row, the
+    controls' log, the values published for the next controller call and a pole length that changes DURING a control period, against
+    the oracle's update_state loop (oracle/schedule_np.py) - for dt_save below, equal to and above dt_control."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, T, n_ctrl = 6, 7, 10
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=64, mpc_horizon=10))
+    rng = Generator(SFC64(21))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-4, 4), rng.uniform(-0.19, 0.19), rng.uniform(-0.6, 0.6))
+                   for _ in range(E)])
+    s0[:, 2], s0[:, 3] = np.cos(s0[:, 0]), np.sin(s0[:, 0])
+    Qs = rng.uniform(-1, 1, (T + 1, E)).astype(f32)
+    n_sim = T * n_ctrl
+    for n_save in (4, 10, 20, 1):
+        from math import gcd
+        stride = 1                                                     # (a pole-length table is per simulation step)
+        rows_sched = n_sim + 1
+        tp = rng.uniform(-0.15, 0.15, (rows_sched, E)).astype(f32)
+        te = rng.choice([-1.0, 1.0], (rows_sched, E)).astype(f32)
+        Ltab = np.repeat(rng.uniform(0.2, 0.5, (n_sim // 7 + 1, E)).astype(f32), 7, axis=0)[:rows_sched]   # changes every 7 steps
+        R = n_sim // n_save + 1
+        s = eng.tensor(s0.copy())
+        states, dd, Qlog = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
+        states[0] = s
+        tp_d, te_d, L_d = eng.tensor(tp), eng.tensor(te), eng.tensor(Ltab)
+        cur_tp, cur_te, cur_L = eng.zeros(E), eng.zeros(E), eng.zeros(E)
+        kw = dict(dt_sim=0.002, period_steps=n_ctrl, states_log=states, dd_log=dd, save_every=n_save, Q_log=Qlog,
+                  target_position_table=tp_d, target_equilibrium_table=te_d, L_table=L_d, sched_stride=stride,
+                  target_position_out=cur_tp, target_equilibrium_out=cur_te, L_out=cur_L)
+        for c in range(T):
+            eng.plant_step(s, Qs[c], n_ctrl, period=c, **kw)
+            g1 = (c + 1) * n_ctrl
+            assert np.array_equal(cur_tp.cpu().numpy(), tp[g1]) and np.array_equal(cur_te.cpu().numpy(), te[g1])
+            assert np.array_equal(cur_L.cpu().numpy(), Ltab[g1])
+        eng.plant_step(s, Qs[T], 0, period=T, **kw)                    # the run's last controller call: record only
+        st_h, dd_h = states.cpu().numpy(), dd.cpu().numpy()
+        assert np.array_equal(Qlog.cpu().numpy(), Qs)
+        assert np.array_equal(st_h[-1], s.cpu().numpy()) if n_sim % n_save == 0 else True
+        for e in range(E):
+            r = s0[e].copy()
+            k = 0
+            Q = Qs[0, e]
+            add, pdd = O.plant_ode(r, Q, Ltab[0, e])
+            rows = [(r.copy(), add, pdd)]
+            for gstep in range(1, n_sim + 1):                          # update_state: L first, integrate, (controller), ode, save
+                L = Ltab[gstep, e]
+                r = O.plant_substep(r, add, pdd, 0.002, L)
+                if gstep % n_ctrl == 0:
+                    Q = Qs[gstep // n_ctrl, e]
+                add, pdd = O.plant_ode(r, Q, L)
+                if gstep % n_save == 0:
+                    rows.append((r.copy(), add, pdd))
+            assert len(rows) == R
+            for i, (rs, a_, p_) in enumerate(rows):
+                assert np.all(np.abs(st_h[i, e] - rs) <= 3e-5 + 3e-5 * np.abs(rs)), (n_save, e, i, st_h[i, e], rs)
+                assert abs(dd_h[i, e, 0] - a_) <= 2e-3 + 1e-4 * abs(a_) and abs(dd_h[i, e, 1] - p_) <= 5e-4 + 1e-4 * abs(p_), (n_save, e, i)
+    eng.close()
+
+
+def _replay(g, tag, i, math_mode, graph=False):
+    """One fixture experiment on the device loop with the reference's own perturbations (SFC64 knots from the host)."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
+    key = f"{tag}/{i}"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    batch_all = SC.RandomExperimentSetter(cfg).draw(i + 1, int(g[f"{tag}/cartpole_seed0"]))
+    import dataclasses
+    b = dataclasses.replace(batch_all, s0=batch_all.s0[i:i + 1], target_position=batch_all.target_position[:, i:i + 1],
+                            target_equilibrium=batch_all.target_equilibrium[:, i:i + 1], interpolation_type=batch_all.interpolation_type[i:])
+    eng = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H, math_mode=math_mode))
+    rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"]) + i))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)                                         # configure()'s draws (controller_mppi_cartpole.py:355-359)
+    stdev = np.float64(g[f"{tag}/stdev"])
+
+    def knots(_c):
+        kn = O.sample_knots(rng, N, H, stdev)
+        rng.uniform(-1.0, 1.0)                                         # the output-noise draw (:553); its amplitude is 0 in this fixture
+        return kn[None]
+
+    # the simulator steps a freshly set controller once on its placeholder state before the experiment (CartPole/__init__.py:759-794)
+    un = eng.zeros(1, H)
+    eng.step(g[f"{key}/call/s"][0][None], un, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+    res = BatchedCartPoleExperiment(eng, seed=0).run_schedule(b, knots_fn=knots, u_nom0=un)
+    return res, b, eng
+
+
+@pytest.mark.parametrize("math_mode", ["precise", "fast"])
+@pytest.mark.parametrize("i", [0, 1])
+def test_reference_experiment_with_moving_target_and_flips_replayed_on_the_device(g, i, math_mode):
+    """A WHOLE experiment of the reference's simulator class - legacy MPPI controller in the loop, target position moving along
+    its random trace ('previous' / '0-derivative-smooth'), target equilibrium flipping, rows saved every 4 ms (dt_control = 20 ms)
+    - replayed by harness.run_schedule: controller steps, plants, schedule look-ups and recording all on the GPU, the host only
+    feeds the reference's perturbations.  To 1e-4 while the trajectories have not diverged (first 10 control steps)."""
+    res, b, eng = _replay(g, "exp_device", i, math_mode)
+    key = f"exp_device/{i}"
+    col = lambda n: g[f"{key}/col/{n}"]                                # noqa: E731
+    from cartpolesimulation_amd import recording as R
+    blk = R.recording_block(res, eng.phys)
+    assert blk["states"].shape[0] == len(col("time")) == b.n_sim // b.n_save + 1
+    # the schedule columns: exact
+    assert np.array_equal(blk["time"], col("time")) and np.array_equal(blk["target_position"][:, 0], col("target_position"))
+    assert np.array_equal(blk["target_equilibrium"][:, 0], col("target_equilibrium"))
+    flips = np.flatnonzero(np.diff(col("target_equilibrium")) != 0)
+    assert len(flips) >= 4
+    K = 10                                                             # control steps compared
+    r = K * b.n_ctrl // b.n_save + 1
+    assert flips[0] < r and np.ptp(col("target_position")[:r]) > 0     # both events fall inside the compared window
+    Qc = res["Q"].cpu().numpy()[:, 0]
+    np.testing.assert_allclose(Qc[:K + 1], g[f"{key}/call/Q"][1:K + 2], atol=1e-4)
+    st = blk["states"][:r, 0]
+    for j, n in enumerate(("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")):
+        np.testing.assert_allclose(st[:, j], col(n)[:r], atol=2e-4, rtol=1e-4, err_msg=n)
+    np.testing.assert_allclose(blk["Q"][:r, 0], col("Q_calculated")[:r], atol=1e-4)
+    np.testing.assert_allclose(blk["Q_ccrc"][:r, 0], col("Q_ccrc")[:r].astype(np.float64), atol=1e-4)
+    np.testing.assert_allclose(blk["dd"][:r, 0, 0], col("angleDD")[:r], atol=5e-3, rtol=1e-3)
+    np.testing.assert_allclose(blk["dd"][:r, 0, 1], col("positionDD")[:r], atol=2e-3, rtol=1e-3)
+    # the whole run stays on the track and its controls in range
+    assert np.abs(blk["states"][:, 0, 4]).max() <= 0.198 + 1e-6 and np.abs(Qc).max() <= 1.0
+    eng.close()
+
+
+@pytest.mark.parametrize("tag,i", [("exp_fine", 0), ("exp_fine", 1), ("exp_coarse", 0)])
+def test_reference_experiments_host_paced(g, tag, i):
+    """The experiments whose legacy controller multiplies its output by (1 + actuator_noise * uniform) on the host
+    (controller_mppi_cartpole.py:553): controller step and plant step on the GPU, that one multiplication in between on the host.
+    Target position / equilibrium come from the schedule vectors cpmppi_plant_step refills; dt_save = dt_control / 2 and 2 x."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    key = f"{tag}/{i}"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    N, H, p_Q = int(g[f"{tag}/N"]), int(g[f"{tag}/H"]), float(g[f"{tag}/p_Q"])
+    assert p_Q == 0.1
+    b = SC.RandomExperimentSetter(cfg).draw(i + 1, int(g[f"{tag}/cartpole_seed0"]))
+    eng = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H))
+    rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"]) + i))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    stdev = np.float64(g[f"{tag}/stdev"])
+    tp_d = eng.tensor(b.target_position[:, i:i + 1].astype(f32))
+    te_d = eng.tensor(b.target_equilibrium[:, i:i + 1].astype(f32))
+    cur_tp, cur_te = tp_d[0].clone(), te_d[0].clone()
+    R = b.n_sim // b.n_save + 1
+    s = eng.tensor(b.s0[i:i + 1].copy())
+    states, dd, Qlog = eng.zeros(R, 1, 6), eng.zeros(R, 1, 2), eng.zeros(b.n_periods + 1, 1)
+    states[0] = s
+    un = eng.zeros(1, H)
+
+    def control(state, tp, te):
+        Qd, _ = eng.step(state, un, tp, te, knots=O.sample_knots(rng, N, H, stdev)[None])
+        Q = f32(Qd.cpu().numpy()[0] * (1 + p_Q * rng.uniform(-1.0, 1.0)))
+        return np.clip(Q, f32(-1), f32(1))
+
+    control(g[f"{key}/call/s"][0][None], float(g[f"{key}/call/tp"][0]), 1.0)          # the placeholder call
+    kw = dict(dt_sim=b.dt_simulation, period_steps=b.n_ctrl, states_log=states, dd_log=dd, save_every=b.n_save, Q_log=Qlog,
+              target_position_table=tp_d, target_equilibrium_table=te_d, sched_stride=b.stride, target_position_out=cur_tp,
+              target_equilibrium_out=cur_te)
+    K = 12
+    for c in range(b.n_periods + 1):
+        if c <= K:
+            np.testing.assert_allclose(s.cpu().numpy()[0], g[f"{key}/call/s"][c + 1], atol=2e-4, rtol=1e-4)
+            assert float(cur_tp[0]) == f32(g[f"{key}/call/tp"][c + 1]) and float(cur_te[0]) == g[f"{key}/call/te"][c + 1]
+        Q = control(s, cur_tp, cur_te)
+        if c <= K:
+            np.testing.assert_allclose(Q, g[f"{key}/call/Q"][c + 1], atol=1e-4)
+        eng.plant_step(s, np.array([Q], f32), b.n_ctrl if c < b.n_periods else 0, period=c, **kw)
+    col = lambda n: g[f"{key}/col/{n}"]                                # noqa: E731
+    r = K * b.n_ctrl // b.n_save
+    st = states.cpu().numpy()[:, 0]
+    np.testing.assert_allclose(st[:r, 0], col("angle")[:r], atol=2e-4)
+    np.testing.assert_allclose(st[:r, 4], col("position")[:r], atol=2e-4)
+    np.testing.assert_allclose(dd.cpu().numpy()[:r, 0, 0], col("angleDD")[:r], atol=5e-3, rtol=1e-3)
+    eng.close()
+
+
+@pytest.mark.parametrize("E,N,H,cost,dt_save", [(5, 512, 20, "default", 0.004), (3, 256, 15, "quadratic_boundary_grad_minimal", 0.04),
+                                                 (1600, 1024, 20, "quadratic_boundary_grad_minimal", 0.02)])
+def test_graph_replayed_schedule_equals_the_launched_loop(E, N, H, cost, dt_save):
+    """run_schedule captured as a HIP graph of control periods (device step counter: Philox offset = schedule row = recording row)
+    and replayed gives the launched loop's recording bit for bit - moving targets, flips, partial last graph included."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
+    cfg = dict(seed=31, length_of_experiment=0.46, dt=dict(saving=dt_save), keep_target_equilibrium_x_seconds_up=0.1,
+               keep_target_equilibrium_x_seconds_down=0.06, turning_points=dict(track_relative_complexity=12),
+               random_initial_state=dict(init_limits=dict(angle=[0.0, 20.0], angleD=40.0, position=0.4, positionD=0.2)))
+    outs = []
+    for graph in (False, True):
+        b = SC.RandomExperimentSetter(cfg).draw(E, 77, L=np.linspace(0.3, 0.45, E).astype(f32))
+        eng = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, cost_function_specification=cost))
+        res = BatchedCartPoleExperiment(eng, seed=7).run_schedule(b, graph=graph, steps_per_graph=8)
+        outs.append({k: res[k].cpu().numpy() for k in ("states", "dd", "Q", "final_state", "u_nom")})
+        if E >= 1600:
+            assert eng.last_launch()["build_variant"] == 1
+        eng.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert b.n_periods == 23 and outs[0]["Q"].shape == (24, E) and np.abs(outs[0]["Q"]).max() > 0.01
+    assert np.ptp(b.target_position, axis=0).min() > 0 and (b.target_equilibrium == -1).any()
+    # the controller did follow the flips: with target_equilibrium = -1 the plugin costs reward the hanging pole
+    assert outs[0]["states"].shape[0] == b.n_sim // b.n_save + 1

@@ -58,7 +58,7 @@ def test_experiment_setter_draws_what_the_reference_draws(g, tag):
         assert np.array_equal(g[f"{tag}/target_position"][:, 0], g[f"{tag}/s0"][:, O.POSITION_IDX].astype(np.float64))   # start_at_target
 
 
-@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0"])
+@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0", "exp_device/0", "exp_device/1"])
 def test_experiment_loop_against_the_simulator_class(g, key):
     """Whole experiments of the REAL CartPole class (moving target, target-equilibrium flips, dt_save != dt_control): the
     oracle's loop reproduces the schedule the controller saw and the recording's time / target columns bit for bit, and the
@@ -87,8 +87,8 @@ def test_experiment_loop_against_the_simulator_class(g, key):
     assert np.array_equal(np.array([c["tp"] for c in calls]), ctp[1:])
     assert np.array_equal(np.array([c["te"] for c in calls]), g[f"{key}/call/te"][1:])
     flips = np.flatnonzero(np.diff(col("target_equilibrium")) != 0)
-    assert len(flips) >= 4 and np.ptp(col("target_position")) > 0.05   # the fixture does exercise a moving target and flips
-    assert len(calls) == out["n_ctrl"] * 0 + len(cs) - 1
+    assert len(flips) >= 4 and np.ptp(col("target_position")) > 0.02   # the fixture does exercise a moving target and flips
+    assert len(calls) == len(cs) - 1
     # --- the dynamics
     K = 12
     Qo, Qf = np.array([c["Q"] for c in calls]), g[f"{key}/call/Q"][1:]

@@ -1,5 +1,8 @@
 """The recording writer: file layout as CartPole/csv_logger.py writes it, column set as
-CartPole/__init__.py:221-259 logs it; readable the way the reference's loaders read it (pandas, comment='#')."""
+CartPole/__init__.py:221-259 logs it, every field in the form the reference's own files have it - pinned to a recording the
+reference's CartPole class wrote (tests/golden/schedule.npz, "csv_rows"); readable the way the reference's loaders read it."""
+import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -13,16 +16,30 @@ REFERENCE_COLUMNS = ["time", "angle", "angleD", "angleDD", "angle_cos", "angle_s
                      "positionDD", "Q_calculated", "Q_applied", "Q_ccrc", "u", "target_position", "target_equilibrium",
                      "L", "L_for_controller", "m_pole", "m_pole_for_controller", "vertical_angle_offset",
                      "vertical_angle_offset_cos", "vertical_angle_offset_sin", "Q_update_time"]
+f32 = np.float32
 
 
 def test_columns_match_reference_order():
     assert R.COLUMNS == REFERENCE_COLUMNS
 
 
+def random_block(rng, T, E, first_update_row=2):
+    s = (rng.standard_normal((T, E, 6)) * 10.0 ** rng.integers(-7, 3, (T, E, 6))).astype(f32)
+    s[3, 1, 0], s[4, 1, 1], s[5, E - 1, 4], s[6, E - 1, 5] = 0.0, -0.0, 1.0, 123456.0
+    Q = rng.uniform(-1, 1, (T, E)).astype(f32)
+    return dict(time=np.cumsum(np.full(T, 0.002 * 5)) - 0.01, states=s, Q=Q, Q_ccrc=np.roll(Q, 1, axis=0),
+                dd=np.stack([(1e3 * rng.standard_normal((T, E))), (1e-6 * rng.standard_normal((T, E)))], axis=-1).astype(f32),
+                target_position=rng.uniform(-0.198, 0.198, (T, E)), target_equilibrium=rng.choice([-1, 1], (T, E)).astype(np.int32),
+                L=np.broadcast_to(rng.uniform(0.2, 0.5, E).astype(f32), (T, E)).copy(), first_update_row=first_update_row)
+
+
 def test_write_and_read_back(tmp_path):
+    rng = np.random.Generator(np.random.SFC64(3))
     T = 7
-    cols = {k: np.arange(T) * (i + 1) * 0.5 for i, k in enumerate(R.COLUMNS)}
-    header = R.create_csv_header(0.14, 0.002, 0.02, 0.02, "mpc", "mppi", PhysicalParameters())
+    phys = PhysicalParameters()
+    block = random_block(rng, T, 2)
+    cols = R.typed_columns(block, 1, phys, q_update_time=0.25)
+    header = R.create_csv_header(0.14, 0.002, 0.02, 0.02, "mpc", "mppi", phys)
     path = R.write_recording(R._unique_path(str(tmp_path), "CPS_test"), cols, header=header)
     lines = open(path).read().splitlines()
     assert lines[0].startswith("# This is CartPole simulation from ") and lines[1].startswith("# Done with git-revision: ")
@@ -30,13 +47,149 @@ def test_write_and_read_back(tmp_path):
     assert "# Saving: 0.02 s" in lines and "# Data:" in lines
     first_data = lines.index("# Data:") + 1
     assert lines[first_data].split(",") == REFERENCE_COLUMNS
-    df = pd.read_csv(path, comment="#")
+    df = pd.read_csv(path, comment="#", float_precision="round_trip")
     assert list(df.columns) == REFERENCE_COLUMNS and len(df) == T
-    np.testing.assert_allclose(df["angleD"].to_numpy(), cols["angleD"])
+    np.testing.assert_array_equal(df["angleD"].to_numpy().astype(f32), block["states"][:, 1, 1])       # shortest float32 digits round-trip
+    np.testing.assert_array_equal(df["target_position"].to_numpy(), block["target_position"][:, 1])
+    assert list(df["L_for_controller"]) == [True] * T and df["Q_update_time"].isna().sum() == 2       # pandas reads 'true' as a bool
     # never overwrite an existing recording (csv_logger.py:76-88)
     p2 = R._unique_path(str(tmp_path), "CPS_test")
     assert p2 != path and p2.endswith("CPS_test-1.csv")
+    with pytest.raises(FileExistsError):
+        R.write_recording(path, cols, header=header)
     assert R.create_csv_file_name("mpc", "mppi", with_date=False) == "CPS_mpc_mppi.csv"
+
+
+def test_float_formats_equal_pythons_and_numpys():
+    """repr(float) and str(numpy.float32) as the native writer formats them, on random bit patterns of every magnitude."""
+    from cartpolesimulation_amd import _lib
+    lib = _lib.load()
+    lib.cpmppi_debug_py_repr.argtypes = [C.c_double, C.c_char_p]
+    lib.cpmppi_debug_np_str_f32.argtypes = [C.c_float, C.c_char_p]
+    rng = np.random.Generator(np.random.SFC64(5))
+    buf = C.create_string_buffer(64)
+    f = rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32).view(f32)
+    f = np.concatenate([f[np.isfinite(f)], np.array([0.0, -0.0, 1.0, 1e-4, 9.999e-5, 1e16, 9.9999e15, 123456.0, 0.1, 1e-45, 3.4e38], f32),
+                        (rng.standard_normal(20000) * 10.0 ** rng.integers(-8, 8, 20000)).astype(f32)])
+    for x in f:
+        n = lib.cpmppi_debug_np_str_f32(float(x), buf)
+        assert buf.raw[:n].decode() == str(x), (x.view(np.uint32), buf.raw[:n], str(x))
+    d = rng.integers(0, 2 ** 63, 100000, dtype=np.uint64).view(np.float64)
+    d = np.concatenate([d[np.isfinite(d)], -d[np.isfinite(d)][:1000], rng.standard_normal(20000) * 10.0 ** rng.integers(-20, 20, 20000),
+                        np.array([0.0, -0.0, 0.020000000000000004, 1e16, 1e-5, 5e-324])])
+    for x in d:
+        n = lib.cpmppi_debug_py_repr(float(x), buf)
+        assert buf.raw[:n].decode() == repr(float(x)), (x, buf.raw[:n])
+
+
+def test_native_writer_is_byte_identical_to_the_csv_module(tmp_path):
+    """cpmppi_write_recordings (host code of libcpmppi.so, no GPU involved) against write_recording (Python's csv module fed the
+    reference's value TYPES) on the same block of E experiments: equal byte for byte - repr of Python floats, str of numpy
+    float32 scalars (incl. exponent notation, integers, negative zero), ints, 'true', empty fields, "\\r\\n" rows, comment block."""
+    rng = np.random.Generator(np.random.SFC64(7))
+    T, E = 57, 5
+    block = random_block(rng, T, E)
+    phys = PhysicalParameters()
+    header = R.create_csv_header(1.14, 0.002, 0.02, 0.01, "mpc", "mppi", phys)
+    title = "This is CartPole simulation from 01.01.2026 at time 00:00:00"
+    a = [str(tmp_path / f"py_{e}.csv") for e in range(E)]
+    b = [str(tmp_path / f"native_{e}.csv") for e in range(E)]
+    for e in range(E):
+        R.write_recording(a[e], R.typed_columns(block, e, phys, 0.0123), title=title, header=header)
+    for threads in (1, 3):
+        for p in b:
+            if os.path.exists(p):
+                os.remove(p)
+        R.write_recordings_native(b, block, phys, header, title=title, q_update_time=0.0123, n_threads=threads)
+        for e in range(E):
+            assert open(a[e], "rb").read() == open(b[e], "rb").read(), (e, threads)
+    df = pd.read_csv(b[1], comment="#")
+    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == T
+
+
+def test_native_writer_never_appends_and_cleans_up_after_a_failure(tmp_path):
+    """advisor r4: a failing call must not leave a half-written dataset behind that a retry then appends to."""
+    from cartpolesimulation_amd import _lib
+    rng = np.random.Generator(np.random.SFC64(8))
+    E = 4
+    block = random_block(rng, 9, E)
+    phys = PhysicalParameters()
+    header = R.create_csv_header(1.0, 0.002, 0.02, 0.02, "mpc", "mppi", phys)
+    good = [str(tmp_path / f"ok_{e}.csv") for e in range(E)]
+    bad = list(good)
+    bad[2] = str(tmp_path / "no_such_dir" / "x.csv")
+    with pytest.raises(_lib.CpmppiError) as ei:
+        R.write_recordings_native(bad, block, phys, header, n_threads=2)
+    assert ei.value.code == -7 and "No such file or directory" in str(ei.value)                  # CPMPPI_ERR_IO with the errno text
+    assert os.listdir(tmp_path) == []                                                            # nothing left: the retry starts clean
+    R.write_recordings_native(good, block, phys, header, n_threads=2)
+    sizes = [os.path.getsize(p) for p in good]
+    with pytest.raises(_lib.CpmppiError) as ei:                                                  # existing names are refused, not appended to
+        R.write_recordings_native(good, block, phys, header)
+    assert ei.value.code == -7 and "File exists" in str(ei.value)
+    assert [os.path.getsize(p) for p in good] == sizes and sorted(os.listdir(tmp_path)) == sorted(os.path.basename(p) for p in good)
+
+
+@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0"])
+def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, key):
+    """The data rows of a recording written by the REFERENCE (its CartPole class + csv_logger, tests/golden/schedule.npz) from the
+    values it logged: fed the same values, both writers here give the same bytes (all columns but the wall-clock Q_update_time)."""
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    col = lambda n: g[f"{key}/col/{n}"]                              # noqa: E731
+    rows = len(col("time"))
+    cfg = json.loads(g[f"{key.split('/')[0]}/config"].item())
+    n_ctrl = int(np.rint(cfg["dt"]["control"] / cfg["dt"]["simulation"]))
+    n_save = int(np.rint(cfg["dt"]["saving"] / cfg["dt"]["simulation"]))
+    st = np.stack([col(n) for n in ("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")], axis=-1).astype(f32)
+    block = dict(time=col("time"), states=st[:, None], dd=np.stack([col("angleDD"), col("positionDD")], axis=-1).astype(f32)[:, None],
+                 Q=col("Q_calculated").astype(f32)[:, None], Q_ccrc=col("Q_ccrc").astype(f32)[:, None],
+                 target_position=col("target_position")[:, None], target_equilibrium=col("target_equilibrium").astype(np.int32)[:, None],
+                 L=col("L").astype(f32)[:, None], first_update_row=-(-n_ctrl // n_save))
+    # (the fixture's columns are what the reference held: float32 values widened by pandas; narrowing them back is exact)
+    assert np.array_equal(block["states"][:, 0, 0].astype(np.float64), col("angle")) and np.array_equal(block["Q"][:, 0].astype(np.float64), col("Q_calculated"))
+    assert np.array_equal(col("u").astype(f32), f32(1.77) * block["Q"][:, 0])                       # u = u_max * Q in float32
+    phys = PhysicalParameters()
+    want = g[f"{key}/csv_rows"].item().split("\r\n")
+    assert want[0].split(",") == REFERENCE_COLUMNS[:-1] and len(want) == rows + 1
+    header = R.create_csv_header(cfg["length_of_experiment"], 0.002, 0.02, cfg["dt"]["saving"], "mppi-cartpole", "", phys)
+    for native in (True, False):
+        path = str(tmp_path / f"{'native' if native else 'python'}.csv")
+        if native:
+            R.write_recordings_native([path], block, phys, header, q_update_time=0.5)
+        else:
+            R.write_recording(path, R.typed_columns(block, 0, phys, 0.5), header=header)
+        got = open(path, newline="").read().split("\r\n")
+        k0 = next(i for i, r in enumerate(got) if r.startswith("time,"))
+        body = [r for r in got[k0:] if r]
+        assert [r.rsplit(",", 1)[0] for r in body] == want, native
+        tails = [r.rsplit(",", 1)[1] for r in body[1:]]
+        assert tails[:block["first_update_row"]] == [""] * block["first_update_row"] and set(tails[block["first_update_row"]:]) == {"0.5"}
+    # the header block (below the title and revision lines) is the reference's too, parameter for parameter, up to its dict-valued
+    # entries (noise, updaters of L / m_pole / vertical_angle_offset, informer), which this build has no counterpart of
+    ref_head = g[f"{key}/csv_preamble"].item().split("\r\n")
+    ours = ["# " + h for h in header]
+    for line in ("# Length of experiment: %s s" % cfg["length_of_experiment"], "# Time intervals dt:", "# Simulation: 0.002 s",
+                 "# Controller update: 0.02 s", "# Saving: %s s" % cfg["dt"]["saving"], "# Controller: mppi-cartpole", "# Data:"):
+        assert line in ref_head and line in ours, line
+
+
+def test_dataset_paths_follow_the_reference_naming(tmp_path):
+    """run_data_generator names every file "Experiment" and csv_logger appends -1, -2, ... (CartPole/data_generator.py:290-322,
+    csv_logger.py:61-91); ML_Pipeline_mode sorts them into Train / Validate / Test by position (split 0.8 / 0.1)."""
+    p = R.dataset_paths(4, str(tmp_path))
+    assert [os.path.basename(x) for x in p] == ["Experiment.csv", "Experiment-1.csv", "Experiment-2.csv", "Experiment-3.csv"]
+    open(p[0], "w").close()                                          # a later run continues the numbering past existing files
+    assert os.path.basename(R.dataset_paths(1, str(tmp_path))[0]) == "Experiment-1.csv"
+    p = R.dataset_paths(2, str(tmp_path / "idx"), secondary_experiment_index=7)
+    assert [os.path.basename(x) for x in p] == ["Experiment-007.csv", "Experiment-007-1.csv"]
+    p = R.dataset_paths(10, str(tmp_path / "ml"), ml_pipeline=True, split=(0.8, 0.1))
+    assert [os.path.basename(os.path.dirname(x)) for x in p] == ["Train"] * 8 + ["Validate"] + ["Test"]
+    assert [os.path.basename(x) for x in p[:3]] == ["Experiment.csv", "Experiment-1.csv", "Experiment-2.csv"] and os.path.basename(p[8]) == "Experiment.csv"
+    f1 = R.experiment_folder(str(tmp_path / "exps"))
+    assert f1.endswith(os.path.join("Experiment-1", "Recordings"))
+    os.makedirs(f1)
+    assert R.experiment_folder(str(tmp_path / "exps")).endswith(os.path.join("Experiment-2", "Recordings"))
+    assert R.experiment_folder(str(tmp_path / "exps"), 3).endswith(os.path.join("Experiment-003-1", "Recordings"))
 
 
 @pytest.mark.gpu
@@ -46,52 +199,31 @@ def test_generate_dataset_on_device(tmp_path):
     from cartpolesimulation_amd.configs import legacy_mppi_config
     E = 4
     eng = MPPIEngine(E, legacy_mppi_config(num_rollouts=512, mpc_horizon=20))
-    paths = R.generate_dataset(eng, E, 0.4, str(tmp_path), seed=3,
-                               init_limits=dict(angle=(0.0, 10.0), angleD=20.0, position=0.3, positionD=0.1))
-    assert len(paths) == E and all(os.path.isfile(p) for p in paths)
+    cfg = dict(length_of_experiment=0.4, dt=dict(saving=0.01), keep_target_equilibrium_x_seconds_up=0.1,
+               turning_points=dict(track_relative_complexity=10),
+               random_initial_state=dict(init_limits=dict(angle=[0.0, 10.0], angleD=20.0, position=0.3, positionD=0.1)))
+    paths = R.generate_dataset(eng, E, str(tmp_path), config=cfg, seed=3)
+    assert [os.path.basename(p) for p in paths] == ["Experiment.csv", "Experiment-1.csv", "Experiment-2.csv", "Experiment-3.csv"]
     df = pd.read_csv(paths[1], comment="#")
-    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == 20
-    np.testing.assert_allclose(np.diff(df["time"]), 0.02, atol=1e-9)
+    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == 41                    # t = 0, 0.01, ..., 0.4
+    np.testing.assert_allclose(np.diff(df["time"]), 0.01, atol=1e-9)
     np.testing.assert_allclose(df["angle_cos"], np.cos(df["angle"]), atol=1e-5)
     np.testing.assert_allclose(df["u"], 1.77 * df["Q_applied"], rtol=1e-6)
-    assert np.abs(df["Q_applied"]).max() <= 1.0 and np.isfinite(df.to_numpy()).all()
+    assert np.abs(df["Q_applied"]).max() <= 1.0 and np.isfinite(df.drop(columns=["Q_update_time"]).to_numpy(dtype=float)).all()
+    assert np.ptp(df["target_position"]) > 0 and set(df["target_equilibrium"]) == {1, -1}    # moving target, flipping equilibrium
+    q = df["Q_calculated"].to_numpy()
+    assert np.array_equal(q[0:40:2], q[1:40:2])                                       # the control is held for dt_control = 2 rows
+    # (Q_ccrc is written with float32 digits, Q_calculated as the double: the same float32 values)
+    assert np.array_equal(df["Q_ccrc"].to_numpy()[2:].astype(np.float32), q[:-2].astype(np.float32)) and (df["Q_ccrc"][:2] == 0).all()
     # second derivatives are those of the logged state under the logged control (cartpole_equations.py:44-105)
     from oracle import oracle_np as O
-    r = df.iloc[5]
-    add, pdd = O.cartpole_ode(np.float32(r.angle_cos), np.float32(r.angle_sin), np.float32(r.angleD),
-                              np.float32(r.positionD), np.float32(1.77 * r.Q_applied), np.float32(r.L))
-    assert abs(add - r.angleDD) < 1e-3 * max(1, abs(add)) and abs(pdd - r.positionDD) < 1e-3 * max(1, abs(pdd))
-
-
-def test_native_writer_is_byte_identical_to_the_csv_module(tmp_path):
-    """cpmppi_write_recordings (host code of libcpmppi.so, no GPU involved) against write_recording (Python's csv module, as
-    the reference writes its files) on the same block of E experiments: the files must be equal byte for byte - Python's float
-    repr of every value (incl. exponent notation, integers, negative zero), "\\r\\n" rows, the comment block."""
-    rng = np.random.Generator(np.random.SFC64(7))
-    T, E = 57, 5
-    s = (rng.standard_normal((T, E, 6)) * 10.0 ** rng.integers(-7, 3, (T, E, 6))).astype(np.float32)
-    s[3, 1, 0], s[4, 1, 1], s[5, 2, 4], s[6, 2, 5] = 0.0, -0.0, 1.0, 123456.0
-    Q = rng.uniform(-1, 1, (T, E)).astype(np.float32)
-    block = dict(s=s, Q=Q, aDD=(1e3 * rng.standard_normal((T, E))).astype(np.float32),
-                 xDD=(1e-6 * rng.standard_normal((T, E))).astype(np.float32), u=(np.float32(1.77) * Q).astype(np.float32))
-    phys = PhysicalParameters()
-    tp = rng.uniform(-0.1, 0.1, E).astype(np.float32)
-    te = np.array([1, -1, 1, 1, -1], np.float32)
-    Lv = rng.uniform(0.2, 0.5, E).astype(np.float32)
-    header = R.create_csv_header(1.14, 0.002, 0.02, 0.02, "mpc", "mppi", phys)
-    title = "This is CartPole simulation from 01.01.2026 at time 00:00:00"
-    a = [str(tmp_path / f"py_{e}.csv") for e in range(E)]
-    b = [str(tmp_path / f"native_{e}.csv") for e in range(E)]
-    for e in range(E):
-        R.write_recording(a[e], R._columns_of(block, e, 0.02, tp[e], te[e], Lv[e], phys), title=title, header=header)
-    for threads in (1, 3):
-        for p in b:
-            if os.path.exists(p):
-                os.remove(p)
-        R.write_recordings_native(b, block, 0.02, tp, te, Lv, phys, header, title=title, n_threads=threads)
-        for e in range(E):
-            assert open(a[e], "rb").read() == open(b[e], "rb").read(), (e, threads)
-    df = pd.read_csv(b[1], comment="#")
-    assert list(df.columns) == REFERENCE_COLUMNS and len(df) == T
-    with pytest.raises(Exception):
-        R.write_recordings_native([str(tmp_path / "no_such_dir" / "x.csv")] * E, block, 0.02, tp, te, Lv, phys, header)
+    for i in (0, 5, 40):
+        r = df.iloc[i]
+        add, pdd = O.cartpole_ode(np.float32(r.angle_cos), np.float32(r.angle_sin), np.float32(r.angleD),
+                                  np.float32(r.positionD), np.float32(1.77 * r.Q_applied), np.float32(r.L))
+        assert abs(add - r.angleDD) < 1e-3 * max(1, abs(add)) and abs(pdd - r.positionDD) < 1e-3 * max(1, abs(pdd)), i
+    # ML pipeline mode: the folder structure SI_Toolkit expects
+    paths = R.generate_dataset(eng, E, str(tmp_path / "ml"), config=dict(cfg, ML_Pipeline_mode=True, split=[0.5, 0.25]), seed=4)
+    assert [os.path.relpath(p, str(tmp_path / "ml")) for p in paths] == [
+        os.path.join("Experiment-1", "Recordings", d, n) for d, n in (("Train", "Experiment.csv"), ("Train", "Experiment-1.csv"),
+                                                                       ("Validate", "Experiment.csv"), ("Test", "Experiment.csv"))]
