@@ -23,7 +23,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
            "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings", "cpmppi_plant_step",
-           "cpmppi_abi_version")
+           "cpmppi_abi_version", "cpmppi_stream_create", "cpmppi_stream_destroy")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -150,6 +150,8 @@ def load():
     lib.cpmppi_write_recordings.argtypes = [C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t, C.POINTER(cpmppi_recording), C.c_int]
     lib.cpmppi_plant_step.argtypes = [vp, C.POINTER(cpmppi_plant_args), vp]
     lib.cpmppi_abi_version.restype = u32
+    lib.cpmppi_stream_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.cpmppi_stream_destroy.argtypes = [vp]
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:

@@ -978,6 +978,12 @@ __global__ __launch_bounds__(BLOCK) void fold_env_kernel(const Params p, const f
   out[env] = f;
 }
 
+// development aid (tools/variant_sweep.py): the two size limits below which the straight-line builds are launched, overridable
+// from the environment so that one library can be swept over them
+static uint64_t env_u64(const char* name, uint64_t dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
+}
 template <int COST, bool FAST, int R, int V, int INTEG = PREDICTOR_ODE_V0>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
                                 const StepPtrs& a) {
@@ -988,8 +994,20 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
       hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_KNOTS, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
     case CPMPPI_NOISE_DELTA_U_TILED:
       hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_TILED, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
-    default:
-      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V, INTEG>), grid, dim3(BLOCK), lds, s, p, a); break;
+    default: {
+      // development aid (tools/dev/placement.py): CPMPPI_LDS_PAD=<bytes> of extra dynamic LDS per workgroup caps how many
+      // workgroups the dispatcher can put on one CU (160 KB each)
+      static const size_t pad = (size_t)env_u64("CPMPPI_LDS_PAD", 0);
+      if (pad) {
+        static bool raised = false;
+        if (!raised) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V, INTEG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad));
+          raised = true;
+        }
+      }
+      hipLaunchKernelGGL((rollout_cost_kernel<COST, FAST, NOISE_PHILOX, R, V, INTEG>), grid, dim3(BLOCK), lds + pad, s, p, a); break;
+    }
   }
   return hipGetLastError();
 }
@@ -1006,6 +1024,8 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 #endif
 constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
+static uint64_t lone_form_max_waves() { return env_u64("CPMPPI_LONE_FORM_MAX_WAVES", 1024ull); }
+static uint64_t latency_max_rollouts() { return env_u64("CPMPPI_LATENCY_MAX_ROLLOUTS", 65536ull); }
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                                const Params& p, const StepPtrs& a, uint32_t* variant_out) {
@@ -1034,12 +1054,12 @@ hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32
     if (rpl == 2) {
       const bool mid = (uint64_t)grid.x * BLOCK * 2 <= MID_SIZE_MAX_ROLLOUTS;
       // at most one wave per SIMD (256 CUs x 4): the phased build with the quiet control step unrolled
-      if ((uint64_t)grid.x * WAVES <= 1024ull) return CPMPPI_LAUNCH_V(true, 2, 3);
+      if ((uint64_t)grid.x * WAVES <= lone_form_max_waves()) return CPMPPI_LAUNCH_V(true, 2, 3);
       if (mid) return CPMPPI_LAUNCH_V(true, 2, 2);
       if (hipError_t fe = fold_first(); fe != hipSuccess) return fe;
       return CPMPPI_LAUNCH_V(true, 2, 1);
     }
-    const bool small = (uint64_t)grid.x * BLOCK <= 65536ull;
+    const bool small = (uint64_t)grid.x * BLOCK <= latency_max_rollouts();
     if (small) return CPMPPI_LAUNCH_V(true, 1, 0);
     if (hipError_t fe = fold_first(); fe != hipSuccess) return fe;
     return CPMPPI_LAUNCH_V(true, 1, 1);
@@ -1938,5 +1958,34 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
 }
 
 uint32_t cpmppi_abi_version(void) { return CPMPPI_ABI_VERSION; }
+
+int cpmppi_stream_create(int device, void** stream_out) {
+  if (!stream_out) return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_stream_create: null argument");
+  *stream_out = nullptr;
+  DeviceGuard guard(device);
+  if (guard.err != hipSuccess) return fail(nullptr, CPMPPI_ERR_HIP, std::string("cpmppi_stream_create: hipSetDevice: ") + hipGetErrorString(guard.err));
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, CPMPPI_ERR_HIP, std::string("cpmppi_stream_create: ") + hipGetErrorString(e));
+  // one bit per CU, all set: the mask only serves to make the runtime give this stream a queue of its own
+  const uint32_t words = ((uint32_t)prop.multiProcessorCount + 31u) / 32u;
+  std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+  if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+  hipStream_t st = nullptr;
+  e = hipExtStreamCreateWithCUMask(&st, words, mask.data());
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);          // (a runtime without CU masks: an ordinary stream)
+  }
+  if (e != hipSuccess) return fail(nullptr, CPMPPI_ERR_HIP, std::string("cpmppi_stream_create: ") + hipGetErrorString(e));
+  *stream_out = st;
+  return CPMPPI_OK;
+}
+
+int cpmppi_stream_destroy(void* stream) {
+  if (!stream) return CPMPPI_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? CPMPPI_OK : fail(nullptr, CPMPPI_ERR_HIP, std::string("cpmppi_stream_destroy: ") + hipGetErrorString(e));
+}
 
 }  // extern "C"

@@ -31,11 +31,25 @@ static __device__ unsigned long long g_wave_t[16384][4];   // s_memrealtime (100
 // -DCPMPPI_SECTION_STAMPS on top (tools/dev/sections.py): s_memtime at the section boundaries of a control step, summed per
 // wave.  `sec[0..6]` accumulate shader cycles per section, `sec[7]` holds the previous stamp.
 static __device__ unsigned int g_wave_sec[16384][8];
+// where a wave runs (tools/dev/placement.py): HW_REG_HW_ID (wave / SIMD / CU / shader array / shader engine) and HW_REG_XCC_ID
+static __device__ unsigned int g_wave_hw[16384][2];
 #define CPMPPI_DBG_STAMP(slot)                                                                       \
   do {                                                                                               \
     const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                        \
-    if ((threadIdx.x & 63u) == 0u && wv_ < 16384u) cpmppi::g_wave_t[wv_][slot] = __builtin_amdgcn_s_memrealtime(); \
+    if ((threadIdx.x & 63u) == 0u && wv_ < 16384u) {                                                 \
+      cpmppi::g_wave_t[wv_][slot] = __builtin_amdgcn_s_memrealtime();                                \
+      if ((slot) == 0) {                                                                             \
+        unsigned hw_, xcc_;                                                                          \
+        asm volatile("s_getreg_b32 %0, hwreg(4)" : "=s"(hw_));                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xcc_));                                     \
+        cpmppi::g_wave_hw[wv_][0] = hw_; cpmppi::g_wave_hw[wv_][1] = xcc_;                           \
+      }                                                                                              \
+    }                                                                                                \
   } while (0)
+#define CPMPPI_HW_READER(NAME)                                                                                          \
+  extern "C" int NAME(unsigned int* hw, unsigned n_waves) {                                                            \
+    return hipMemcpyFromSymbol(hw, HIP_SYMBOL(cpmppi::g_wave_hw), (size_t)n_waves * 8) == hipSuccess ? 0 : -1;         \
+  }
 // one reader per translation unit (the arrays are per unit): extern "C" int NAME(cold, cycles, stamps, n_waves, reset)
 #define CPMPPI_DEBUG_READER(NAME)                                                                                      \
   extern "C" int NAME(unsigned int* wave_cold, unsigned long long* wave_cycles, unsigned long long* stamps,            \

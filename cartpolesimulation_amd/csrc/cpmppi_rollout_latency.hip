@@ -10,4 +10,5 @@ CPMPPI_LATENCY_INSTANCES(CPMPPI_DEFINE_ROLLOUT)
 #ifdef CPMPPI_DEBUG_COUNTERS
 CPMPPI_DEBUG_READER(cpmppi_debug_read_latency)
 CPMPPI_SECTION_READER(cpmppi_debug_sections_latency)
+CPMPPI_HW_READER(cpmppi_debug_hw_latency)
 #endif

@@ -10,4 +10,5 @@ CPMPPI_MID_INSTANCES(CPMPPI_DEFINE_ROLLOUT)
 #ifdef CPMPPI_DEBUG_COUNTERS
 CPMPPI_DEBUG_READER(cpmppi_debug_read_mid)
 CPMPPI_SECTION_READER(cpmppi_debug_sections_mid)
+CPMPPI_HW_READER(cpmppi_debug_hw_mid)
 #endif

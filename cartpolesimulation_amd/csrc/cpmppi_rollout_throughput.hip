@@ -10,4 +10,5 @@ CPMPPI_THROUGHPUT_INSTANCES(CPMPPI_DEFINE_ROLLOUT)
 // diagnostic build only: event counters, per-wave lifetimes and time stamps of this unit's kernels (tools/dev/cold_counts.py)
 CPMPPI_DEBUG_READER(cpmppi_debug_read)
 CPMPPI_SECTION_READER(cpmppi_debug_sections_throughput)
+CPMPPI_HW_READER(cpmppi_debug_hw_throughput)
 #endif

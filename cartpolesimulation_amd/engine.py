@@ -50,7 +50,16 @@ class MPPIEngine:
         if rc != 0:
             raise _L.CpmppiError(rc, self.lib.cpmppi_last_error(self._h).decode())
 
+    def use_stream(self, stream):
+        """Enqueue every later call of this engine on `stream` (a torch.cuda.Stream; None = torch's current stream again) -
+        env groups that run side by side each keep their own stream (pipeline.py) without a stream context per call."""
+        self._fixed_stream = None if stream is None else C.c_void_p(stream.cuda_stream)
+        self._fixed_stream_obj = stream                              # (keeps it alive)
+
     def _stream(self):
+        fixed = getattr(self, "_fixed_stream", None)
+        if fixed is not None:
+            return fixed
         # the caller's current stream as a raw handle (torch.cuda.current_stream() builds a Stream object: ~5 us per call,
         # three calls per control step at the host seam)
         raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -102,62 +102,113 @@ class BatchedCartPoleExperiment:
         state and nominal sequences; rows are the simulation steps 0, n_save, 2 n_save, ...
         ``u_nom0`` [E,H]: nominal sequences to start from (a controller that has been stepped before; default zeros).
         ``knots_fn(c)`` (tests): perturbation knots [E,N,P] for controller call c instead of the in-kernel Philox draw."""
-        eng, b = self.engine, batch
-        E, T = b.E, b.n_periods
-        if b.dt_simulation != self.dt_simulation or b.n_ctrl != self.n_sub:
+        run = ScheduleRun(self.engine, batch, self.seed, env_offset=env_offset, knots_fn=knots_fn, u_nom0=u_nom0)
+        if batch.dt_simulation != self.dt_simulation or batch.n_ctrl != self.n_sub:
             raise ValueError("the batch was drawn for other time scales than this experiment runner's")
+        if graph and knots_fn is None and run.T > 0:
+            run.capture(steps_per_graph)
+            while run.periods_left:
+                run.enqueue_next()
+        else:
+            while run.periods_left:
+                run.enqueue_next()
+        return run.finish()
+
+
+class ScheduleRun:
+    """The device loop of BatchedCartPoleExperiment.run_schedule as an object that enqueues one piece at a time, so that several
+    runs - env groups on their own streams, pipeline.run_schedule_groups - can be interleaved by one host thread."""
+
+    def __init__(self, engine, batch, seed, env_offset=0, knots_fn=None, u_nom0=None):
+        self.eng, self.b, self.seed, self.env_offset, self.knots_fn = engine, batch, int(seed), int(env_offset), knots_fn
+        eng, b = engine, batch
+        E, T = b.E, b.n_periods
+        self.T, self.c = T, 0
         R = b.n_sim // b.n_save + 1
-        s = eng.tensor(b.s0).clone()
+        self.s = s = eng.tensor(b.s0).clone()
         tp_tab = eng.tensor(b.target_position.astype(np.float32))                 # the controller computes in float32
         te_tab = eng.tensor(b.target_equilibrium.astype(np.float32))
         L_tab = eng.tensor(b.L_table) if b.L_table is not None else None
         if L_tab is not None and (b.stride != 1 or L_tab.shape[0] != b.n_sim + 1):
             raise ValueError("a pole-length table is per simulation step: draw the batch with stride 1 (dt_save = dt_simulation)")
-        cur_tp, cur_te = tp_tab[0].clone(), te_tab[0].clone()
-        cur_L = L_tab[0].clone() if L_tab is not None else (eng.tensor(b.L) if b.L is not None else None)
-        u_nom, Q = (eng.zeros(E, eng.H) if u_nom0 is None else eng.tensor(u_nom0, (E, eng.H)).clone()), eng.empty(E)
-        states, dd, Qs = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
-        states[0] = s
-        tail = b.n_sim - T * b.n_ctrl                                             # simulation steps after the last controller call
-        plant = dict(dt_sim=b.dt_simulation, period_steps=b.n_ctrl, L=None if L_tab is not None else cur_L, states_log=states,
-                     dd_log=dd, save_every=b.n_save, Q_log=Qs, target_position_table=tp_tab, target_equilibrium_table=te_tab,
-                     L_table=L_tab, sched_stride=b.stride, target_position_out=cur_tp, target_equilibrium_out=cur_te,
-                     L_out=cur_L if L_tab is not None else None)
+        self.cur_tp, self.cur_te = tp_tab[0].clone(), te_tab[0].clone()
+        self.cur_L = L_tab[0].clone() if L_tab is not None else (eng.tensor(b.L) if b.L is not None else None)
+        self.u_nom = eng.zeros(E, eng.H) if u_nom0 is None else eng.tensor(u_nom0, (E, eng.H)).clone()
+        self.Q = eng.empty(E)
+        self.states, self.dd, self.Qs = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
+        self.states[0] = s
+        self.tail = b.n_sim - T * b.n_ctrl                                        # simulation steps after the last controller call
+        self.plant = dict(dt_sim=b.dt_simulation, period_steps=b.n_ctrl, L=None if L_tab is not None else self.cur_L,
+                          states_log=self.states, dd_log=self.dd, save_every=b.n_save, Q_log=self.Qs, target_position_table=tp_tab,
+                          target_equilibrium_table=te_tab, L_table=L_tab, sched_stride=b.stride, target_position_out=self.cur_tp,
+                          target_equilibrium_out=self.cur_te, L_out=self.cur_L if L_tab is not None else None)
+        self.counter = self.graph = None
+        self.per = 0
 
-        def control(c, counter=None):
-            if knots_fn is not None:
-                eng.step(s, u_nom, cur_tp, cur_te, L=cur_L, knots=knots_fn(c), Q_out=Q)
-            elif counter is not None:
-                eng.step(s, u_nom, cur_tp, cur_te, L=cur_L, seed=self.seed, offset_dev=counter, env_offset=env_offset, Q_out=Q)
-            else:
-                eng.step(s, u_nom, cur_tp, cur_te, L=cur_L, seed=self.seed, offset=c, env_offset=env_offset, Q_out=Q)
+    @property
+    def periods_left(self):
+        return self.c < self.T
 
-        if graph and knots_fn is None and T > 0:
-            counter = torch.zeros(1, dtype=torch.int64, device=s.device)          # controller calls made = Philox step counter
-
-            def one_period():
-                control(None, counter)
-                eng.plant_step(s, Q, b.n_ctrl, period_dev=counter, **plant)
-
-            side = torch.cuda.Stream(device=s.device)
-            side.wait_stream(torch.cuda.current_stream(s.device))
-            g = torch.cuda.CUDAGraph()
-            per = max(1, min(int(steps_per_graph), T))
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
-                    for _ in range(per):
-                        one_period()
-            torch.cuda.current_stream(s.device).wait_stream(side)
-            for _ in range(T // per):
-                g.replay()
-            for _ in range(T % per):
-                one_period()
-            control(None, counter)                                               # the run's last controller call
-            eng.plant_step(s, Q, tail, period_dev=counter, **plant)
+    def _control(self, c):
+        eng = self.eng
+        if self.knots_fn is not None:
+            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, knots=self.knots_fn(c), Q_out=self.Q)
+        elif self.counter is not None:
+            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset_dev=self.counter,
+                     env_offset=self.env_offset, Q_out=self.Q)
         else:
-            for c in range(T):
-                control(c)
-                eng.plant_step(s, Q, b.n_ctrl, period=c, **plant)
-            control(T)
-            eng.plant_step(s, Q, tail, period=T, **plant)
-        return dict(states=states, dd=dd, Q=Qs, final_state=s, u_nom=u_nom, batch=b)
+            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=c, env_offset=self.env_offset,
+                     Q_out=self.Q)
+
+    def _period(self, c):
+        self._control(c)
+        if self.counter is not None:
+            self.eng.plant_step(self.s, self.Q, self.b.n_ctrl, period_dev=self.counter, **self.plant)
+        else:
+            self.eng.plant_step(self.s, self.Q, self.b.n_ctrl, period=c, **self.plant)
+
+    def capture(self, steps_per_graph=10):
+        """Capture `steps_per_graph` control periods as ONE HIP graph (device step counter: Philox offset = schedule row =
+        recording row, no launch argument changes between periods); enqueue_next then replays it."""
+        dev = self.s.device
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)              # controller calls made
+        fixed = getattr(self.eng, "_fixed_stream_obj", None)
+        cap = torch.cuda.Stream(device=dev)
+        launch = fixed if fixed is not None else torch.cuda.current_stream(dev)
+        cap.wait_stream(launch)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        self.graph = torch.cuda.CUDAGraph()
+        self.per = max(1, min(int(steps_per_graph), self.T))
+        self.eng.use_stream(cap)
+        try:
+            with torch.cuda.stream(cap):
+                with torch.cuda.graph(self.graph, stream=cap):
+                    for _ in range(self.per):
+                        self._period(None)
+        finally:
+            self.eng.use_stream(fixed)
+        launch.wait_stream(cap)
+
+    def enqueue_next(self):
+        """The next control period(s) of the run: one period launched, or one replay of the captured graph."""
+        if self.graph is not None and self.T - self.c >= self.per:
+            fixed = getattr(self.eng, "_fixed_stream_obj", None)
+            if fixed is not None:
+                with torch.cuda.stream(fixed):
+                    self.graph.replay()
+            else:
+                self.graph.replay()
+            self.c += self.per
+        else:
+            self._period(self.c)
+            self.c += 1
+
+    def finish(self):
+        """The run's last controller call (+ the trailing simulation steps of a length that is not a whole number of periods)."""
+        assert not self.periods_left
+        self._control(self.T)
+        if self.counter is not None:
+            self.eng.plant_step(self.s, self.Q, self.tail, period_dev=self.counter, **self.plant)
+        else:
+            self.eng.plant_step(self.s, self.Q, self.tail, period=self.T, **self.plant)
+        return dict(states=self.states, dd=self.dd, Q=self.Qs, final_state=self.s, u_nom=self.u_nom, batch=self.b)

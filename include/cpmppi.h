@@ -477,6 +477,14 @@ typedef struct {
 int cpmppi_write_recordings(const char* const* paths, const char* preamble, size_t preamble_len, const cpmppi_recording* rec,
                             int n_threads);
 
+/* A HIP stream with a hardware queue OF ITS OWN (hipExtStreamCreateWithCUMask with every CU enabled): the runtime multiplexes
+ * ordinary streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams that land on the same
+ * queue run their kernels one after the other - which defeats env groups that are meant to run side by side
+ * (cartpolesimulation_amd/pipeline.py; measured: two groups of C3 on pooled streams 327 us per step, serialised, against 175 us).
+ * The returned hipStream_t is an ordinary stream for every other purpose; destroy it with cpmppi_stream_destroy. */
+int cpmppi_stream_create(int device, void** stream_out);
+int cpmppi_stream_destroy(void* stream);
+
 /* The ABI version this library was BUILT as (CPMPPI_ABI_VERSION of its header): lets a client that was compiled against another
  * header notice before it passes a struct of the wrong layout (cpmppi_create refuses a mismatching cpmppi_config.abi_version). */
 uint32_t cpmppi_abi_version(void);
