@@ -351,9 +351,27 @@ class Workload:
         i_last = warmup + steps - 1
         u_final = self.final_u_nom(i_last)
         assert torch.isfinite(u_final).all(), "non-finite nominal controls"
+        self.collective_report = None
         if self.ctx["collective"]:        # the last gather delivered this rank's block (and finite blocks from every other rank)
             last = (self.native.gathered[(i_last + 1) & 1] if self.native else self.gathered[i_last & 1]).view(W, self.E * self.H)
             assert torch.equal(last[rank], u_final.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
+            # did the collective really span W ranks?  Every rank contributes the checksum of what IT computed (one all-gather of a
+            # double through torch.distributed, outside the timed region); the W blocks this rank received through the library's
+            # communicator must carry exactly those checksums and - the envs differ per rank - be pairwise distinct.  Plus what
+            # RCCL itself reports about the communicator (ncclCommCount / ncclCommUserRank).
+            mine = u_final.double().sum().reshape(1)
+            sums = torch.empty(W, dtype=torch.float64, device=mine.device)
+            dist.all_gather_into_tensor(sums, mine)
+            got = last.double().sum(dim=1)
+            blocks_match = bool(torch.equal(got, sums))
+            distinct = bool(W == 1 or len({float(x) for x in got.tolist()}) == W)
+            info = self.native.info() if self.native else {"world": W, "rank": rank, "rccl_ranks": dist.get_world_size(),
+                                                           "rccl_rank": dist.get_rank(), "rccl_version": 0}
+            self.collective_report = {"impl": self.collective_impl, "ranks_requested": W, "rccl_ranks": info["rccl_ranks"],
+                                      "rccl_rank_of_rank0": info["rccl_rank"], "rccl_version": info.get("rccl_version"),
+                                      "stream_memory_ops": info.get("stream_memory_ops"),
+                                      "rank_blocks_match_every_ranks_own_checksum": blocks_match, "rank_blocks_distinct": distinct}
+            assert blocks_match and distinct and info["rccl_ranks"] == W, f"the collective did not span {W} ranks: {self.collective_report}"
         k_ms = float(np.mean(rollout_ms))
         E, N, H = self.E, self.N, self.H
         return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
@@ -615,10 +633,16 @@ def main():
             dist.all_gather_into_tensor(out, mine)
             assert torch.equal(out.view(world, 4)[:, 0], torch.arange(world, dtype=torch.float32))
             dist.barrier()
+            blocks = out.view(world, 4)
+            coll = {"impl": "torch.distributed all_gather_into_tensor over gloo (dry run: CPU tensors, no RCCL)", "ranks_requested": world,
+                    "rccl_ranks": None, "backend_ranks": dist.get_world_size(),
+                    "rank_blocks_distinct": bool(world == 1 or len({float(x) for x in blocks[:, 0].tolist()}) == world)}
+        else:
+            coll = None
         if rank == 0:
             print(json.dumps({"metric": f"MPPI rollouts/sec ({args.rollouts} samples x {args.horizon}-step horizon)",
                               "value": None, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "dry_run": True,
+                              "warmup": args.warmup, "dry_run": True, "config": {"collective": coll},
                               "note": "launcher / collective plumbing check on CPU (gloo); no kernel ran"}), flush=True)
         if in_rank:
             dist.destroy_process_group()
@@ -753,7 +777,7 @@ def main():
                        else "GRU-6IN-32H1-32H2-5OUT (synthetic weights)",
                        "parallelism": f"env-sharded x{world}, one RCCL all-gather of u_nom per step" if world > 1
                        else "single GPU",
-                       **({"collective": main_wl.collective_impl} if main_wl.collective_impl else {})},
+                       **({"collective": main_wl.collective_report or {"impl": main_wl.collective_impl}} if main_wl.collective_impl else {})},
             "roofline": roof or {"bound": "hbm", "kernel": "rollout_cost_kernel", "achieved": r["alg_gbs"],
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["alg_gbs"] / HBM_PEAK_GBS,
                                  "traffic": traffic, "traffic_source": (f"profiled earlier, not in this run: {traffic_src}"

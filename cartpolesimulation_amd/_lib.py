@@ -23,7 +23,7 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
            "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings", "cpmppi_plant_step",
-           "cpmppi_abi_version", "cpmppi_stream_create", "cpmppi_stream_destroy")
+           "cpmppi_abi_version", "cpmppi_stream_create", "cpmppi_stream_destroy", "cpmppi_comm_get_info")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -78,6 +78,11 @@ class cpmppi_recording(C.Structure):
                 ("Q", C.c_void_p), ("Q_ccrc", C.c_void_p), ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p),
                 ("L", C.c_void_p), ("m_pole", C.c_double), ("u_max", C.c_float), ("first_update_row", C.c_uint32),
                 ("q_update_time", C.c_double)]
+
+
+class cpmppi_comm_info(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32),
+                ("rccl_version", C.c_int32), ("stream_memory_ops", C.c_uint32), ("gathers_enqueued", C.c_uint32)]
 
 
 PREDICTOR_ODE_V0, PREDICTOR_GRU = 0, 1
@@ -152,6 +157,7 @@ def load():
     lib.cpmppi_abi_version.restype = u32
     lib.cpmppi_stream_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.cpmppi_stream_destroy.argtypes = [vp]
+    lib.cpmppi_comm_get_info.argtypes = [vp, C.POINTER(cpmppi_comm_info)]
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:

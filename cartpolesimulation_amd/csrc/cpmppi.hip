@@ -1355,6 +1355,15 @@ int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* a, float* recv_
   if (cpmppi_comm::comm_error_pending(h))
     return fail(h, CPMPPI_ERR_COMM, "cpmppi_step_gather: an earlier step's device-side wait for an all-gather timed out; "
                                     "cpmppi_comm_sync reports and clears the condition");
+  // a stream being captured would bake THIS step's number into the graph: every replay would re-publish it and the side
+  // stream's wait for the next step could never be satisfied (advisor, round 4)
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_step_gather: the launch stream is being captured; a step with its all-gather "
+                                         "carries a step number and cannot be part of a graph");
+    (void)hipGetLastError();
+  }
   const bool in_place = !a->u_nom_out || a->u_nom_out == a->u_nom;
   cpmppi_comm::GatherTicket t;
   cpmppi_comm::begin_step_gather(h->comm, in_place ? a->u_nom : a->u_nom_out, &t);

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 
 #include <rccl/rccl.h>      // types only (ncclComm_t, ncclUniqueId, ncclFloat); every function is looked up with dlsym
@@ -52,6 +53,9 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // optional: what RCCL itself says the communicator is
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
@@ -81,6 +85,9 @@ bool load_rccl(const char* path) {
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.dl, "ncclCommDestroy"));
   r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.dl, "ncclAllGather"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.dl, "ncclGetErrorString"));
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.dl, "ncclCommCount"));
+  r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.dl, "ncclCommUserRank"));
+  r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.dl, "ncclGetVersion"));
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
     r.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
     dlclose(r.dl);
@@ -143,9 +150,39 @@ hipError_t upload_slow_path_words(CommState* c) {
   return hipMemcpy(c->flags + 4, w, sizeof(w), hipMemcpyHostToDevice);
 }
 
+// Host wait for the side stream with a way out.  In stream-memory-operation mode the side stream's wait for a published step
+// (hipStreamWaitValue32) has no timeout of its own: if the rollout launch that should publish never does (it failed, it was
+// aborted), the stream would wedge and hipStreamSynchronize / hipStreamDestroy with it (advisor, round 4).  So: poll the stream up
+// to the handle's timeout; then RELEASE the wait from the host - signal memory is host-writable: the highest step number any
+// enqueued wait asks for is stored into it -, raise the error for device and host, and wait again.  The released all-gathers send
+// whatever their buffers hold; the error tells every consumer of this rank not to use them (and see cpmppi.h on the peers).
+// -> true if the escape was taken.
+bool drain_side_stream(CommState* c) {
+  if (!c->side) return false;
+  if (!c->published || c->timeout_ticks == ~0ull) { (void)hipStreamSynchronize(c->side); return false; }
+  const double limit_s = (double)c->timeout_ticks * 1.0e-8;
+  timespec t0, t;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(c->side);
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    if ((double)(t.tv_sec - t0.tv_sec) + 1.0e-9 * (double)(t.tv_nsec - t0.tv_nsec) > limit_s) break;
+    timespec nap{0, 200000};
+    nanosleep(&nap, nullptr);
+  }
+  (void)hipGetLastError();
+  __atomic_store_n(c->err_host, 1u, __ATOMIC_RELEASE);
+  const unsigned one = 1u;
+  (void)hipMemcpy(c->flags + 3, &one, sizeof(one), hipMemcpyHostToDevice);      // (the side stream is non-blocking: this copy does not queue behind it)
+  __atomic_store_n(reinterpret_cast<volatile unsigned*>(c->published), c->gather_index, __ATOMIC_RELEASE);
+  (void)hipStreamSynchronize(c->side);
+  return true;
+}
+
 void destroy(CommState* c) {
   if (!c) return;
-  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->side) (void)drain_side_stream(c);
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   if (c->ready) (void)hipEventDestroy(c->ready);
   for (hipEvent_t e : c->done)
@@ -296,7 +333,7 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
     COMM_HIP(h, hipGetLastError());
     c->pending_post = 0u;
   }
-  COMM_HIP(h, hipStreamSynchronize(c->side));
+  (void)drain_side_stream(c);          // (bounded: a side stream still waiting for a step that never publishes is released, with the error raised)
   for (bool& p : c->pending) p = false;
   if (__atomic_load_n(c->err_host, __ATOMIC_ACQUIRE) != 0u) {
     // reported once; cleared for device and host so that the handle can go on (the steps since the error left their
@@ -328,10 +365,38 @@ int cpmppi_debug_comm_delay(cpmppi_handle* h, unsigned microseconds) {
   cpmppi_internal_comm(h)->debug_delay_us = microseconds;
   return CPMPPI_OK;
 }
+// tests only: the side stream is made to wait for a step that NO launch will ever publish (what a failed or aborted rollout
+// launch leaves behind) - cpmppi_comm_sync / cpmppi_comm_destroy must get out of it
+int cpmppi_debug_comm_orphan_wait(cpmppi_handle* h) {
+  if (!h || !cpmppi_internal_comm(h)) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c->published) return 1;          // (the waiter kernel has its own timeout)
+  OnDevice guard(cpmppi_internal_device(h));
+  const unsigned g = c->gather_index;
+  COMM_HIP(h, hipStreamWaitValue32(c->side, c->published, g + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  c->gather_index = g + 1u;
+  return CPMPPI_OK;
+}
 // tests only: 1 = stream memory operations order the side stream, 0 = the fallback waiter kernel
 int cpmppi_debug_comm_mode(cpmppi_handle* h) {
   if (!h || !cpmppi_internal_comm(h)) return CPMPPI_ERR_BAD_ARG;
   return cpmppi_internal_comm(h)->published ? 1 : 0;
+}
+
+int cpmppi_comm_get_info(cpmppi_handle* h, cpmppi_comm_info* out) {
+  if (!h || !out) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_get_info: no communicator (cpmppi_comm_init)");
+  memset(out, 0, sizeof(*out));
+  out->world = (uint32_t)c->world; out->rank = (uint32_t)c->rank;
+  out->rccl_ranks = out->rccl_rank = -1;
+  int v = 0;
+  if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &v) == ncclSuccess) out->rccl_ranks = v;
+  if (g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm, &v) == ncclSuccess) out->rccl_rank = v;
+  if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == ncclSuccess) out->rccl_version = v;
+  out->stream_memory_ops = c->published ? 1u : 0u;
+  out->gathers_enqueued = c->gather_index;
+  return CPMPPI_OK;
 }
 
 int cpmppi_comm_destroy(cpmppi_handle* h) {

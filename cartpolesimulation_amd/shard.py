@@ -150,6 +150,15 @@ class NativeGather:
         e = self.engine
         e._check(e.lib.cpmppi_comm_sync(e._h))
 
+    def info(self):
+        """cpmppi_comm_get_info: what RCCL itself says the communicator is (ranks, this rank, version) next to what it was told."""
+        import ctypes as C
+        from . import _lib as _L
+        e = self.engine
+        out = _L.cpmppi_comm_info()
+        e._check(e.lib.cpmppi_comm_get_info(e._h, C.byref(out)))
+        return {n: int(getattr(out, n)) for n, _ in out._fields_}
+
     def close(self):
         e = self.engine
         if getattr(e, "_h", None) and e._h.value:

@@ -419,7 +419,23 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* str
  *   cpmppi_comm_set_timeout  how long a device-side wait of cpmppi_step_gather may last, in seconds (default 10; <= 0: for
  *                          ever): the finalize of a step that is about to overwrite a buffer an all-gather still reads
  *                          waits for that gather, which completes only when EVERY rank has joined it
+ *   cpmppi_comm_get_info   what the communicator IS, as RCCL itself reports it (ncclCommCount / ncclCommUserRank), next to what
+ *                          cpmppi_comm_init was told: a bench line can then state how many ranks the collective really spanned
+ * The wait for a published step on the side stream (hipStreamWaitValue32) has no timeout of its own and cpmppi_comm_set_timeout
+ * does not cover it; cpmppi_comm_sync and cpmppi_comm_destroy therefore poll the side stream for at most the timeout and then
+ * release the wait from the host, raise the error and return CPMPPI_ERR_COMM (a rollout launch that never published - failed,
+ * aborted - cannot wedge them).  cpmppi_step_gather refuses a stream that is being captured.
+ * PEERS: a rank whose device-side wait timed out keeps its buffers intact and its already-enqueued all-gathers still run, so the
+ * other ranks receive a well-formed but STALE block from it and no error of their own.  Treat gathered blocks as unverified until
+ * cpmppi_comm_sync has returned CPMPPI_OK on EVERY rank (exchange the return codes with the collective of your choice).
  * Errors: CPMPPI_ERR_COMM.  RCCL is bound at run time: the library loads without it. */
+typedef struct {
+  uint32_t world, rank;            /* as given to cpmppi_comm_init */
+  int32_t rccl_ranks, rccl_rank;   /* ncclCommCount / ncclCommUserRank of the communicator; -1 = this RCCL does not export them */
+  int32_t rccl_version;            /* ncclGetVersion (e.g. 22606), 0 = unknown */
+  uint32_t stream_memory_ops;      /* 1 = hipStreamWaitValue32 / WriteValue32 order the side stream, 0 = the one-lane waiter kernel */
+  uint32_t gathers_enqueued;       /* cpmppi_step_gather calls so far */
+} cpmppi_comm_info;
 #define CPMPPI_COMM_ID_BYTES 128
 #define CPMPPI_COMM_SLOTS 4
 int cpmppi_comm_unique_id(void* id_out, const char* rccl_path);
@@ -429,6 +445,7 @@ int cpmppi_comm_wait(cpmppi_handle* h, uint32_t slot, void* stream);
 int cpmppi_comm_sync(cpmppi_handle* h);
 int cpmppi_comm_set_timeout(cpmppi_handle* h, double seconds);
 int cpmppi_comm_destroy(cpmppi_handle* h);
+int cpmppi_comm_get_info(cpmppi_handle* h, cpmppi_comm_info* out);
 
 /* cpmppi_step + the all-gather of its result in ONE call - the production form of the per-step collective:
  * recv_all[world][E*H] <- all-gather of the nominal sequences this step writes (args->u_nom_out, or args->u_nom when the

@@ -34,6 +34,13 @@ def test_gpus_flag_starts_that_many_ranks(n):
     out = _line(r.stdout)
     assert out["n_gpus"] == n and out["steps"] == 4 and out["warmup"] == 1
     assert out["value"] is None and out["dry_run"] is True
+    # the line says what the collective spanned (a real run: what RCCL itself reports through ncclCommCount)
+    coll = out["config"]["collective"]
+    if n == 1:
+        assert coll is None                              # a single process: no rendezvous, no collective
+    else:
+        assert coll["ranks_requested"] == n and coll["backend_ranks"] == n and coll["rank_blocks_distinct"] is True
+        assert coll["rccl_ranks"] is None and "gloo" in coll["impl"]
 
 
 def test_rank_count_must_match_gpus_flag():

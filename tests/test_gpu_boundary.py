@@ -689,6 +689,59 @@ def test_step_gather_timeout_drops_the_step_and_reaches_the_host(waiter, monkeyp
     g.close(); eng.close(); ref.close()
 
 
+def test_comm_sync_and_destroy_escape_a_wait_that_nothing_will_satisfy():
+    """advisor r4: in stream-memory-operation mode the side stream's wait for a published step has no timeout of its own.  A step
+    that never publishes (here: an orphan wait enqueued by a test hook) must not wedge cpmppi_comm_sync / cpmppi_comm_destroy:
+    they poll for the handle's timeout, release the wait from the host, and report CPMPPI_ERR_COMM; the handle works afterwards.
+    And cpmppi_step_gather refuses a stream that is being captured (a graph would re-publish a baked step number)."""
+    import time
+    from cartpolesimulation_amd import _lib as L
+    eng, ref, g, s0, tp, te = _gather_setup(seed=63)
+    E, H = eng.E, eng.H
+    if eng.lib.cpmppi_debug_comm_mode(eng._h) != 1:
+        pytest.skip("no stream memory operations on this device")
+    u, u_ref = eng.zeros(E, H), ref.zeros(E, H)
+    recv = torch.zeros(1, E * H, device=u.device)
+    eng.step(s0, u, tp, te, seed=5, offset=0, gather_into=recv)
+    ref.step(s0, u_ref, tp, te, seed=5, offset=0)
+    g.sync()
+    assert torch.equal(recv.view(E, H), u_ref)
+    assert eng.lib.cpmppi_comm_set_timeout(eng._h, 0.05) == 0
+    assert eng.lib.cpmppi_debug_comm_orphan_wait(eng._h) == 0          # the side stream now waits for a step nobody launches
+    t0 = time.perf_counter()
+    with pytest.raises(L.CpmppiError) as ei:
+        g.sync()
+    dt = time.perf_counter() - t0
+    assert ei.value.code == -6 and 0.04 < dt < 5.0, dt                 # bounded by the timeout, not for ever
+    g.sync()                                                           # reported once, cleared
+    eng.lib.cpmppi_comm_set_timeout(eng._h, 10.0)
+    for i in (1, 2):                                                   # the handle and its communicator work again
+        eng.step(s0, u, tp, te, seed=5, offset=i, gather_into=recv)
+        ref.step(s0, u_ref, tp, te, seed=5, offset=i)
+    g.sync()
+    assert torch.equal(u, u_ref) and torch.equal(recv.view(E, H), u_ref)
+    info = g.info()
+    assert info["world"] == 1 and info["rccl_ranks"] == 1 and info["rccl_rank"] == 0 and info["stream_memory_ops"] == 1
+    assert info["gathers_enqueued"] == 4 and info["rccl_version"] > 20000
+    # a captured launch stream is refused
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(L.CpmppiError) as ei:
+            with torch.cuda.graph(graph, stream=side):
+                eng.step(s0, u, tp, te, seed=5, offset=3, gather_into=recv)
+    assert ei.value.code == -1 and "captured" in str(ei.value)
+    torch.cuda.current_stream().wait_stream(side)
+    # destroy with an orphan wait pending: returns (bounded), does not hang
+    assert eng.lib.cpmppi_comm_set_timeout(eng._h, 0.05) == 0
+    assert eng.lib.cpmppi_debug_comm_orphan_wait(eng._h) == 0
+    t0 = time.perf_counter()
+    g.close()
+    assert time.perf_counter() - t0 < 5.0
+    eng.close(); ref.close()
+
+
 def test_failed_step_leaves_the_event_recorder_intact():
     """A step that fails validation while profiling is on (GRU requested without a model) must not leave a half-recorded
     bracket: the steps before and after it are still reported."""

@@ -25,27 +25,28 @@ from cartpolesimulation_amd.configs import MPPIConfig  # noqa: E402
 from cartpolesimulation_amd.engine import MPPIEngine  # noqa: E402
 
 
-class Group:
-    def __init__(self, e0, e1, N, H, rpl, s0, tp, te, Lt, stream, seed):
-        self.eng = MPPIEngine(e1 - e0, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=rpl))
-        self.u = self.eng.zeros(e1 - e0, H)
-        self.Q = self.eng.empty(e1 - e0)
-        self.stream = stream
-        with torch.cuda.stream(stream):
-            self.prep = self.eng.prepare_step(s0[e0:e1].contiguous(), self.u, tp[e0:e1].contiguous(), te[e0:e1].contiguous(),
-                                              L=Lt[e0:e1].contiguous(), seed=seed, offset=0, env_offset=e0, Q_out=self.Q)
+class Groups:
+    """pipeline.EnvGroups (dedicated-queue streams, prepared argument blocks) over the synthetic inputs."""
+
+    def __init__(self, E, N, H, G, rpl, s0, tp, te, Lt, seed):
+        from cartpolesimulation_amd.pipeline import EnvGroups
+        self.g = EnvGroups(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=rpl), G)
+        self.u = torch.zeros(E, H, device=s0.device)
+        self.Q = torch.empty(E, device=s0.device)
+        self.preps = self.g.prepare_step(s0, self.u, tp, te, L=Lt, seed=seed, Q_out=self.Q)
+        self.g.fork()
+        self.eng = self.g.engines[0]
 
 
 def run(groups, K, offset0=0):
     """K steps of every group, enqueued round-robin; returns the wall time per step of all envs (seconds)."""
-    for g in groups:
-        g.u.zero_()
+    groups.u.zero_()
     torch.cuda.synchronize()
+    groups.g.fork()
     t0 = time.perf_counter()
     for i in range(K):
-        for g in groups:
-            with torch.cuda.stream(g.stream):
-                g.prep.run(offset=offset0 + i)
+        for p in groups.preps:
+            p.run(offset=offset0 + i)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / K
 
@@ -64,28 +65,17 @@ def main():
     E, N, H = args.envs, args.rollouts, args.horizon
     dev = torch.device("cuda", 0)
     s0, tp, te, Lt = synthetic_inputs(E, H, 3, dev)
-    setups = {}
-    for G in args.groups:
+    res, sums = {}, {}
+    for G in args.groups:                                      # (one set of groups alive at a time: every stream owns a hardware queue)
         for rpl in args.rpl:
-            if E % G:
+            if G > E:
                 continue
-            streams = [torch.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else [torch.cuda.current_stream(dev)]
-            per = E // G
-            setups[(G, rpl)] = [Group(g * per, (g + 1) * per, N, H, rpl, s0, tp, te, Lt, streams[g], 1234) for g in range(G)]
-    torch.cuda.synchronize()
-    # bit-identity across splits (same lane mapping): the nominal sequences after 3 steps
-    sums = {}
-    for key, groups in setups.items():
-        run(groups, 3)
-        sums[key] = torch.cat([g.u for g in groups]).double().abs().sum().item()
-        info = groups[0].eng.last_launch()
-        sums[key] = (sums[key], info["kernel"], info["blocks"])
-    res = {k: [] for k in setups}
-    for rnd in range(args.rounds):
-        for key, groups in setups.items():
-            t = run(groups, args.steps)
-            if rnd:
-                res[key].append(t * 1e6)
+            groups = Groups(E, N, H, G, rpl, s0, tp, te, Lt, 1234)
+            run(groups, 3)                                     # checksum of the nominal sequences after 3 steps: the split changes nothing
+            info = groups.eng.last_launch()
+            sums[(G, rpl)] = (groups.u.double().abs().sum().item(), info["kernel"], info["blocks"])
+            res[(G, rpl)] = [run(groups, args.steps) * 1e6 for _ in range(args.rounds)][1:]
+            groups.g.close()
     print(f"E={E} N={N} H={H}: wall time per step of all {E} envs, us (median / min over {args.rounds - 1} rounds of {args.steps} steps)")
     out = []
     for (G, rpl), v in res.items():
