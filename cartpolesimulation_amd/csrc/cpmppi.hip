@@ -1025,7 +1025,9 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
 static uint64_t lone_form_max_waves() { return env_u64("CPMPPI_LONE_FORM_MAX_WAVES", 1024ull); }
-static uint64_t latency_max_rollouts() { return env_u64("CPMPPI_LATENCY_MAX_ROLLOUTS", 65536ull); }
+// (round 5, tools/variant_sweep.py: between 65536 and 131072 rollouts - where the size rule still picks one rollout per lane - the
+// straight-line latency build beats the throughput build's loop: 48 x 2048 x 50 71.3 vs 79.8 us, 96 x 1024 x 50 74.9 vs 83.3)
+static uint64_t latency_max_rollouts() { return env_u64("CPMPPI_LATENCY_MAX_ROLLOUTS", 131071ull); }
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                                const Params& p, const StepPtrs& a, uint32_t* variant_out) {

@@ -374,6 +374,7 @@ int cpmppi_debug_comm_orphan_wait(cpmppi_handle* h) {
   OnDevice guard(cpmppi_internal_device(h));
   const unsigned g = c->gather_index;
   COMM_HIP(h, hipStreamWaitValue32(c->side, c->published, g + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  COMM_HIP(h, hipStreamWriteValue32(c->side, c->flags + 2, g + 1u, 0));     // (what follows a step's wait: its gather's completion)
   c->gather_index = g + 1u;
   return CPMPPI_OK;
 }

@@ -251,7 +251,7 @@ class MPPIEngine:
 
     def plant_step(self, s, Q, n_substeps, dt_sim=0.002, period=0, period_dev=None, period_steps=None, L=None, states_log=None,
                    dd_log=None, save_every=None, Q_log=None, target_position_table=None, target_equilibrium_table=None,
-                   L_table=None, sched_stride=1, target_position_out=None, target_equilibrium_out=None, L_out=None):
+                   L_table=None, sched_stride=1, target_position_out=None, target_equilibrium_out=None, L_out=None, _prepare=False):
         """cpmppi_plant_step: one control period of the simulated cartpoles with the experiment schedule and the recording in the
         same launch (include/cpmppi.h).  ``s`` [E,6] in place under held ``Q`` [E]; logs ``states_log`` [rows,E,6], ``dd_log``
         [rows,E,2], ``Q_log`` [periods,E]; schedule tables [sched_rows,E] sampled every ``sched_stride`` simulation steps; ``*_out``
@@ -297,10 +297,17 @@ class MPPIEngine:
         outs = [dev(n, t.reshape(E, 1) if t is not None else None, (1,)) for n, t in (
             ("target_position_out", target_position_out), ("target_equilibrium_out", target_equilibrium_out), ("L_out", L_out))]
         a.target_position_out, a.target_equilibrium_out, a.L_out = [t.data_ptr() if t is not None else None for t in outs]
-        keep = (Q, Lt)                                                   # (alive until the launch is enqueued)
+        keep = (s, Q, Lt, period_dev, states_log, dd_log, Q_log, tabs, outs)
+        if _prepare:
+            return PreparedPlantStep(self, a, keep)
         self._check(self.lib.cpmppi_plant_step(self._h, C.byref(a), self._stream()))
         del keep
         return s
+
+    def prepare_plant_step(self, *args, **kwargs):
+        """The argument block of ``plant_step(...)`` built and validated ONCE (a closed loop calls it every control period with the
+        same buffers): ``.run(period=..., n_substeps=...)`` only updates those two fields and enqueues the launch."""
+        return self.plant_step(*args, _prepare=True, **kwargs)
 
     # ------------------------------------------------------------------ GRU predictor (BASELINE configs[4])
     GRU_KEYS = ("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "w_out", "b_out")
@@ -560,6 +567,21 @@ class MPPIEngine:
         (the host seam's staging block, a closed loop): ``.run(offset=...)`` only updates the Philox step counter and
         enqueues the launch - the per-call argument handling of ``step`` is ~10 us of a 55 us control step."""
         return self.step(*args, _prepare=True, **kwargs)
+
+
+class PreparedPlantStep:
+    """A validated cpmppi_plant_step argument block plus the tensors it points into (MPPIEngine.prepare_plant_step)."""
+
+    def __init__(self, engine, args, keep):
+        self.engine, self.args, self._keep = engine, args, keep
+
+    def run(self, period=None, n_substeps=None):
+        if period is not None:
+            self.args.period = int(period)
+        if n_substeps is not None:
+            self.args.n_substeps = int(n_substeps)
+        e = self.engine
+        e._check(e.lib.cpmppi_plant_step(e._h, C.byref(self.args), e._stream()))
 
 
 class PreparedStep:

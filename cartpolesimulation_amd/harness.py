@@ -144,6 +144,7 @@ class ScheduleRun:
                           target_equilibrium_out=self.cur_te, L_out=self.cur_L if L_tab is not None else None)
         self.counter = self.graph = None
         self.per = 0
+        self._prep = self._prep_plant = None                       # argument blocks built once (the launched Philox loop)
 
     @property
     def periods_left(self):
@@ -161,6 +162,16 @@ class ScheduleRun:
                      Q_out=self.Q)
 
     def _period(self, c):
+        if self.counter is None and self.knots_fn is None:
+            # the launched loop: two library calls per period on argument blocks built once (the Python-side argument handling of
+            # step + plant_step is ~30 us per period - more than the GPU needs for a few dozen envs)
+            if self._prep is None:
+                self._prep = self.eng.prepare_step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=0,
+                                                   env_offset=self.env_offset, Q_out=self.Q)
+                self._prep_plant = self.eng.prepare_plant_step(self.s, self.Q, self.b.n_ctrl, period=0, **self.plant)
+            self._prep.run(offset=c)
+            self._prep_plant.run(period=c)
+            return
         self._control(c)
         if self.counter is not None:
             self.eng.plant_step(self.s, self.Q, self.b.n_ctrl, period_dev=self.counter, **self.plant)

@@ -724,6 +724,7 @@ def test_comm_sync_and_destroy_escape_a_wait_that_nothing_will_satisfy():
     assert info["world"] == 1 and info["rccl_ranks"] == 1 and info["rccl_rank"] == 0 and info["stream_memory_ops"] == 1
     assert info["gathers_enqueued"] == 4 and info["rccl_version"] > 20000
     # a captured launch stream is refused
+    s0, tp, te = eng.tensor(s0), eng.tensor(tp), eng.tensor(te)     # (no upload inside the capture)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     graph = torch.cuda.CUDAGraph()

@@ -1,32 +1,57 @@
-import sys, time, tempfile, shutil, torch
-sys.path.insert(0, '/root/repo')
-from cartpolesimulation_amd.configs import legacy_mppi_config
-from cartpolesimulation_amd.engine import MPPIEngine
-from cartpolesimulation_amd import recording as R
-from cartpolesimulation_amd import harness as Hn
-E = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-eng = MPPIEngine(E, legacy_mppi_config(num_rollouts=3500, mpc_horizon=35))
-out = tempfile.mkdtemp()
-# time the device loop alone
-import numpy as np
-rng = np.random.Generator(np.random.SFC64(0))
-s0 = Hn.generate_random_initial_states(E, rng, eng.phys.TrackHalfLength)
-exp = Hn.BatchedCartPoleExperiment(eng, seed=0)
-exp.run(s0, 20); torch.cuda.synchronize()
-t0 = time.perf_counter(); res = exp.run(s0, 500); torch.cuda.synchronize(); t1 = time.perf_counter()
-print(f"device loop: {E} envs x 500 control steps (10 s each) in {t1 - t0:.2f} s = {E * 500 / (t1 - t0):.3g} control steps/s")
+"""Development tool (GPU): end-to-end time of the batched data generator (schedule tabulation, device loop, recording block, native
+writer) for E experiments of `length` seconds with the reference's shipped MPPI size (3500 x 35), launched / graph-replayed / as env
+groups.  python tools/dev/gen_time.py [E] [length]"""
 import os
-for native in (True, False):
-    t0 = time.perf_counter(); paths = R.generate_dataset(eng, E, 10.0, out, seed=0, native=native); t1 = time.perf_counter()
-    print(f"generate_dataset total ({'native writer' if native else 'python csv module'}): {t1 - t0:.2f} s for {len(paths)} files "
-          f"({sum(os.path.getsize(p) for p in paths) / 1e6:.1f} MB)")
-# the writer alone, on the recording of the run above, by thread count
-Lv = np.full(E, eng.phys.L, np.float32)
-block = R._host_block(res, Lv, eng.phys)
-header = R.create_csv_header(10.0, 0.002, 0.02, 0.02, "mpc", "mppi", eng.phys)
-for nt in (1, 4, 16, 0):
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cartpolesimulation_amd import recording as R  # noqa: E402
+from cartpolesimulation_amd import schedule as SC  # noqa: E402
+from cartpolesimulation_amd.configs import legacy_mppi_config  # noqa: E402
+from cartpolesimulation_amd.engine import MPPIEngine  # noqa: E402
+from cartpolesimulation_amd.harness import BatchedCartPoleExperiment  # noqa: E402
+from cartpolesimulation_amd.pipeline import EnvGroups, run_schedule_groups  # noqa: E402
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+length = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+mppi = legacy_mppi_config(num_rollouts=3500, mpc_horizon=35)
+eng = MPPIEngine(E, mppi)
+cfg = dict(seed=1, length_of_experiment=length)
+t0 = time.perf_counter()
+batch = SC.RandomExperimentSetter(cfg).draw(E, 2)
+print(f"schedule tables for {E} experiments x {length} s ({batch.target_position.shape[0]} rows): {time.perf_counter() - t0:.3f} s")
+exp = BatchedCartPoleExperiment(eng, seed=1)
+for name, fn in (("launched", lambda: exp.run_schedule(batch)), ("graph of 10 periods", lambda: exp.run_schedule(batch, graph=True))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); res = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"device loop, {name}: {batch.n_periods + 1} controller calls x {E} envs in {dt:.3f} s = {E * (batch.n_periods + 1) / dt:.3g} control steps/s "
+          f"({dt / (batch.n_periods + 1) * 1e6:.1f} us per period)")
+for G in (2, 4):
+    g = EnvGroups(E, mppi, G)
+    run_schedule_groups(g, batch, 1); torch.cuda.synchronize()
+    t0 = time.perf_counter(); res_g = run_schedule_groups(g, batch, 1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"device loop, {G} env groups: {dt:.3f} s = {E * (batch.n_periods + 1) / dt:.3g} control steps/s ({dt / (batch.n_periods + 1) * 1e6:.1f} us per period)")
+    g.close()
+t0 = time.perf_counter(); block = R.recording_block(res, eng.phys); print(f"recording block (device -> host, per-row columns): {time.perf_counter() - t0:.3f} s")
+out = tempfile.mkdtemp()
+header = R.create_csv_header(length, 0.002, 0.02, 0.02, "mpc", "mppi", eng.phys)
+for nt in (1, 0):
     paths = [os.path.join(out, f"w{nt}_{e}.csv") for e in range(E)]
     t0 = time.perf_counter()
-    R.write_recordings_native(paths, block, 0.02, np.zeros(E, np.float32), np.ones(E, np.float32), Lv, eng.phys, header, n_threads=nt)
-    print(f"cpmppi_write_recordings alone, n_threads={nt or 'auto'}: {time.perf_counter() - t0:.3f} s")
+    R.write_recordings_native(paths, block, eng.phys, header, n_threads=nt)
+    print(f"cpmppi_write_recordings, n_threads={nt or 'auto'}: {time.perf_counter() - t0:.3f} s ({sum(os.path.getsize(p) for p in paths) / 1e6:.1f} MB)")
+t0 = time.perf_counter()
+R.write_recording(os.path.join(out, "py.csv"), R.typed_columns(block, 0, eng.phys), header=header)
+print(f"one file through Python's csv module: {time.perf_counter() - t0:.3f} s (x {E} files)")
+for groups in (1, 2):
+    d = tempfile.mkdtemp()
+    t0 = time.perf_counter(); paths = R.generate_dataset(eng, E, d, config=cfg, groups=groups); dt = time.perf_counter() - t0
+    print(f"generate_dataset end to end, groups={groups}: {dt:.2f} s for {len(paths)} files")
+    shutil.rmtree(d)
 shutil.rmtree(out)
