@@ -265,3 +265,60 @@ def equilibrium_table(times, steps, te0, keep_up, keep_down):
                 k += 1
         out[:, cols] = seq[:, None]
     return out
+
+
+def parameter_table(updater, times, py_random=None, np_random=None):
+    """A physical parameter that changes in time (cartpole_physical_parameters.yml `L:` / `m_pole:` blocks; CartPole/parameter_updater.py
+    ParameterUpdater, called by CartPole.update_parameters at the START of every simulation step with the time BEFORE the step,
+    CartPole/__init__.py:529-537) -> float32 [len(times)]: entry g is the value the simulator holds DURING step g (entry 0: the
+    initial value).  Modes as in the reference: 'constant', 'increase', 'bounce', 'random walk', 'random', 'random_gaussian';
+    `change_every_x_seconds` (empty = every step), `reset_every_x_seconds`, `range_clip`.  The value is carried in float32 (the
+    reference keeps it in a 0-d float32 array: `current + increment` and the clip are float32 operations).  Random modes draw from
+    `py_random` (random.Random: the reference uses the module-level random()) / `np_random` (numpy RandomState: np.random.uniform /
+    normal); seeded like the reference's globals they give the reference's own sequence."""
+    import random as _random
+    u = dict(updater)
+    inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                      # noqa: E731
+    change_every, reset_every = inf(u["change_every_x_seconds"]), inf(u["reset_every_x_seconds"])
+    mode, increment, clip = u["mode"], u["increment"], u["range_clip"]
+    py_random = py_random or _random.Random(0)
+    np_random = np_random or np.random.RandomState(0)
+    init = u["init_value"]
+    if init == "random":
+        init = np_random.uniform(*u["range_random"])
+    cur = f32(init)
+    last_change = last_reset = 0.0
+    direction = 1
+    out = np.empty(len(times), f32)
+    out[0] = cur
+    for g in range(1, len(times)):
+        t = times[g - 1]
+        if change_every and t - last_change < change_every:
+            pass
+        elif reset_every and mode != "constant" and t - last_reset >= reset_every:
+            last_reset = t
+            cur = f32(init)
+        else:
+            last_change = t
+            if mode in ("random", "random_gaussian"):
+                cur = f32(np_random.uniform(*u["range_random"]) if mode == "random" else np_random.normal(init, increment))
+                out[g] = cur
+                continue
+            if mode == "constant":
+                inc = 0.0
+            elif mode == "random walk":
+                inc = (1.0 if py_random.random() < 0.5 else -1.0) * increment
+            elif mode == "increase":
+                inc = increment
+            elif mode == "bounce":
+                inc = direction * increment
+                nxt = cur + f32(inc)
+                if nxt >= clip[1] or nxt <= clip[0]:
+                    direction = -direction
+            else:
+                raise ValueError("mode with value {} not valid".format(mode))
+            cur = cur + f32(inc)
+            if clip:
+                cur = f32(np.clip(cur, f32(clip[0]), f32(clip[1])))
+        out[g] = cur
+    return out

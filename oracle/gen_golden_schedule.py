@@ -159,10 +159,14 @@ class CallLog:
         return Q
 
 
-def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None):
+def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None, L_updater=None):
     DG.load_config = lambda name: copy.deepcopy(cfg)
     if p_Q is not None:                                            # (cartpole_physical_parameters.yml `actuator_noise`, read at :83)
         LEG.p_Q = p_Q
+    shipped_L = copy.deepcopy(APP.config["cartpole"]["L"])
+    if L_updater is not None:                                      # (cartpole_physical_parameters.yml `L:` block, read by CartPole.__init__ :120)
+        APP.config["cartpole"]["L"] = dict(L_updater)
+        out[f"{tag}/L_updater"] = np.array(json.dumps(L_updater))
     RES = DG.random_experiment_setter()
     out[f"{tag}/config"] = np.array(json.dumps(cfg))
     out[f"{tag}/N"], out[f"{tag}/H"], out[f"{tag}/ctrl_seed"] = np.int64(N), np.int64(H), np.int64(ctrl_seed)
@@ -205,16 +209,29 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
         for name in ("s", "time", "tp", "te", "L", "Q", "u", "minS"):
             out[f"{key}/call/{name}"] = np.array([c[name] for c in calls])
         out[f"{key}/interpolation_type"] = np.array(inst_interp[-1])
+        if L_updater is not None:
+            out[f"{key}/L_steps"] = np.array(L_log[-1], dtype=np.float64)   # float(L) after every update_parameters call (one per simulation step)
         print(f"{key}: {len(data)} rows, {len(calls)} controller calls, interpolation {inst_interp[-1]}, "
               f"te flips at rows {np.flatnonzero(np.diff(data['target_equilibrium'].to_numpy()) != 0) + 1}, "
               f"target range [{data['target_position'].min():.4f}, {data['target_position'].max():.4f}]")
+    APP.config["cartpole"]["L"] = shipped_L
 
 
-inst_interp = []
+inst_interp, L_log = [], []
 
 
 def inst_run(inst, d):
     inst_interp.append(inst.interpolation_type)
+    # the pole length the simulator holds after each update_parameters call (CartPole/__init__.py:529-537): an instance attribute in
+    # front of the bound method records it, the method itself is the reference's
+    steps, inner = [], inst.update_parameters
+
+    def update_parameters():
+        inner()
+        steps.append(float(APP.L))
+
+    inst.update_parameters = update_parameters
+    L_log.append(steps)
     stderr = sys.stderr
     sys.stderr = io.StringIO()                                     # (tqdm's progress bar)
     try:
@@ -249,5 +266,11 @@ if __name__ == "__main__":
     # but the controller's own update stands between its nominal sequence and the plant - what a device-resident loop computes
     gen_experiments(out, "exp_device", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=79, length_of_experiment=0.5)), 2, 900,
                     ctrl_seed=4321, p_Q=0.0)
+    # a pole length that changes DURING the experiment (every 7 simulation steps, inside control periods): the plant's order of events
+    # with update_parameters, and the recording's L column
+    gen_experiments(out, "exp_varL", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=80, length_of_experiment=0.4)), 1, 950,
+                    ctrl_seed=777, p_Q=0.0,
+                    L_updater=dict(init_value=0.395, change_every_x_seconds=0.014, mode="bounce", range_random=[0.2, 0.5], range_clip=[0.36, 0.43],
+                                   increment=0.01, reset_every_x_seconds="inf"))
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
     print("wrote", os.path.join(OUT, "schedule.npz"), len(out), "arrays")

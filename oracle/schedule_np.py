@@ -212,14 +212,16 @@ def schedule_tables(trace, te0, length, dt_sim, keep_up, keep_down):
     return times, tp, te
 
 
-def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS):
+def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L_steps=None):
     """One experiment as CartPole.run_cartpole_random_experiment runs it (noise, latency, disturbance OFF as shipped).
-    controller_step(s, time, target_position, target_equilibrium, L) -> Q.  Returns dict(rows: column -> list, calls)."""
+    controller_step(s, time, target_position, target_equilibrium, L) -> Q.  Returns dict(rows: column -> list, calls).
+    ``L_steps`` [n + 1]: a pole length that changes in time - entry g is what the simulator holds DURING simulation step g
+    (update_parameters is the first thing update_state does, CartPole/__init__.py:285, 529-537); entry 0 the initial value."""
     c = config
     dt_sim = c["dt"]["simulation"]
     n_ctrl = max(1, int(np.rint(c["dt"]["control"] / dt_sim)))                                  # :909-916
     n_save = max(1, int(np.rint(c["dt"]["saving"] / dt_sim)))                                   # :925-933
-    Lf = float(p.L if L is None else L)
+    Lf = float(p.L if L is None else L) if L_steps is None else float(L_steps[0])
     inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                          # noqa: E731
     times, tp_g, te_g = schedule_tables(setup["trace"], setup["target_equilibrium"], c["length_of_experiment"], dt_sim,
                                         inf(c["keep_target_equilibrium_x_seconds_up"]), inf(c["keep_target_equilibrium_x_seconds_down"]))
@@ -228,10 +230,10 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS):
 
     def control(g):
         Q = controller_step(s.copy(), times[g], tp_g[g], te_g[g], Lf)
-        calls.append(dict(s=s.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q)))
+        calls.append(dict(s=s.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q), L=Lf))
         return f32(Q)
 
-    rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium")}
+    rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium", "L")}
     Q_ccrc = f32(0.0)                                                                           # :838
     Q = control(0)                                                                              # set_cartpole_state_at_t0 :842-852
     aDD, xDD = O.plant_ode(s, Q, Lf, p)                                                         # :859-860
@@ -239,11 +241,13 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS):
     def save(g):
         rows["time"].append(times[g]); rows["s"].append(s.copy()); rows["angleDD"].append(aDD); rows["positionDD"].append(xDD)
         rows["Q"].append(Q); rows["Q_ccrc"].append(Q_ccrc); rows["u"].append(O.Q2u(Q, p))
-        rows["target_position"].append(tp_g[g]); rows["target_equilibrium"].append(te_g[g])
+        rows["target_position"].append(tp_g[g]); rows["target_equilibrium"].append(te_g[g]); rows["L"].append(Lf)
 
     save(0)                                                                                     # :875 (the t = 0 row)
     ctrl_counter = save_counter = 0
     for g in range(1, len(times)):                                                              # update_state, :283-324
+        if L_steps is not None:
+            Lf = float(L_steps[g])                                                              # update_parameters
         s = O.plant_substep(s, aDD, xDD, dt_sim, Lf, p)                                         # integration, bounce, cos/sin, wrap
         ctrl_counter += 1
         if ctrl_counter == n_ctrl:                                                              # Update_Q :475-527

@@ -202,6 +202,72 @@ def test_reference_experiments_host_paced(g, tag, i):
     eng.close()
 
 
+def test_reference_experiment_with_a_changing_pole_length_on_the_device_loop(g):
+    """exp_varL: the reference's simulator with its pole-length updater switched on ('bounce', a change every 7 simulation steps,
+    i.e. INSIDE control periods).  schedule.parameter_table gives the per-step table, harness.run_schedule runs the experiment with
+    it - plant, schedule, recording on the GPU; the controller keeps predicting with the default length, as the reference's legacy
+    controller does.  To 1e-4 over the first ten control steps; the recording's L column exactly."""
+    import dataclasses
+    from cartpolesimulation_amd import recording as R
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import ScheduleRun
+    tag, key = "exp_varL", "exp_varL/0"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    cfg["dt"]["saving"] = cfg["dt"]["simulation"]                      # (a pole-length table is per simulation step: stride 1)
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    b = SC.RandomExperimentSetter(cfg).draw(1, int(g[f"{tag}/cartpole_seed0"]))
+    Ltab = SC.parameter_table(json.loads(g[f"{tag}/L_updater"].item()), b.times)
+    b = dataclasses.replace(b, L_table=Ltab[:, None].copy())
+    eng = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H))
+    rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"])))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    stdev = np.float64(g[f"{tag}/stdev"])
+
+    def knots(_c):
+        kn = O.sample_knots(rng, N, H, stdev)
+        rng.uniform(-1.0, 1.0)
+        return kn[None]
+
+    un = eng.zeros(1, H)
+    eng.step(g[f"{key}/call/s"][0][None], un, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+    run = ScheduleRun(eng, b, 0, knots_fn=knots, u_nom0=un)
+    # the legacy controller ignores the pole length it is told (its predictor is configured without variable_parameters,
+    # controller_mppi_cartpole.py:51-52): the controller's L vector is pinned to the default, the PLANT follows the table
+    run.plant["L_out"] = None
+    run.cur_L = None
+    while run.periods_left:
+        run.enqueue_next()
+    res = run.finish()
+    blk = R.recording_block(res, eng.phys)
+    n_save_ref = 2                                                     # the fixture saved every 4 ms = every second simulation step
+    st = blk["states"][::n_save_ref, 0]
+    col = lambda n: g[f"{key}/col/{n}"]                                # noqa: E731
+    assert np.array_equal(blk["L"][::n_save_ref, 0].astype(np.float64), col("L")) and len(np.unique(col("L"))) > 8
+    K = 10
+    r = K * b.n_ctrl // n_save_ref + 1
+    Qc = res["Q"].cpu().numpy()[:, 0]
+    np.testing.assert_allclose(Qc[:K + 1], g[f"{key}/call/Q"][1:K + 2], atol=1e-4)
+    for j, n in enumerate(("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")):
+        np.testing.assert_allclose(st[:r, j], col(n)[:r], atol=2e-4, rtol=1e-4, err_msg=n)
+    np.testing.assert_allclose(blk["dd"][::n_save_ref, 0, 0][:r], col("angleDD")[:r], atol=5e-3, rtol=1e-3)
+    # teeth: with the pole length held constant the plant's angular acceleration is off by far more than the tolerance
+    b0 = dataclasses.replace(b, L_table=None)
+    rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"])))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    un0 = eng.zeros(1, H)
+    eng.step(g[f"{key}/call/s"][0][None], un0, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+    run0 = ScheduleRun(eng, b0, 0, knots_fn=knots, u_nom0=un0)
+    while run0.periods_left:
+        run0.enqueue_next()
+    dd0 = run0.finish()["dd"].cpu().numpy()[::n_save_ref, 0, 0]
+    assert np.abs(dd0[:r] - col("angleDD")[:r]).max() > 0.05
+    eng.close()
+
+
 @pytest.mark.parametrize("E,N,H,cost,dt_save", [(5, 512, 20, "default", 0.004), (3, 256, 15, "quadratic_boundary_grad_minimal", 0.04),
                                                  (1600, 1024, 20, "quadratic_boundary_grad_minimal", 0.02)])
 def test_graph_replayed_schedule_equals_the_launched_loop(E, N, H, cost, dt_save):

@@ -119,3 +119,35 @@ def test_row_and_call_counts_follow_the_time_scales(g):
         assert len(g[f"{key}/col/time"]) == n // n_save + 1
         assert len(g[f"{key}/call/time"]) == 2 + n // n_ctrl
         assert n_ctrl / n_save == per_call
+
+
+def test_experiment_with_a_pole_length_that_changes_during_control_periods(g):
+    """exp_varL: the reference's simulator with its L updater in 'bounce' mode, a change every 7 simulation steps (inside control
+    periods).  The oracle's loop with the recorded per-step pole length reproduces the plant (update_parameters is the first thing a
+    simulation step does), the recording's L column exactly, and the closed loop to 1e-4 over the first controller calls."""
+    tag, key = "exp_varL", "exp_varL/0"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    st = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]))))
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    ctrl = O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]), N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))
+    cs = g[f"{key}/call/s"]
+    ctrl.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+    L_steps = np.concatenate([[float(f32(0.395))], g[f"{key}/L_steps"]])
+    assert len(np.unique(L_steps)) > 10
+    # (the legacy controller predicts with the default pole length whatever the simulator tells it: its module-level predictor is
+    # configured without variable_parameters, controller_mppi_cartpole.py:51-52)
+    out = S.run_experiment(st, cfg, lambda s, t, tp, te, L: ctrl.step(s, f32(tp), L=O.DEFAULT_PARAMS.L), L_steps=L_steps)
+    rows, calls = out["rows"], out["calls"]
+    assert np.array_equal(rows["L"], g[f"{key}/col/L"]) and np.array_equal(np.array([c["L"] for c in calls]), g[f"{key}/call/L"][1:])
+    assert np.array_equal(rows["time"], g[f"{key}/col/time"]) and np.array_equal(rows["target_position"], g[f"{key}/col/target_position"])
+    K = 12
+    np.testing.assert_allclose(np.array([c["Q"] for c in calls])[:K], g[f"{key}/call/Q"][1:K + 1], atol=1e-4)
+    np.testing.assert_allclose(np.array([c["s"] for c in calls])[:K], cs[1:K + 1], atol=1e-4, rtol=1e-4)
+    r = (K - 1) * out["n_ctrl"] // out["n_save"]
+    np.testing.assert_allclose(rows["angleDD"][:r], g[f"{key}/col/angleDD"][:r], atol=1e-3, rtol=1e-4)
+    # ... and with the pole length held at its initial value the plant does NOT follow the reference (the test has teeth)
+    ctrl2 = O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]), N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))
+    ctrl2.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+    st2 = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]))))
+    out2 = S.run_experiment(st2, cfg, lambda s, t, tp, te, L: ctrl2.step(s, f32(tp), L=O.DEFAULT_PARAMS.L))
+    assert np.abs(out2["rows"]["angleDD"][:r] - g[f"{key}/col/angleDD"][:r]).max() > 0.05

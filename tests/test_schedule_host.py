@@ -89,3 +89,24 @@ def test_batch_is_reproducible_and_experiments_differ():
     h1, h2 = rs.draw(4, 100), rs.draw(4, 104)
     assert np.array_equal(np.concatenate([h1.s0, h2.s0]), a.s0)
     assert np.array_equal(np.concatenate([h1.target_position, h2.target_position], axis=1), a.target_position)
+
+
+def test_parameter_table_reproduces_the_references_updater(g):
+    """schedule.parameter_table against the pole length the reference's simulator held after every update_parameters call
+    (ParameterUpdater in 'bounce' mode, float32 arithmetic, clip), and the other modes' basic behaviour."""
+    u = json.loads(g["exp_varL/L_updater"].item())
+    times = SC.accumulated_times(200, 0.002)
+    tab = SC.parameter_table(u, times)
+    assert tab.dtype == np.float32 and np.array_equal(tab[1:].astype(np.float64), g["exp_varL/0/L_steps"]) and tab[0] == np.float32(0.395)
+    const = SC.parameter_table(dict(u, mode="constant"), times)
+    assert (const == np.float32(0.395)).all()
+    inc = SC.parameter_table(dict(u, mode="increase", increment=0.001, range_clip=[0.2, 0.5]), times)
+    assert (np.diff(inc) >= 0).all() and inc[-1] > inc[0] and len(np.unique(inc)) == 200 // 7 + 1
+    import random
+    rw = SC.parameter_table(dict(u, mode="random walk", change_every_x_seconds=None, increment=0.002, range_clip=[0.2, 0.5]), times,
+                            py_random=random.Random(3))
+    assert {float(x) for x in np.round(np.abs(np.diff(rw)).astype(np.float64), 4)} == {0.002}                    # empty change_every: a step on every simulation step
+    rnd = SC.parameter_table(dict(u, mode="random"), times, np_random=np.random.RandomState(4))
+    assert rnd.min() >= 0.2 and rnd.max() <= 0.5 and len(np.unique(rnd)) == 200 // 7 + 1
+    rst = SC.parameter_table(dict(u, mode="increase", increment=0.001, range_clip=[0.2, 0.5], reset_every_x_seconds=0.1), times)
+    assert (rst == np.float32(0.395)).sum() > 8                                 # back to the initial value every 0.1 s
