@@ -516,29 +516,31 @@ class GroupedWorkload:
         full = synthetic_inputs(E, H, seed=2 + ctx["rank"], device=ctx["device"])
         self.parts = [Workload(ctx, e1 - e0, N, H, math=math, engine=eng, inputs=tuple(t[e0:e1].contiguous() for t in full), env_base=base + e0)
                       for eng, (e0, e1) in zip(self.groups.engines, self.groups.slices)]
-        self.preps = [w.eng.prepare_step(w.s0, w.u_nom, w.tp, w.te, L=w.L, seed=w.seed, offset=0, env_offset=w.env_base, Q_out=w.Q_out)
-                      for w in self.parts]
+        # one argument block over all envs; cpmppi_groups_run enqueues every group's launch of a step from C
+        self.u_all = torch.zeros(E, H, device=ctx["device"])
+        self.Q_all = torch.empty(E, device=ctx["device"])
+        self.full_inputs = full
+        self.step_all = self.groups.prepare(full[0], self.u_all, full[1], full[2], L=full[3], seed=self.parts[0].seed, Q_out=self.Q_all)
         torch.cuda.synchronize()
 
     def run(self, steps, warmup):
         import numpy as np
         import torch
         self.groups.fork()
-        self.stream_overlap = self.groups.overlap(self.preps)          # (outside the timed region) 1.0 = the groups were serialised
-        for w in self.parts:
-            w.u_nom.zero_()
-        for i in range(warmup):
-            for p in self.preps:
-                p.run(offset=i)
+        self.stream_overlap = self.groups.overlap(self.step_all)       # (outside the timed region) 1.0 = the groups were serialised
+        self.u_all.zero_()
+        torch.cuda.synchronize()
+        self.groups.fork()
+        self.groups.run(self.step_all, None, periods=warmup, offset=0)
         torch.cuda.synchronize()
         for w in self.parts:
             w.eng.set_profiling(True, group=8 if steps >= 16 else 1)
         t0 = time.perf_counter()
-        for i in range(steps):
-            for p in self.preps:                                    # one launch per group and step, round robin; nothing else
-                p.run(offset=warmup + i)
+        self.groups.run(self.step_all, None, periods=steps, offset=warmup)   # K steps of every group: ONE library call, nothing else
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        for w, (e0, e1) in zip(self.parts, self.groups.slices):         # (the parts verify from the nominal sequences the timed steps left)
+            w.u_nom.copy_(self.u_all[e0:e1])
         k = []
         for w in self.parts:
             r, _ = w.eng.get_profile()

@@ -23,7 +23,9 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_sample_tiled", "cpmppi_tile_delta_u", "cpmppi_cem_gmm_sample", "cpmppi_comm_unique_id",
            "cpmppi_comm_init", "cpmppi_comm_gather", "cpmppi_comm_wait", "cpmppi_comm_sync", "cpmppi_comm_destroy",
            "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings", "cpmppi_plant_step",
-           "cpmppi_abi_version", "cpmppi_stream_create", "cpmppi_stream_destroy", "cpmppi_comm_get_info")
+           "cpmppi_abi_version", "cpmppi_stream_create", "cpmppi_stream_destroy", "cpmppi_comm_get_info",
+           "cpmppi_groups_create", "cpmppi_groups_destroy", "cpmppi_groups_count", "cpmppi_groups_slice", "cpmppi_groups_handle",
+           "cpmppi_groups_stream", "cpmppi_groups_fork", "cpmppi_groups_join", "cpmppi_groups_run", "cpmppi_groups_last_error")
 COMM_ID_BYTES, COMM_SLOTS = 128, 4
 
 
@@ -70,7 +72,8 @@ class cpmppi_plant_args(C.Structure):
                 ("Q_log", C.c_void_p), ("ctrl_rows", C.c_uint64),
                 ("target_position_table", C.c_void_p), ("target_equilibrium_table", C.c_void_p), ("L_table", C.c_void_p),
                 ("sched_rows", C.c_uint64), ("sched_stride", C.c_uint32),
-                ("target_position_out", C.c_void_p), ("target_equilibrium_out", C.c_void_p), ("L_out", C.c_void_p)]
+                ("target_position_out", C.c_void_p), ("target_equilibrium_out", C.c_void_p), ("L_out", C.c_void_p),
+                ("row_envs", C.c_uint32)]
 
 
 class cpmppi_recording(C.Structure):
@@ -158,6 +161,21 @@ def load():
     lib.cpmppi_stream_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.cpmppi_stream_destroy.argtypes = [vp]
     lib.cpmppi_comm_get_info.argtypes = [vp, C.POINTER(cpmppi_comm_info)]
+    lib.cpmppi_groups_create.argtypes = [C.POINTER(cpmppi_config), C.c_int, u32, u32, C.POINTER(vp)]
+    lib.cpmppi_groups_destroy.argtypes = [vp]
+    lib.cpmppi_groups_destroy.restype = None
+    lib.cpmppi_groups_count.argtypes = [vp]
+    lib.cpmppi_groups_count.restype = u32
+    lib.cpmppi_groups_slice.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.cpmppi_groups_handle.argtypes = [vp, u32]
+    lib.cpmppi_groups_handle.restype = vp
+    lib.cpmppi_groups_stream.argtypes = [vp, u32]
+    lib.cpmppi_groups_stream.restype = vp
+    lib.cpmppi_groups_fork.argtypes = [vp, vp]
+    lib.cpmppi_groups_join.argtypes = [vp, vp]
+    lib.cpmppi_groups_run.argtypes = [vp, C.POINTER(cpmppi_step_args), C.POINTER(cpmppi_plant_args), u32]
+    lib.cpmppi_groups_last_error.argtypes = [vp]
+    lib.cpmppi_groups_last_error.restype = C.c_char_p
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]
     lib.cpmppi_version.restype = C.c_char_p
     for name in EXPORTS:

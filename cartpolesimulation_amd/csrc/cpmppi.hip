@@ -273,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void rwa_kernel(const Params p, const float*
 // env per lane).  The pole length may change from one simulation step to the next (CartPole/__init__.py:529-537): its folded
 // constants are re-formed only on a change.
 struct PlantDev {
-  uint32_t E, n_sub, period_steps, save_every, sched_stride;
+  uint32_t E, row_envs, n_sub, period_steps, save_every, sched_stride;
   float dt_sim;
   uint64_t period, save_rows, ctrl_rows, sched_rows;
   const unsigned long long* period_dev;
@@ -287,8 +287,8 @@ struct PlantDev {
 
 __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, const PlantDev a) {
   const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
-  const uint32_t E = a.E;
-  if (env >= E) return;
+  if (env >= a.E) return;
+  const uint32_t E = a.row_envs;                                       // envs per ROW of the logs and tables (>= a.E: an env group's slice)
   // a period the device counter cannot name (still 0) is advanced from the schedule's first row and neither recorded nor published
   uint64_t c = a.period;
   bool known = true;
@@ -1914,6 +1914,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: save_every / period_steps missing");
   const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table;
   if (tables && a->sched_rows == 0) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: schedule tables need sched_rows > 0");
+  if (a->row_envs != 0 && a->row_envs < a->E) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: row_envs < E");
   // a host-named period must lie inside the control log it is to be written to (rows of the state logs that fall outside are
   // skipped by the kernel, as for a device counter)
   if (!a->period_dev && a->Q_log && a->period >= a->ctrl_rows)
@@ -1927,7 +1928,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   Params plant = h->prm;                  // the simulated system's own pole mass (see cpmppi_set_pole_mass)
   plant.m_pole = h->plant_m_pole;
   PlantDev d{};
-  d.E = a->E; d.n_sub = a->n_substeps; d.period_steps = period_steps; d.save_every = save_every ? save_every : 1u;
+  d.E = a->E; d.row_envs = a->row_envs ? a->row_envs : a->E; d.n_sub = a->n_substeps; d.period_steps = period_steps; d.save_every = save_every ? save_every : 1u;
   d.sched_stride = a->sched_stride ? a->sched_stride : 1u;
   d.dt_sim = a->dt_sim;
   d.period = a->period; d.save_rows = a->save_rows; d.ctrl_rows = a->ctrl_rows; d.sched_rows = a->sched_rows ? a->sched_rows : 1u;

@@ -34,10 +34,28 @@ class MPPIEngine:
         if rc != 0:
             raise _L.CpmppiError(rc, self.lib.cpmppi_last_error(None).decode())
 
+    @classmethod
+    def from_handle(cls, handle, E, mppi: MPPIConfig = None, phys: PhysicalParameters = None, device=0):
+        """An engine over a handle somebody else owns (an env group's: pipeline.EnvGroups / cpmppi_groups_create); `close()` then
+        only forgets it."""
+        self = cls.__new__(cls)
+        self.lib = _L.load()
+        self.mppi = mppi or MPPIConfig()
+        self.phys = phys or PhysicalParameters()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.E, self.N, self.H = int(E), int(self.mppi.num_rollouts), int(self.mppi.mpc_horizon)
+        self.P = self.mppi.num_knots
+        self._cfg = build_c_config(self.E, self.mppi, self.phys)
+        self._m_pole = float(np.float32(self.phys.m_pole))
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
+
     # ------------------------------------------------------------------ plumbing
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self.lib.cpmppi_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.cpmppi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -35,47 +35,80 @@ def split_envs(E, groups):
 
 
 class EnvGroups:
-    """G engines + G streams over one device's E envs.  Tensors handed to `prepare_step` are the FULL [E, ...] arrays; every group
-    works on its contiguous slice of them in place."""
+    """The library's env groups (cpmppi_groups_*: G handles + G dedicated-queue streams over one device's E envs) with an
+    MPPIEngine view of every group.  Tensors handed to `prepare` / `prepare_step` are the FULL [E, ...] arrays; every group works on
+    its contiguous slice of them in place."""
 
     def __init__(self, E, mppi: MPPIConfig = None, groups=2, phys: PhysicalParameters = None, device=0, env_offset=0):
+        from .configs import build_c_config
+        self.lib = _L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("cartpolesimulation_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU fallback.")
         self.E, self.env_offset = int(E), int(env_offset)
-        self.slices = split_envs(E, groups)
-        self.engines, self.streams = [], []
-        self._raw = []
-        for (e0, e1) in self.slices:
-            eng = MPPIEngine(e1 - e0, mppi, phys, device)
-            # a stream with a hardware queue of its own (cpmppi_stream_create): pooled streams may share a queue and then serialise
-            raw = C.c_void_p()
-            rc = eng.lib.cpmppi_stream_create(eng.device.index, C.byref(raw))
-            if rc != 0:
-                raise _L.CpmppiError(rc, eng.lib.cpmppi_last_error(None).decode())
-            self._raw.append(raw)
-            st = torch.cuda.ExternalStream(raw.value, device=eng.device)
+        self.mppi, self.phys = mppi or MPPIConfig(), phys or PhysicalParameters()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        cfg = build_c_config(self.E, self.mppi, self.phys)
+        self._g = C.c_void_p()
+        rc = self.lib.cpmppi_groups_create(C.byref(cfg), self.device.index, int(groups), self.env_offset, C.byref(self._g))
+        if rc != 0:
+            raise _L.CpmppiError(rc, self.lib.cpmppi_groups_last_error(None).decode())
+        self.slices, self.engines, self.streams = [], [], []
+        for i in range(self.lib.cpmppi_groups_count(self._g)):
+            first, n = C.c_uint32(), C.c_uint32()
+            self.lib.cpmppi_groups_slice(self._g, i, C.byref(first), C.byref(n))
+            self.slices.append((first.value, first.value + n.value))
+            eng = MPPIEngine.from_handle(self.lib.cpmppi_groups_handle(self._g, i), n.value, self.mppi, self.phys, self.device.index)
+            st = torch.cuda.ExternalStream(self.lib.cpmppi_groups_stream(self._g, i), device=self.device)
             eng.use_stream(st)
             self.engines.append(eng)
             self.streams.append(st)
-        self.device = self.engines[0].device
-        self.H, self.N = self.engines[0].H, self.engines[0].N
+        # builds and validates argument blocks over ALL envs (it never launches: the handle behind it is group 0's)
+        self.args_engine = MPPIEngine.from_handle(self.lib.cpmppi_groups_handle(self._g, 0), self.E, self.mppi, self.phys, self.device.index)
+        self.H, self.N = self.args_engine.H, self.args_engine.N
 
     def __len__(self):
         return len(self.engines)
 
+    def _check(self, rc):
+        if rc != 0:
+            raise _L.CpmppiError(rc, self.lib.cpmppi_groups_last_error(self._g).decode())
+
+    def _cur(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
     def fork(self):
         """Every group stream waits for what has been enqueued on the caller's current stream (uploads, allocations)."""
-        cur = torch.cuda.current_stream(self.device)
-        for st in self.streams:
-            st.wait_stream(cur)
+        self._check(self.lib.cpmppi_groups_fork(self._g, self._cur()))
 
     def join(self):
         """The caller's current stream waits for every group (before results are read or freed on it)."""
-        cur = torch.cuda.current_stream(self.device)
-        for st in self.streams:
-            cur.wait_stream(st)
+        self._check(self.lib.cpmppi_groups_join(self._g, self._cur()))
+
+    def prepare(self, s0, u_nom, target_position, target_equilibrium, L=None, seed=0, Q_out=None, S_out=None, **kw):
+        """-> ONE PreparedStep over the full [E, ...] device tensors (in-kernel Philox noise keyed by the global env index), to be
+        handed to `run`."""
+        if Q_out is None:
+            Q_out = torch.empty(self.E, dtype=torch.float32, device=self.device)
+        return self.args_engine.prepare_step(s0, u_nom, target_position, target_equilibrium, L=L, seed=seed, offset=0, env_offset=0,
+                                             Q_out=Q_out, S_out=S_out, **kw)
+
+    def run(self, step=None, plant=None, periods=1, offset=0, period=0, n_substeps=None):
+        """cpmppi_groups_run: `periods` control periods of every group enqueued from C, round robin - step (Philox step counter
+        offset + k) and, if given, plant step (period + k).  `step` / `plant`: PreparedStep / PreparedPlantStep over the full arrays."""
+        sa = pa = None
+        if step is not None:
+            step.args.offset = int(offset)
+            sa = C.byref(step.args)
+        if plant is not None:
+            plant.args.period = int(period)
+            if n_substeps is not None:
+                plant.args.n_substeps = int(n_substeps)
+            pa = C.byref(plant.args)
+        self._check(self.lib.cpmppi_groups_run(self._g, sa, pa, int(periods)))
 
     def prepare_step(self, s0, u_nom, target_position, target_equilibrium, L=None, seed=0, Q_out=None, S_out=None, **kw):
-        """-> one PreparedStep per group over the slices of the given [E, ...] device tensors (in-kernel Philox noise keyed by the
-        global env index)."""
+        """-> one PreparedStep per GROUP over the slices of the given [E, ...] device tensors (for callers that pace the groups
+        themselves; `prepare` + `run` is the one-call form)."""
         E = self.E
         for name, t in (("s0", s0), ("u_nom", u_nom), ("target_position", target_position), ("target_equilibrium", target_equilibrium)):
             if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == E):
@@ -89,59 +122,72 @@ class EnvGroups:
                                           Q_out=Q_out[e0:e1], S_out=None if S_out is None else S_out[e0:e1], **kw))
         return preps
 
-    def overlap(self, preps, steps=20):
+    def overlap(self, step, steps=20):
         """Do the groups really run side by side?  `steps` steps of every group one group after the other, then all together:
-        -> sum of the groups' times alone / time together (1.0 = serialised on one hardware queue, ~G = perfect overlap)."""
+        -> sum of the groups' times alone / time together (1.0 = serialised on one hardware queue, ~G = perfect overlap).
+        `step`: a PreparedStep over the full arrays (`prepare`)."""
         import time
+        preps = []
+        a = step.args
+        keep = step._keep
+        for eng, (e0, e1) in zip(self.engines, self.slices):          # the same launches, one group at a time
+            b = type(a)()
+            C.memmove(C.byref(b), C.byref(a), C.sizeof(a))
+            n = e1 - e0
+            f = 4                                                      # bytes per float
+            b.E = n
+            b.s0 = a.s0 + e0 * 6 * f; b.u_nom = a.u_nom + e0 * self.H * f
+            b.target_position = a.target_position + e0 * f; b.target_equilibrium = a.target_equilibrium + e0 * f
+            b.L = (a.L + e0 * f) if a.L else None
+            b.Q_out = a.Q_out + e0 * f
+            b.S_out = (a.S_out + e0 * self.N * f) if a.S_out else None
+            b.env_offset = self.env_offset + e0
+            preps.append((eng, b))
         torch.cuda.synchronize(self.device)
 
         def timed(which):
             t0 = time.perf_counter()
             for i in range(steps):
-                for p in which:
-                    p.run(offset=10_000 + i)
+                for eng, b in which:
+                    b.offset = 10_000 + i
+                    eng._check(eng.lib.cpmppi_step(eng._h, C.byref(b), eng._stream()))
             torch.cuda.synchronize(self.device)
             return time.perf_counter() - t0
 
         timed(preps)                                                   # warm
         alone = sum(timed([p]) for p in preps)
-        return alone / timed(preps)
+        together = timed(preps)
+        del keep
+        return alone / together
 
     def close(self):
-        for eng in self.engines:
-            eng.close()
-        if self.engines:
+        if getattr(self, "_g", None) is not None and self._g.value:
             torch.cuda.synchronize(self.device)
-            lib = _L.load()
-            for raw in self._raw:
-                lib.cpmppi_stream_destroy(raw)
-        self.engines, self._raw, self.streams = [], [], []
+            for eng in self.engines:
+                eng.close()
+            self.args_engine.close()
+            self.lib.cpmppi_groups_destroy(self._g)
+            self._g = C.c_void_p()
+        self.engines, self.streams = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def run_schedule_groups(groups: EnvGroups, batch, seed, graph=False, steps_per_graph=10):
+def run_schedule_groups(groups: EnvGroups, batch, seed):
     """harness.BatchedCartPoleExperiment.run_schedule with the experiments split over the env groups: every group runs its own
-    chain of (controller step, plant step) launches on its own stream, the host interleaves the enqueueing.  -> the same result
-    dict (device tensors concatenated along the env axis)."""
-    import dataclasses
+    chain of (controller step, plant step) launches on its own stream; ALL periods of ALL groups are enqueued by one library call
+    (cpmppi_groups_run), the groups working in place on their slices of the batch's buffers.  -> the same result dict."""
     from .harness import ScheduleRun
-    runs = []
-    for eng, (e0, e1) in zip(groups.engines, groups.slices):
-        sub = dataclasses.replace(batch, s0=batch.s0[e0:e1], target_position=np.ascontiguousarray(batch.target_position[:, e0:e1]),
-                                  target_equilibrium=np.ascontiguousarray(batch.target_equilibrium[:, e0:e1]),
-                                  interpolation_type=batch.interpolation_type[e0:e1], L=None if batch.L is None else batch.L[e0:e1],
-                                  L_table=None if batch.L_table is None else np.ascontiguousarray(batch.L_table[:, e0:e1]))
-        runs.append(ScheduleRun(eng, sub, seed, env_offset=groups.env_offset + e0))
-    groups.fork()                                              # (the runs' buffers were set up on the caller's stream)
-    if graph:
-        for r in runs:
-            if r.T > 0:
-                r.capture(steps_per_graph)
-    while any(r.periods_left for r in runs):
-        for r in runs:
-            if r.periods_left:
-                r.enqueue_next()
-    outs = [r.finish() for r in runs]
+    eng = groups.args_engine
+    run = ScheduleRun(eng, batch, seed)                        # the batch's buffers and logs, set up on the caller's stream
+    step = groups.prepare(run.s, run.u_nom, run.cur_tp, run.cur_te, L=run.cur_L, seed=seed, Q_out=run.Q)
+    plant = eng.prepare_plant_step(run.s, run.Q, batch.n_ctrl, period=0, **run.plant)
+    groups.fork()
+    groups.run(step, plant, periods=run.T, offset=0, period=0)
+    groups.run(step, plant, periods=1, offset=run.T, period=run.T, n_substeps=run.tail)   # the run's last controller call (+ trailing steps)
     groups.join()
-    cat = lambda k, dim: torch.cat([o[k] for o in outs], dim=dim)   # noqa: E731
-    return dict(states=cat("states", 1), dd=cat("dd", 1), Q=cat("Q", 1), final_state=cat("final_state", 0), u_nom=cat("u_nom", 0),
-                batch=batch)
+    return dict(states=run.states, dd=run.dd, Q=run.Qs, final_state=run.s, u_nom=run.u_nom, batch=batch)

@@ -230,7 +230,7 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
         from .pipeline import EnvGroups, run_schedule_groups
         eg = EnvGroups(n, engine.mppi, int(groups), engine.phys, engine.device.index)
         try:
-            res = run_schedule_groups(eg, batch, cfg["seed"], graph=graph)
+            res = run_schedule_groups(eg, batch, cfg["seed"])
             torch.cuda.synchronize()
         finally:
             eg.close()

@@ -45,7 +45,7 @@ extern "C" {
                                    3: cpmppi_config.ode_predictor (+ cost ids 4 / 5, cpmppi_last_launch, cpmppi_comm_set_timeout);
                                    4: cpmppi_plant_step / cpmppi_plant_args (the experiment schedule), cpmppi_write_recordings takes
                                       per-row columns (cpmppi_recording), cpmppi_launch_info.cost_plugin, CPMPPI_ERR_IO,
-                                      cpmppi_comm_info.  cpmppi_abi_version() reports what a loaded library was built as. */
+                                      cpmppi_comm_info, cpmppi_groups_*.  cpmppi_abi_version() reports what a loaded library was built as. */
 #define CPMPPI_STATE_DIM 6u
 #define CPMPPI_MAX_HORIZON 1024u
 
@@ -398,6 +398,8 @@ typedef struct {
   float* target_position_out;           /* [E] */
   float* target_equilibrium_out;        /* [E] */
   float* L_out;                         /* [E] */
+  uint32_t row_envs;                    /* envs per ROW of the logs and tables (0 = E): an env group that works on a slice of a larger
+                                           batch's buffers passes the batch's env count and pointers to its first env (cpmppi_groups_run) */
 } cpmppi_plant_args;
 int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* stream);
 
@@ -501,6 +503,35 @@ int cpmppi_write_recordings(const char* const* paths, const char* preamble, size
  * The returned hipStream_t is an ordinary stream for every other purpose; destroy it with cpmppi_stream_destroy. */
 int cpmppi_stream_create(int device, void** stream_out);
 int cpmppi_stream_destroy(void* stream);
+
+/* ENV GROUPS: the E envs of one device as `groups` contiguous groups, each with a handle and a dedicated-queue stream of its own,
+ * every group running its OWN chain of launches - independent MPPI problem instances need not march in step (a launch of a few
+ * dozen envs ends with its slowest wave, waves differ by 20-40 %; measured on MI355X: 64 envs x 2048 x 50 74.5 -> 64.6 us per
+ * step of all envs with two groups, 64 x 4096 x 100 237 -> 178 us).  No reference counterpart beyond its share-nothing job arrays
+ * (others/EulerClusterScripts/ParallelDataGeneration.sh:2-17).  Philox keys are GLOBAL env indices (env_offset + env): a result
+ * does not depend on the split (bit-identical to the unsplit launch whenever both pick the same lane mapping).
+ *   cpmppi_groups_create   cfg->E = all envs of the device; env_offset = global index of env 0 (rank * E when sharded over GPUs)
+ *   cpmppi_groups_slice / _handle / _stream   a group's envs [first, first + n), its handle (cost weights, GRU model, ... are set
+ *                          per handle) and its hipStream_t
+ *   cpmppi_groups_fork     every group stream waits for what `stream` has enqueued so far (uploads, allocations)
+ *   cpmppi_groups_join     `stream` waits for every group
+ *   cpmppi_groups_run      `periods` control periods of EVERY group enqueued from C, round robin (period k, group g: cpmppi_step
+ *                          with the Philox step counter step->offset + k, then - if `plant` is given - cpmppi_plant_step with period
+ *                          plant->period + k).  `step` and `plant` describe the FULL [E, ...] arrays exactly as for one handle over
+ *                          all envs; every group works on its slice of them in place (plant->row_envs is filled in).  No group waits
+ *                          for another.  step->offset_dev / plant->period_dev (one shared device counter) are refused.
+ * Errors as for the single-handle calls; text in cpmppi_groups_last_error. */
+typedef struct cpmppi_groups cpmppi_groups;
+int cpmppi_groups_create(const cpmppi_config* cfg, int device, uint32_t groups, uint32_t env_offset, cpmppi_groups** out);
+void cpmppi_groups_destroy(cpmppi_groups* g);
+uint32_t cpmppi_groups_count(const cpmppi_groups* g);
+int cpmppi_groups_slice(const cpmppi_groups* g, uint32_t group, uint32_t* first_env, uint32_t* n_envs);
+cpmppi_handle* cpmppi_groups_handle(cpmppi_groups* g, uint32_t group);
+void* cpmppi_groups_stream(cpmppi_groups* g, uint32_t group);
+int cpmppi_groups_fork(cpmppi_groups* g, void* stream);
+int cpmppi_groups_join(cpmppi_groups* g, void* stream);
+int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods);
+const char* cpmppi_groups_last_error(const cpmppi_groups* g);
 
 /* The ABI version this library was BUILT as (CPMPPI_ABI_VERSION of its header): lets a client that was compiled against another
  * header notice before it passes a struct of the wrong layout (cpmppi_create refuses a mismatching cpmppi_config.abi_version). */

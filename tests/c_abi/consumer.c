@@ -6,7 +6,8 @@
  * (host pointers), prints Q of every env per step ("Q ..." / "Qh ...") and the final nominal sequence of env 0; then the
  * same steps a third time through the multi-GPU entry points with ONE rank (cpmppi_comm_unique_id / cpmppi_comm_init /
  * cpmppi_step_gather with two alternating nominal-sequence buffers / cpmppi_comm_sync): "Qg ..." per step, and "g ..." =
- * the gathered copy of env 0's final sequence (must equal "u ..."). */
+ * the gathered copy of env 0's final sequence (must equal "u ...").  Last, the data generator's device loop through the env-group
+ * entry points (cpmppi_groups_create / fork / run / join) with cpmppi_plant_step's schedule tables and recording: "R", "Qc", "D". */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -108,5 +109,65 @@ int main(int argc, char** argv) {
     cpmppi_comm_destroy(h);
   }
   cpmppi_destroy(h);
+  /* ---- the data generator's device loop from plain C: env groups (two handles, two dedicated-queue streams), a moving target
+   * and a flipping equilibrium read from schedule tables, rows saved every 5 simulation steps - T control periods of both groups
+   * enqueued by ONE cpmppi_groups_run call, then the run's last controller call.  "R ..." = the last saved state of every env,
+   * "Qc ..." = the last control: must equal the Python harness (one chain, no groups) bit for bit. ---- */
+  {
+    const uint32_t T = (uint32_t)steps + 3, n_ctrl = 10, n_save = 5, stride = 5, rows = T * n_ctrl / n_save + 1, srows = T * n_ctrl / stride + 1;
+    cpmppi_groups* gr = NULL;
+    if (cpmppi_abi_version() != CPMPPI_ABI_VERSION) { fprintf(stderr, "abi %u\n", cpmppi_abi_version()); return 9; }
+    if (cpmppi_groups_create(&cfg, 0, 2, 0, &gr) != CPMPPI_OK) { fprintf(stderr, "groups: %s\n", cpmppi_groups_last_error(NULL)); return 9; }
+    float* htab = (float*)malloc((size_t)srows * E * 2 * sizeof(float));
+    for (uint32_t r = 0; r < srows; ++r)
+      for (uint32_t e = 0; e < E; ++e) {
+        htab[(size_t)r * E + e] = 0.002f * (float)((r * 7u + e * 3u) % 40u) - 0.04f;                    /* target position */
+        htab[(size_t)(srows + r) * E + e] = ((r / 6u + e) % 2u) ? -1.0f : 1.0f;                          /* target equilibrium */
+      }
+    float *s, *un, *Qd, *tab, *cur, *slog, *ddlog, *Qlog;
+    HIPCHECK(hipMalloc((void**)&s, (size_t)E * 6 * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&un, (size_t)E * H * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&Qd, (size_t)E * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&tab, (size_t)srows * E * 2 * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&cur, (size_t)E * 2 * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&slog, (size_t)rows * E * 6 * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&ddlog, (size_t)rows * E * 2 * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&Qlog, (size_t)(T + 1) * E * sizeof(float)));
+    HIPCHECK(hipMemcpy(s, hs, (size_t)E * 6 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(slog, hs, (size_t)E * 6 * sizeof(float), hipMemcpyHostToDevice));                /* row 0: the initial state */
+    HIPCHECK(hipMemset(un, 0, (size_t)E * H * sizeof(float)));
+    HIPCHECK(hipMemcpy(tab, htab, (size_t)srows * E * 2 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(cur, htab, (size_t)E * sizeof(float), hipMemcpyHostToDevice));                     /* row 0 of both tables */
+    HIPCHECK(hipMemcpy(cur + E, htab + (size_t)srows * E, (size_t)E * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipDeviceSynchronize());
+    cpmppi_step_args a;
+    memset(&a, 0, sizeof a);
+    a.E = E; a.s0 = s; a.u_nom = un; a.target_position = cur; a.target_equilibrium = cur + E; a.L = tgt + 2 * E;
+    a.noise_kind = CPMPPI_NOISE_PHILOX; a.seed = seed; a.offset = 0; a.Q_out = Qd;
+    cpmppi_plant_args b;
+    memset(&b, 0, sizeof b);
+    b.E = E; b.s = s; b.Q = Qd; b.L = tgt + 2 * E; b.n_substeps = n_ctrl; b.period_steps = n_ctrl; b.dt_sim = 0.002f; b.period = 0;
+    b.states_log = slog; b.dd_log = ddlog; b.save_rows = rows; b.save_every = n_save; b.Q_log = Qlog; b.ctrl_rows = T + 1;
+    b.target_position_table = tab; b.target_equilibrium_table = tab + (size_t)srows * E; b.sched_rows = srows; b.sched_stride = stride;
+    b.target_position_out = cur; b.target_equilibrium_out = cur + E;
+    if (cpmppi_groups_fork(gr, NULL) != CPMPPI_OK || cpmppi_groups_run(gr, &a, &b, T) != CPMPPI_OK) { fprintf(stderr, "groups run: %s\n", cpmppi_groups_last_error(gr)); return 9; }
+    a.offset = T; b.period = T; b.n_substeps = 0;                                                         /* the last controller call: record only */
+    if (cpmppi_groups_run(gr, &a, &b, 1) != CPMPPI_OK || cpmppi_groups_join(gr, NULL) != CPMPPI_OK) { fprintf(stderr, "groups run: %s\n", cpmppi_groups_last_error(gr)); return 9; }
+    HIPCHECK(hipDeviceSynchronize());
+    float* hr = (float*)malloc((size_t)E * 6 * sizeof(float));
+    HIPCHECK(hipMemcpy(hr, slog + (size_t)(rows - 1) * E * 6, (size_t)E * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    printf("R");
+    for (uint32_t i = 0; i < E * 6; ++i) printf(" %.9g", hr[i]);
+    printf("\n");
+    HIPCHECK(hipMemcpy(hq, Qlog + (size_t)T * E, (size_t)E * sizeof(float), hipMemcpyDeviceToHost));
+    printf("Qc");
+    for (uint32_t e = 0; e < E; ++e) printf(" %.9g", hq[e]);
+    printf("\n");
+    HIPCHECK(hipMemcpy(hr, ddlog + (size_t)(rows - 1) * E * 2, (size_t)E * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    printf("D");
+    for (uint32_t i = 0; i < E * 2; ++i) printf(" %.9g", hr[i]);
+    printf("\n");
+    cpmppi_groups_destroy(gr);
+  }
   return 0;
 }

@@ -58,3 +58,27 @@ def test_c_consumer_matches_the_python_binding(tmp_path):
     assert np.array_equal(np.stack(Q_py), Q_c), (np.stack(Q_py), Q_c)
     assert np.array_equal(un.cpu().numpy()[0], u_c)
     assert np.abs(Q_c).max() > 1e-3
+    # ---- the data generator's loop from C through the env-group entry points == the Python harness as ONE chain
+    (R_c,), (Qc_c,), (D_c,) = rows("R"), rows("Qc"), rows("D")
+    T, n_ctrl, n_save, stride = steps + 3, 10, 5, 5
+    srows = T * n_ctrl // stride + 1
+    r = np.arange(srows, dtype=np.uint32)[:, None]
+    e = np.arange(E, dtype=np.uint32)[None, :]
+    tp_tab = (f32(0.002) * ((r * 7 + e * 3) % 40).astype(f32) - f32(0.04)).astype(f32)
+    te_tab = np.where(((r // 6 + e) % 2) != 0, f32(-1.0), f32(1.0)).astype(f32)
+    s = eng.tensor(s0.copy())
+    un2, Q2 = eng.zeros(E, H), eng.empty(E)
+    tp_d, te_d = eng.tensor(tp_tab), eng.tensor(te_tab)
+    cur_tp, cur_te = tp_d[0].clone(), te_d[0].clone()
+    Lv = eng.tensor(np.full(E, 0.395, f32))
+    R = T * n_ctrl // n_save + 1
+    states, dd, Qlog = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
+    states[0] = s
+    kw = dict(dt_sim=0.002, period_steps=n_ctrl, L=Lv, states_log=states, dd_log=dd, save_every=n_save, Q_log=Qlog, target_position_table=tp_d,
+              target_equilibrium_table=te_d, sched_stride=stride, target_position_out=cur_tp, target_equilibrium_out=cur_te)
+    for c in range(T + 1):
+        eng.step(s, un2, cur_tp, cur_te, L=Lv, seed=seed, offset=c, Q_out=Q2)
+        eng.plant_step(s, Q2, n_ctrl if c < T else 0, period=c, **kw)
+    torch.cuda.synchronize()
+    assert np.array_equal(states[-1].cpu().numpy().reshape(-1), R_c) and np.array_equal(Qlog[T].cpu().numpy(), Qc_c)
+    assert np.array_equal(dd[-1].cpu().numpy().reshape(-1), D_c) and np.abs(Qc_c).max() > 1e-3

@@ -38,9 +38,11 @@ def test_grouped_steps_equal_the_unsplit_launch(E, N, H, groups, rpl):
         one.step(s0, u1, tp, te, L=Lt, seed=77, offset=i, env_offset=1000, Q_out=Q1)
     g = EnvGroups(E, cfg, groups, env_offset=1000)
     u2, Q2 = one.zeros(E, H), one.empty(E)
-    preps = g.prepare_step(s0, u2, tp, te, L=Lt, seed=77, Q_out=Q2)
+    step = g.prepare(s0, u2, tp, te, L=Lt, seed=77, Q_out=Q2)
     g.fork()
-    for i in range(5):
+    g.run(step, None, periods=3, offset=0)                             # cpmppi_groups_run: every group's launches enqueued from C
+    preps = g.prepare_step(s0, u2, tp, te, L=Lt, seed=77, Q_out=Q2)    # ... and the caller-paced form, one prepared step per group
+    for i in (3, 4):
         for p in preps:
             p.run(offset=i)
     g.join()
@@ -51,13 +53,14 @@ def test_grouped_steps_equal_the_unsplit_launch(E, N, H, groups, rpl):
     else:
         np.testing.assert_allclose(u2.cpu().numpy(), u1.cpu().numpy(), atol=1e-4)
     assert float(u2.abs().max()) > 0.01
+    assert g.overlap(step, steps=5) > 0.5                              # (a ratio near 1 would mean the groups ran one after the other)
     g.close(); one.close()
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_grouped_data_generator_loop_equals_the_single_chain(graph):
-    """harness.run_schedule (one chain) vs pipeline.run_schedule_groups (3 groups, launched or captured per group as HIP graphs):
-    identical recordings - states, second derivatives, controls - for experiments with moving targets and equilibrium flips."""
+def test_grouped_data_generator_loop_equals_the_single_chain():
+    """harness.run_schedule (one chain) vs pipeline.run_schedule_groups (3 groups working in place on their slices of the batch's
+    buffers, all periods enqueued by one cpmppi_groups_run call): identical recordings - states, second derivatives, controls -
+    for experiments with moving targets and equilibrium flips."""
     from cartpolesimulation_amd import schedule as SC
     from cartpolesimulation_amd.configs import MPPIConfig
     from cartpolesimulation_amd.engine import MPPIEngine
@@ -72,9 +75,15 @@ def test_grouped_data_generator_loop_equals_the_single_chain(graph):
     eng = MPPIEngine(E, mppi)
     a = BatchedCartPoleExperiment(eng, seed=9).run_schedule(b)
     g = EnvGroups(E, mppi, 3)
-    c = run_schedule_groups(g, b, seed=9, graph=graph, steps_per_graph=6)
+    c = run_schedule_groups(g, b, seed=9)
     torch.cuda.synchronize()
     for k in ("states", "dd", "Q", "final_state", "u_nom"):
         assert torch.equal(a[k], c[k]), k
     assert a["Q"].shape == (b.n_periods + 1, E) and float(a["Q"].abs().max()) > 0.01
+    # a shared device counter cannot serve several groups
+    from cartpolesimulation_amd import _lib as L
+    cnt = torch.zeros(1, dtype=torch.int64, device=a["Q"].device)
+    bad = g.args_engine.prepare_step(a["final_state"], a["u_nom"], a["Q"][0], a["Q"][0], seed=1, offset_dev=cnt)
+    with pytest.raises(L.CpmppiError):
+        g.run(bad, None, periods=1)
     g.close(); eng.close()
