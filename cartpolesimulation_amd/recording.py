@@ -204,7 +204,8 @@ def experiment_folder(root, secondary_experiment_index=None, digits=3):
 
 
 def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, seed=None, cartpole_seed=None, L=None, native=True,
-                     graph=False, secondary_experiment_index=None, controller_name="mpc", optimizer_name="mppi", title=None, groups=1):
+                     graph=False, secondary_experiment_index=None, controller_name="mpc", optimizer_name="mppi", title=None, groups=1,
+                     rank=0, world=1):
     """Batched run_data_generator: ``config`` = config_data_gen.yml as a dict (or overrides of the shipped file, see
     schedule.merged_config) - length_of_experiment, the three dt, the random initial state, the target trace's turning points
     and interpolation types, the target-equilibrium dwell times, number_of_experiments, ML_Pipeline_mode / split.  All
@@ -212,23 +213,34 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     ``seed`` overrides config['seed'] (the shipped file leaves it empty = clock); ``cartpole_seed`` seeds the per-experiment
     generators of the turning points (default: seed + 1).  ``groups`` > 1: the experiments run as that many independent env groups,
     each on its own stream (pipeline.py: 15-25 % more experiments per second for a few dozen envs; `engine` then only provides the
-    problem definition)."""
+    problem definition).  ``rank`` / ``world``: one process per GPU, each generating its contiguous block of the run's experiments
+    (schedule.draw_shard: the same experiments as the single-process run) and writing them like a job of the reference's array
+    would - `secondary_experiment_index` defaults to the rank (run_data_generator.py -i, others/EulerClusterScripts/
+    ParallelDataGeneration.sh:17), so no two ranks ever ask for the same file name; no collective is involved."""
     import time
     from .harness import BatchedCartPoleExperiment
     from .schedule import RandomExperimentSetter, merged_config
     cfg = merged_config(config)
     if seed is not None:
         cfg["seed"] = int(seed)
-    n = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
+    n_total = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
+    cseed = cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1
+    _first = 0                                                     # global index of this process's first experiment (Philox keys)
+    if int(world) > 1:
+        from .schedule import draw_shard
+        batch, _first = draw_shard(cfg, n_total, cseed, rank, world, L=L)
+        if secondary_experiment_index is None:
+            secondary_experiment_index = int(rank)
+    else:
+        batch = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength).draw(n_total, cseed, L=L)
+    n = batch.E
     if n > engine.E:
         raise ValueError(f"{n} experiments on an engine created for {engine.E} envs")
-    setter = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength)
-    batch = setter.draw(n, cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1, L=L)
     import torch
     t0 = time.perf_counter()
     if int(groups) > 1:
         from .pipeline import EnvGroups, run_schedule_groups
-        eg = EnvGroups(n, engine.mppi, int(groups), engine.phys, engine.device.index)
+        eg = EnvGroups(n, engine.mppi, int(groups), engine.phys, engine.device.index, env_offset=_first)
         try:
             res = run_schedule_groups(eg, batch, cfg["seed"])
             torch.cuda.synchronize()
@@ -236,7 +248,7 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
             eg.close()
     else:
         exp = BatchedCartPoleExperiment(engine, batch.dt_simulation, batch.dt_control, seed=cfg["seed"])
-        res = exp.run_schedule(batch, graph=graph)
+        res = exp.run_schedule(batch, graph=graph, env_offset=_first)
         torch.cuda.synchronize()
     per_call = (time.perf_counter() - t0) / (batch.n_periods + 1)   # what Q_update_time can honestly say: wall time per controller update of the batch
     phys = engine.phys
@@ -275,8 +287,10 @@ def main(argv=None):
     args = ap.parse_args(argv)
     cfg = legacy_mppi_config(num_rollouts=args.rollouts, mpc_horizon=args.horizon) if args.cost == "legacy_mppi_cartpole" \
         else MPPIConfig(num_rollouts=args.rollouts, mpc_horizon=args.horizon, cost_function_specification=args.cost)
-    eng = MPPIEngine(args.experiments, cfg)
-    paths = generate_dataset(eng, args.experiments, args.out, seed=args.seed,
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))     # one process per GPU under torchrun
+    from .shard import env_shard
+    eng = MPPIEngine(env_shard(args.experiments, world, rank)[1], cfg, device=int(os.environ.get("LOCAL_RANK", "0")))
+    paths = generate_dataset(eng, args.experiments, args.out, seed=args.seed, rank=rank, world=world,
                              config=dict(length_of_experiment=args.length, ML_Pipeline_mode=args.ml_pipeline,
                                          dt=dict(saving=args.dt_save)), groups=args.groups,
                              secondary_experiment_index=None if args.secondary_experiment_index < 0 else args.secondary_experiment_index)

@@ -145,6 +145,12 @@ class RandomExperimentSetter:
                                           start, end, frac, self.thl)
         return s0, t_knots, y_knots, interp, te
 
+    def skip(self, k):
+        """Advance the run by k experiments without tabulating them (a rank that owns a later block of the run's experiments)."""
+        for _ in range(int(k)):
+            self._one(np.random.Generator(np.random.SFC64(0)))
+        return self
+
     def draw(self, E, cartpole_seed, L=None):
         """The next E experiments of the run -> ExperimentBatch."""
         c = self.config
@@ -322,3 +328,15 @@ def parameter_table(updater, times, py_random=None, np_random=None):
                 cur = f32(np.clip(cur, f32(clip[0]), f32(clip[1])))
         out[g] = cur
     return out
+
+
+def draw_shard(config, n_total, cartpole_seed, rank=0, world=1, L=None):
+    """Rank `rank` of `world` processes' share of a run of `n_total` experiments: the contiguous block shard.env_shard gives it, drawn
+    from the SAME random streams as the single-process run (the union over the ranks is that run, experiment for experiment) - the
+    share-nothing fan-out of others/EulerClusterScripts/ParallelDataGeneration.sh:2-17 with reproducible content.
+    -> (ExperimentBatch, first experiment index)."""
+    from .shard import env_shard
+    start, count = env_shard(n_total, world, rank)
+    setter = RandomExperimentSetter(config).skip(start)
+    Lv = None if L is None else np.broadcast_to(np.asarray(L, f32), (n_total,))[start:start + count]
+    return setter.draw(count, int(cartpole_seed) + start, L=Lv), start

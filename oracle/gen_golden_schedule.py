@@ -272,5 +272,10 @@ if __name__ == "__main__":
                     ctrl_seed=777, p_Q=0.0,
                     L_updater=dict(init_value=0.395, change_every_x_seconds=0.014, mode="bounce", range_random=[0.2, 0.5], range_clip=[0.36, 0.43],
                                    increment=0.01, reset_every_x_seconds="inf"))
+    # an experiment whose length is not a whole number of control periods (25 simulation steps: controller calls at 0, 10, 20, five
+    # trailing steps) and shorter than the first turning point (no turning points at all: the target is 0 whatever the start)
+    gen_experiments(out, "exp_tail", data_gen_config(**dict(fast, seed=81, length_of_experiment=0.05,
+                                                            turning_points=dict(track_relative_complexity=1))), 1, 960,
+                    ctrl_seed=555, p_Q=0.0)
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
     print("wrote", os.path.join(OUT, "schedule.npz"), len(out), "arrays")

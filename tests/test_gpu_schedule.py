@@ -148,6 +148,23 @@ def test_reference_experiment_with_moving_target_and_flips_replayed_on_the_devic
     eng.close()
 
 
+def test_reference_experiment_that_ends_inside_a_control_period(g):
+    """exp_tail on the device loop: 25 simulation steps = two control periods + five trailing steps after the last controller call
+    (cpmppi_plant_step with n_substeps < period_steps), three saved rows, no turning points."""
+    res, b, eng = _replay(g, "exp_tail", 0, "fast")
+    key = "exp_tail/0"
+    assert (b.n_sim, b.n_periods, b.n_ctrl) == (25, 2, 10) and res["states"].shape[0] == 3 and res["Q"].shape[0] == 3
+    np.testing.assert_allclose(res["Q"].cpu().numpy()[:, 0], g[f"{key}/call/Q"][1:], atol=1e-4)
+    st = res["states"].cpu().numpy()[:, 0]
+    for j, n in enumerate(("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")):
+        np.testing.assert_allclose(st[:, j], g[f"{key}/col/{n}"], atol=2e-4, rtol=1e-4, err_msg=n)
+    np.testing.assert_allclose(res["dd"].cpu().numpy()[:, 0, 0], g[f"{key}/col/angleDD"], atol=5e-3, rtol=1e-3)
+    # the five trailing steps did advance the plant beyond the last saved row
+    assert not np.array_equal(res["final_state"].cpu().numpy()[0], st[-1])
+    assert (b.target_position == 0.0).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("tag,i", [("exp_fine", 0), ("exp_fine", 1), ("exp_coarse", 0)])
 def test_reference_experiments_host_paced(g, tag, i):
     """The experiments whose legacy controller multiplies its output by (1 + actuator_noise * uniform) on the host

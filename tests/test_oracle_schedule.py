@@ -151,3 +151,21 @@ def test_experiment_with_a_pole_length_that_changes_during_control_periods(g):
     st2 = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]))))
     out2 = S.run_experiment(st2, cfg, lambda s, t, tp, te, L: ctrl2.step(s, f32(tp), L=O.DEFAULT_PARAMS.L))
     assert np.abs(out2["rows"]["angleDD"][:r] - g[f"{key}/col/angleDD"][:r]).max() > 0.05
+
+
+def test_experiment_that_ends_inside_a_control_period(g):
+    """exp_tail: 25 simulation steps = two control periods and five trailing steps, no turning points (length x complexity < 1: the
+    target is 0 whatever the start, random_target_generator.py:31-33): controller calls at t = 0, 0.02, 0.04, three saved rows."""
+    key = "exp_tail/0"
+    cfg = json.loads(g["exp_tail/config"].item())
+    st = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g["exp_tail/cartpole_seed0"]))))
+    ctrl = O.LegacyMPPIController(int(g["exp_tail/ctrl_seed"]), int(g["exp_tail/N"]), int(g["exp_tail/H"]), SQRTRHOINV=0.02, p_Q=0.0)
+    cs = g[f"{key}/call/s"]
+    ctrl.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+    out = S.run_experiment(st, cfg, lambda s, t, tp, te, L: ctrl.step(s, f32(tp), L=L))
+    assert len(out["times"]) == 26 and len(out["calls"]) == 3 and len(out["rows"]["time"]) == 3
+    assert np.array_equal(out["rows"]["time"], g[f"{key}/col/time"]) and np.array_equal(out["rows"]["target_position"], np.zeros(3))
+    assert st["s0"][O.POSITION_IDX] != 0.0 and np.array_equal(st["s0"], cs[1])
+    np.testing.assert_allclose(np.array([c["Q"] for c in out["calls"]]), g[f"{key}/call/Q"][1:], atol=1e-4)
+    np.testing.assert_allclose(out["rows"]["s"], np.stack([g[f"{key}/col/{n}"] for n in ("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")], axis=-1),
+                               atol=1e-4, rtol=1e-4)

@@ -227,3 +227,13 @@ def test_generate_dataset_on_device(tmp_path):
     assert [os.path.relpath(p, str(tmp_path / "ml")) for p in paths] == [
         os.path.join("Experiment-1", "Recordings", d, n) for d, n in (("Train", "Experiment.csv"), ("Train", "Experiment-1.csv"),
                                                                        ("Validate", "Experiment.csv"), ("Test", "Experiment.csv"))]
+    # one process per GPU: two ranks' blocks of the same run = the single-process run, row for row (global Philox keys, the same
+    # random streams); every rank names its files like a job of the reference's array (-i rank)
+    whole = R.generate_dataset(eng, E, str(tmp_path / "whole"), config=cfg, seed=6)
+    parts = []
+    for r in range(2):
+        parts += R.generate_dataset(eng, E, str(tmp_path / "ranks"), config=cfg, seed=6, rank=r, world=2)
+    assert [os.path.basename(p) for p in parts] == ["Experiment-000.csv", "Experiment-000-1.csv", "Experiment-001.csv", "Experiment-001-1.csv"]
+    for a, b in zip(whole, parts):
+        da, db = (pd.read_csv(p, comment="#", float_precision="round_trip").drop(columns=["Q_update_time"]) for p in (a, b))
+        assert da.equals(db), (a, b)

@@ -42,7 +42,7 @@ def test_batch_draw_equals_consecutive_reference_experiments(g, tag):
     assert np.array_equal(b.target_equilibrium[0], g[f"{tag}/target_equilibrium"])
 
 
-@pytest.mark.parametrize("tag,K", [("exp_fine", 2), ("exp_coarse", 1), ("exp_device", 2)])
+@pytest.mark.parametrize("tag,K", [("exp_fine", 2), ("exp_coarse", 1), ("exp_device", 2), ("exp_tail", 1)])
 def test_tables_equal_what_the_simulator_handed_its_controller_and_logged(g, tag, K):
     """The rows the device loop will read - at the controller's instants and at the saved rows - against the REAL simulator class:
     target position and equilibrium handed to every controller call, the recording's time / target columns, the initial state."""
@@ -110,3 +110,18 @@ def test_parameter_table_reproduces_the_references_updater(g):
     assert rnd.min() >= 0.2 and rnd.max() <= 0.5 and len(np.unique(rnd)) == 200 // 7 + 1
     rst = SC.parameter_table(dict(u, mode="increase", increment=0.001, range_clip=[0.2, 0.5], reset_every_x_seconds=0.1), times)
     assert (rst == np.float32(0.395)).sum() > 8                                 # back to the initial value every 0.1 s
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_run_is_the_single_process_run(world):
+    """One process per GPU, each drawing its block of the run's experiments (schedule.draw_shard): the union over the ranks equals
+    the single-process run, experiment for experiment - uneven blocks included (7 experiments over 2 / 3 ranks)."""
+    cfg = dict(seed=12, length_of_experiment=3.0, start_at_target=False, target_position_end=None)
+    whole = SC.RandomExperimentSetter(cfg).draw(7, 300, L=np.linspace(0.3, 0.45, 7))
+    parts = [SC.draw_shard(cfg, 7, 300, rank=r, world=world, L=np.linspace(0.3, 0.45, 7)) for r in range(world)]
+    assert [first for _, first in parts] == [sum(p.E for p, _ in parts[:r]) for r in range(world)] and sum(p.E for p, _ in parts) == 7
+    assert np.array_equal(np.concatenate([p.s0 for p, _ in parts]), whole.s0)
+    assert np.array_equal(np.concatenate([p.target_position for p, _ in parts], axis=1), whole.target_position)
+    assert np.array_equal(np.concatenate([p.target_equilibrium for p, _ in parts], axis=1), whole.target_equilibrium)
+    assert sum((p.interpolation_type for p, _ in parts), []) == whole.interpolation_type
+    assert np.array_equal(np.concatenate([p.L for p, _ in parts]), whole.L)
