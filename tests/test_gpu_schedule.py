@@ -82,6 +82,58 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
     eng.close()
 
 
+@pytest.mark.parametrize("n_ctrl,n_save,stride", [(10, 4, 2), (4, 6, 2), (1, 1, 1), (25, 10, 5), (10, 20, 10), (7, 3, 1)])
+def test_plant_step_tables_at_any_stride_and_time_scale(n_ctrl, n_save, stride):
+    """cpmppi_plant_step with schedule tables sampled every `stride` simulation steps (the gcd of control and saving periods, as
+    schedule.py builds them), control periods of 1 ... 25 simulation steps, saving periods that divide them or not: the published
+    next-call values, the rows that are saved (and only those), the plant - against the oracle loop."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, T = 4, 5
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=64, mpc_horizon=10))
+    rng = Generator(SFC64(100 * n_ctrl + n_save))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-4, 4), rng.uniform(-0.19, 0.19), rng.uniform(-0.6, 0.6))
+                   for _ in range(E)])
+    Qs = rng.uniform(-1, 1, (T + 1, E)).astype(f32)
+    Lv = rng.uniform(0.25, 0.45, E).astype(f32)
+    n_sim = T * n_ctrl
+    srows = n_sim // stride + 1
+    tp = rng.uniform(-0.15, 0.15, (srows, E)).astype(f32)
+    te = rng.choice([-1.0, 1.0], (srows, E)).astype(f32)
+    R = n_sim // n_save + 1
+    s = eng.tensor(s0.copy())
+    guard = 3.0
+    states, dd, Qlog = eng.zeros(R + 2, E, 6) + guard, eng.zeros(R + 2, E, 2) + guard, eng.zeros(T + 1, E)
+    states[0] = s
+    cur_tp, cur_te = eng.zeros(E), eng.zeros(E)
+    kw = dict(dt_sim=0.002, period_steps=n_ctrl, L=Lv, states_log=states[:R], dd_log=dd[:R], save_every=n_save, Q_log=Qlog,
+              target_position_table=eng.tensor(tp), target_equilibrium_table=eng.tensor(te), sched_stride=stride,
+              target_position_out=cur_tp, target_equilibrium_out=cur_te)
+    for c in range(T):
+        eng.plant_step(s, Qs[c], n_ctrl, period=c, **kw)
+        row = min((c + 1) * n_ctrl // stride, srows - 1)
+        assert np.array_equal(cur_tp.cpu().numpy(), tp[row]) and np.array_equal(cur_te.cpu().numpy(), te[row])
+    eng.plant_step(s, Qs[T], 0, period=T, **kw)
+    st_h, dd_h = states.cpu().numpy(), dd.cpu().numpy()
+    assert (st_h[R:] == guard).all() and (dd_h[R:] == guard).all()                  # nothing beyond the logs' rows
+    for e in range(E):
+        r, Q = s0[e].copy(), Qs[0, e]
+        add, pdd = O.plant_ode(r, Q, Lv[e])
+        rows = [(r.copy(), add, pdd)]
+        for gstep in range(1, n_sim + 1):
+            r = O.plant_substep(r, add, pdd, 0.002, Lv[e])
+            if gstep % n_ctrl == 0:
+                Q = Qs[gstep // n_ctrl, e]
+            add, pdd = O.plant_ode(r, Q, Lv[e])
+            if gstep % n_save == 0:
+                rows.append((r.copy(), add, pdd))
+        assert len(rows) == R
+        for i, (rs, a_, p_) in enumerate(rows):
+            assert np.all(np.abs(st_h[i, e] - rs) <= 3e-5 + 3e-5 * np.abs(rs)), (e, i)
+            assert abs(dd_h[i, e, 0] - a_) <= 2e-3 + 1e-4 * abs(a_) and abs(dd_h[i, e, 1] - p_) <= 5e-4 + 1e-4 * abs(p_), (e, i)
+    eng.close()
+
+
 def _replay(g, tag, i, math_mode, graph=False):
     """One fixture experiment on the device loop with the reference's own perturbations (SFC64 knots from the host)."""
     from cartpolesimulation_amd import schedule as SC
