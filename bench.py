@@ -359,12 +359,14 @@ class Workload:
             # double through torch.distributed, outside the timed region); the W blocks this rank received through the library's
             # communicator must carry exactly those checksums and - the envs differ per rank - be pairwise distinct.  Plus what
             # RCCL itself reports about the communicator (ncclCommCount / ncclCommUserRank).
-            mine = u_final.double().sum().reshape(1)
-            sums = torch.empty(W, dtype=torch.float64, device=mine.device)
+            # (an EXACT checksum: the float32 bit patterns summed as integers - independent of any reduction order)
+            bits = lambda t: t.contiguous().view(torch.int32).to(torch.int64)            # noqa: E731
+            mine = bits(u_final.view(-1)).sum().reshape(1)
+            sums = torch.empty(W, dtype=torch.int64, device=mine.device)
             dist.all_gather_into_tensor(sums, mine)
-            got = last.double().sum(dim=1)
+            got = bits(last).sum(dim=1)
             blocks_match = bool(torch.equal(got, sums))
-            distinct = bool(W == 1 or len({float(x) for x in got.tolist()}) == W)
+            distinct = bool(W == 1 or len({int(x) for x in got.tolist()}) == W)
             info = self.native.info() if self.native else {"world": W, "rank": rank, "rccl_ranks": dist.get_world_size(),
                                                            "rccl_rank": dist.get_rank(), "rccl_version": 0}
             self.collective_report = {"impl": self.collective_impl, "ranks_requested": W, "rccl_ranks": info["rccl_ranks"],

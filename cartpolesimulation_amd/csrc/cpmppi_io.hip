@@ -144,7 +144,15 @@ int write_one(const Job& j, uint32_t e, std::string& buf, std::string& tmp) {
   int err = 0;
   if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) err = errno ? errno : EIO;
   if (fclose(f) != 0 && !err) err = errno ? errno : EIO;
-  if (!err && link(tmp.c_str(), j.paths[e]) != 0) err = errno ? errno : EIO;      // (link fails if the name appeared meanwhile; rename would replace it)
+  if (!err && link(tmp.c_str(), j.paths[e]) != 0) {                               // (link fails if the name appeared meanwhile; rename would replace it)
+    const int le = errno;
+    // a file system without hard links (some network / FUSE mounts): rename, after one more look that the name is still free
+    if ((le == EPERM || le == EOPNOTSUPP || le == ENOSYS || le == EMLINK) && access(j.paths[e], F_OK) != 0) {
+      if (rename(tmp.c_str(), j.paths[e]) != 0) err = errno ? errno : EIO;
+      return err;
+    }
+    err = le ? le : EIO;
+  }
   remove(tmp.c_str());
   return err;
 }
