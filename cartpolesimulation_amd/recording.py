@@ -38,16 +38,23 @@ def create_csv_file_name(controller_name="mpc", optimizer_name="mppi", prefix="C
     return prefix + ("_" + title if title else "") + name_controller + date + ".csv"
 
 
-def _unique_path(folder, csv_name, taken=()):
-    """CartPole/csv_logger.py:61-91: never overwrite, append -1, -2, ... (`taken`: names already given out in this batch)."""
+def _unique_path(folder, csv_name, taken=(), start=None):
+    """CartPole/csv_logger.py:61-91: never overwrite, append -1, -2, ... (`taken`: names already given out in this batch;
+    `start`: {base: first index worth trying} - a batch of n files would otherwise probe n^2 / 2 names)."""
     os.makedirs(folder, exist_ok=True)
     if not csv_name.endswith(".csv"):
         csv_name += ".csv"
     path = os.path.join(folder, csv_name)
-    base, idx = path[:-4], 1
+    base = path[:-4]
+    idx = 0 if start is None else start.get(base, 0)       # 0: the plain name has not been tried yet
+    if idx > 0:
+        path = f"{base}-{idx}.csv"
+    idx += 1
     while os.path.isfile(path) or path in taken:
         path = f"{base}-{idx}.csv"
         idx += 1
+    if start is not None:
+        start[base] = idx
     return path
 
 
@@ -180,7 +187,7 @@ def dataset_paths(n, out_dir, ml_pipeline=False, split=(0.8, 0.1), secondary_exp
     """The files run_data_generator gives its experiments (CartPole/data_generator.py:290-322 + csv_logger.py:61-91): all are
     called "Experiment" (or "Experiment-007" with a secondary index) and the logger makes the names unique by appending -1, -2, ...;
     in ML_Pipeline_mode they go to Train / Validate / Test by their position in the run."""
-    paths, taken = [], set()
+    paths, taken, start = [], set(), {}
     for i in range(n):
         if ml_pipeline:
             sub = "Train" if i < int(split[0] * n) else ("Validate" if i < int((split[0] + split[1]) * n) else "Test")
@@ -188,7 +195,7 @@ def dataset_paths(n, out_dir, ml_pipeline=False, split=(0.8, 0.1), secondary_exp
         else:
             folder = out_dir
             name = "Experiment" if secondary_experiment_index is None else f"Experiment-{secondary_experiment_index:0{digits}d}"
-        p = _unique_path(folder, name, taken)
+        p = _unique_path(folder, name, taken, start)
         taken.add(p)
         paths.append(p)
     return paths
