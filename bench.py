@@ -367,13 +367,17 @@ class Workload:
             got = bits(last).sum(dim=1)
             blocks_match = bool(torch.equal(got, sums))
             distinct = bool(W == 1 or len({int(x) for x in got.tolist()}) == W)
-            info = self.native.info() if self.native else {"world": W, "rank": rank, "rccl_ranks": dist.get_world_size(),
-                                                           "rccl_rank": dist.get_rank(), "rccl_version": 0}
-            self.collective_report = {"impl": self.collective_impl, "ranks_requested": W, "rccl_ranks": info["rccl_ranks"],
-                                      "rccl_rank_of_rank0": info["rccl_rank"], "rccl_version": info.get("rccl_version"),
+            # rccl_*: what ncclCommCount / ncclCommUserRank / ncclGetVersion answer for libcpmppi's own communicator
+            # (cpmppi_comm_get_info); null on the torch.distributed form, whose communicator is not ours to query - there
+            # backend_ranks is the process group's size
+            info = self.native.info() if self.native else {}
+            self.collective_report = {"impl": self.collective_impl, "ranks_requested": W, "rccl_ranks": info.get("rccl_ranks"),
+                                      "rccl_rank_of_rank0": info.get("rccl_rank"), "rccl_version": info.get("rccl_version"),
                                       "stream_memory_ops": info.get("stream_memory_ops"),
+                                      "backend": dist.get_backend(), "backend_ranks": dist.get_world_size(),
                                       "rank_blocks_match_every_ranks_own_checksum": blocks_match, "rank_blocks_distinct": distinct}
-            assert blocks_match and distinct and info["rccl_ranks"] == W, f"the collective did not span {W} ranks: {self.collective_report}"
+            spans = info["rccl_ranks"] == W if self.native else dist.get_world_size() == W
+            assert blocks_match and distinct and spans, f"the collective did not span {W} ranks: {self.collective_report}"
         k_ms = float(np.mean(rollout_ms))
         E, N, H = self.E, self.N, self.H
         return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
