@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <exception>
 #include <vector>
 
 #include "cpmppi.h"
@@ -1102,7 +1103,7 @@ int cpmppi_last_launch(const cpmppi_handle* h, cpmppi_launch_info* out) {
   return CPMPPI_OK;
 }
 
-int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
+int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) try {
   if (!cfg || !out) return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_create: null argument");
   *out = nullptr;
   if (cfg->abi_version != CPMPPI_ABI_VERSION)
@@ -1174,7 +1175,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) {
   }
   *out = h;
   return CPMPPI_OK;
-}
+} catch (const std::exception&) { return CPMPPI_ERR_NOMEM; }   // (no C++ exception leaves the C ABI)
 
 void cpmppi_destroy(cpmppi_handle* h) {
   if (!h) return;
@@ -1614,7 +1615,7 @@ int cpmppi_get_profile(cpmppi_handle* h, float* rollout_ms, float* finalize_ms, 
   return CPMPPI_OK;
 }
 
-int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
+int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) try {
   if (!h) return CPMPPI_ERR_BAD_ARG;
   if (!m || m->hidden != 32 || m->layers != 2 || m->inputs != 6 || m->outputs != 5)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_set_gru: only GRU-6IN-32H1-32H2-5OUT is built");
@@ -1728,7 +1729,7 @@ int cpmppi_set_gru(cpmppi_handle* h, const cpmppi_gru_model* m) {
   if (!h->gru16_image) CPMPPI_HIP(h, hipMalloc(&h->gru16_image, img16.size()));
   CPMPPI_HIP(h, hipMemcpy(h->gru16_image, img16.data(), img16.size(), hipMemcpyHostToDevice));
   return CPMPPI_OK;
-}
+} catch (const std::exception&) { return CPMPPI_ERR_NOMEM; }   // (no C++ exception leaves the C ABI)
 
 int cpmppi_gru_predict(cpmppi_handle* h, uint32_t B, uint32_t horizon, const float* s0, const float* Q, const float* h0,
                        float* traj_out, float* h_out, void* stream) {
@@ -1971,7 +1972,7 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
 
 uint32_t cpmppi_abi_version(void) { return CPMPPI_ABI_VERSION; }
 
-int cpmppi_stream_create(int device, void** stream_out) {
+int cpmppi_stream_create(int device, void** stream_out) try {
   if (!stream_out) return fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_stream_create: null argument");
   *stream_out = nullptr;
   DeviceGuard guard(device);
@@ -1992,7 +1993,7 @@ int cpmppi_stream_create(int device, void** stream_out) {
   if (e != hipSuccess) return fail(nullptr, CPMPPI_ERR_HIP, std::string("cpmppi_stream_create: ") + hipGetErrorString(e));
   *stream_out = st;
   return CPMPPI_OK;
-}
+} catch (const std::exception&) { return CPMPPI_ERR_NOMEM; }   // (no C++ exception leaves the C ABI)
 
 int cpmppi_stream_destroy(void* stream) {
   if (!stream) return CPMPPI_OK;

@@ -16,6 +16,7 @@
 // interpreter in between; the argument blocks describe the FULL [E, ...] arrays and every group works on its slice in place.
 #include <hip/hip_runtime.h>
 
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -75,7 +76,9 @@ int cpmppi_groups_create(const cpmppi_config* cfg, int device, uint32_t groups, 
   *out = nullptr;
   if (cfg->E == 0 || groups == 0) return gfail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_create: E and groups must be > 0");
   if (groups > cfg->E) groups = cfg->E;
-  cpmppi_groups* g = new cpmppi_groups();
+  cpmppi_groups* g = nullptr;
+  try {                                          // (no C++ exception leaves the C ABI)
+  g = new cpmppi_groups();
   g->cfg = *cfg; g->device = device; g->E = cfg->E; g->env_offset = env_offset;
   const uint32_t base = cfg->E / groups, extra = cfg->E % groups;      // contiguous, as even as possible
   uint32_t e0 = 0;
@@ -111,6 +114,11 @@ int cpmppi_groups_create(const cpmppi_config* cfg, int device, uint32_t groups, 
   }
   *out = g;
   return CPMPPI_OK;
+  } catch (const std::exception&) {
+    cpmppi_groups_destroy(g);
+    try { g_groups_create_error = "cpmppi_groups_create: out of host memory"; } catch (...) {}
+    return CPMPPI_ERR_NOMEM;
+  }
 }
 
 uint32_t cpmppi_groups_count(const cpmppi_groups* g) { return g ? (uint32_t)g->g.size() : 0u; }
@@ -154,6 +162,7 @@ int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmp
     return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run: plant->period_dev is one shared device counter; the groups count their periods from plant->period");
   const cpmppi_config& c = g->cfg;
   const size_t N = c.N, H = c.H, P = (H + c.period - 1u) / c.period + 1u;
+  try {
   // per-group argument blocks: the caller's, moved to the group's first env
   std::vector<cpmppi_step_args> sa(g->g.size());
   std::vector<cpmppi_plant_args> pa(g->g.size());
@@ -200,6 +209,9 @@ int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmp
     }
   }
   return CPMPPI_OK;
+  } catch (const std::exception&) {
+    return CPMPPI_ERR_NOMEM;
+  }
 }
 
 }  // extern "C"

@@ -24,6 +24,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -148,7 +150,9 @@ int write_one(const Job& j, uint32_t e, std::string& buf, std::string& tmp) {
     const int le = errno;
     // a file system without hard links (some network / FUSE mounts): rename, after one more look that the name is still free
     if ((le == EPERM || le == EOPNOTSUPP || le == ENOSYS || le == EMLINK) && access(j.paths[e], F_OK) != 0) {
-      if (rename(tmp.c_str(), j.paths[e]) != 0) err = errno ? errno : EIO;
+      if (rename(tmp.c_str(), j.paths[e]) == 0) return 0;
+      err = errno ? errno : EIO;
+      remove(tmp.c_str());
       return err;
     }
     err = le ? le : EIO;
@@ -169,27 +173,44 @@ int cpmppi_write_recordings(const char* const* paths, const char* preamble, size
   const uint32_t E = rec->E;
   for (uint32_t e = 0; e < E; ++e)
     if (!paths[e]) return cpmppi_internal_fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_write_recordings: null path");
+  std::vector<char> written;
+  try {                                          // (threads and row buffers: no C++ exception leaves the C ABI)
+  {
+    std::vector<std::string> names(paths, paths + E);                    // two files of one call under one name would share a temporary
+    std::sort(names.begin(), names.end());
+    const auto dup = std::adjacent_find(names.begin(), names.end());
+    if (dup != names.end())
+      return cpmppi_internal_fail(nullptr, CPMPPI_ERR_BAD_ARG, "cpmppi_write_recordings: the same path twice: " + *dup);
+  }
   const Job j{paths, preamble, preamble_len, rec};
   unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
   if (nt > 32) nt = 32;
   if (nt > E) nt = E;
   std::vector<int> failed(nt, -1), failed_errno(nt, 0);
-  std::vector<char> written(E, 0);
+  written.assign(E, 0);
   auto work = [&](unsigned w) {
-    std::string buf, tmp;
-    buf.reserve(preamble_len + (size_t)rec->rows * 400);
-    for (uint32_t e = w; e < E; e += nt) {
-      const int err = write_one(j, e, buf, tmp);
-      if (err == 0) written[e] = 1;
-      else if (failed[w] < 0) { failed[w] = (int)e; failed_errno[w] = err; }
+    uint32_t e = w;
+    try {
+      std::string buf, tmp;
+      buf.reserve(preamble_len + (size_t)rec->rows * 400);
+      for (; e < E; e += nt) {
+        const int err = write_one(j, e, buf, tmp);
+        if (err == 0) written[e] = 1;
+        else if (failed[w] < 0) { failed[w] = (int)e; failed_errno[w] = err; }
+      }
+    } catch (const std::exception&) {            // (a row buffer that could not grow)
+      if (failed[w] < 0) { failed[w] = (int)e; failed_errno[w] = ENOMEM; }
     }
   };
-  if (nt == 1) {
-    work(0);
-  } else {
+  {
     std::vector<std::thread> th;
-    for (unsigned w = 0; w < nt; ++w) th.emplace_back(work, w);
+    th.reserve(nt);
+    unsigned started = 0;
+    try {
+      for (; started + 1 < nt; ++started) th.emplace_back(work, started);
+    } catch (const std::exception&) {}           // no more threads to be had: this thread takes the rest
+    for (unsigned w = started; w < nt; ++w) work(w);
     for (auto& t : th) t.join();
   }
   std::string msg;
@@ -205,6 +226,11 @@ int cpmppi_write_recordings(const char* const* paths, const char* preamble, size
     return cpmppi_internal_fail(nullptr, CPMPPI_ERR_IO, msg + " (the recordings this call had written were removed)");
   }
   return CPMPPI_OK;
+  } catch (const std::exception&) {              // out of host memory (every worker has been joined or was never started)
+    for (uint32_t e = 0; e < E && e < written.size(); ++e)
+      if (written[e]) remove(paths[e]);
+    return CPMPPI_ERR_NOMEM;
+  }
 }
 
 // tests: repr(float) / str(numpy.float32) as this unit formats them (compared with Python's and numpy's own on random values)

@@ -57,7 +57,8 @@ typedef enum {
   CPMPPI_ERR_HIP = -4,          /* a HIP runtime call failed (text in cpmppi_last_error) */
   CPMPPI_ERR_ALIGN = -5,        /* pointer not 4-byte aligned */
   CPMPPI_ERR_COMM = -6,         /* RCCL missing or an RCCL call failed (text in cpmppi_last_error) */
-  CPMPPI_ERR_IO = -7            /* a file could not be created or written (cpmppi_write_recordings; errno text in cpmppi_last_error) */
+  CPMPPI_ERR_IO = -7,           /* a file could not be created or written (cpmppi_write_recordings; errno text in cpmppi_last_error) */
+  CPMPPI_ERR_NOMEM = -8         /* host memory exhausted (no C++ exception ever leaves the library) */
 } cpmppi_status;
 
 /* cost_id: which in-tree cost formulation the rollout kernel evaluates. */

@@ -128,6 +128,11 @@ def test_native_writer_never_appends_and_cleans_up_after_a_failure(tmp_path):
         R.write_recordings_native(good, block, phys, header)
     assert ei.value.code == -7 and "File exists" in str(ei.value)
     assert [os.path.getsize(p) for p in good] == sizes and sorted(os.listdir(tmp_path)) == sorted(os.path.basename(p) for p in good)
+    twice = [str(tmp_path / f"new_{e}.csv") for e in (0, 1, 2, 1)]                                # one name twice in a call: refused up front
+    with pytest.raises(_lib.CpmppiError) as ei:
+        R.write_recordings_native(twice, block, phys, header, n_threads=4)
+    assert ei.value.code == -1 and "new_1.csv" in str(ei.value)
+    assert sorted(os.listdir(tmp_path)) == sorted(os.path.basename(p) for p in good)
 
 
 @pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0"])
