@@ -284,9 +284,10 @@ struct PlantDev {
   float *states_log, *dd_log, *Q_log;
   const float *tp_table, *te_table, *L_table;
   float *tp_out, *te_out, *L_out;
+  const float *m_pole, *m_table, *Lc_table;
 };
 
-__global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, const PlantDev a) {
+__global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const PlantDev a) {
   const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
   if (env >= a.E) return;
   const uint32_t E = a.row_envs;                                       // envs per ROW of the logs and tables (>= a.E: an env group's slice)
@@ -303,7 +304,9 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, const Plan
     const uint64_t r = g / a.sched_stride;
     return (size_t)(r < a.sched_rows ? r : a.sched_rows - 1u) * E + env;
   };
+  Params p = p0;                                                       // (this env's copy: its pole mass may differ and change)
   float Lcur = a.L_table ? a.L_table[sched_row(g0)] : (a.L ? a.L[env] : p.L_default);
+  p.m_pole = a.m_table ? a.m_table[sched_row(g0)] : (a.m_pole ? a.m_pole[env] : p0.m_pole);
   EnvConst ec = make_env_const(p, Lcur);
   float* se = a.s + (size_t)env * 6;
   State<float> st{se[0], se[1], se[2], se[3], se[4], se[5]};
@@ -320,9 +323,11 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, const Plan
   log_dd(g0);
   for (uint32_t i = 0; i < a.n_sub; ++i) {
     const uint64_t g = g0 + i + 1u;
-    if (a.L_table) {                                                   // update_parameters (:529-537) comes first in update_state
-      const float Ln = a.L_table[sched_row(g)];
-      if (Ln != Lcur) { Lcur = Ln; ec = make_env_const(p, Lcur); }
+    if (a.L_table || a.m_table) {                                      // update_parameters (:529-537) comes first in update_state
+      const size_t r = sched_row(g);
+      const float Ln = a.L_table ? a.L_table[r] : Lcur;
+      const float mn = a.m_table ? a.m_table[r] : p.m_pole;
+      if (Ln != Lcur || mn != p.m_pole) { Lcur = Ln; p.m_pole = mn; ec = make_env_const(p, Lcur); }
     }
     plant_substep(st, aDD, xDD, a.dt_sim, p, ec);
     ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p, const Plan
     const size_t r = sched_row(g0 + a.n_sub);
     if (a.tp_table && a.tp_out) a.tp_out[env] = a.tp_table[r];
     if (a.te_table && a.te_out) a.te_out[env] = a.te_table[r];
-    if (a.L_table && a.L_out) a.L_out[env] = a.L_table[r];
+    if (a.L_table && a.L_out) a.L_out[env] = (a.Lc_table ? a.Lc_table : a.L_table)[r];
   }
 }
 
@@ -1913,7 +1918,9 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   const uint32_t save_every = a->save_every ? a->save_every : period_steps;
   if ((a->states_log || a->dd_log) && save_every == 0)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: save_every / period_steps missing");
-  const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table;
+  const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table || a->m_pole_table || a->L_controller_table;
+  if (a->L_controller_table && !a->L_table)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: L_controller_table stands in for L_table in L_out: give both");
   if (tables && a->sched_rows == 0) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: schedule tables need sched_rows > 0");
   if (a->row_envs != 0 && a->row_envs < a->E) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: row_envs < E");
   // a host-named period must lie inside the control log it is to be written to (rows of the state logs that fall outside are
@@ -1923,6 +1930,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   if (misaligned(a->s) || misaligned(a->Q) || misaligned(a->L) || misaligned(a->states_log) || misaligned(a->dd_log) ||
       misaligned(a->Q_log) || misaligned(a->target_position_table) || misaligned(a->target_equilibrium_table) ||
       misaligned(a->L_table) || misaligned(a->target_position_out) || misaligned(a->target_equilibrium_out) || misaligned(a->L_out) ||
+      misaligned(a->m_pole) || misaligned(a->m_pole_table) || misaligned(a->L_controller_table) ||
       (a->period_dev && ((uintptr_t)a->period_dev & 7u)))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_step: misaligned");
   CPMPPI_ON_DEVICE(h);
@@ -1938,6 +1946,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   d.states_log = a->states_log; d.dd_log = a->dd_log; d.Q_log = a->Q_log;
   d.tp_table = a->target_position_table; d.te_table = a->target_equilibrium_table; d.L_table = a->L_table;
   d.tp_out = a->target_position_out; d.te_out = a->target_equilibrium_out; d.L_out = a->L_out;
+  d.m_pole = a->m_pole; d.m_table = a->m_pole_table; d.Lc_table = a->L_controller_table;
   hipLaunchKernelGGL(plant_kernel, dim3((a->E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, d);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;

@@ -10,7 +10,8 @@
 //     least two exponent digits; ".0" after an integer);
 //   * numpy float32 scalars (the state, angleDD, positionDD, Q_applied, Q_ccrc, u): str(numpy.float32) - the shortest digit
 //     string that reads back to the same FLOAT (numpy's Dragon4 in unique mode = std::to_chars(float)), same layout rule;
-//   * target_equilibrium: an int; L_for_controller / m_pole_for_controller: the string 'true'; Q_update_time: None -> empty
+//   * target_equilibrium: an int; L_for_controller / m_pole_for_controller: the controller informer's 'true' / 'default';
+//     Q_update_time: None -> empty
 //     before the first controller update inside the loop.
 // Rows end with "\r\n" (csv.writer's default line terminator), fields are joined with ',' and never need quoting; the comment
 // block and the column-name row come from the caller as ready-made bytes.  A batched run of E experiments ends with E files:
@@ -133,7 +134,12 @@ int write_one(const Job& j, uint32_t e, std::string& buf, std::string& tmp) {
     buf.push_back(',');
     buf.append(num, snprintf(num, sizeof(num), "%d", (int)r.target_equilibrium[i]));
     f64col((double)r.L[i]);
-    buf.append(",true,", 6); buf.append(mp, mpl); buf.append(",true,0.0,1.0,0.0,", 18);
+    const bool told = !r.informed || r.informed[i];
+    const char* inf = told ? ",true" : ",default";
+    const size_t infl = told ? 5 : 8;
+    buf.append(inf, infl);
+    if (r.m_pole_rows) f64col((double)r.m_pole_rows[i]); else { buf.push_back(','); buf.append(mp, mpl); }
+    buf.append(inf, infl); buf.append(",0.0,1.0,0.0,", 13);
     if (t >= r.first_update_row) buf.append(qt, qtl);
     buf.append("\r\n", 2);
   }

@@ -129,10 +129,17 @@ class ScheduleRun:
         tp_tab = eng.tensor(b.target_position.astype(np.float32))                 # the controller computes in float32
         te_tab = eng.tensor(b.target_equilibrium.astype(np.float32))
         L_tab = eng.tensor(b.L_table) if b.L_table is not None else None
-        if L_tab is not None and (b.stride != 1 or L_tab.shape[0] != b.n_sim + 1):
-            raise ValueError("a pole-length table is per simulation step: draw the batch with stride 1 (dt_save = dt_simulation)")
+        m_tab = eng.tensor(b.m_pole_table) if b.m_pole_table is not None else None
+        for tab in (L_tab, m_tab):
+            if tab is not None and (b.stride != 1 or tab.shape[0] != b.n_sim + 1):
+                raise ValueError("a pole-length / pole-mass table is per simulation step: draw the batch with stride 1 (dt_save = dt_simulation)")
+        Lc_tab = None
+        if L_tab is not None and b.informed is not None:                            # what the controller is TOLD: the true length or the initial one
+            told = np.asarray(b.informed, bool)
+            Lc_tab = eng.tensor(np.where(told if told.ndim == 2 else told[:, None], np.asarray(b.L_table, np.float32),
+                                         np.asarray(b.L_table, np.float32)[0]))
         self.cur_tp, self.cur_te = tp_tab[0].clone(), te_tab[0].clone()
-        self.cur_L = L_tab[0].clone() if L_tab is not None else (eng.tensor(b.L) if b.L is not None else None)
+        self.cur_L = (Lc_tab if Lc_tab is not None else L_tab)[0].clone() if L_tab is not None else (eng.tensor(b.L) if b.L is not None else None)
         self.u_nom = eng.zeros(E, eng.H) if u_nom0 is None else eng.tensor(u_nom0, (E, eng.H)).clone()
         self.Q = eng.empty(E)
         self.states, self.dd, self.Qs = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
@@ -141,7 +148,8 @@ class ScheduleRun:
         self.plant = dict(dt_sim=b.dt_simulation, period_steps=b.n_ctrl, L=None if L_tab is not None else self.cur_L,
                           states_log=self.states, dd_log=self.dd, save_every=b.n_save, Q_log=self.Qs, target_position_table=tp_tab,
                           target_equilibrium_table=te_tab, L_table=L_tab, sched_stride=b.stride, target_position_out=self.cur_tp,
-                          target_equilibrium_out=self.cur_te, L_out=self.cur_L if L_tab is not None else None)
+                          target_equilibrium_out=self.cur_te, L_out=self.cur_L if L_tab is not None else None, m_pole_table=m_tab,
+                          L_controller_table=Lc_tab)
         self.counter = self.graph = None
         self.per = 0
         self._prep = self._prep_plant = None                       # argument blocks built once (the launched Philox loop)

@@ -129,10 +129,16 @@ def recording_block(result, phys, L_default=None):
         L = np.asarray(b.L_table, f32)[np.minimum(steps, b.L_table.shape[0] - 1)]
     else:
         L = np.broadcast_to(np.asarray(b.L if b.L is not None else (phys.L if L_default is None else L_default), f32), (R, E))
-    return dict(time=np.ascontiguousarray(b.times[steps]), states=states, dd=dd, Q=np.ascontiguousarray(Q), Q_ccrc=Q_ccrc,
-                target_position=np.ascontiguousarray(b.target_position[rows]),
-                target_equilibrium=np.ascontiguousarray(b.target_equilibrium[rows].astype(np.int32)),
-                L=np.ascontiguousarray(L, dtype=f32), first_update_row=int(-(-b.n_ctrl // b.n_save)))
+    out = dict(time=np.ascontiguousarray(b.times[steps]), states=states, dd=dd, Q=np.ascontiguousarray(Q), Q_ccrc=Q_ccrc,
+               target_position=np.ascontiguousarray(b.target_position[rows]),
+               target_equilibrium=np.ascontiguousarray(b.target_equilibrium[rows].astype(np.int32)),
+               L=np.ascontiguousarray(L, dtype=f32), first_update_row=int(-(-b.n_ctrl // b.n_save)))
+    if b.m_pole_table is not None:                                   # the `m_pole:` updater's values, row by row
+        out["m_pole"] = np.ascontiguousarray(np.asarray(b.m_pole_table, f32)[np.minimum(steps, b.m_pole_table.shape[0] - 1)])
+    if b.informed is not None:                                       # the controller informer's answer in force at the row
+        told = np.asarray(b.informed, bool)[np.minimum(steps, len(b.informed) - 1)]
+        out["informed"] = np.ascontiguousarray(np.broadcast_to(told if told.ndim == 2 else told[:, None], (R, E)), dtype=np.uint8)
+    return out
 
 
 def typed_columns(block, env, phys, q_update_time=0.0):
@@ -140,13 +146,15 @@ def typed_columns(block, env, phys, q_update_time=0.0):
     s, dd, Q = block["states"][:, env], block["dd"][:, env], block["Q"][:, env]
     R = s.shape[0]
     py = lambda a: [float(x) for x in a]                            # noqa: E731  (Python floats: written with repr)
-    u_max, m_pole = f32(phys.u_max), float(f32(phys.m_pole))
+    u_max = f32(phys.u_max)
+    m_pole = py(block["m_pole"][:, env]) if block.get("m_pole") is not None else [float(f32(phys.m_pole))] * R
+    told = ["true" if x else "default" for x in block["informed"][:, env]] if block.get("informed") is not None else ["true"] * R
     cols = {"time": py(block["time"]), "angle": list(s[:, 0]), "angleD": list(s[:, 1]), "angleDD": list(dd[:, 0]),
             "angle_cos": list(s[:, 2]), "angle_sin": list(s[:, 3]), "position": list(s[:, 4]), "positionD": list(s[:, 5]),
             "positionDD": list(dd[:, 1]), "Q_calculated": py(Q), "Q_applied": list(Q), "Q_ccrc": list(block["Q_ccrc"][:, env]),
             "u": list(u_max * Q), "target_position": py(block["target_position"][:, env]),
             "target_equilibrium": [int(x) for x in block["target_equilibrium"][:, env]], "L": py(block["L"][:, env]),
-            "L_for_controller": ["true"] * R, "m_pole": [m_pole] * R, "m_pole_for_controller": ["true"] * R,
+            "L_for_controller": told, "m_pole": m_pole, "m_pole_for_controller": told,
             "vertical_angle_offset": [0.0] * R, "vertical_angle_offset_cos": [1.0] * R, "vertical_angle_offset_sin": [0.0] * R,
             "Q_update_time": [None if r < block["first_update_row"] else float(q_update_time) for r in range(R)]}
     assert list(cols) == COLUMNS
@@ -173,6 +181,12 @@ def write_recordings_native(paths, block, phys, header, title=None, q_update_tim
     for k, a in arrs.items():
         setattr(rec, k, a.ctypes.data)
     rec.m_pole, rec.u_max = float(f32(phys.m_pole)), float(f32(phys.u_max))
+    for k, field, dt in (("m_pole", "m_pole_rows", f32), ("informed", "informed", np.uint8)):
+        if block.get(k) is not None:
+            arrs[k] = a = np.ascontiguousarray(block[k], dtype=dt)
+            if a.shape != (R, E):
+                raise ValueError(f"recording block: {k} is {a.shape}, expected {(R, E)}")
+            setattr(rec, field, a.ctypes.data)
     rec.first_update_row, rec.q_update_time = int(block["first_update_row"]), float(q_update_time)
     pre = preamble_bytes(header, title=title)
     cpaths = (C.c_char_p * E)(*[os.fsencode(p) for p in paths])
@@ -212,7 +226,7 @@ def experiment_folder(root, secondary_experiment_index=None, digits=3):
 
 def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, seed=None, cartpole_seed=None, L=None, native=True,
                      graph=False, secondary_experiment_index=None, controller_name="mpc", optimizer_name="mppi", title=None, groups=1,
-                     rank=0, world=1):
+                     rank=0, world=1, parameters=None):
     """Batched run_data_generator: ``config`` = config_data_gen.yml as a dict (or overrides of the shipped file, see
     schedule.merged_config) - length_of_experiment, the three dt, the random initial state, the target trace's turning points
     and interpolation types, the target-equilibrium dwell times, number_of_experiments, ML_Pipeline_mode / split.  All
@@ -223,7 +237,10 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     problem definition).  ``rank`` / ``world``: one process per GPU, each generating its contiguous block of the run's experiments
     (schedule.draw_shard: the same experiments as the single-process run) and writing them like a job of the reference's array
     would - `secondary_experiment_index` defaults to the rank (run_data_generator.py -i, others/EulerClusterScripts/
-    ParallelDataGeneration.sh:17), so no two ranks ever ask for the same file name; no collective is involved."""
+    ParallelDataGeneration.sh:17), so no two ranks ever ask for the same file name; no collective is involved.
+    ``parameters``: the `L` / `m_pole` / `inform_controller_about_parameters_change` blocks of cartpole_physical_parameters.yml's
+    `cartpole:` section - a pole length and a pole mass that change DURING the experiments (CartPole/parameter_updater.py) and a
+    controller that is told the true length only part of the time (schedule.apply_parameter_schedule)."""
     import time
     from .harness import BatchedCartPoleExperiment
     from .schedule import RandomExperimentSetter, merged_config
@@ -235,11 +252,15 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     _first = 0                                                     # global index of this process's first experiment (Philox keys)
     if int(world) > 1:
         from .schedule import draw_shard
-        batch, _first = draw_shard(cfg, n_total, cseed, rank, world, L=L)
+        batch, _first = draw_shard(cfg, n_total, cseed, rank, world, L=L, stride=1 if parameters else None)
         if secondary_experiment_index is None:
             secondary_experiment_index = int(rank)
     else:
-        batch = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength).draw(n_total, cseed, L=L)
+        batch = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength).draw(n_total, cseed, L=L,
+                                                                                                stride=1 if parameters else None)
+    if parameters:
+        from .schedule import apply_parameter_schedule
+        batch = apply_parameter_schedule(batch, parameters, seed=cseed, first=_first)
     n = batch.E
     if n > engine.E:
         raise ValueError(f"{n} experiments on an engine created for {engine.E} envs")

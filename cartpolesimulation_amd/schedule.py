@@ -69,6 +69,9 @@ class ExperimentBatch:
     interpolation_type: list = field(default_factory=list)
     L: np.ndarray = None                # [E] float32 constant pole length per experiment, or None (the handle's default)
     L_table: np.ndarray = None          # [rows_L, E] float32 with its own stride 1 (per simulation step), or None
+    m_pole_table: np.ndarray = None     # [n_sim + 1, E] float32 per simulation step: the PLANT's pole mass, or None (the handle's)
+    informed: np.ndarray = None         # [n_sim + 1, E] bool per simulation step: is the controller handed the true pole length /
+                                        # mass (informer_table) or the initial ones; None = always (mode 'ON', as shipped)
 
     @property
     def E(self):
@@ -151,8 +154,9 @@ class RandomExperimentSetter:
             self._one(np.random.Generator(np.random.SFC64(0)))
         return self
 
-    def draw(self, E, cartpole_seed, L=None):
-        """The next E experiments of the run -> ExperimentBatch."""
+    def draw(self, E, cartpole_seed, L=None, stride=None):
+        """The next E experiments of the run -> ExperimentBatch.  ``stride``: simulation steps per table row (default: the gcd of
+        the control and saving periods; 1 when per-step parameter tables are to be attached, apply_parameter_schedule)."""
         c = self.config
         dt_sim, dt_ctrl, dt_save = c["dt"]["simulation"], c["dt"]["control"], c["dt"]["saving"]
         n_ctrl = max(1, int(np.rint(dt_ctrl / dt_sim)))                              # CartPole/__init__.py:909-916
@@ -160,7 +164,11 @@ class RandomExperimentSetter:
         length = c["length_of_experiment"]
         n_sim = int(np.ceil(length / dt_sim))                                        # :648
         times = accumulated_times(n_sim, dt_sim)
-        stride = gcd(n_ctrl, n_save)
+        if stride is None:
+            stride = gcd(n_ctrl, n_save)
+        elif stride < 1 or gcd(n_ctrl, n_save) % int(stride):
+            raise ValueError("stride must divide the control and the saving period")
+        stride = int(stride)
         steps = np.arange(0, n_sim + 1, stride)
         frac = c["track_fraction_usable_for_target_position"]
         hi = np.float64(f32(frac) * self.thl)                                        # random_target_generator.py:85 (float32 bounds)
@@ -330,7 +338,66 @@ def parameter_table(updater, times, py_random=None, np_random=None):
     return out
 
 
-def draw_shard(config, n_total, cartpole_seed, rank=0, world=1, L=None):
+def informer_table(informer, times, n_ctrl, np_random=None):
+    """`inform_controller_about_parameters_change` (cartpole_physical_parameters.yml; CartPole/controller_informer.py:5-50): the
+    simulator asks its ControllerInformer at every controller update - simulation steps 0, n_ctrl, 2 n_ctrl, ... with the time AFTER
+    the step (CartPole/__init__.py:495-500) - whether to hand the controller the TRUE pole length / mass or the initial ones, and
+    logs the answer in the L_for_controller / m_pole_for_controller columns.  -> bool [len(times)]: the answer in force after step g.
+    Modes 'ON', 'OFF', 'switching_regular' (on after x seconds off, off after y seconds on; starts off), 'switching_random' (the
+    dwell times drawn from U(0, x) / U(0, y) of `np_random` - a numpy RandomState; the reference draws from numpy's global one)."""
+    mode = informer["mode"]
+    on_after, off_after = informer["change_to_on_after_x_seconds_off"], informer["change_to_off_after_x_seconds_on"]
+    out = np.empty(len(times), bool)
+    if mode in ("ON", "OFF"):
+        out[:] = mode == "ON"
+        return out
+    if mode not in ("switching_regular", "switching_random"):
+        raise ValueError(f"unknown informer mode {mode!r}")
+    rnd = mode == "switching_random"
+    if rnd:
+        np_random = np_random or np.random.RandomState(0)
+        on_after_now, off_after_now = np_random.uniform(0, on_after), np_random.uniform(0, off_after)
+    else:
+        on_after_now, off_after_now = on_after, off_after
+    told, since_on, since_off = False, 0.0, 0.0
+    for g in range(len(times)):
+        if g % n_ctrl == 0:
+            t = times[g]
+            if not told and t - since_off >= on_after_now:
+                told, since_on = True, t
+                if rnd:
+                    on_after_now = np_random.uniform(0, on_after)
+            elif told and t - since_on >= off_after_now:
+                told, since_off = False, t
+                if rnd:
+                    off_after_now = np_random.uniform(0, off_after)
+        out[g] = told
+    return out
+
+
+def apply_parameter_schedule(batch, parameters, seed=0, first=0):
+    """The simulator's time-varying physical parameters for a batch drawn with stride 1: `parameters` holds any of the blocks `L`,
+    `m_pole` (ParameterUpdater configs) and `inform_controller_about_parameters_change` of cartpole_physical_parameters.yml's
+    `cartpole:` section.  -> the batch with L_table / m_pole_table / informed filled in (one column per experiment).  Deterministic
+    modes give every experiment the same column, as in the reference; the random modes draw per experiment from generators seeded
+    with seed + first + e (the reference draws from the process-global, clock-seeded generators: nothing to reproduce there)."""
+    import dataclasses
+    import random as _random
+    if batch.stride != 1:
+        raise ValueError("parameter tables are per simulation step: draw the batch with stride=1")
+    E, out = batch.E, {}
+    for name, field_ in (("L", "L_table"), ("m_pole", "m_pole_table")):
+        if parameters.get(name) is not None:
+            out[field_] = np.stack([parameter_table(parameters[name], batch.times, _random.Random(int(seed) + first + e),
+                                                    np.random.RandomState(int(seed) + first + e)) for e in range(E)], axis=1)
+    inf = parameters.get("inform_controller_about_parameters_change")
+    if inf is not None:
+        out["informed"] = np.stack([informer_table(inf, batch.times, batch.n_ctrl, np.random.RandomState(int(seed) + first + e + 1))
+                                    for e in range(E)], axis=1)
+    return dataclasses.replace(batch, **out)
+
+
+def draw_shard(config, n_total, cartpole_seed, rank=0, world=1, L=None, stride=None):
     """Rank `rank` of `world` processes' share of a run of `n_total` experiments: the contiguous block shard.env_shard gives it, drawn
     from the SAME random streams as the single-process run (the union over the ranks is that run, experiment for experiment) - the
     share-nothing fan-out of others/EulerClusterScripts/ParallelDataGeneration.sh:2-17 with reproducible content.
@@ -339,4 +406,4 @@ def draw_shard(config, n_total, cartpole_seed, rank=0, world=1, L=None):
     start, count = env_shard(n_total, world, rank)
     setter = RandomExperimentSetter(config).skip(start)
     Lv = None if L is None else np.broadcast_to(np.asarray(L, f32), (n_total,))[start:start + count]
-    return setter.draw(count, int(cartpole_seed) + start, L=Lv), start
+    return setter.draw(count, int(cartpole_seed) + start, L=Lv, stride=stride), start

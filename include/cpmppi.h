@@ -366,7 +366,8 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
  *   2. second derivatives of (s, q) with the pole length of step c*period_steps; dd_log[r][E][2] = (angleDD, positionDD) if that
  *      step is a saved one (r = step / save_every < save_rows) - the row whose state the PREVIOUS period stored, completed with
  *      the control computed from it (save_csv_routine runs after Update_Q, :316-324)
- *   3. n_substeps x { pole length of the step (L_table, else L / config.L_default); Euler-Cromer + edge bounce + cos / sin + wrap;
+ *   3. n_substeps x { pole length and pole mass of the step (L_table, else L / config.L_default; m_pole_table, else m_pole /
+ *      config.m_pole: update_parameters, :529-537); Euler-Cromer + edge bounce + cos / sin + wrap;
  *      second derivatives; if step % save_every == 0: states_log[step / save_every][E][6] = state, and dd_log unless the step ends
  *      the period }
  *   4. *_out[E] = row ((c + 1)*period_steps) of the tables: what the NEXT controller call is handed (updated_attributes
@@ -374,7 +375,8 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
  * n_substeps = 0 records only (1. and 2.: the run's last controller call is followed by no plant step, :690-716).
  * period_dev: c = *period_dev - 1, the device step counter of cpmppi_step_args.offset_dev (already advanced by the step); a
  * counter that is still 0 advances the plant from table row 0 WITHOUT recording or publishing.  Any log / table / out pointer may
- * be NULL.  Noise, latency and actuator disturbance: OFF, as in the shipped YAML.  m_pole: config.m_pole (see cpmppi_set_pole_mass). */
+ * be NULL.  Noise, latency and actuator disturbance: OFF, as in the shipped YAML.  The pole MASS the controller computes with is
+ * the handle's (config.m_pole / cpmppi_set_pole_mass), whatever the plant's: a per-env controller-side mass does not exist. */
 typedef struct {
   uint32_t E;
   float* s;                             /* [E,6] in / out */
@@ -401,6 +403,11 @@ typedef struct {
   float* L_out;                         /* [E] */
   uint32_t row_envs;                    /* envs per ROW of the logs and tables (0 = E): an env group that works on a slice of a larger
                                            batch's buffers passes the batch's env count and pointers to its first env (cpmppi_groups_run) */
+  const float* m_pole;                  /* [E] the PLANT's pole mass when there is no m_pole_table; NULL = config.m_pole */
+  const float* m_pole_table;            /* [sched_rows][E] a pole mass that changes in time, like L_table (the `m_pole:` updater) */
+  const float* L_controller_table;      /* [sched_rows][E] what L_out publishes instead of L_table: the pole length the CONTROLLER is
+                                           told (inform_controller_about_parameters_change, CartPole/controller_informer.py: the true
+                                           value or the initial one); NULL = L_table */
 } cpmppi_plant_args;
 int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* stream);
 
@@ -470,7 +477,7 @@ int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* args, float* re
  * (tests/golden/schedule.npz "csv_rows"): every column in the representation of the TYPE the reference holds it in -
  *   time, Q_calculated, target_position, L, m_pole, the vertical-angle-offset columns: Python floats -> repr(float) of the double
  *   the state, angleDD / positionDD, Q_applied, Q_ccrc, u: numpy float32 scalars -> str(numpy.float32), shortest float32 digits
- *   target_equilibrium: an int; L_for_controller / m_pole_for_controller: the controller informer's 'true'
+ *   target_equilibrium: an int; L_for_controller / m_pole_for_controller: the controller informer's 'true' / 'default'
  *   Q_update_time: empty until the first controller update inside the loop, then `q_update_time` (the reference logs the wall
  *   clock of its controller call there: not reproducible by construction)
  * rows end with "\r\n".  One thread per file.
@@ -493,6 +500,10 @@ typedef struct {
   float u_max;                          /* u = u_max * Q in float32 (CartPole/cartpole_equations.py:119-127) */
   uint32_t first_update_row;            /* rows before it have an empty Q_update_time */
   double q_update_time;
+  const float* m_pole_rows;             /* [rows][E] a pole mass that changed during the run (the float32 values the simulator held), or
+                                           NULL: `m_pole` in every row */
+  const uint8_t* informed;              /* [rows][E] L_for_controller / m_pole_for_controller: 1 = 'true', 0 = 'default' (the controller
+                                           informer's state when the row was saved); NULL = 'true' in every row (mode ON, as shipped) */
 } cpmppi_recording;
 int cpmppi_write_recordings(const char* const* paths, const char* preamble, size_t preamble_len, const cpmppi_recording* rec,
                             int n_threads);

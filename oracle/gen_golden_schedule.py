@@ -155,11 +155,13 @@ class CallLog:
         Q = self.inner(s, time, updated_attributes)
         a = updated_attributes
         self.calls.append(dict(s=s_in, time=float(time), tp=float(a["target_position"]), te=float(a["target_equilibrium"]),
-                               L=float(a["L"]), Q=f32(Q), u=self.ctrl.u_prev.copy(), minS=float(np.min(self.ctrl.S_tilde_k))))
+                               L=float(a["L"]), m_pole=float(a.get("m_pole", np.nan)), Q=f32(Q), u=self.ctrl.u_prev.copy(),
+                               minS=float(np.min(self.ctrl.S_tilde_k))))
         return Q
 
 
-def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None, L_updater=None):
+def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None, L_updater=None, m_pole_updater=None,
+                    informer=None):
     DG.load_config = lambda name: copy.deepcopy(cfg)
     if p_Q is not None:                                            # (cartpole_physical_parameters.yml `actuator_noise`, read at :83)
         LEG.p_Q = p_Q
@@ -167,6 +169,14 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
     if L_updater is not None:                                      # (cartpole_physical_parameters.yml `L:` block, read by CartPole.__init__ :120)
         APP.config["cartpole"]["L"] = dict(L_updater)
         out[f"{tag}/L_updater"] = np.array(json.dumps(L_updater))
+    shipped_m, shipped_inf = copy.deepcopy(APP.config["cartpole"]["m_pole"]), copy.deepcopy(
+        APP.config["cartpole"]["inform_controller_about_parameters_change"])
+    if m_pole_updater is not None:                                 # (the `m_pole:` block, :123)
+        APP.config["cartpole"]["m_pole"] = dict(m_pole_updater)
+        out[f"{tag}/m_pole_updater"] = np.array(json.dumps(m_pole_updater))
+    if informer is not None:                                       # (`inform_controller_about_parameters_change`, :128)
+        APP.config["cartpole"]["inform_controller_about_parameters_change"] = dict(informer)
+        out[f"{tag}/informer"] = np.array(json.dumps(informer))
     RES = DG.random_experiment_setter()
     out[f"{tag}/config"] = np.array(json.dumps(cfg))
     out[f"{tag}/N"], out[f"{tag}/H"], out[f"{tag}/ctrl_seed"] = np.int64(N), np.int64(H), np.int64(ctrl_seed)
@@ -206,32 +216,39 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
         body = [r.rsplit(",", 1)[0] for r in rows[k0:] if r]         # without the last column (Q_update_time)
         out[f"{key}/csv_rows"] = np.array("\r\n".join(body))
         out[f"{key}/csv_preamble"] = np.array("\r\n".join(rows[3:k0]))   # header block below the title / revision lines
-        for name in ("s", "time", "tp", "te", "L", "Q", "u", "minS"):
+        for name in ("s", "time", "tp", "te", "L", "m_pole", "Q", "u", "minS"):
             out[f"{key}/call/{name}"] = np.array([c[name] for c in calls])
         out[f"{key}/interpolation_type"] = np.array(inst_interp[-1])
         if L_updater is not None:
             out[f"{key}/L_steps"] = np.array(L_log[-1], dtype=np.float64)   # float(L) after every update_parameters call (one per simulation step)
+        if m_pole_updater is not None:
+            out[f"{key}/m_pole_steps"] = np.array(M_log[-1], dtype=np.float64)
         print(f"{key}: {len(data)} rows, {len(calls)} controller calls, interpolation {inst_interp[-1]}, "
               f"te flips at rows {np.flatnonzero(np.diff(data['target_equilibrium'].to_numpy()) != 0) + 1}, "
               f"target range [{data['target_position'].min():.4f}, {data['target_position'].max():.4f}]")
     APP.config["cartpole"]["L"] = shipped_L
+    APP.config["cartpole"]["m_pole"] = shipped_m
+    APP.config["cartpole"]["inform_controller_about_parameters_change"] = shipped_inf
+    APP.L[...], APP.m_pole[...] = shipped_L["init_value"], shipped_m["init_value"]      # (module-level arrays the updaters write into)
 
 
-inst_interp, L_log = [], []
+inst_interp, L_log, M_log = [], [], []
 
 
 def inst_run(inst, d):
     inst_interp.append(inst.interpolation_type)
     # the pole length the simulator holds after each update_parameters call (CartPole/__init__.py:529-537): an instance attribute in
     # front of the bound method records it, the method itself is the reference's
-    steps, inner = [], inst.update_parameters
+    steps, steps_m, inner = [], [], inst.update_parameters
 
     def update_parameters():
         inner()
         steps.append(float(APP.L))
+        steps_m.append(float(APP.m_pole))
 
     inst.update_parameters = update_parameters
     L_log.append(steps)
+    M_log.append(steps_m)
     stderr = sys.stderr
     sys.stderr = io.StringIO()                                     # (tqdm's progress bar)
     try:
@@ -277,5 +294,15 @@ if __name__ == "__main__":
     gen_experiments(out, "exp_tail", data_gen_config(**dict(fast, seed=81, length_of_experiment=0.05,
                                                             turning_points=dict(track_relative_complexity=1))), 1, 960,
                     ctrl_seed=555, p_Q=0.0)
+    # pole length AND pole mass changing during the experiment, the controller told about it only part of the time
+    # (inform_controller_about_parameters_change 'switching_regular': the value handed to the controller alternates between the true
+    # one and the initial one; the recording's L_for_controller / m_pole_for_controller columns say which)
+    gen_experiments(out, "exp_varM", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=82, length_of_experiment=0.4)), 1, 970,
+                    ctrl_seed=888, p_Q=0.0,
+                    L_updater=dict(init_value=0.395, change_every_x_seconds=0.014, mode="bounce", range_random=[0.2, 0.5], range_clip=[0.36, 0.43],
+                                   increment=0.01, reset_every_x_seconds="inf"),
+                    m_pole_updater=dict(init_value=0.087, change_every_x_seconds=0.022, mode="bounce", range_random=[0.015, 0.15],
+                                        range_clip=[0.07, 0.1], increment=0.004, reset_every_x_seconds="inf"),
+                    informer=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.05, change_to_off_after_x_seconds_on=0.07))
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
     print("wrote", os.path.join(OUT, "schedule.npz"), len(out), "arrays")

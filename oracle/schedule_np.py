@@ -16,6 +16,8 @@ slopes are restated from their published algorithms (scipy 1.15: interpolate/_in
 _call_previousnext; _ppoly.pyx evaluate_bpoly1; BPoly._construct_from_derivatives gives c = [ya, ya, yb, yb] exactly when both
 slopes are zero) and reproduce scipy's doubles bit for bit on the fixture.
 """
+from dataclasses import replace
+
 import numpy as np
 
 from . import oracle_np as O
@@ -212,11 +214,50 @@ def schedule_tables(trace, te0, length, dt_sim, keep_up, keep_down):
     return times, tp, te
 
 
-def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L_steps=None):
+def controller_informer(cfg, np_random=None):
+    """ControllerInformer (CartPole/controller_informer.py:5-50; `inform_controller_about_parameters_change`): is the controller
+    handed the TRUE pole length / pole mass or the initial ones?  -> get(time_now) -> bool, to be called where the simulator calls
+    get_parameters (at every controller update, CartPole/__init__.py:495-500, and - time 0 - when the experiment is set up).
+    'switching_random' draws from `np_random` (the reference: numpy's global generator, two draws at construction)."""
+    mode = cfg["mode"]
+    on_after, off_after = cfg["change_to_on_after_x_seconds_off"], cfg["change_to_off_after_x_seconds_on"]
+    st = dict(true=False, t_on=0.0, t_off=0.0)
+    if mode == "switching_random":
+        st["on_r"], st["off_r"] = np_random.uniform(0, on_after), np_random.uniform(0, off_after)     # :11-12
+
+    def get(t):
+        if mode == "OFF":
+            st["true"] = False
+        elif mode == "ON":
+            st["true"] = True
+        elif mode == "switching_regular":                                                       # :25-33
+            if not st["true"]:
+                if t - st["t_off"] >= on_after:
+                    st["true"], st["t_on"] = True, t
+            elif t - st["t_on"] >= off_after:
+                st["true"], st["t_off"] = False, t
+        elif mode == "switching_random":                                                        # :34-44
+            if not st["true"]:
+                if t - st["t_off"] >= st["on_r"]:
+                    st["true"], st["t_on"] = True, t
+                    st["on_r"] = np_random.uniform(0, on_after)
+            elif t - st["t_on"] >= st["off_r"]:
+                st["true"], st["t_off"] = False, t
+                st["off_r"] = np_random.uniform(0, off_after)
+        else:
+            raise ValueError(mode)
+        return st["true"]
+
+    return get
+
+
+def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L_steps=None, m_pole_steps=None, informer=None):
     """One experiment as CartPole.run_cartpole_random_experiment runs it (noise, latency, disturbance OFF as shipped).
     controller_step(s, time, target_position, target_equilibrium, L) -> Q.  Returns dict(rows: column -> list, calls).
     ``L_steps`` [n + 1]: a pole length that changes in time - entry g is what the simulator holds DURING simulation step g
-    (update_parameters is the first thing update_state does, CartPole/__init__.py:285, 529-537); entry 0 the initial value."""
+    (update_parameters is the first thing update_state does, CartPole/__init__.py:285, 529-537); entry 0 the initial value.
+    ``m_pole_steps``: the same for the pole mass (the plant's; the controller is TOLD, 'm_pole' of updated_attributes - `calls`
+    records it).  ``informer``: controller_informer(...) or None = 'ON'."""
     c = config
     dt_sim = c["dt"]["simulation"]
     n_ctrl = max(1, int(np.rint(c["dt"]["control"] / dt_sim)))                                  # :909-916
@@ -227,13 +268,22 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
                                         inf(c["keep_target_equilibrium_x_seconds_up"]), inf(c["keep_target_equilibrium_x_seconds_down"]))
     s = np.array(setup["s0"], dtype=f32)
     calls = []
+    L_init = Lf
+    m_init = float(p.m_pole) if m_pole_steps is None else float(m_pole_steps[0])
+    mf = m_init
+    if m_pole_steps is not None:
+        p = replace(p, m_pole=f32(mf))
+    informed = [True]
 
     def control(g):
-        Q = controller_step(s.copy(), times[g], tp_g[g], te_g[g], Lf)
-        calls.append(dict(s=s.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q), L=Lf))
+        informed[0] = True if informer is None else bool(informer(times[g]))                    # :495-500 (get_parameters, twice: idempotent)
+        L_c, m_c = (Lf, mf) if informed[0] else (L_init, m_init)
+        Q = controller_step(s.copy(), times[g], tp_g[g], te_g[g], L_c)
+        calls.append(dict(s=s.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q), L=L_c, m_pole=m_c))
         return f32(Q)
 
-    rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium", "L")}
+    rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium", "L",
+                            "m_pole", "informed")}
     Q_ccrc = f32(0.0)                                                                           # :838
     Q = control(0)                                                                              # set_cartpole_state_at_t0 :842-852
     aDD, xDD = O.plant_ode(s, Q, Lf, p)                                                         # :859-860
@@ -242,12 +292,16 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
         rows["time"].append(times[g]); rows["s"].append(s.copy()); rows["angleDD"].append(aDD); rows["positionDD"].append(xDD)
         rows["Q"].append(Q); rows["Q_ccrc"].append(Q_ccrc); rows["u"].append(O.Q2u(Q, p))
         rows["target_position"].append(tp_g[g]); rows["target_equilibrium"].append(te_g[g]); rows["L"].append(Lf)
+        rows["m_pole"].append(mf); rows["informed"].append(informed[0])
 
     save(0)                                                                                     # :875 (the t = 0 row)
     ctrl_counter = save_counter = 0
     for g in range(1, len(times)):                                                              # update_state, :283-324
         if L_steps is not None:
             Lf = float(L_steps[g])                                                              # update_parameters
+        if m_pole_steps is not None and float(m_pole_steps[g]) != mf:
+            mf = float(m_pole_steps[g])
+            p = replace(p, m_pole=f32(mf))
         s = O.plant_substep(s, aDD, xDD, dt_sim, Lf, p)                                         # integration, bounce, cos/sin, wrap
         ctrl_counter += 1
         if ctrl_counter == n_ctrl:                                                              # Update_Q :475-527

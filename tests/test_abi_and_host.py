@@ -60,19 +60,21 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
         subprocess.run([gxx, "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cpmppi.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cpmppi_config), sizeof(cpmppi_step_args), '
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cpmppi_config), sizeof(cpmppi_step_args), '
                    'sizeof(cpmppi_gru_model), offsetof(cpmppi_step_args, noise), offsetof(cpmppi_step_args, Q_out), '
                    'offsetof(cpmppi_step_args, offset_dev), offsetof(cpmppi_step_args, u_nom_out), '
                    'sizeof(cpmppi_plant_args), offsetof(cpmppi_plant_args, period), offsetof(cpmppi_plant_args, save_every), '
                    'offsetof(cpmppi_plant_args, sched_stride), offsetof(cpmppi_plant_args, row_envs), sizeof(cpmppi_recording), '
-                   'offsetof(cpmppi_recording, q_update_time), sizeof(cpmppi_comm_info) + sizeof(cpmppi_launch_info)); return 0; }\n')
+                   'offsetof(cpmppi_recording, q_update_time), sizeof(cpmppi_comm_info) + sizeof(cpmppi_launch_info), '
+                   'offsetof(cpmppi_plant_args, L_controller_table), offsetof(cpmppi_recording, informed)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     A, P, R = _lib.cpmppi_step_args, _lib.cpmppi_plant_args, _lib.cpmppi_recording
     assert got == [C.sizeof(_lib.cpmppi_config), C.sizeof(A), C.sizeof(_lib.cpmppi_gru_model), A.noise.offset, A.Q_out.offset,
                    A.offset_dev.offset, A.u_nom_out.offset, C.sizeof(P), P.period.offset, P.save_every.offset, P.sched_stride.offset,
-                   P.row_envs.offset, C.sizeof(R), R.q_update_time.offset, C.sizeof(_lib.cpmppi_comm_info) + C.sizeof(_lib.cpmppi_launch_info)]
+                   P.row_envs.offset, C.sizeof(R), R.q_update_time.offset, C.sizeof(_lib.cpmppi_comm_info) + C.sizeof(_lib.cpmppi_launch_info),
+                   P.L_controller_table.offset, R.informed.offset]
 
 
 def test_integration_doc_binding_matches_the_library():

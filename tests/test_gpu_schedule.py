@@ -1,6 +1,7 @@
 """GPU: the data generator's experiment schedule in the device loop: cpmppi_plant_step reading the schedule
 tables and recording at the saving period, harness.run_schedule, against the oracle's experiment loop and against whole experiments
 the reference's own simulator class ran (tests/golden/schedule.npz: moving target, target-equilibrium flips, dt_save != dt_control)."""
+import dataclasses
 import json
 import os
 
@@ -43,20 +44,24 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
         tp = rng.uniform(-0.15, 0.15, (rows_sched, E)).astype(f32)
         te = rng.choice([-1.0, 1.0], (rows_sched, E)).astype(f32)
         Ltab = np.repeat(rng.uniform(0.2, 0.5, (n_sim // 7 + 1, E)).astype(f32), 7, axis=0)[:rows_sched]   # changes every 7 steps
+        mtab = np.repeat(rng.uniform(0.03, 0.15, (n_sim // 11 + 1, E)).astype(f32), 11, axis=0)[:rows_sched]  # the pole MASS: every 11
+        Lctab = rng.uniform(0.2, 0.5, (rows_sched, E)).astype(f32)    # what the controller is told instead of the true length
         R = n_sim // n_save + 1
         s = eng.tensor(s0.copy())
         states, dd, Qlog = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
         states[0] = s
         tp_d, te_d, L_d = eng.tensor(tp), eng.tensor(te), eng.tensor(Ltab)
         cur_tp, cur_te, cur_L = eng.zeros(E), eng.zeros(E), eng.zeros(E)
+        told = n_save in (4, 1)                                        # with and without a separate controller-side table
         kw = dict(dt_sim=0.002, period_steps=n_ctrl, states_log=states, dd_log=dd, save_every=n_save, Q_log=Qlog,
                   target_position_table=tp_d, target_equilibrium_table=te_d, L_table=L_d, sched_stride=stride,
-                  target_position_out=cur_tp, target_equilibrium_out=cur_te, L_out=cur_L)
+                  target_position_out=cur_tp, target_equilibrium_out=cur_te, L_out=cur_L, m_pole_table=eng.tensor(mtab),
+                  L_controller_table=eng.tensor(Lctab) if told else None)
         for c in range(T):
             eng.plant_step(s, Qs[c], n_ctrl, period=c, **kw)
             g1 = (c + 1) * n_ctrl
             assert np.array_equal(cur_tp.cpu().numpy(), tp[g1]) and np.array_equal(cur_te.cpu().numpy(), te[g1])
-            assert np.array_equal(cur_L.cpu().numpy(), Ltab[g1])
+            assert np.array_equal(cur_L.cpu().numpy(), (Lctab if told else Ltab)[g1])
         eng.plant_step(s, Qs[T], 0, period=T, **kw)                    # the run's last controller call: record only
         st_h, dd_h = states.cpu().numpy(), dd.cpu().numpy()
         assert np.array_equal(Qlog.cpu().numpy(), Qs)
@@ -65,14 +70,15 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
             r = s0[e].copy()
             k = 0
             Q = Qs[0, e]
-            add, pdd = O.plant_ode(r, Q, Ltab[0, e])
+            pm = lambda gs: dataclasses.replace(O.DEFAULT_PARAMS, m_pole=mtab[gs, e])   # noqa: E731
+            add, pdd = O.plant_ode(r, Q, Ltab[0, e], pm(0))
             rows = [(r.copy(), add, pdd)]
-            for gstep in range(1, n_sim + 1):                          # update_state: L first, integrate, (controller), ode, save
+            for gstep in range(1, n_sim + 1):                          # update_state: L and m_pole first, integrate, (controller), ode, save
                 L = Ltab[gstep, e]
-                r = O.plant_substep(r, add, pdd, 0.002, L)
+                r = O.plant_substep(r, add, pdd, 0.002, L, pm(gstep))
                 if gstep % n_ctrl == 0:
                     Q = Qs[gstep // n_ctrl, e]
-                add, pdd = O.plant_ode(r, Q, L)
+                add, pdd = O.plant_ode(r, Q, L, pm(gstep))
                 if gstep % n_save == 0:
                     rows.append((r.copy(), add, pdd))
             assert len(rows) == R
@@ -334,6 +340,89 @@ def test_reference_experiment_with_a_changing_pole_length_on_the_device_loop(g):
         run0.enqueue_next()
     dd0 = run0.finish()["dd"].cpu().numpy()[::n_save_ref, 0, 0]
     assert np.abs(dd0[:r] - col("angleDD")[:r]).max() > 0.05
+    eng.close()
+
+
+def test_reference_experiment_with_changing_pole_mass_and_a_switching_informer_on_the_device_loop(g):
+    """exp_varM: the reference's simulator with BOTH parameter updaters on (pole length every 7, pole MASS every 11 simulation steps)
+    and its controller informer in 'switching_regular' mode.  schedule.parameter_table / informer_table give the per-step tables,
+    harness.ScheduleRun runs the experiment with them: the plant follows the changing mass (1e-4 over the first ten control steps),
+    the vector the next controller call reads its pole length from holds what the reference's controller was TOLD (the true length or
+    the initial one), and the recording carries the reference's L / m_pole / *_for_controller columns."""
+    from cartpolesimulation_amd import recording as R
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import ScheduleRun
+    tag, key = "exp_varM", "exp_varM/0"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    cfg["dt"]["saving"] = cfg["dt"]["simulation"]                      # (parameter tables are per simulation step: stride 1)
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    b = SC.RandomExperimentSetter(cfg).draw(1, int(g[f"{tag}/cartpole_seed0"]))
+    Ltab = SC.parameter_table(json.loads(g[f"{tag}/L_updater"].item()), b.times)
+    mtab = SC.parameter_table(json.loads(g[f"{tag}/m_pole_updater"].item()), b.times)
+    told = SC.informer_table(json.loads(g[f"{tag}/informer"].item()), b.times, b.n_ctrl)
+    b = dataclasses.replace(b, L_table=Ltab[:, None].copy(), m_pole_table=mtab[:, None].copy(), informed=told)
+    eng = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H))
+    stdev = np.float64(g[f"{tag}/stdev"])
+
+    def run_with(batch):
+        rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"])))
+        for _ in range(5):
+            rng.uniform(-1.0, 1.0)
+
+        def knots(_c):
+            kn = O.sample_knots(rng, N, H, stdev)
+            rng.uniform(-1.0, 1.0)
+            return kn[None]
+
+        un = eng.zeros(1, H)
+        eng.step(g[f"{key}/call/s"][0][None], un, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+        run = ScheduleRun(eng, batch, 0, knots_fn=knots, u_nom0=un)
+        # the legacy controller ignores the pole length it is told (controller_mppi_cartpole.py:51-52): its L stays the default;
+        # the published vector is kept aside and compared with what the reference's calls were handed
+        handed = run.cur_L
+        run.cur_L = None
+        told_L = [float(handed.cpu().numpy()[0])] if handed is not None else []
+        while run.periods_left:
+            run.enqueue_next()
+            if handed is not None:
+                told_L.append(float(handed.cpu().numpy()[0]))
+        return run.finish(), np.array(told_L, f32)
+
+    res, told_L = run_with(b)
+    assert np.array_equal(told_L, g[f"{key}/call/L"][1:].astype(f32)) and len(np.unique(told_L)) > 4
+    blk = R.recording_block(res, eng.phys)
+    n_save_ref = 2                                                     # the fixture saved every 4 ms = every second simulation step
+    col = lambda n: g[f"{key}/col/{n}"]                                # noqa: E731
+    assert np.array_equal(blk["L"][::n_save_ref, 0].astype(np.float64), col("L"))
+    assert np.array_equal(blk["m_pole"][::n_save_ref, 0].astype(np.float64), col("m_pole")) and len(np.unique(col("m_pole"))) > 5
+    assert np.array_equal(np.where(blk["informed"][::n_save_ref, 0], "true", "default"), col("m_pole_for_controller"))
+    K = 10
+    r = K * b.n_ctrl // n_save_ref + 1
+    st = blk["states"][::n_save_ref, 0]
+    np.testing.assert_allclose(res["Q"].cpu().numpy()[:K + 1, 0], g[f"{key}/call/Q"][1:K + 2], atol=1e-4)
+    for j, n in enumerate(("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")):
+        np.testing.assert_allclose(st[:r, j], col(n)[:r], atol=2e-4, rtol=1e-4, err_msg=n)
+    np.testing.assert_allclose(blk["dd"][::n_save_ref, 0, 0][:r], col("angleDD")[:r], atol=5e-3, rtol=1e-3)
+    np.testing.assert_allclose(blk["dd"][::n_save_ref, 0, 1][:r], col("positionDD")[:r], atol=2e-3, rtol=1e-3)
+    # teeth: with the pole MASS held at the handle's value the plant's angular acceleration is off by more than the tolerance
+    res0, _ = run_with(dataclasses.replace(b, m_pole_table=None))
+    assert np.abs(res0["dd"].cpu().numpy()[::n_save_ref, 0, 0][:r] - col("angleDD")[:r]).max() > 0.02
+    # the recording of this run, native writer == Python writer, with the reference's per-row columns
+    import tempfile
+    d = tempfile.mkdtemp()
+    header = R.create_csv_header(cfg["length_of_experiment"], 0.002, 0.02, 0.002, "mppi-cartpole", "", eng.phys)
+    R.write_recordings_native([os.path.join(d, "n.csv")], blk, eng.phys, header)
+    R.write_recording(os.path.join(d, "p.csv"), R.typed_columns(blk, 0, eng.phys), header=header)
+    assert open(os.path.join(d, "n.csv"), "rb").read() == open(os.path.join(d, "p.csv"), "rb").read()
+    body = open(os.path.join(d, "n.csv"), newline="").read().split("\r\n")
+    k0 = next(i for i, x in enumerate(body) if x.startswith("time,"))
+    ref_rows = g[f"{key}/csv_rows"].item().split("\r\n")
+    names = ref_rows[0].split(",")
+    for n in ("L", "L_for_controller", "m_pole", "m_pole_for_controller", "time", "target_position", "target_equilibrium"):
+        j = names.index(n)
+        assert [x.split(",")[j] for x in body[k0 + 1:] if x][::n_save_ref] == [x.split(",")[j] for x in ref_rows[1:]], n
     eng.close()
 
 

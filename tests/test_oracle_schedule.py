@@ -153,6 +153,50 @@ def test_experiment_with_a_pole_length_that_changes_during_control_periods(g):
     assert np.abs(out2["rows"]["angleDD"][:r] - g[f"{key}/col/angleDD"][:r]).max() > 0.05
 
 
+def test_experiment_with_pole_mass_and_length_changing_and_a_switching_informer(g):
+    """exp_varM: the reference's simulator with BOTH parameter updaters in 'bounce' mode (L every 7, m_pole every 11 simulation steps)
+    and `inform_controller_about_parameters_change` 'switching_regular' (the controller is handed the true values only part of the
+    time).  The oracle's loop reproduces the plant under the changing pole mass, the recording's L / m_pole / *_for_controller columns
+    and what every controller call was told (L, m_pole) exactly; the informer is the oracle's restatement, not a recorded input."""
+    tag, key = "exp_varM", "exp_varM/0"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    st = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]))))
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    new_ctrl = lambda: O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]), N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))   # noqa: E731
+    cs = g[f"{key}/call/s"]
+    L_steps = np.concatenate([[float(f32(0.395))], g[f"{key}/L_steps"]])
+    m_steps = np.concatenate([[float(f32(0.087))], g[f"{key}/m_pole_steps"]])
+    assert len(np.unique(L_steps)) > 5 and len(np.unique(m_steps)) > 5
+    inf_cfg = json.loads(g[f"{tag}/informer"].item())
+
+    def run(**kw):
+        ctrl = new_ctrl()
+        ctrl.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+        st_ = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]))))
+        return S.run_experiment(st_, cfg, lambda s, t, tp, te, L: ctrl.step(s, f32(tp), L=O.DEFAULT_PARAMS.L), **kw)
+
+    out = run(L_steps=L_steps, m_pole_steps=m_steps, informer=S.controller_informer(inf_cfg))
+    rows, calls = out["rows"], out["calls"]
+    assert np.array_equal(rows["L"], g[f"{key}/col/L"]) and np.array_equal(rows["m_pole"], g[f"{key}/col/m_pole"])
+    told = np.where(rows["informed"], "true", "default")
+    assert np.array_equal(told, g[f"{key}/col/L_for_controller"]) and np.array_equal(told, g[f"{key}/col/m_pole_for_controller"])
+    assert 0.2 < rows["informed"].mean() < 0.8 and np.count_nonzero(np.diff(rows["informed"].astype(int))) >= 4
+    # what the controller calls were told: the initial values are handed over as the YAML's doubles, the true ones as the simulator's
+    # float32 values - compared in float32, the precision a controller computes in (the t = 0 call is not told the mass, :866-878)
+    assert np.array_equal(f32([c["L"] for c in calls]), f32(g[f"{key}/call/L"][1:]))
+    assert np.array_equal(f32([c["m_pole"] for c in calls])[1:], f32(g[f"{key}/call/m_pole"][2:]))
+    assert np.array_equal(rows["time"], g[f"{key}/col/time"]) and np.array_equal(rows["target_position"], g[f"{key}/col/target_position"])
+    K = 12
+    np.testing.assert_allclose(np.array([c["Q"] for c in calls])[:K], g[f"{key}/call/Q"][1:K + 1], atol=1e-4)
+    np.testing.assert_allclose(np.array([c["s"] for c in calls])[:K], cs[1:K + 1], atol=1e-4, rtol=1e-4)
+    r = (K - 1) * out["n_ctrl"] // out["n_save"]
+    np.testing.assert_allclose(rows["angleDD"][:r], g[f"{key}/col/angleDD"][:r], atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(rows["positionDD"][:r], g[f"{key}/col/positionDD"][:r], atol=1e-3, rtol=1e-4)
+    # ... with the pole MASS held at its initial value the plant does not follow the reference (the test has teeth)
+    out2 = run(L_steps=L_steps)
+    assert np.abs(out2["rows"]["angleDD"][:r] - g[f"{key}/col/angleDD"][:r]).max() > 0.02
+
+
 def test_experiment_that_ends_inside_a_control_period(g):
     """exp_tail: 25 simulation steps = two control periods and five trailing steps, no turning points (length x complexity < 1: the
     target is 0 whatever the start, random_target_generator.py:31-33): controller calls at t = 0, 0.02, 0.04, three saved rows."""

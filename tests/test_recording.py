@@ -2,6 +2,7 @@
 CartPole/__init__.py:221-259 logs it, every field in the form the reference's own files have it - pinned to a recording the
 reference's CartPole class wrote (tests/golden/schedule.npz, "csv_rows"); readable the way the reference's loaders read it."""
 import ctypes as C
+import dataclasses
 import json
 import os
 
@@ -135,7 +136,7 @@ def test_native_writer_never_appends_and_cleans_up_after_a_failure(tmp_path):
     assert sorted(os.listdir(tmp_path)) == sorted(os.path.basename(p) for p in good)
 
 
-@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0"])
+@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0", "exp_varM/0"])
 def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, key):
     """The data rows of a recording written by the REFERENCE (its CartPole class + csv_logger, tests/golden/schedule.npz) from the
     values it logged: fed the same values, both writers here give the same bytes (all columns but the wall-clock Q_update_time)."""
@@ -150,6 +151,11 @@ def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, ke
                  Q=col("Q_calculated").astype(f32)[:, None], Q_ccrc=col("Q_ccrc").astype(f32)[:, None],
                  target_position=col("target_position")[:, None], target_equilibrium=col("target_equilibrium").astype(np.int32)[:, None],
                  L=col("L").astype(f32)[:, None], first_update_row=-(-n_ctrl // n_save))
+    if key.startswith("exp_varM"):                                   # a pole mass that changes, a controller informer that switches
+        block["m_pole"] = col("m_pole").astype(f32)[:, None]
+        block["informed"] = (col("L_for_controller") == "true").astype(np.uint8)[:, None]
+        assert len(np.unique(block["m_pole"])) > 5 and 0 < block["informed"].mean() < 1
+        assert np.array_equal(col("L_for_controller"), col("m_pole_for_controller"))
     # (the fixture's columns are what the reference held: float32 values widened by pandas; narrowing them back is exact)
     assert np.array_equal(block["states"][:, 0, 0].astype(np.float64), col("angle")) and np.array_equal(block["Q"][:, 0].astype(np.float64), col("Q_calculated"))
     assert np.array_equal(col("u").astype(f32), f32(1.77) * block["Q"][:, 0])                       # u = u_max * Q in float32
@@ -242,3 +248,39 @@ def test_generate_dataset_on_device(tmp_path):
     for a, b in zip(whole, parts):
         da, db = (pd.read_csv(p, comment="#", float_precision="round_trip").drop(columns=["Q_update_time"]) for p in (a, b))
         assert da.equals(db), (a, b)
+    # the simulator's parameter updaters and controller informer (cartpole_physical_parameters.yml): a pole length and a pole mass that
+    # change during the run, a controller that is told the true length only part of the time - the columns follow the tables, the
+    # second derivatives are those of the row's OWN length and mass, and groups / ranks change nothing
+    from cartpolesimulation_amd import schedule as SC
+    prm = dict(L=dict(init_value=0.395, change_every_x_seconds=0.014, mode="bounce", range_random=[0.2, 0.5], range_clip=[0.3, 0.45],
+                      increment=0.01, reset_every_x_seconds="inf"),
+               m_pole=dict(init_value=0.087, change_every_x_seconds=0.03, mode="random walk", range_random=[0.015, 0.15],
+                           range_clip=[0.05, 0.12], increment=0.004, reset_every_x_seconds="inf"),
+               inform_controller_about_parameters_change=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.05,
+                                                              change_to_off_after_x_seconds_on=0.07))
+    pp = R.generate_dataset(eng, E, str(tmp_path / "prm"), config=cfg, seed=7, parameters=prm)
+    times = SC.accumulated_times(200, 0.002)
+    Ltab = SC.parameter_table(prm["L"], times)
+    told = SC.informer_table(prm["inform_controller_about_parameters_change"], times, 10)
+    masses = []
+    for e, pth in enumerate(pp):
+        d = pd.read_csv(pth, comment="#", float_precision="round_trip")
+        assert np.array_equal(d["L"].to_numpy().astype(np.float32), Ltab[::5]) and len(np.unique(d["L"])) > 8
+        assert list(d["L_for_controller"]) == ["true" if x else "default" for x in told[::5]] == list(d["m_pole_for_controller"])
+        m = d["m_pole"].to_numpy().astype(np.float32)
+        masses.append(m)
+        assert len(np.unique(m)) > 3 and m.min() >= np.float32(0.05) and m.max() <= np.float32(0.12) and m[0] == np.float32(0.087)
+        for i in (0, 7, 23, 40):
+            r = d.iloc[i]
+            par = dataclasses.replace(O.DEFAULT_PARAMS, m_pole=np.float32(r.m_pole))
+            add, pdd = O.cartpole_ode(np.float32(r.angle_cos), np.float32(r.angle_sin), np.float32(r.angleD), np.float32(r.positionD),
+                                      np.float32(1.77 * r.Q_applied), np.float32(r.L), par)
+            assert abs(add - r.angleDD) < 1e-3 * max(1, abs(add)) and abs(pdd - r.positionDD) < 1e-3 * max(1, abs(pdd)), (e, i)
+    assert not np.array_equal(masses[0], masses[1])                                    # a random walk per experiment
+    again = R.generate_dataset(eng, E, str(tmp_path / "prm_groups"), config=cfg, seed=7, parameters=prm, groups=2)
+    ranks = []
+    for r in range(2):
+        ranks += R.generate_dataset(eng, E, str(tmp_path / "prm_ranks"), config=cfg, seed=7, parameters=prm, rank=r, world=2)
+    for a, b2, c2 in zip(pp, again, ranks):
+        da, db, dc = (pd.read_csv(p, comment="#", float_precision="round_trip").drop(columns=["Q_update_time"]) for p in (a, b2, c2))
+        assert da.equals(db) and da.equals(dc), (a, b2, c2)

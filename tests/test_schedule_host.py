@@ -125,3 +125,71 @@ def test_sharded_run_is_the_single_process_run(world):
     assert np.array_equal(np.concatenate([p.target_equilibrium for p, _ in parts], axis=1), whole.target_equilibrium)
     assert sum((p.interpolation_type for p, _ in parts), []) == whole.interpolation_type
     assert np.array_equal(np.concatenate([p.L for p, _ in parts]), whole.L)
+
+
+def test_pole_mass_table_and_informer_table_reproduce_the_references(g):
+    """exp_varM: the simulator's `m_pole:` updater ('bounce', a change every 11 simulation steps) and its controller informer in
+    'switching_regular' mode.  schedule.parameter_table gives the pole mass the simulator held after every update_parameters call,
+    schedule.informer_table the answer its informer gave - the recording's *_for_controller columns and what every controller call
+    was handed (the true pole length or the initial one)."""
+    from oracle import schedule_np as SN
+    cfg = json.loads(g["exp_varM/config"].item())
+    n = int(np.ceil(cfg["length_of_experiment"] / cfg["dt"]["simulation"]))
+    n_ctrl, n_save = int(np.rint(cfg["dt"]["control"] / cfg["dt"]["simulation"])), int(np.rint(cfg["dt"]["saving"] / cfg["dt"]["simulation"]))
+    times = SC.accumulated_times(n, cfg["dt"]["simulation"])
+    m = SC.parameter_table(json.loads(g["exp_varM/m_pole_updater"].item()), times)
+    assert m.dtype == np.float32 and np.array_equal(m[1:].astype(np.float64), g["exp_varM/0/m_pole_steps"]) and m[0] == np.float32(0.087)
+    L = SC.parameter_table(json.loads(g["exp_varM/L_updater"].item()), times)
+    assert np.array_equal(L[1:].astype(np.float64), g["exp_varM/0/L_steps"])
+    inf = json.loads(g["exp_varM/informer"].item())
+    told = SC.informer_table(inf, times, n_ctrl)
+    assert told.shape == (n + 1,) and not told[0]
+    assert np.array_equal(np.where(told[::n_save], "true", "default"), g["exp_varM/0/col/L_for_controller"])
+    calls = np.arange(0, n + 1, n_ctrl)
+    L_told = np.where(told[calls], L[calls], L[0])                                     # the float32 the controller computes with
+    assert np.array_equal(L_told, g["exp_varM/0/call/L"][1:].astype(np.float32))
+    assert np.array_equal(np.where(told[calls], m[calls], m[0])[1:], g["exp_varM/0/call/m_pole"][2:].astype(np.float32))
+    # the other modes; 'switching_random' against the checker's restatement of the class on the same random stream
+    assert SC.informer_table(dict(inf, mode="ON"), times, n_ctrl).all() and not SC.informer_table(dict(inf, mode="OFF"), times, n_ctrl).any()
+    rnd = dict(inf, mode="switching_random", change_to_on_after_x_seconds_off=0.09, change_to_off_after_x_seconds_on=0.12)
+    got = SC.informer_table(rnd, times, n_ctrl, np_random=np.random.RandomState(5))
+    ref = SN.controller_informer(rnd, np_random=np.random.RandomState(5))
+    want, cur = np.empty(n + 1, bool), False
+    for k in range(n + 1):
+        if k % n_ctrl == 0:
+            cur = ref(times[k])
+        want[k] = cur
+    assert np.array_equal(got, want) and 2 <= np.count_nonzero(np.diff(got.astype(int)))
+    with pytest.raises(ValueError):
+        SC.informer_table(dict(inf, mode="sometimes"), times, n_ctrl)
+
+
+def test_a_batch_drawn_at_stride_one_carries_the_parameter_schedule():
+    """draw(stride=1) tabulates the same experiments per simulation step (the default stride's rows are every gcd-th of them);
+    apply_parameter_schedule attaches the simulator's parameter updaters and informer, one column per experiment, and the random
+    modes do not depend on how the run is split over processes."""
+    cfg = dict(seed=9, length_of_experiment=0.5, dt=dict(saving=0.008))
+    a = SC.RandomExperimentSetter(cfg).draw(3, 40)
+    b = SC.RandomExperimentSetter(cfg).draw(3, 40, stride=1)
+    assert a.stride == 2 and b.stride == 1 and np.array_equal(a.s0, b.s0)
+    assert np.array_equal(a.target_position, b.target_position[::2]) and np.array_equal(a.target_equilibrium, b.target_equilibrium[::2])
+    with pytest.raises(ValueError):
+        SC.RandomExperimentSetter(cfg).draw(3, 40, stride=4)
+    prm = dict(L=dict(init_value=0.395, change_every_x_seconds=0.01, mode="increase", range_random=[0.2, 0.5], range_clip=[0.2, 0.5],
+                      increment=0.001, reset_every_x_seconds=0.2),
+               m_pole=dict(init_value="random", change_every_x_seconds=0.05, mode="random", range_random=[0.015, 0.15], range_clip=None,
+                           increment=0.002, reset_every_x_seconds="inf"),
+               inform_controller_about_parameters_change=dict(mode="switching_random", change_to_on_after_x_seconds_off=0.1,
+                                                              change_to_off_after_x_seconds_on=0.1))
+    with pytest.raises(ValueError):
+        SC.apply_parameter_schedule(a, prm)
+    full = SC.apply_parameter_schedule(b, prm, seed=5)
+    n = b.n_sim + 1
+    assert full.L_table.shape == full.m_pole_table.shape == full.informed.shape == (n, 3)
+    assert np.array_equal(full.L_table[:, 0], full.L_table[:, 2]) and np.array_equal(full.L_table[:, 0], SC.parameter_table(prm["L"], b.times))
+    assert full.L_table[:, 0].max() > 0.4 and np.count_nonzero(np.diff(full.L_table[:, 0]) < 0) == 2        # grows, reset every 0.2 s
+    assert not np.array_equal(full.m_pole_table[:, 0], full.m_pole_table[:, 1]) and not np.array_equal(full.informed[:, 0], full.informed[:, 1])
+    assert full.m_pole_table.min() >= np.float32(0.015) and full.m_pole_table.max() <= np.float32(0.15)
+    tail, first = SC.draw_shard(cfg, 3, 40, rank=1, world=2, stride=1)
+    part = SC.apply_parameter_schedule(tail, prm, seed=5, first=first)
+    assert first == 2 and np.array_equal(part.m_pole_table[:, 0], full.m_pole_table[:, 2]) and np.array_equal(part.informed[:, 0], full.informed[:, 2])
