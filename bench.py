@@ -235,7 +235,8 @@ class Workload:
         E, H, rank = self.E, self.H, self.ctx["rank"]
         Workload._serial += 1
         ok, why = 1, ""
-        if os.environ.get("CPMPPI_BENCH_COLLECTIVE", "native") not in ("native", "native-events") or self.ctx["backend"] != "nccl":
+        want = os.environ.get("CPMPPI_BENCH_COLLECTIVE")          # unset: the library's own RCCL communicator under the nccl backend
+        if want not in (None, "native", "native-events") or (want is None and self.ctx["backend"] != "nccl"):
             ok, why = 0, "torch.distributed requested (CPMPPI_BENCH_COLLECTIVE / non-RCCL backend)"
         else:
             try:
