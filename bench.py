@@ -685,7 +685,7 @@ def main():
     verified, to_verify = {}, [("main", main_wl)]
 
     # BASELINE's other configurations, measured by EVERY rank (the collective is part of them), reported by rank 0
-    extras = {}
+    extras, side_failed = {}, []
     if (not args.no_extra_configs and args.config is None and args.predictor == "ode" and args.predictor_type == "ODE_v0"
             and args.noise == "philox" and args.math == "fast"):
         side = [("C4", PRESETS["C4"], "ode", 200, 20)]
@@ -696,8 +696,16 @@ def main():
                                                                       ("C2_predictor_ODE", (E, N, H), "ode:ODE", 20, 3)]
         for name, (e_, n_, h_), pred, steps_, warm_ in side:
             pred, ptype = (pred.split(":") + ["ODE_v0"])[:2]
-            w = Workload(ctx, e_, n_, h_, predictor=pred, predictor_type=ptype)
-            rr = w.run(steps_, warm_)
+            try:
+                w = Workload(ctx, e_, n_, h_, predictor=pred, predictor_type=ptype)
+                rr = w.run(steps_, warm_)
+            except Exception as ex:  # noqa: BLE001
+                if world > 1:
+                    raise                                  # (the other ranks are inside the same collective sequence)
+                # a side configuration must not cost the run its headline line: say what failed, go on
+                extras[name] = {"error": f"{type(ex).__name__}: {ex}"}
+                side_failed.append(name)
+                continue
             impl = w.collective_impl
             if rank == 0 and not args.no_verify and world == 1:
                 to_verify.append((name, w))                # (closed after its verification)
@@ -732,8 +740,13 @@ def main():
             # share-nothing structure of the problem allows and one launch per step cannot use
             for name, base, groups, steps_, warm_ in (("C4_pipelined", "C4", 2, 200, 20), ("C3_pipelined", "C3", 2, 100, 10)):
                 e_, n_, h_ = PRESETS[base]
-                gw = GroupedWorkload(ctx, e_, n_, h_, groups)
-                rr = gw.run(steps_, warm_)
+                try:
+                    gw = GroupedWorkload(ctx, e_, n_, h_, groups)
+                    rr = gw.run(steps_, warm_)
+                except Exception as ex:  # noqa: BLE001
+                    extras[name] = {"error": f"{type(ex).__name__}: {ex}"}
+                    side_failed.append(name)
+                    continue
                 if not args.no_verify:
                     to_verify.append((name, gw))
                 else:
@@ -743,7 +756,7 @@ def main():
                                 "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
                                 "groups": groups, "group_kernel_ms": rr["group_kernel_ms"], "kernels": rr["kernels"],
                                 "stream_overlap": rr["stream_overlap"],
-                                "vs_one_launch_per_step": extras[base]["ms_per_step"] / rr["ms_per_step"] if base in extras else None,
+                                "vs_one_launch_per_step": extras[base]["ms_per_step"] / rr["ms_per_step"] if "ms_per_step" in extras.get(base, {}) else None,
                                 "roofline_valu": {"bound": "fp32-valu", "unit": "TFLOP/s", "peak": FP32_VALU_PEAK_TFLOPS,
                                                   "achieved": algorithmic_flops_per_rollout(h_) * e_ * n_ / (rr["ms_per_step"] * 1e-3) / 1e12,
                                                   "frac": algorithmic_flops_per_rollout(h_) * e_ * n_ / (rr["ms_per_step"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
@@ -887,6 +900,9 @@ def main():
     if bad:                                               # a timed configuration whose results the oracle does not confirm
         print(f"bench.py: verification FAILED for {bad}: " + json.dumps({k: verified[k] for k in bad}), file=sys.stderr, flush=True)
         sys.exit(3)
+    if side_failed:                                       # the line was printed (its `configs` entries carry the error); not a clean run
+        print(f"bench.py: side configurations FAILED to run: " + json.dumps({k: extras[k] for k in side_failed}), file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 if __name__ == "__main__":
