@@ -285,6 +285,8 @@ struct PlantDev {
   const float *tp_table, *te_table, *L_table;
   float *tp_out, *te_out, *L_out;
   const float *m_pole, *m_table, *Lc_table;
+  const float* Qd_table;
+  float Q_bias;
 };
 
 __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const PlantDev a) {
@@ -310,9 +312,11 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const Pla
   EnvConst ec = make_env_const(p, Lcur);
   float* se = a.s + (size_t)env * 6;
   State<float> st{se[0], se[1], se[2], se[3], se[4], se[5]};
-  const float q = a.Q[env];
-  const float u = p.u_max * q;
+  float q = a.Q[env];
   if (a.Q_log && known && c < a.ctrl_rows) a.Q_log[(size_t)c * E + env] = q;
+  if (a.Qd_table && known && c < a.ctrl_rows)                          // add_control_noise (:523-524): two float32 additions
+    q = __fadd_rn(__fadd_rn(q, a.Qd_table[(size_t)c * E + env]), a.Q_bias);
+  const float u = p.u_max * q;
   float aDD, xDD;
   ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);             // CartPole/__init__.py:316-320 (Update_Q, Q2u, cartpole_ode)
   auto log_dd = [&](uint64_t g) {
@@ -1919,6 +1923,8 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   if ((a->states_log || a->dd_log) && save_every == 0)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: save_every / period_steps missing");
   const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table || a->m_pole_table || a->L_controller_table;
+  if (a->Q_disturbance_table && a->ctrl_rows == 0)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: Q_disturbance_table needs ctrl_rows > 0");
   if (a->L_controller_table && !a->L_table)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: L_controller_table stands in for L_table in L_out: give both");
   if (tables && a->sched_rows == 0) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: schedule tables need sched_rows > 0");
@@ -1930,7 +1936,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   if (misaligned(a->s) || misaligned(a->Q) || misaligned(a->L) || misaligned(a->states_log) || misaligned(a->dd_log) ||
       misaligned(a->Q_log) || misaligned(a->target_position_table) || misaligned(a->target_equilibrium_table) ||
       misaligned(a->L_table) || misaligned(a->target_position_out) || misaligned(a->target_equilibrium_out) || misaligned(a->L_out) ||
-      misaligned(a->m_pole) || misaligned(a->m_pole_table) || misaligned(a->L_controller_table) ||
+      misaligned(a->m_pole) || misaligned(a->m_pole_table) || misaligned(a->L_controller_table) || misaligned(a->Q_disturbance_table) ||
       (a->period_dev && ((uintptr_t)a->period_dev & 7u)))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_step: misaligned");
   CPMPPI_ON_DEVICE(h);
@@ -1947,6 +1953,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   d.tp_table = a->target_position_table; d.te_table = a->target_equilibrium_table; d.L_table = a->L_table;
   d.tp_out = a->target_position_out; d.te_out = a->target_equilibrium_out; d.L_out = a->L_out;
   d.m_pole = a->m_pole; d.m_table = a->m_pole_table; d.Lc_table = a->L_controller_table;
+  d.Qd_table = a->Q_disturbance_table; d.Q_bias = a->Q_bias;
   hipLaunchKernelGGL(plant_kernel, dim3((a->E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, d);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;

@@ -129,7 +129,8 @@ int write_one(const Job& j, uint32_t e, std::string& buf, std::string& tmp) {
     const float q = r.Q[i];
     buf.append(num, py_repr(r.time[t], num));
     f32col(s[0]); f32col(s[1]); f32col(dd[0]); f32col(s[2]); f32col(s[3]); f32col(s[4]); f32col(s[5]); f32col(dd[1]);
-    f64col((double)q); f32col(q); f32col(r.Q_ccrc[i]); f32col(r.u_max * q);
+    const float qa = r.Q_applied ? r.Q_applied[i] : q;
+    f64col((double)q); f32col(qa); f32col(r.Q_ccrc[i]); f32col(r.u_max * qa);
     f64col(r.target_position[i]);
     buf.push_back(',');
     buf.append(num, snprintf(num, sizeof(num), "%d", (int)r.target_equilibrium[i]));

@@ -150,6 +150,11 @@ class ScheduleRun:
                           target_equilibrium_table=te_tab, L_table=L_tab, sched_stride=b.stride, target_position_out=self.cur_tp,
                           target_equilibrium_out=self.cur_te, L_out=self.cur_L if L_tab is not None else None, m_pole_table=m_tab,
                           L_controller_table=Lc_tab)
+        if b.Q_disturbance is not None:                                           # the simulator's additive control disturbance
+            qd = np.ascontiguousarray(b.Q_disturbance, np.float32)
+            if qd.shape != (T + 1, E):
+                raise ValueError(f"Q_disturbance is {qd.shape}, expected one row per controller call {(T + 1, E)}")
+            self.plant.update(Q_disturbance_table=eng.tensor(qd), Q_bias=float(b.Q_bias))
         self.counter = self.graph = None
         self.per = 0
         self._prep = self._prep_plant = None                       # argument blocks built once (the launched Philox loop)

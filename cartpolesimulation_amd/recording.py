@@ -123,7 +123,10 @@ def recording_block(result, phys, L_default=None):
     steps = np.arange(R) * b.n_save
     k = np.minimum(steps // b.n_ctrl, Qc.shape[0] - 1)               # controller call whose control is in force at the row
     Q = Qc[k]
-    Q_ccrc = np.where((k > 0)[:, None], Qc[np.maximum(k - 1, 0)], f32(0.0)).astype(f32)
+    Qa = Qc
+    if b.Q_disturbance is not None:                                  # Q_applied = (Q_calculated + disturbance) + bias, float32 (plant_kernel)
+        Qa = ((Qc + np.asarray(b.Q_disturbance, f32)).astype(f32) + f32(b.Q_bias)).astype(f32)
+    Q_ccrc = np.where((k > 0)[:, None], Qa[np.maximum(k - 1, 0)], f32(0.0)).astype(f32)
     rows = b.rows_at(steps)
     if b.L_table is not None:
         L = np.asarray(b.L_table, f32)[np.minimum(steps, b.L_table.shape[0] - 1)]
@@ -133,6 +136,8 @@ def recording_block(result, phys, L_default=None):
                target_position=np.ascontiguousarray(b.target_position[rows]),
                target_equilibrium=np.ascontiguousarray(b.target_equilibrium[rows].astype(np.int32)),
                L=np.ascontiguousarray(L, dtype=f32), first_update_row=int(-(-b.n_ctrl // b.n_save)))
+    if Qa is not Qc:
+        out["Q_applied"] = np.ascontiguousarray(Qa[k])
     if b.m_pole_table is not None:                                   # the `m_pole:` updater's values, row by row
         out["m_pole"] = np.ascontiguousarray(np.asarray(b.m_pole_table, f32)[np.minimum(steps, b.m_pole_table.shape[0] - 1)])
     if b.informed is not None:                                       # the controller informer's answer in force at the row
@@ -144,6 +149,7 @@ def recording_block(result, phys, L_default=None):
 def typed_columns(block, env, phys, q_update_time=0.0):
     """One experiment of a recording block as the reference's column dict, every value in the TYPE the reference logs it in."""
     s, dd, Q = block["states"][:, env], block["dd"][:, env], block["Q"][:, env]
+    Qa = block["Q_applied"][:, env] if block.get("Q_applied") is not None else Q
     R = s.shape[0]
     py = lambda a: [float(x) for x in a]                            # noqa: E731  (Python floats: written with repr)
     u_max = f32(phys.u_max)
@@ -151,8 +157,8 @@ def typed_columns(block, env, phys, q_update_time=0.0):
     told = ["true" if x else "default" for x in block["informed"][:, env]] if block.get("informed") is not None else ["true"] * R
     cols = {"time": py(block["time"]), "angle": list(s[:, 0]), "angleD": list(s[:, 1]), "angleDD": list(dd[:, 0]),
             "angle_cos": list(s[:, 2]), "angle_sin": list(s[:, 3]), "position": list(s[:, 4]), "positionD": list(s[:, 5]),
-            "positionDD": list(dd[:, 1]), "Q_calculated": py(Q), "Q_applied": list(Q), "Q_ccrc": list(block["Q_ccrc"][:, env]),
-            "u": list(u_max * Q), "target_position": py(block["target_position"][:, env]),
+            "positionDD": list(dd[:, 1]), "Q_calculated": py(Q), "Q_applied": list(Qa), "Q_ccrc": list(block["Q_ccrc"][:, env]),
+            "u": list(u_max * Qa), "target_position": py(block["target_position"][:, env]),
             "target_equilibrium": [int(x) for x in block["target_equilibrium"][:, env]], "L": py(block["L"][:, env]),
             "L_for_controller": told, "m_pole": m_pole, "m_pole_for_controller": told,
             "vertical_angle_offset": [0.0] * R, "vertical_angle_offset_cos": [1.0] * R, "vertical_angle_offset_sin": [0.0] * R,
@@ -181,7 +187,7 @@ def write_recordings_native(paths, block, phys, header, title=None, q_update_tim
     for k, a in arrs.items():
         setattr(rec, k, a.ctypes.data)
     rec.m_pole, rec.u_max = float(f32(phys.m_pole)), float(f32(phys.u_max))
-    for k, field, dt in (("m_pole", "m_pole_rows", f32), ("informed", "informed", np.uint8)):
+    for k, field, dt in (("m_pole", "m_pole_rows", f32), ("informed", "informed", np.uint8), ("Q_applied", "Q_applied", f32)):
         if block.get(k) is not None:
             arrs[k] = a = np.ascontiguousarray(block[k], dtype=dt)
             if a.shape != (R, E):
@@ -240,7 +246,8 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     ParallelDataGeneration.sh:17), so no two ranks ever ask for the same file name; no collective is involved.
     ``parameters``: the `L` / `m_pole` / `inform_controller_about_parameters_change` blocks of cartpole_physical_parameters.yml's
     `cartpole:` section - a pole length and a pole mass that change DURING the experiments (CartPole/parameter_updater.py) and a
-    controller that is told the true length only part of the time (schedule.apply_parameter_schedule)."""
+    controller that is told the true length only part of the time - and its `controlDisturbance` / `controlBias` / `seed`: the additive
+    control disturbance the reference's author collects training data with (schedule.apply_parameter_schedule)."""
     import time
     from .harness import BatchedCartPoleExperiment
     from .schedule import RandomExperimentSetter, merged_config
@@ -250,14 +257,14 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     n_total = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
     cseed = cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1
     _first = 0                                                     # global index of this process's first experiment (Philox keys)
+    _stride = 1 if parameters and any(parameters.get(k) is not None for k in ("L", "m_pole", "inform_controller_about_parameters_change")) else None
     if int(world) > 1:
         from .schedule import draw_shard
-        batch, _first = draw_shard(cfg, n_total, cseed, rank, world, L=L, stride=1 if parameters else None)
+        batch, _first = draw_shard(cfg, n_total, cseed, rank, world, L=L, stride=_stride)
         if secondary_experiment_index is None:
             secondary_experiment_index = int(rank)
     else:
-        batch = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength).draw(n_total, cseed, L=L,
-                                                                                                stride=1 if parameters else None)
+        batch = RandomExperimentSetter(cfg, track_half_length=engine.phys.TrackHalfLength).draw(n_total, cseed, L=L, stride=_stride)
     if parameters:
         from .schedule import apply_parameter_schedule
         batch = apply_parameter_schedule(batch, parameters, seed=cseed, first=_first)

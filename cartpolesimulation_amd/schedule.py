@@ -72,6 +72,8 @@ class ExperimentBatch:
     m_pole_table: np.ndarray = None     # [n_sim + 1, E] float32 per simulation step: the PLANT's pole mass, or None (the handle's)
     informed: np.ndarray = None         # [n_sim + 1, E] bool per simulation step: is the controller handed the true pole length /
                                         # mass (informer_table) or the initial ones; None = always (mode 'ON', as shipped)
+    Q_disturbance: np.ndarray = None    # [n_periods + 1, E] float32 = controlDisturbance * N(0, 1) per controller call, or None:
+    Q_bias: float = 0.0                 # the plant is driven by Q_applied = (Q_calculated + Q_disturbance) + Q_bias (float32)
 
     @property
     def E(self):
@@ -375,17 +377,41 @@ def informer_table(informer, times, n_ctrl, np_random=None):
     return out
 
 
+def control_disturbance(E, n_calls, seed, first=0):
+    """The standard normal draws behind the simulator's additive control disturbance (CartPole/noise_control_signal.py:14-16;
+    `controlDisturbance_mode: additive`, the shipped mode - with amplitude 0): ONE generator for all experiments of a run (the
+    module-level `rng`, CartPole/__init__.py:75, SFC64(cartpole seed)), float32 draws; every experiment takes two draws outside its run
+    (set_cartpole_state_at_t0 when its controller is set, :792, and when the simulator is reset, :733) and then one per controller
+    call (:881-882 at t = 0, :523-524 inside the loop).  -> float32 [n_calls, E] for the experiments first .. first + E - 1 of the
+    run: the reference's own numbers for a seeded run, whatever the split over processes."""
+    per = int(n_calls) + 2
+    z = np.random.Generator(np.random.SFC64(int(seed))).standard_normal(size=(int(first) + int(E)) * per, dtype=f32)
+    return np.ascontiguousarray(z.reshape(-1, per)[int(first):, 2:].T)
+
+
 def apply_parameter_schedule(batch, parameters, seed=0, first=0):
     """The simulator's time-varying physical parameters for a batch drawn with stride 1: `parameters` holds any of the blocks `L`,
     `m_pole` (ParameterUpdater configs) and `inform_controller_about_parameters_change` of cartpole_physical_parameters.yml's
-    `cartpole:` section.  -> the batch with L_table / m_pole_table / informed filled in (one column per experiment).  Deterministic
+    `cartpole:` section, and its control disturbance: `controlDisturbance` (+ `controlBias`, `controlDisturbance_mode` 'additive' /
+    'OFF', `seed` = the section's own seed, which seeds the disturbance's generator: control_disturbance).
+    -> the batch with L_table / m_pole_table / informed / Q_disturbance filled in (one column per experiment).  Deterministic
     modes give every experiment the same column, as in the reference; the random modes draw per experiment from generators seeded
     with seed + first + e (the reference draws from the process-global, clock-seeded generators: nothing to reproduce there)."""
     import dataclasses
     import random as _random
-    if batch.stride != 1:
+    per_step = [k for k in ("L", "m_pole", "inform_controller_about_parameters_change") if parameters.get(k) is not None]
+    if per_step and batch.stride != 1:
         raise ValueError("parameter tables are per simulation step: draw the batch with stride=1")
     E, out = batch.E, {}
+    mode = parameters.get("controlDisturbance_mode", "additive")
+    if mode not in ("additive", "OFF"):
+        raise NotImplementedError(f"controlDisturbance_mode {mode!r}: 'additive' (the shipped mode) and 'OFF' are supported")
+    amp, bias = float(parameters.get("controlDisturbance") or 0.0), float(parameters.get("controlBias") or 0.0)
+    if mode == "additive" and (amp != 0.0 or bias != 0.0):
+        if parameters.get("seed") is None:
+            raise ValueError("parameters['seed'] is empty: the reference then seeds the disturbance from the clock; give a seed")
+        z = control_disturbance(E, batch.n_periods + 1, parameters["seed"], first)
+        out["Q_disturbance"], out["Q_bias"] = f32(amp) * z, float(f32(bias))
     for name, field_ in (("L", "L_table"), ("m_pole", "m_pole_table")):
         if parameters.get(name) is not None:
             out[field_] = np.stack([parameter_table(parameters[name], batch.times, _random.Random(int(seed) + first + e),

@@ -362,7 +362,8 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
  *   simulation step g = 0 is the initial state; control period c advances steps c*period_steps + 1 .. (c + 1)*period_steps;
  *   table row of step g = min(g / sched_stride, sched_rows - 1): the value the simulator holds AFTER step g's updates.
  * One call = one control period, ONE kernel:
- *   1. held control q = Q[env]; Q_log[c][E] = q (c < ctrl_rows)
+ *   1. held control q = Q[env]; Q_log[c][E] = q (c < ctrl_rows); with a Q_disturbance_table the plant is driven by
+ *      q_applied = (q + Q_disturbance_table[c][env]) + Q_bias instead (add_control_noise after Update_Q, :523-524)
  *   2. second derivatives of (s, q) with the pole length of step c*period_steps; dd_log[r][E][2] = (angleDD, positionDD) if that
  *      step is a saved one (r = step / save_every < save_rows) - the row whose state the PREVIOUS period stored, completed with
  *      the control computed from it (save_csv_routine runs after Update_Q, :316-324)
@@ -408,6 +409,11 @@ typedef struct {
   const float* L_controller_table;      /* [sched_rows][E] what L_out publishes instead of L_table: the pole length the CONTROLLER is
                                            told (inform_controller_about_parameters_change, CartPole/controller_informer.py: the true
                                            value or the initial one); NULL = L_table */
+  const float* Q_disturbance_table;     /* [ctrl_rows][E] the simulator's additive control disturbance (CartPole/noise_control_signal.py:
+                                           14-16): the plant of period c is driven by Q_applied = (Q + table[c]) + Q_bias in float32,
+                                           table = controlDisturbance * N(0,1) drawn on the host; Q_log keeps the CALCULATED control.
+                                           NULL = none.  Needs ctrl_rows > 0 */
+  float Q_bias;                         /* controlBias */
 } cpmppi_plant_args;
 int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* stream);
 
@@ -504,6 +510,8 @@ typedef struct {
                                            NULL: `m_pole` in every row */
   const uint8_t* informed;              /* [rows][E] L_for_controller / m_pole_for_controller: 1 = 'true', 0 = 'default' (the controller
                                            informer's state when the row was saved); NULL = 'true' in every row (mode ON, as shipped) */
+  const float* Q_applied;               /* [rows][E] the control the plant was driven by when it differs from the calculated one (control
+                                           disturbance): the Q_applied and u columns; NULL = Q */
 } cpmppi_recording;
 int cpmppi_write_recordings(const char* const* paths, const char* preamble, size_t preamble_len, const cpmppi_recording* rec,
                             int n_threads);

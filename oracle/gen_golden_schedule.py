@@ -161,7 +161,7 @@ class CallLog:
 
 
 def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None, L_updater=None, m_pole_updater=None,
-                    informer=None):
+                    informer=None, disturbance=None):
     DG.load_config = lambda name: copy.deepcopy(cfg)
     if p_Q is not None:                                            # (cartpole_physical_parameters.yml `actuator_noise`, read at :83)
         LEG.p_Q = p_Q
@@ -177,6 +177,12 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
     if informer is not None:                                       # (`inform_controller_about_parameters_change`, :128)
         APP.config["cartpole"]["inform_controller_about_parameters_change"] = dict(informer)
         out[f"{tag}/informer"] = np.array(json.dumps(informer))
+    if disturbance is not None:
+        # controlDisturbance / controlBias (cartpole_physical_parameters.yml; mode 'additive' as shipped, amplitude 0 as shipped): module-
+        # level 0-d float32 arrays read at every controller update (:521-524), and the module-level generator `rng` (:75) they draw from
+        APP.controlDisturbance[...], APP.controlBias[...] = disturbance["controlDisturbance"], disturbance["controlBias"]
+        APP.rng = Generator(SFC64(disturbance["seed"]))
+        out[f"{tag}/disturbance"] = np.array(json.dumps(disturbance))
     RES = DG.random_experiment_setter()
     out[f"{tag}/config"] = np.array(json.dumps(cfg))
     out[f"{tag}/N"], out[f"{tag}/H"], out[f"{tag}/ctrl_seed"] = np.int64(N), np.int64(H), np.int64(ctrl_seed)
@@ -230,6 +236,8 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
     APP.config["cartpole"]["m_pole"] = shipped_m
     APP.config["cartpole"]["inform_controller_about_parameters_change"] = shipped_inf
     APP.L[...], APP.m_pole[...] = shipped_L["init_value"], shipped_m["init_value"]      # (module-level arrays the updaters write into)
+    if disturbance is not None:
+        APP.controlDisturbance[...], APP.controlBias[...] = 0.0, 0.0
 
 
 inst_interp, L_log, M_log = [], [], []
@@ -304,5 +312,10 @@ if __name__ == "__main__":
                     m_pole_updater=dict(init_value=0.087, change_every_x_seconds=0.022, mode="bounce", range_random=[0.015, 0.15],
                                         range_clip=[0.07, 0.1], increment=0.004, reset_every_x_seconds="inf"),
                     informer=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.05, change_to_off_after_x_seconds_on=0.07))
+    # the simulator's CONTROL DISTURBANCE switched on (shipped: mode 'additive' with amplitude 0; its author's note: 0.2-0.5 for data
+    # collection): Q_applied = Q_calculated + controlDisturbance * N(0, 1) + controlBias at every controller update, two experiments
+    # in a row drawing from ONE generator
+    gen_experiments(out, "exp_dist", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=83, length_of_experiment=0.4)), 2, 980,
+                    ctrl_seed=999, p_Q=0.0, disturbance=dict(controlDisturbance=0.3, controlBias=0.05, seed=4242))
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
     print("wrote", os.path.join(OUT, "schedule.npz"), len(out), "arrays")

@@ -251,13 +251,18 @@ def controller_informer(cfg, np_random=None):
     return get
 
 
-def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L_steps=None, m_pole_steps=None, informer=None):
+def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L_steps=None, m_pole_steps=None, informer=None,
+                   disturbance=None):
     """One experiment as CartPole.run_cartpole_random_experiment runs it (noise, latency, disturbance OFF as shipped).
     controller_step(s, time, target_position, target_equilibrium, L) -> Q.  Returns dict(rows: column -> list, calls).
     ``L_steps`` [n + 1]: a pole length that changes in time - entry g is what the simulator holds DURING simulation step g
     (update_parameters is the first thing update_state does, CartPole/__init__.py:285, 529-537); entry 0 the initial value.
     ``m_pole_steps``: the same for the pole mass (the plant's; the controller is TOLD, 'm_pole' of updated_attributes - `calls`
-    records it).  ``informer``: controller_informer(...) or None = 'ON'."""
+    records it).  ``informer``: controller_informer(...) or None = 'ON'.
+    ``disturbance`` = (z, controlDisturbance, controlBias): the simulator's additive control disturbance (CartPole/
+    noise_control_signal.py:14-16 at every controller update, CartPole/__init__.py:523-524, 881-882): Q_applied = Q_calculated +
+    controlDisturbance * z[call] + controlBias in float32 (0-d float32 arrays and a float32 draw: the Python float Q_calculated is the
+    weak operand); the plant, `u` and the next call's Q_ccrc use Q_applied."""
     c = config
     dt_sim = c["dt"]["simulation"]
     n_ctrl = max(1, int(np.rint(c["dt"]["control"] / dt_sim)))                                  # :909-916
@@ -283,16 +288,27 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
         return f32(Q)
 
     rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium", "L",
-                            "m_pole", "informed")}
+                            "m_pole", "informed", "Q_calculated")}
+    n_call = [0]
+
+    def applied(Qc):
+        k = n_call[0]
+        n_call[0] += 1
+        if disturbance is None:
+            return Qc
+        z, mult, bias = disturbance
+        return f32(f32(f32(Qc) + f32(f32(mult) * f32(z[k]))) + f32(bias))
+
     Q_ccrc = f32(0.0)                                                                           # :838
-    Q = control(0)                                                                              # set_cartpole_state_at_t0 :842-852
+    Q_calc = control(0)                                                                         # set_cartpole_state_at_t0 :842-852
+    Q = applied(Q_calc)                                                                         # :881-882
     aDD, xDD = O.plant_ode(s, Q, Lf, p)                                                         # :859-860
 
     def save(g):
         rows["time"].append(times[g]); rows["s"].append(s.copy()); rows["angleDD"].append(aDD); rows["positionDD"].append(xDD)
         rows["Q"].append(Q); rows["Q_ccrc"].append(Q_ccrc); rows["u"].append(O.Q2u(Q, p))
         rows["target_position"].append(tp_g[g]); rows["target_equilibrium"].append(te_g[g]); rows["L"].append(Lf)
-        rows["m_pole"].append(mf); rows["informed"].append(informed[0])
+        rows["m_pole"].append(mf); rows["informed"].append(informed[0]); rows["Q_calculated"].append(Q_calc)
 
     save(0)                                                                                     # :875 (the t = 0 row)
     ctrl_counter = save_counter = 0
@@ -306,7 +322,8 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
         ctrl_counter += 1
         if ctrl_counter == n_ctrl:                                                              # Update_Q :475-527
             Q_ccrc = Q
-            Q = control(g)
+            Q_calc = control(g)
+            Q = applied(Q_calc)                                                                 # :523-524
             ctrl_counter = 0
         aDD, xDD = O.plant_ode(s, Q, Lf, p)                                                     # :319-320
         save_counter += 1

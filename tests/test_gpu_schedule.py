@@ -46,6 +46,7 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
         Ltab = np.repeat(rng.uniform(0.2, 0.5, (n_sim // 7 + 1, E)).astype(f32), 7, axis=0)[:rows_sched]   # changes every 7 steps
         mtab = np.repeat(rng.uniform(0.03, 0.15, (n_sim // 11 + 1, E)).astype(f32), 11, axis=0)[:rows_sched]  # the pole MASS: every 11
         Lctab = rng.uniform(0.2, 0.5, (rows_sched, E)).astype(f32)    # what the controller is told instead of the true length
+        qd, qb = rng.normal(0, 0.3, (T + 1, E)).astype(f32), f32(0.05)  # the simulator's additive control disturbance
         R = n_sim // n_save + 1
         s = eng.tensor(s0.copy())
         states, dd, Qlog = eng.zeros(R, E, 6), eng.zeros(R, E, 2), eng.zeros(T + 1, E)
@@ -56,7 +57,8 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
         kw = dict(dt_sim=0.002, period_steps=n_ctrl, states_log=states, dd_log=dd, save_every=n_save, Q_log=Qlog,
                   target_position_table=tp_d, target_equilibrium_table=te_d, L_table=L_d, sched_stride=stride,
                   target_position_out=cur_tp, target_equilibrium_out=cur_te, L_out=cur_L, m_pole_table=eng.tensor(mtab),
-                  L_controller_table=eng.tensor(Lctab) if told else None)
+                  L_controller_table=eng.tensor(Lctab) if told else None, Q_disturbance_table=eng.tensor(qd), Q_bias=float(qb))
+        Qa = ((Qs + qd).astype(f32) + qb).astype(f32)                  # what drives the plant; the log keeps the calculated control
         for c in range(T):
             eng.plant_step(s, Qs[c], n_ctrl, period=c, **kw)
             g1 = (c + 1) * n_ctrl
@@ -69,7 +71,7 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
         for e in range(E):
             r = s0[e].copy()
             k = 0
-            Q = Qs[0, e]
+            Q = Qa[0, e]
             pm = lambda gs: dataclasses.replace(O.DEFAULT_PARAMS, m_pole=mtab[gs, e])   # noqa: E731
             add, pdd = O.plant_ode(r, Q, Ltab[0, e], pm(0))
             rows = [(r.copy(), add, pdd)]
@@ -77,7 +79,7 @@ def test_plant_step_follows_the_oracle_loop_row_by_row():
                 L = Ltab[gstep, e]
                 r = O.plant_substep(r, add, pdd, 0.002, L, pm(gstep))
                 if gstep % n_ctrl == 0:
-                    Q = Qs[gstep // n_ctrl, e]
+                    Q = Qa[gstep // n_ctrl, e]
                 add, pdd = O.plant_ode(r, Q, L, pm(gstep))
                 if gstep % n_save == 0:
                     rows.append((r.copy(), add, pdd))
@@ -423,6 +425,69 @@ def test_reference_experiment_with_changing_pole_mass_and_a_switching_informer_o
     for n in ("L", "L_for_controller", "m_pole", "m_pole_for_controller", "time", "target_position", "target_equilibrium"):
         j = names.index(n)
         assert [x.split(",")[j] for x in body[k0 + 1:] if x][::n_save_ref] == [x.split(",")[j] for x in ref_rows[1:]], n
+    eng.close()
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_reference_experiment_with_control_disturbance_on_the_device_loop(g, i):
+    """exp_dist: the reference's simulator with its additive control disturbance on (controlDisturbance 0.3, controlBias 0.05), two
+    experiments in a row on one generator.  schedule.apply_parameter_schedule draws both experiments' disturbances, the device loop
+    drives the plants with Q_applied = (Q_calculated + disturbance) + bias: states to 1e-4 over the first ten control steps, and
+    the recording's Q_calculated / Q_applied / Q_ccrc / u columns."""
+    from cartpolesimulation_amd import recording as R
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
+    tag, key = "exp_dist", f"exp_dist/{i}"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    d = json.loads(g[f"{tag}/disturbance"].item())
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    both = SC.RandomExperimentSetter(cfg).draw(2, int(g[f"{tag}/cartpole_seed0"]))
+    both = SC.apply_parameter_schedule(both, dict(controlDisturbance=d["controlDisturbance"], controlBias=d["controlBias"], seed=d["seed"]))
+    b = dataclasses.replace(both, s0=both.s0[i:i + 1], target_position=both.target_position[:, i:i + 1],
+                            target_equilibrium=both.target_equilibrium[:, i:i + 1], interpolation_type=both.interpolation_type[i:],
+                            Q_disturbance=both.Q_disturbance[:, i:i + 1].copy())
+    eng = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H))
+    rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"]) + i))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    stdev = np.float64(g[f"{tag}/stdev"])
+
+    def knots(_c):
+        kn = O.sample_knots(rng, N, H, stdev)
+        rng.uniform(-1.0, 1.0)
+        return kn[None]
+
+    un = eng.zeros(1, H)
+    eng.step(g[f"{key}/call/s"][0][None], un, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+    res = BatchedCartPoleExperiment(eng, seed=0).run_schedule(b, knots_fn=knots, u_nom0=un)
+    blk = R.recording_block(res, eng.phys)
+    col = lambda n: g[f"{key}/col/{n}"]                                # noqa: E731
+    K = 10
+    r = K * b.n_ctrl // b.n_save + 1
+    np.testing.assert_allclose(res["Q"].cpu().numpy()[:K + 1, 0], g[f"{key}/call/Q"][1:K + 2], atol=1e-4)
+    st = blk["states"][:, 0]
+    for j, n in enumerate(("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")):
+        np.testing.assert_allclose(st[:r, j], col(n)[:r], atol=2e-4, rtol=1e-4, err_msg=n)
+    np.testing.assert_allclose(blk["Q"][:r, 0], col("Q_calculated")[:r], atol=1e-4)
+    np.testing.assert_allclose(blk["Q_applied"][:r, 0], col("Q_applied")[:r], atol=1e-4)
+    np.testing.assert_allclose(blk["Q_ccrc"][:r, 0], col("Q_ccrc")[:r], atol=1e-4)
+    assert np.abs(blk["Q_applied"][:, 0] - blk["Q"][:, 0]).max() > 0.3
+    # the disturbance itself is exact: applied - calculated of OUR run is the float32 sum the reference's arithmetic gives for OUR controls
+    qc = res["Q"].cpu().numpy()[:, 0]
+    assert np.array_equal(blk["Q_applied"][::5, 0], ((qc + b.Q_disturbance[:, 0]).astype(f32) + f32(b.Q_bias)).astype(f32))
+    np.testing.assert_allclose(blk["dd"][:r, 0, 0], col("angleDD")[:r], atol=5e-3, rtol=1e-3)
+    cols = R.typed_columns(blk, 0, eng.phys)
+    assert np.array_equal(f32(cols["u"]), f32(1.77) * blk["Q_applied"][:, 0]) and cols["Q_calculated"] == [float(x) for x in blk["Q"][:, 0]]
+    # teeth: without the disturbance the states leave the reference's within the first control steps
+    rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"]) + i))
+    for _ in range(5):
+        rng.uniform(-1.0, 1.0)
+    un0 = eng.zeros(1, H)
+    eng.step(g[f"{key}/call/s"][0][None], un0, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+    res0 = BatchedCartPoleExperiment(eng, seed=0).run_schedule(dataclasses.replace(b, Q_disturbance=None), knots_fn=knots, u_nom0=un0)
+    assert np.abs(res0["states"].cpu().numpy()[:r, 0, 1] - col("angleD")[:r]).max() > 0.1
     eng.close()
 
 

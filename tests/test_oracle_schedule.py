@@ -197,6 +197,55 @@ def test_experiment_with_pole_mass_and_length_changing_and_a_switching_informer(
     assert np.abs(out2["rows"]["angleDD"][:r] - g[f"{key}/col/angleDD"][:r]).max() > 0.02
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_experiment_with_the_control_disturbance_switched_on(g, i):
+    """exp_dist: the reference's simulator with controlDisturbance 0.3 and controlBias 0.05 (mode 'additive', as shipped), two
+    experiments in a row on ONE module-level generator: per experiment two draws outside the run, then one per controller update.  The oracle's loop reproduces Q_applied from the recorded Q_calculated bit for bit (float32 arithmetic) and
+    the closed loop under the disturbed control to 1e-4."""
+    tag, key = "exp_dist", f"exp_dist/{i}"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    d = json.loads(g[f"{tag}/disturbance"].item())
+    es = S.ExperimentSetter(cfg)
+    for j in range(i + 1):
+        st = es.set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]) + j)))
+    n_upd = len(g[f"{key}/call/time"]) - 1                            # the t = 0 call + the updates inside the loop
+    stream = Generator(SFC64(d["seed"]))
+    z = None
+    for j in range(i + 1):                # every experiment: 2 draws outside the run (set_cartpole_state_at_t0 when the controller is
+        z = stream.standard_normal(size=2 + n_upd, dtype=f32)[2:]     # set, :792, and when the simulator is reset, :733), then its updates
+    col = lambda name: g[f"{key}/col/{name}"]                         # noqa: E731
+    # the arithmetic alone, from the recorded controls: Q_applied = (Q_calculated + 0.3 z) + 0.05 in float32
+    per_call = col("Q_calculated")[::5]                               # (rows every 2 simulation steps, a controller update every 10)
+    want = f32(f32(f32(per_call) + f32(0.3) * z) + f32(0.05))
+    assert np.array_equal(want, col("Q_applied")[::5].astype(f32)) and np.abs(want - f32(per_call)).max() > 0.3
+    assert np.array_equal(col("u").astype(f32), f32(1.77) * col("Q_applied").astype(f32))
+    assert np.array_equal(col("Q_ccrc")[5:], col("Q_applied")[:-5]) and (col("Q_ccrc")[:5] == 0).all()
+    # the loop
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    ctrl = O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]) + i, N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))
+    cs = g[f"{key}/call/s"]
+    ctrl.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+    out = S.run_experiment(st, cfg, lambda s, t, tp, te, L: ctrl.step(s, f32(tp), L=L), disturbance=(z, d["controlDisturbance"], d["controlBias"]))
+    rows, calls = out["rows"], out["calls"]
+    assert np.array_equal(rows["time"], col("time")) and np.array_equal(rows["target_position"], col("target_position"))
+    K = 10
+    np.testing.assert_allclose(np.array([c["Q"] for c in calls])[:K], g[f"{key}/call/Q"][1:K + 1], atol=1e-4)
+    np.testing.assert_allclose(np.array([c["s"] for c in calls])[:K], cs[1:K + 1], atol=1e-4, rtol=1e-4)
+    r = (K - 1) * out["n_ctrl"] // out["n_save"]
+    np.testing.assert_allclose(rows["Q"][:r], col("Q_applied")[:r], atol=1e-4)
+    np.testing.assert_allclose(rows["Q_calculated"][:r], col("Q_calculated")[:r], atol=1e-4)
+    np.testing.assert_allclose(rows["Q_ccrc"][:r], col("Q_ccrc")[:r], atol=1e-4)
+    np.testing.assert_allclose(rows["angleDD"][:r], col("angleDD")[:r], atol=2e-3, rtol=1e-4)
+    # without the disturbance the loop does not follow (the test has teeth)
+    ctrl2 = O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]) + i, N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))
+    ctrl2.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+    es2 = S.ExperimentSetter(cfg)
+    for j in range(i + 1):
+        st2 = es2.set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]) + j)))
+    out2 = S.run_experiment(st2, cfg, lambda s, t, tp, te, L: ctrl2.step(s, f32(tp), L=L))
+    assert np.abs(out2["rows"]["angleDD"][:r] - col("angleDD")[:r]).max() > 0.5
+
+
 def test_experiment_that_ends_inside_a_control_period(g):
     """exp_tail: 25 simulation steps = two control periods and five trailing steps, no turning points (length x complexity < 1: the
     target is 0 whatever the start, random_target_generator.py:31-33): controller calls at t = 0, 0.02, 0.04, three saved rows."""

@@ -136,7 +136,7 @@ def test_native_writer_never_appends_and_cleans_up_after_a_failure(tmp_path):
     assert sorted(os.listdir(tmp_path)) == sorted(os.path.basename(p) for p in good)
 
 
-@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0", "exp_varM/0"])
+@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0", "exp_varM/0", "exp_dist/1"])
 def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, key):
     """The data rows of a recording written by the REFERENCE (its CartPole class + csv_logger, tests/golden/schedule.npz) from the
     values it logged: fed the same values, both writers here give the same bytes (all columns but the wall-clock Q_update_time)."""
@@ -151,6 +151,9 @@ def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, ke
                  Q=col("Q_calculated").astype(f32)[:, None], Q_ccrc=col("Q_ccrc").astype(f32)[:, None],
                  target_position=col("target_position")[:, None], target_equilibrium=col("target_equilibrium").astype(np.int32)[:, None],
                  L=col("L").astype(f32)[:, None], first_update_row=-(-n_ctrl // n_save))
+    if key.startswith("exp_dist"):                                   # the control disturbance: Q_applied differs from Q_calculated
+        block["Q_applied"] = col("Q_applied").astype(f32)[:, None]
+        assert np.abs(block["Q_applied"] - block["Q"]).max() > 0.3
     if key.startswith("exp_varM"):                                   # a pole mass that changes, a controller informer that switches
         block["m_pole"] = col("m_pole").astype(f32)[:, None]
         block["informed"] = (col("L_for_controller") == "true").astype(np.uint8)[:, None]
@@ -158,7 +161,7 @@ def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, ke
         assert np.array_equal(col("L_for_controller"), col("m_pole_for_controller"))
     # (the fixture's columns are what the reference held: float32 values widened by pandas; narrowing them back is exact)
     assert np.array_equal(block["states"][:, 0, 0].astype(np.float64), col("angle")) and np.array_equal(block["Q"][:, 0].astype(np.float64), col("Q_calculated"))
-    assert np.array_equal(col("u").astype(f32), f32(1.77) * block["Q"][:, 0])                       # u = u_max * Q in float32
+    assert np.array_equal(col("u").astype(f32), f32(1.77) * block.get("Q_applied", block["Q"])[:, 0])   # u = u_max * Q_applied in float32
     phys = PhysicalParameters()
     want = g[f"{key}/csv_rows"].item().split("\r\n")
     assert want[0].split(",") == REFERENCE_COLUMNS[:-1] and len(want) == rows + 1
@@ -257,7 +260,8 @@ def test_generate_dataset_on_device(tmp_path):
                m_pole=dict(init_value=0.087, change_every_x_seconds=0.03, mode="random walk", range_random=[0.015, 0.15],
                            range_clip=[0.05, 0.12], increment=0.004, reset_every_x_seconds="inf"),
                inform_controller_about_parameters_change=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.05,
-                                                              change_to_off_after_x_seconds_on=0.07))
+                                                              change_to_off_after_x_seconds_on=0.07),
+               controlDisturbance=0.2, controlBias=-0.02, seed=11)
     pp = R.generate_dataset(eng, E, str(tmp_path / "prm"), config=cfg, seed=7, parameters=prm)
     times = SC.accumulated_times(200, 0.002)
     Ltab = SC.parameter_table(prm["L"], times)
@@ -269,6 +273,10 @@ def test_generate_dataset_on_device(tmp_path):
         assert list(d["L_for_controller"]) == ["true" if x else "default" for x in told[::5]] == list(d["m_pole_for_controller"])
         m = d["m_pole"].to_numpy().astype(np.float32)
         masses.append(m)
+        zq = SC.control_disturbance(E, 21, 11)[:, e]                                    # one draw per controller call: rows 0, 2, 4, ...
+        qc_, qa_ = d["Q_calculated"].to_numpy().astype(np.float32), d["Q_applied"].to_numpy().astype(np.float32)
+        assert np.array_equal(qa_[::2], ((qc_[::2] + np.float32(0.2) * zq).astype(np.float32) + np.float32(-0.02)).astype(np.float32))
+        assert np.array_equal(d["u"].to_numpy().astype(np.float32), np.float32(1.77) * qa_) and np.abs(qa_ - qc_).max() > 0.2
         assert len(np.unique(m)) > 3 and m.min() >= np.float32(0.05) and m.max() <= np.float32(0.12) and m[0] == np.float32(0.087)
         for i in (0, 7, 23, 40):
             r = d.iloc[i]

@@ -193,3 +193,29 @@ def test_a_batch_drawn_at_stride_one_carries_the_parameter_schedule():
     tail, first = SC.draw_shard(cfg, 3, 40, rank=1, world=2, stride=1)
     part = SC.apply_parameter_schedule(tail, prm, seed=5, first=first)
     assert first == 2 and np.array_equal(part.m_pole_table[:, 0], full.m_pole_table[:, 2]) and np.array_equal(part.informed[:, 0], full.informed[:, 2])
+
+
+def test_control_disturbance_draws_are_the_references(g):
+    """exp_dist: two experiments of the reference's simulator in a row with controlDisturbance 0.3, controlBias 0.05 on ONE seeded
+    module-level generator.  schedule.control_disturbance gives every experiment's draws - also to a process that owns only the second
+    experiment - and the float32 arithmetic of apply_parameter_schedule + recording_block's form of it reproduces the recorded
+    Q_applied from the recorded Q_calculated bit for bit."""
+    d = json.loads(g["exp_dist/disturbance"].item())
+    cfg = json.loads(g["exp_dist/config"].item())
+    n_calls = len(g["exp_dist/0/call/time"]) - 1
+    z = SC.control_disturbance(2, n_calls, d["seed"])
+    assert z.shape == (n_calls, 2) and z.dtype == np.float32
+    assert np.array_equal(SC.control_disturbance(1, n_calls, d["seed"], first=1)[:, 0], z[:, 1])
+    b = SC.RandomExperimentSetter(cfg).draw(2, int(g["exp_dist/cartpole_seed0"]))
+    b = SC.apply_parameter_schedule(b, dict(controlDisturbance=d["controlDisturbance"], controlBias=d["controlBias"], seed=d["seed"]))
+    assert b.Q_disturbance.shape == (b.n_periods + 1, 2) and b.Q_bias == float(np.float32(0.05)) and b.L_table is None
+    for i in range(2):
+        qc = g[f"exp_dist/{i}/col/Q_calculated"][::5].astype(np.float32)
+        qa = ((qc + b.Q_disturbance[:, i]).astype(np.float32) + np.float32(b.Q_bias)).astype(np.float32)
+        assert np.array_equal(qa, g[f"exp_dist/{i}/col/Q_applied"][::5].astype(np.float32))
+    with pytest.raises(ValueError):
+        SC.apply_parameter_schedule(b, dict(controlDisturbance=0.2))                    # no seed: the reference would use the clock
+    with pytest.raises(NotImplementedError):
+        SC.apply_parameter_schedule(b, dict(controlDisturbance=0.2, seed=1, controlDisturbance_mode="truncnorm"))
+    off = SC.apply_parameter_schedule(b, dict(controlDisturbance=0.2, seed=1, controlDisturbance_mode="OFF"))
+    assert off.Q_disturbance is b.Q_disturbance                                          # (nothing added)
