@@ -688,11 +688,13 @@ def main():
     extras, side_failed = {}, []
     if (not args.no_extra_configs and args.config is None and args.predictor == "ode" and args.predictor_type == "ODE_v0"
             and args.noise == "philox" and args.math == "fast"):
-        side = [("C4", PRESETS["C4"], "ode", 200, 20)]
+        # (the small configurations are warmed for a full pass before their timed pass: the first ~15 ms of such launches after the
+        # GPU has sat idle behind host work run 5-9 % slower - profiles/r5/prof_overhead.txt, first round against the later ones)
+        side = [("C4", PRESETS["C4"], "ode", 200, 220)]
         if world == 1:
             # ... and the headline shape on the reference's OTHER in-tree ODE predictor, the one its shipped config_controllers.yml
             # names (predictor_specification "ODE": Euler-Cromer substeps, no edge bounce)
-            side = [("C3", PRESETS["C3"], "ode", 100, 10)] + side + [("C5_gru", (256, 1024, 50), "gru", 20, 3),
+            side = [("C3", PRESETS["C3"], "ode", 100, 110)] + side + [("C5_gru", (256, 1024, 50), "gru", 20, 3),
                                                                       ("C2_predictor_ODE", (E, N, H), "ode:ODE", 20, 3)]
         for name, (e_, n_, h_), pred, steps_, warm_ in side:
             pred, ptype = (pred.split(":") + ["ODE_v0"])[:2]
@@ -738,7 +740,7 @@ def main():
         if world == 1 and not collective:
             # the same small configurations with their envs in independent groups, each on its own stream (pipeline.py): what the
             # share-nothing structure of the problem allows and one launch per step cannot use
-            for name, base, groups, steps_, warm_ in (("C4_pipelined", "C4", 2, 200, 20), ("C3_pipelined", "C3", 2, 100, 10)):
+            for name, base, groups, steps_, warm_ in (("C4_pipelined", "C4", 2, 200, 220), ("C3_pipelined", "C3", 2, 100, 110)):
                 e_, n_, h_ = PRESETS[base]
                 try:
                     gw = GroupedWorkload(ctx, e_, n_, h_, groups)

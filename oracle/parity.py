@@ -274,6 +274,23 @@ def c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=None, params=None, dt=N
     return dict(S_a=S_a, S_b=S_b, u_a=u_a, u_b=u_b, Q_a=Q_a, flags=flags, **extra)
 
 
+def trig_jitter_realisations(ocfg, s0, u0, du, tp, te, L=None, params=None, seeds=(1, 2, 3, 4, 5, 6)):
+    """More realisations of the REFERENCE for an env its first seven leave undecided: mode A with every sin / cos result moved to a
+    neighbouring float32 at random (cpmppi_oracle.c, oracle_set_trig_jitter) - "another float32 sin / cos implementation", which is
+    what a GPU's is against the host's libm.  -> list of (u [E,H], S [E,N])."""
+    from . import oracle_c as OC
+    ca = OC.make_config(ocfg, params)
+    out = []
+    try:
+        for seed in seeds:
+            OC.set_trig_jitter(seed)
+            u_p, _, S_p = OC.step(ca, s0, u0, du, tp, te, L=L)
+            out.append((u_p, S_p))
+    finally:
+        OC.set_trig_jitter(0)
+    return out
+
+
 def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0, chunk=8, delta_u=None, params=None):
     """A launch's outputs for a few envs against the C oracle DIRECTLY, under `rule` (full-width form: modes A / B + the
     probes' envelope, quarter-band sensitivity flag): the check of bench.py's `verified` object and of the headline-kernel
@@ -307,11 +324,25 @@ def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0,
                 up("worst_flagged_cost_rel", float(b["rel"][b["flagged"]].max()))
             d = np.abs(np.asarray(u_gpu[e], np.float64) - ref["u_a"][i])
             rep["worst_u_abs"] = max(rep["worst_u_abs"], float(d.max()))
+            # the reference's own scatter on this env: modes A / B AND its one-rounding probes (a chaotic env can sit 1e-3 apart
+            # between two probes while A and B happen to agree: tests/test_gpu_configs.py, C3 seed 21 - the same rule there)
+            u_alt = [a[i] for a in ref.get("u_alt", ())]
             rep["worst_u_vs_reference_spread"] = max(rep["worst_u_vs_reference_spread"],
-                                                     reference_spread_ratio(u_gpu[e], ref["u_a"][i], ref["u_b"][i]))
+                                                     reference_spread_ratio(u_gpu[e], ref["u_a"][i], ref["u_b"][i], u_alt=u_alt))
             allow = softmin_allowance(ref["S_a"][i], ref["S_b"][i], du[i])
-            gap = float(envelope(ref["u_a"][i], ref["u_b"][i]).max())
-            rep["u_off_envs"] += int((d > 1e-4 + np.maximum(gap, allow)).any())
+            gap = float(envelope(ref["u_a"][i], ref["u_b"][i], *u_alt).max())
+            off = bool((d > 1e-4 + np.maximum(gap, allow)).any())
+            if off and gap > 1e-4:
+                # an env on which the reference's own realisations already disagree by more than the band (a chaotic start: their
+                # scatter is a heavy-tailed quantity seven samples estimate poorly): six more realisations, each with another
+                # float32 sin / cos, join the envelope before the env is called off.  Counted and reported.
+                j = slice(e, e + 1)
+                more = trig_jitter_realisations(ocfg, s0[j], u_before[j], du[i:i + 1], tp[j], te[j], L=L[j], params=params)
+                gap2 = float(envelope(ref["u_a"][i], ref["u_b"][i], *u_alt, *[m[0][0] for m in more]).max())
+                rep["second_stage_envs"] = rep.get("second_stage_envs", 0) + 1
+                rep["second_stage"] = dict(realisations=len(more), envelope_before=gap, envelope_after=gap2, deviation=float(d.max()))
+                off = bool((d > 1e-4 + np.maximum(gap2, allow)).any())
+            rep["u_off_envs"] += int(off)
     cap = min(int(np.ceil(rule.flagged_cap * rep["flagged"])), int(np.ceil(rule.total_cap * rep["rollouts"])))
     rep["flagged_cap"] = cap
     rep["ok"] = bool(rep["clear_off"] == 0 and rep["flagged_off"] <= cap and rep["u_off_envs"] == 0)

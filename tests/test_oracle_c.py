@@ -85,3 +85,65 @@ def test_c_threads_are_deterministic():
     a = OC.step(cfg, s0, np.zeros((1, H), f32), du, 0.0, 1.0, n_threads=1)
     b = OC.step(cfg, s0, np.zeros((1, H), f32), du, 0.0, 1.0, n_threads=4)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+
+
+def test_verify_envs_says_yes_no_and_asks_for_more_realisations(monkeypatch):
+    """oracle/parity.py verify_envs, the rule behind bench.py's `verified` objects, on the CPU: a chaotic env (18 rad/s, 100 control
+    steps: the reference's own realisations disagree on the update by more than the 1e-4 band) and a calm one.
+      * another float32 sin / cos implementation of the reference (what a GPU is against the host's libm) is accepted;
+      * a different pole mass is not;
+      * an update outside the first seven realisations' envelope on the chaotic env makes the checker draw six more before it
+        says no (counted in the report) - and it still says no when they do not reach it;
+      * a bucket nothing fell into reports None, not 0."""
+    from oracle import parity as PR
+    N, H = 1024, 100
+    ocfg = O.MPPIConfig(N=N, H=H)
+    rng = np.random.Generator(np.random.SFC64(5))
+    states = [(-0.2, 0.4, 0.01, 0.02)]
+    for trial in range(2):                                         # (the second draw of this stream: measured envelope 6e-4)
+        chaotic = (rng.uniform(-3, 3), rng.uniform(15, 21) * rng.choice([-1, 1]), rng.uniform(-0.15, 0.15), rng.uniform(-0.3, 0.3))
+        u0c = (0.1 * rng.standard_normal((1, H))).astype(np.float32)
+        knc = (0.2121 * rng.standard_normal((1, N, 11))).astype(np.float32)
+    states.append(chaotic)
+    s0 = np.array([[a, ad, np.cos(a), np.sin(a), x, xd] for a, ad, x, xd in states], np.float32)
+    u0 = np.concatenate([np.zeros((1, H), np.float32), u0c])
+    kn = np.concatenate([(0.2121 * rng.standard_normal((1, N, 11))).astype(np.float32), knc])
+    tp, te, L = np.full(2, 0.05, np.float32), np.ones(2, np.float32), np.full(2, 0.395, np.float32)
+    du = np.stack([O.interpolate_knots(kn[e], H) for e in range(2)])
+    (u_j, S_j), = PR.trig_jitter_realisations(ocfg, s0, u0, du, tp, te, L=L, seeds=(21,))
+    rep = PR.verify_envs(ocfg, s0, u0, kn, tp, te, L, S_j, u_j)
+    assert rep["ok"] and rep["clear"] > N // 2 and rep["clear_off"] == 0 and rep["worst_cost_rel"] is not None
+    ref = PR.c_oracle_step_with_flags(ocfg, s0, u0, du, tp, te, L=L, probes=True)
+    gap = float(PR.envelope(ref["u_a"][1], ref["u_b"][1], *[a[1] for a in ref["u_alt"]]).max())
+    assert gap > 1e-4                                              # the chaotic env is one
+    import dataclasses
+    heavy = dataclasses.replace(O.DEFAULT_PARAMS, m_pole=np.float32(0.09))
+    assert not PR.verify_envs(ocfg, s0, u0, kn, tp, te, L, S_j, u_j, params=heavy)["ok"]
+    # outside the envelope of the first seven on the chaotic env
+    u_far = u_j.copy()
+    u_far[1, 3] = np.float32(ref["u_a"][1][3] + 2.5 * (gap + 1e-4))
+    calls = []
+    real = PR.trig_jitter_realisations
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    monkeypatch.setattr(PR, "trig_jitter_realisations", counted)
+    rep = PR.verify_envs(ocfg, s0, u0, kn, tp, te, L, S_j, u_far)
+    assert calls == [1] and rep["second_stage_envs"] == 1 and rep["second_stage"]["realisations"] == 6
+    assert not rep["ok"] and rep["u_off_envs"] == 1 and rep["second_stage"]["envelope_after"] < 2.5 * gap
+    # ... and accepted when the further realisations do scatter that far (here: one that is handed in)
+    monkeypatch.setattr(PR, "trig_jitter_realisations", lambda *a, **k: [(u_far[1:2], S_j[1:2])])
+    assert PR.verify_envs(ocfg, s0, u0, kn, tp, te, L, S_j, u_far)["ok"]
+    # on the CALM env no second look is taken: outside is outside
+    monkeypatch.setattr(PR, "trig_jitter_realisations", counted)
+    u_bad = u_j.copy()
+    u_bad[0, 0] += np.float32(5e-4)
+    del calls[:]
+    rep = PR.verify_envs(ocfg, s0, u0, kn, tp, te, L, S_j, u_bad)
+    assert not rep["ok"] and calls == [] and "second_stage_envs" not in rep
+    # an empty bucket: nothing compared is not a perfect match
+    one = PR.verify_envs(ocfg, s0[:1], u0[:1], kn[:1], tp[:1], te[:1], L[:1], S_j[:1], u_j[:1])
+    if one["flagged"] == 0:
+        assert one["worst_flagged_excess"] is None and one["worst_flagged_cost_rel"] is None
