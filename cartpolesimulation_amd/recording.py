@@ -302,32 +302,65 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
 
 
 def main(argv=None):
-    """python -m cartpolesimulation_amd.recording --experiments 64 --length 10 --out ./Experiment_Recordings/ --seed 1"""
+    """python -m cartpolesimulation_amd.recording --experiments 64 --length 10 --out ./Experiment_Recordings/ --seed 1
+    python -m cartpolesimulation_amd.recording --config-root <CartPoleSimulation checkout> --seed 1     (its YAML files decide)"""
     import argparse
-    from .configs import MPPIConfig, legacy_mppi_config
+    from .configs import MPPIConfig, legacy_mppi_config, load_reference_yaml, mppi_config_from_yaml
     from .engine import MPPIEngine
     ap = argparse.ArgumentParser(description="Batched CartPole data generator on MI355X (reference: run_data_generator.py)")
-    ap.add_argument("--experiments", "--envs", type=int, default=64, dest="experiments")
-    ap.add_argument("--length", type=float, default=10.0, help="length of each experiment in seconds")
-    ap.add_argument("--out", default="./Experiment_Recordings/")
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--rollouts", type=int, default=3500)
-    ap.add_argument("--horizon", type=int, default=35)
-    ap.add_argument("--dt-save", type=float, default=0.02)
-    ap.add_argument("--ml-pipeline", action="store_true", help="Train / Validate / Test folders (config_data_gen.yml: ML_Pipeline_mode)")
+    ap.add_argument("--config-root", default=None,
+                    help="a CartPoleSimulation checkout: config_data_gen.yml (experiments, lengths, time scales, target traces, split), "
+                         "cartpole_physical_parameters.yml (the plant's constants, parameter updaters, informer, control disturbance) and the "
+                         "mppi section of Control_Toolkit_ASF/config_optimizers.yml + the mpc cost / predictor are read from it, as "
+                         "run_data_generator.py reads them from its working directory; the flags below override them when given")
+    ap.add_argument("--experiments", "--envs", type=int, default=None, dest="experiments")
+    ap.add_argument("--length", type=float, default=None, help="length of each experiment in seconds")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--rollouts", type=int, default=None)
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--dt-save", type=float, default=None)
+    ap.add_argument("--ml-pipeline", action="store_true", default=None,
+                    help="Train / Validate / Test folders (config_data_gen.yml: ML_Pipeline_mode)")
     ap.add_argument("-i", "--secondary_experiment_index", type=int, default=-1)
     ap.add_argument("--groups", type=int, default=1, help="independent env groups, each on its own stream (pipeline.py)")
-    ap.add_argument("--cost", default="legacy_mppi_cartpole",
+    ap.add_argument("--cost", default=None,
                     choices=["legacy_mppi_cartpole", "default", "quadratic_boundary_grad_minimal", "quadratic_boundary_grad"])
     args = ap.parse_args(argv)
-    cfg = legacy_mppi_config(num_rollouts=args.rollouts, mpc_horizon=args.horizon) if args.cost == "legacy_mppi_cartpole" \
-        else MPPIConfig(num_rollouts=args.rollouts, mpc_horizon=args.horizon, cost_function_specification=args.cost)
+    phys, parameters, dg = None, None, {}
+    if args.config_root:
+        from .schedule import active_parameters
+        import yaml
+        phys, cfgs = load_reference_yaml(args.config_root)
+        dg = dict(cfgs["data_gen"])
+        if dg.get("controller", "mpc") != "mpc":
+            raise SystemExit(f"config_data_gen.yml names controller {dg['controller']!r}: the batched generator runs the MPPI optimizer of `mpc`")
+        over = {k: v for k, v in (("num_rollouts", args.rollouts), ("mpc_horizon", args.horizon), ("cost_function_specification", args.cost))
+                if v is not None and v != "legacy_mppi_cartpole"}
+        cfg = legacy_mppi_config(**{k: v for k, v in over.items() if k != "cost_function_specification"}) if args.cost == "legacy_mppi_cartpole" \
+            else mppi_config_from_yaml(cfgs, **over)
+        with open(os.path.join(args.config_root, "cartpole_physical_parameters.yml")) as fh:
+            parameters = active_parameters(yaml.safe_load(fh)["cartpole"])
+        if parameters and parameters.get("seed") is None and "controlDisturbance" in parameters:
+            parameters["seed"] = args.seed
+    else:
+        n, h, cost = args.rollouts or 3500, args.horizon or 35, args.cost or "legacy_mppi_cartpole"
+        cfg = legacy_mppi_config(num_rollouts=n, mpc_horizon=h) if cost == "legacy_mppi_cartpole" \
+            else MPPIConfig(num_rollouts=n, mpc_horizon=h, cost_function_specification=cost)
+        dg = dict(length_of_experiment=10.0, dt=dict(saving=0.02), number_of_experiments=64)
+    if args.length is not None:
+        dg["length_of_experiment"] = args.length
+    if args.dt_save is not None:
+        dg["dt"] = dict(dg.get("dt") or {}, saving=args.dt_save)
+    if args.ml_pipeline is not None:
+        dg["ML_Pipeline_mode"] = bool(args.ml_pipeline)
+    seed = args.seed if args.seed is not None else (dg.get("seed") if dg.get("seed") is not None else 0)
+    n_exp = args.experiments if args.experiments is not None else int(dg.get("number_of_experiments", 64))
+    out = args.out if args.out is not None else dg.get("PATH_TO_EXPERIMENT_RECORDINGS_DEFAULT", "./Experiment_Recordings/")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))     # one process per GPU under torchrun
     from .shard import env_shard
-    eng = MPPIEngine(env_shard(args.experiments, world, rank)[1], cfg, device=int(os.environ.get("LOCAL_RANK", "0")))
-    paths = generate_dataset(eng, args.experiments, args.out, seed=args.seed, rank=rank, world=world,
-                             config=dict(length_of_experiment=args.length, ML_Pipeline_mode=args.ml_pipeline,
-                                         dt=dict(saving=args.dt_save)), groups=args.groups,
+    eng = MPPIEngine(env_shard(n_exp, world, rank)[1], cfg, phys=phys, device=int(os.environ.get("LOCAL_RANK", "0")))
+    paths = generate_dataset(eng, n_exp, out, seed=seed, rank=rank, world=world, config=dg, groups=args.groups, parameters=parameters,
                              secondary_experiment_index=None if args.secondary_experiment_index < 0 else args.secondary_experiment_index)
     print(f"wrote {len(paths)} recordings under {os.path.dirname(paths[0])}")
 

@@ -423,6 +423,25 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
     return dataclasses.replace(batch, **out)
 
 
+def active_parameters(cartpole_section):
+    """The blocks of cartpole_physical_parameters.yml's `cartpole:` section that make a run differ from one with constant parameters,
+    an always-informed controller and no control disturbance -> the `parameters` dict of apply_parameter_schedule /
+    recording.generate_dataset, or None when there is none (the shipped file: updaters 'constant', informer 'ON', disturbance 0)."""
+    sec, out = cartpole_section, {}
+    for name in ("L", "m_pole"):
+        blk = sec.get(name)
+        if isinstance(blk, dict) and (blk.get("mode", "constant") != "constant" or blk.get("init_value") == "random"):
+            out[name] = dict(blk)
+    inf = sec.get("inform_controller_about_parameters_change")
+    if isinstance(inf, dict) and inf.get("mode", "ON") != "ON":
+        out["inform_controller_about_parameters_change"] = dict(inf)
+    mode = sec.get("controlDisturbance_mode", "OFF")
+    if mode != "OFF" and (float(sec.get("controlDisturbance") or 0.0) != 0.0 or float(sec.get("controlBias") or 0.0) != 0.0):
+        out.update(controlDisturbance_mode=mode, controlDisturbance=sec.get("controlDisturbance"), controlBias=sec.get("controlBias"),
+                   seed=sec.get("seed"))
+    return out or None
+
+
 def draw_shard(config, n_total, cartpole_seed, rank=0, world=1, L=None, stride=None):
     """Rank `rank` of `world` processes' share of a run of `n_total` experiments: the contiguous block shard.env_shard gives it, drawn
     from the SAME random streams as the single-process run (the union over the ranks is that run, experiment for experiment) - the

@@ -292,3 +292,51 @@ def test_generate_dataset_on_device(tmp_path):
     for a, b2, c2 in zip(pp, again, ranks):
         da, db, dc = (pd.read_csv(p, comment="#", float_precision="round_trip").drop(columns=["Q_update_time"]) for p in (a, b2, c2))
         assert da.equals(db) and da.equals(dc), (a, b2, c2)
+
+
+@pytest.mark.gpu
+def test_generator_cli_reads_a_checkouts_yaml_files(tmp_path, capsys):
+    """python -m cartpolesimulation_amd.recording --config-root <checkout>: config_data_gen.yml decides the experiments, the physical-
+    parameters file the plant and its parameter schedule (here: a pole length in 'bounce' mode, an informer that is OFF, a control
+    disturbance), config_optimizers.yml's mppi section the controller - what run_data_generator.py reads from its working directory."""
+    pytest.importorskip("torch")
+    import yaml
+    from cartpolesimulation_amd import schedule as SC
+    root = tmp_path / "checkout"
+    (root / "Control_Toolkit_ASF").mkdir(parents=True)
+    (root / "SI_Toolkit_ASF").mkdir()
+    dg = SC.default_data_gen_config()
+    dg.update(seed=5, length_of_experiment=0.2, number_of_experiments=3, PATH_TO_EXPERIMENT_RECORDINGS_DEFAULT=str(tmp_path / "rec") + "/")
+    dg["dt"]["saving"] = 0.01
+    dg["turning_points"]["track_relative_complexity"] = 10
+    dump = lambda rel, obj: (root / rel).write_text(yaml.safe_dump(obj))     # noqa: E731
+    dump("config_data_gen.yml", dg)
+    dump("cartpole_physical_parameters.yml", dict(cartpole=dict(
+        seed=3, m_cart=0.23, u_max=1.77, M_fric=3.22, J_fric=5.0e-5, v_max=0.8, cart_length=4.4e-2, track_length=44.0e-2, g=9.81, k="1.0/3.0",
+        controlDisturbance_mode="additive", controlDisturbance=0.1, controlBias=0.0,
+        L=dict(init_value=0.395, change_every_x_seconds=0.014, mode="bounce", range_random=[0.2, 0.5], range_clip=[0.3, 0.45], increment=0.01,
+               reset_every_x_seconds="inf"),
+        m_pole=dict(init_value=0.087, change_every_x_seconds=2, mode="constant", range_random=[0.015, 0.15], range_clip=[0.015, 0.15],
+                    increment=0.002, reset_every_x_seconds="inf"),
+        inform_controller_about_parameters_change=dict(mode="OFF", change_to_on_after_x_seconds_off=1.5, change_to_off_after_x_seconds_on=4))))
+    dump("Control_Toolkit_ASF/config_optimizers.yml", dict(mppi=dict(seed=None, mpc_horizon=20, mpc_timestep=0.02, num_rollouts=256, cc_weight=1.0,
+                                                                     R=1.0, LBD=100.0, NU=1000.0, SQRTRHOINV=0.03,
+                                                                     period_interpolation_inducing_points=10)))
+    dump("Control_Toolkit_ASF/config_controllers.yml", dict(mpc=dict(optimizer="mppi", predictor_specification="ODE_v0",
+                                                                     cost_function_specification="quadratic_boundary_grad_minimal")))
+    dump("Control_Toolkit_ASF/config_cost_function.yml", dict(cost_function_name_default="quadratic_boundary_grad_minimal",
+                                                              CartPole=dict(quadratic_boundary_grad_minimal={})))
+    dump("SI_Toolkit_ASF/config_predictors.yml", dict(predictors=dict(ODE_v0_default=dict(predictor_type="ODE_v0", intermediate_steps=10))))
+    R.main(["--config-root", str(root)])
+    assert "wrote 3 recordings" in capsys.readouterr().out
+    files = sorted(os.listdir(tmp_path / "rec"))
+    assert files == ["Experiment-1.csv", "Experiment-2.csv", "Experiment.csv"]
+    d = pd.read_csv(tmp_path / "rec" / "Experiment-1.csv", comment="#", float_precision="round_trip")
+    assert len(d) == 21 and len(np.unique(d["L"])) > 4 and set(d["L_for_controller"]) == {"default"} and set(d["m_pole"]) == {float(f32(0.087))}
+    qc, qa = d["Q_calculated"].to_numpy().astype(f32), d["Q_applied"].to_numpy().astype(f32)
+    z = SC.control_disturbance(3, 11, 3)[:, 1]                                          # experiment 1 of the run, seed of the YAML
+    assert np.array_equal(qa[::2], ((qc[::2] + f32(0.1) * z).astype(f32) + f32(0.0)).astype(f32))
+    # flags override the files
+    R.main(["--config-root", str(root), "--experiments", "2", "--length", "0.1", "--out", str(tmp_path / "rec2")])
+    assert sorted(os.listdir(tmp_path / "rec2")) == ["Experiment-1.csv", "Experiment.csv"]
+    assert len(pd.read_csv(tmp_path / "rec2" / "Experiment.csv", comment="#")) == 11

@@ -219,3 +219,23 @@ def test_control_disturbance_draws_are_the_references(g):
         SC.apply_parameter_schedule(b, dict(controlDisturbance=0.2, seed=1, controlDisturbance_mode="truncnorm"))
     off = SC.apply_parameter_schedule(b, dict(controlDisturbance=0.2, seed=1, controlDisturbance_mode="OFF"))
     assert off.Q_disturbance is b.Q_disturbance                                          # (nothing added)
+
+
+def test_active_parameters_of_a_physical_parameters_file():
+    """schedule.active_parameters: which blocks of cartpole_physical_parameters.yml's `cartpole:` section change a run.  The shipped
+    file (read from the reference checkout when it is mounted) has none: updaters 'constant', informer 'ON', disturbance amplitude 0."""
+    import yaml
+    ref = "/root/reference/cartpole_physical_parameters.yml"
+    if os.path.isfile(ref):
+        with open(ref) as fh:
+            assert SC.active_parameters(yaml.safe_load(fh)["cartpole"]) is None
+    sec = dict(seed=7, controlDisturbance_mode="additive", controlDisturbance=0.0, controlBias=0.0,
+               L=dict(init_value=0.395, mode="constant"), m_pole=dict(init_value=0.087, mode="constant"),
+               inform_controller_about_parameters_change=dict(mode="ON"))
+    assert SC.active_parameters(sec) is None
+    got = SC.active_parameters(dict(sec, controlDisturbance=0.3, L=dict(init_value="random", mode="constant"),
+                                    m_pole=dict(init_value=0.087, mode="bounce"),
+                                    inform_controller_about_parameters_change=dict(mode="OFF")))
+    assert set(got) == {"L", "m_pole", "inform_controller_about_parameters_change", "controlDisturbance_mode", "controlDisturbance",
+                        "controlBias", "seed"} and got["seed"] == 7 and got["controlDisturbance"] == 0.3
+    assert SC.active_parameters(dict(sec, controlDisturbance=0.3, controlDisturbance_mode="OFF")) is None
