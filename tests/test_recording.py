@@ -340,3 +340,33 @@ def test_generator_cli_reads_a_checkouts_yaml_files(tmp_path, capsys):
     R.main(["--config-root", str(root), "--experiments", "2", "--length", "0.1", "--out", str(tmp_path / "rec2")])
     assert sorted(os.listdir(tmp_path / "rec2")) == ["Experiment-1.csv", "Experiment.csv"]
     assert len(pd.read_csv(tmp_path / "rec2" / "Experiment.csv", comment="#")) == 11
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Control_Toolkit_ASF"), reason="reference checkout not mounted")
+def test_generator_cli_on_the_reference_checkout(monkeypatch):
+    """--config-root on the reference's own tree (CPU: engine and run captured): its config_data_gen.yml as shipped, the mppi
+    section of config_optimizers.yml, the mpc cost and predictor of config_controllers.yml, the shipped physical parameters (nothing
+    active in them: no parameter schedule is built)."""
+    import cartpolesimulation_amd.engine as ENG
+    seen = {}
+
+    class Engine:
+        def __init__(self, E, cfg, phys=None, device=0):
+            seen.update(E=E, cfg=cfg, phys=phys)
+
+    def gen(engine, n, out, **kw):
+        seen.update(n=n, out=out, **kw)
+        return [os.path.join(out, "Experiment.csv")]
+
+    monkeypatch.setattr(ENG, "MPPIEngine", Engine)
+    monkeypatch.setattr(R, "generate_dataset", gen)
+    R.main(["--config-root", "/root/reference", "--seed", "4", "--experiments", "8"])
+    import yaml
+    dg = yaml.safe_load(open("/root/reference/config_data_gen.yml"))
+    opt = yaml.safe_load(open("/root/reference/Control_Toolkit_ASF/config_optimizers.yml"))["mppi"]
+    assert seen["E"] == 8 and seen["n"] == 8 and seen["seed"] == 4 and seen["parameters"] is None
+    assert seen["config"]["length_of_experiment"] == dg["length_of_experiment"] and seen["config"]["dt"] == dg["dt"]
+    assert seen["config"]["turning_points"] == dg["turning_points"] and seen["out"] == dg["PATH_TO_EXPERIMENT_RECORDINGS_DEFAULT"]
+    assert seen["cfg"].num_rollouts == opt["num_rollouts"] and seen["cfg"].mpc_horizon == opt["mpc_horizon"]
+    assert seen["cfg"].cost_function_specification == "quadratic_boundary_grad_minimal" and seen["cfg"].predictor_type == "ODE"
+    assert abs(seen["phys"].m_pole - 0.087) < 1e-6 and abs(seen["phys"].TrackHalfLength - 0.198) < 1e-6
