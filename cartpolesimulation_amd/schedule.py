@@ -385,8 +385,14 @@ def control_disturbance(E, n_calls, seed, first=0):
     call (:881-882 at t = 0, :523-524 inside the loop).  -> float32 [n_calls, E] for the experiments first .. first + E - 1 of the
     run: the reference's own numbers for a seeded run, whatever the split over processes."""
     per = int(n_calls) + 2
-    z = np.random.Generator(np.random.SFC64(int(seed))).standard_normal(size=(int(first) + int(E)) * per, dtype=f32)
-    return np.ascontiguousarray(z.reshape(-1, per)[int(first):, 2:].T)
+    gen = np.random.Generator(np.random.SFC64(int(seed)))
+    skip = int(first) * per                                        # the draws of the experiments before ours (SFC64 cannot jump ahead,
+    while skip > 0:                                                # and a normal takes a variable number of words: drawn and dropped)
+        n = min(skip, 1 << 22)
+        gen.standard_normal(size=n, dtype=f32)
+        skip -= n
+    z = gen.standard_normal(size=int(E) * per, dtype=f32)
+    return np.ascontiguousarray(z.reshape(-1, per)[:, 2:].T)
 
 
 def apply_parameter_schedule(batch, parameters, seed=0, first=0):
@@ -413,13 +419,23 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
         z = control_disturbance(E, batch.n_periods + 1, parameters["seed"], first)
         out["Q_disturbance"], out["Q_bias"] = f32(amp) * z, float(f32(bias))
     for name, field_ in (("L", "L_table"), ("m_pole", "m_pole_table")):
-        if parameters.get(name) is not None:
-            out[field_] = np.stack([parameter_table(parameters[name], batch.times, _random.Random(int(seed) + first + e),
+        blk = parameters.get(name)
+        if blk is None:
+            continue
+        if blk.get("mode") in ("constant", "increase", "bounce") and blk.get("init_value") != "random":
+            col = parameter_table(blk, batch.times)               # the same for every experiment: tabulated once
+            out[field_] = np.ascontiguousarray(np.broadcast_to(col[:, None], (len(col), E)))
+        else:
+            out[field_] = np.stack([parameter_table(blk, batch.times, _random.Random(int(seed) + first + e),
                                                     np.random.RandomState(int(seed) + first + e)) for e in range(E)], axis=1)
     inf = parameters.get("inform_controller_about_parameters_change")
     if inf is not None:
-        out["informed"] = np.stack([informer_table(inf, batch.times, batch.n_ctrl, np.random.RandomState(int(seed) + first + e + 1))
-                                    for e in range(E)], axis=1)
+        if inf.get("mode") != "switching_random":
+            col = informer_table(inf, batch.times, batch.n_ctrl)
+            out["informed"] = np.ascontiguousarray(np.broadcast_to(col[:, None], (len(col), E)))
+        else:
+            out["informed"] = np.stack([informer_table(inf, batch.times, batch.n_ctrl, np.random.RandomState(int(seed) + first + e + 1))
+                                        for e in range(E)], axis=1)
     return dataclasses.replace(batch, **out)
 
 
