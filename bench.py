@@ -530,11 +530,12 @@ class GroupedWorkload:
         self.step_all = self.groups.prepare(full[0], self.u_all, full[1], full[2], L=full[3], seed=self.parts[0].seed, Q_out=self.Q_all)
         torch.cuda.synchronize()
 
-    def run(self, steps, warmup):
+    def run(self, steps, warmup, overlap=True):
         import numpy as np
         import torch
         self.groups.fork()
-        self.stream_overlap = self.groups.overlap(self.step_all)       # (outside the timed region) 1.0 = the groups were serialised
+        # (outside the timed region) 1.0 = the groups were serialised
+        self.stream_overlap = self.groups.overlap(self.step_all) if overlap else None
         self.u_all.zero_()
         torch.cuda.synchronize()
         self.groups.fork()
@@ -747,6 +748,10 @@ def main():
             for name, base, groups, steps_, warm_ in (("C4_pipelined", "C4", 2, 200, 220), ("C3_pipelined", "C3", 2, 100, 110)):
                 e_, n_, h_ = PRESETS[base]
                 try:
+                    # the yardstick first: the SAME code path with ONE group = one launch per step, enqueued from C, wall time only
+                    one = GroupedWorkload(ctx, e_, n_, h_, 1)
+                    one_ms = one.run(steps_, warm_, overlap=False)["ms_per_step"]
+                    one.close()
                     gw = GroupedWorkload(ctx, e_, n_, h_, groups)
                     rr = gw.run(steps_, warm_)
                 except Exception as ex:  # noqa: BLE001
@@ -762,7 +767,7 @@ def main():
                                 "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
                                 "groups": groups, "group_kernel_ms": rr["group_kernel_ms"], "kernels": rr["kernels"],
                                 "stream_overlap": rr["stream_overlap"],
-                                "vs_one_launch_per_step": extras[base]["ms_per_step"] / rr["ms_per_step"] if "ms_per_step" in extras.get(base, {}) else None,
+                                "one_group_ms_per_step": one_ms, "vs_one_launch_per_step": one_ms / rr["ms_per_step"],
                                 "roofline_valu": {"bound": "fp32-valu", "unit": "TFLOP/s", "peak": FP32_VALU_PEAK_TFLOPS,
                                                   "achieved": algorithmic_flops_per_rollout(h_) * e_ * n_ / (rr["ms_per_step"] * 1e-3) / 1e12,
                                                   "frac": algorithmic_flops_per_rollout(h_) * e_ * n_ / (rr["ms_per_step"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,

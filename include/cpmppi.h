@@ -526,8 +526,8 @@ int cpmppi_stream_destroy(void* stream);
 
 /* ENV GROUPS: the E envs of one device as `groups` contiguous groups, each with a handle and a dedicated-queue stream of its own,
  * every group running its OWN chain of launches - independent MPPI problem instances need not march in step (a launch of a few
- * dozen envs ends with its slowest wave, waves differ by 20-40 %; measured on MI355X: 64 envs x 2048 x 50 75.5 -> 65 us per
- * step of all envs with two groups, 64 x 4096 x 100 226 -> 178 us).  No reference counterpart beyond its share-nothing job arrays
+ * dozen envs ends with its slowest wave, waves differ by 20-40 %; measured on MI355X: 64 envs x 2048 x 50 74.5 -> 63.8 us per
+ * step of all envs with two groups, 64 x 4096 x 100 224.6 -> 177.1 us).  No reference counterpart beyond its share-nothing job arrays
  * (others/EulerClusterScripts/ParallelDataGeneration.sh:2-17).  Philox keys are GLOBAL env indices (env_offset + env): a result
  * does not depend on the split (bit-identical to the unsplit launch whenever both pick the same lane mapping).
  *   cpmppi_groups_create   cfg->E = all envs of the device; env_offset = global index of env 0 (rank * E when sharded over GPUs)
