@@ -75,7 +75,7 @@ class cpmppi_plant_args(C.Structure):
                 ("target_position_out", C.c_void_p), ("target_equilibrium_out", C.c_void_p), ("L_out", C.c_void_p),
                 ("row_envs", C.c_uint32),
                 ("m_pole", C.c_void_p), ("m_pole_table", C.c_void_p), ("L_controller_table", C.c_void_p),
-                ("Q_disturbance_table", C.c_void_p), ("Q_bias", C.c_float)]
+                ("Q_disturbance_table", C.c_void_p), ("Q_bias", C.c_float), ("Q_applied_out", C.c_void_p)]
 
 
 class cpmppi_recording(C.Structure):

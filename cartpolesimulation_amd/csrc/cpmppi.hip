@@ -287,6 +287,7 @@ struct PlantDev {
   const float *m_pole, *m_table, *Lc_table;
   const float* Qd_table;
   float Q_bias;
+  float* Qa_out;
 };
 
 __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const PlantDev a) {
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const Pla
   if (a.Q_log && known && c < a.ctrl_rows) a.Q_log[(size_t)c * E + env] = q;
   if (a.Qd_table && known && c < a.ctrl_rows)                          // add_control_noise (:523-524): two float32 additions
     q = __fadd_rn(__fadd_rn(q, a.Qd_table[(size_t)c * E + env]), a.Q_bias);
+  if (a.Qa_out) a.Qa_out[env] = q;                                     // the next call's Q_ccrc (:489)
   const float u = p.u_max * q;
   float aDD, xDD;
   ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);             // CartPole/__init__.py:316-320 (Update_Q, Q2u, cartpole_ode)
@@ -1937,6 +1939,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
       misaligned(a->Q_log) || misaligned(a->target_position_table) || misaligned(a->target_equilibrium_table) ||
       misaligned(a->L_table) || misaligned(a->target_position_out) || misaligned(a->target_equilibrium_out) || misaligned(a->L_out) ||
       misaligned(a->m_pole) || misaligned(a->m_pole_table) || misaligned(a->L_controller_table) || misaligned(a->Q_disturbance_table) ||
+      misaligned(a->Q_applied_out) ||
       (a->period_dev && ((uintptr_t)a->period_dev & 7u)))
     return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_step: misaligned");
   CPMPPI_ON_DEVICE(h);
@@ -1953,7 +1956,7 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   d.tp_table = a->target_position_table; d.te_table = a->target_equilibrium_table; d.L_table = a->L_table;
   d.tp_out = a->target_position_out; d.te_out = a->target_equilibrium_out; d.L_out = a->L_out;
   d.m_pole = a->m_pole; d.m_table = a->m_pole_table; d.Lc_table = a->L_controller_table;
-  d.Qd_table = a->Q_disturbance_table; d.Q_bias = a->Q_bias;
+  d.Qd_table = a->Q_disturbance_table; d.Q_bias = a->Q_bias; d.Qa_out = a->Q_applied_out;
   hipLaunchKernelGGL(plant_kernel, dim3((a->E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, d);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;

@@ -191,7 +191,7 @@ int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmp
       b.target_position_out = at(b.target_position_out, e0); b.target_equilibrium_out = at(b.target_equilibrium_out, e0);
       b.L_out = at(b.L_out, e0);
       b.m_pole = at(b.m_pole, e0); b.m_pole_table = at(b.m_pole_table, e0); b.L_controller_table = at(b.L_controller_table, e0);
-      b.Q_disturbance_table = at(b.Q_disturbance_table, e0);
+      b.Q_disturbance_table = at(b.Q_disturbance_table, e0); b.Q_applied_out = at(b.Q_applied_out, e0);
       pa[i] = b;
     }
   }

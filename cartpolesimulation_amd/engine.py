@@ -270,14 +270,15 @@ class MPPIEngine:
     def plant_step(self, s, Q, n_substeps, dt_sim=0.002, period=0, period_dev=None, period_steps=None, L=None, states_log=None,
                    dd_log=None, save_every=None, Q_log=None, target_position_table=None, target_equilibrium_table=None,
                    L_table=None, sched_stride=1, target_position_out=None, target_equilibrium_out=None, L_out=None, m_pole=None,
-                   m_pole_table=None, L_controller_table=None, Q_disturbance_table=None, Q_bias=0.0, _prepare=False):
+                   m_pole_table=None, L_controller_table=None, Q_disturbance_table=None, Q_bias=0.0, Q_applied_out=None, _prepare=False):
         """cpmppi_plant_step: one control period of the simulated cartpoles with the experiment schedule and the recording in the
         same launch (include/cpmppi.h).  ``s`` [E,6] in place under held ``Q`` [E]; logs ``states_log`` [rows,E,6], ``dd_log``
         [rows,E,2], ``Q_log`` [periods,E]; schedule tables [sched_rows,E] sampled every ``sched_stride`` simulation steps; ``*_out``
         [E] receive the row the NEXT controller call reads.  ``n_substeps`` = 0 records only.  ``m_pole`` [E] / ``m_pole_table``
         [sched_rows,E]: the PLANT's pole mass (default: the config's); ``L_controller_table``: what ``L_out`` publishes instead of
         ``L_table`` (the pole length the controller is told, CartPole/controller_informer.py).  ``Q_disturbance_table`` [periods,E]
-        + ``Q_bias``: the plant is driven by (Q + table[period]) + Q_bias (the simulator's additive control disturbance)."""
+        + ``Q_bias``: the plant is driven by (Q + table[period]) + Q_bias (the simulator's additive control disturbance);
+        ``Q_applied_out`` [E] receives that control (the next controller call's ``previous_input``)."""
         if not (torch.is_tensor(s) and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()):
             raise ValueError("s must be a contiguous float32 ROCm tensor (it is updated in place)")
         E = s.shape[0]
@@ -322,13 +323,15 @@ class MPPIEngine:
             if Q_log is not None and qd.shape[0] != Q_log.shape[0]:
                 raise ValueError("Q_disturbance_table and Q_log must have the same number of rows (one per controller call)")
             a.Q_disturbance_table, a.ctrl_rows, a.Q_bias = qd.data_ptr(), qd.shape[0], float(Q_bias)
+        qa = dev("Q_applied_out", Q_applied_out.reshape(E, 1) if Q_applied_out is not None else None, (1,))
+        a.Q_applied_out = qa.data_ptr() if qa is not None else None
         mt = self.tensor(m_pole).reshape(E) if m_pole is not None else None
         a.m_pole = mt.data_ptr() if mt is not None else None
         a.sched_rows, a.sched_stride = (sched[0] if sched else 0), int(sched_stride)
         outs = [dev(n, t.reshape(E, 1) if t is not None else None, (1,)) for n, t in (
             ("target_position_out", target_position_out), ("target_equilibrium_out", target_equilibrium_out), ("L_out", L_out))]
         a.target_position_out, a.target_equilibrium_out, a.L_out = [t.data_ptr() if t is not None else None for t in outs]
-        keep = (s, Q, Lt, mt, qd, period_dev, states_log, dd_log, Q_log, tabs, outs)
+        keep = (s, Q, Lt, mt, qd, qa, period_dev, states_log, dd_log, Q_log, tabs, outs)
         if _prepare:
             return PreparedPlantStep(self, a, keep)
         self._check(self.lib.cpmppi_plant_step(self._h, C.byref(a), self._stream()))

@@ -156,9 +156,20 @@ class ScheduleRun:
             if qd.shape != (T + 1, E):
                 raise ValueError(f"Q_disturbance is {qd.shape}, expected one row per controller call {(T + 1, E)}")
             self.plant.update(Q_disturbance_table=eng.tensor(qd), Q_bias=float(b.Q_bias))
+        # the control applied in the last period = the next call's Q_ccrc / "Q_applied_-1" (CartPole/__init__.py:489, 517-518), for the
+        # cost plugins that read a previous input (0 before the first update, :838)
+        from .optimizer_mppi import PREVIOUS_INPUT_COSTS
+        self.prev_Q = None
+        if eng.mppi.cost_function_specification in PREVIOUS_INPUT_COSTS:
+            self.prev_Q = eng.zeros(E)
+            self.plant.update(Q_applied_out=self.prev_Q)
         self.counter = self.graph = None
         self.per = 0
         self._prep = self._prep_plant = None                       # argument blocks built once (the launched Philox loop)
+
+    @property
+    def _prev(self):
+        return {} if self.prev_Q is None else {"previous_input": self.prev_Q}
 
     @property
     def periods_left(self):
@@ -167,13 +178,13 @@ class ScheduleRun:
     def _control(self, c):
         eng = self.eng
         if self.knots_fn is not None:
-            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, knots=self.knots_fn(c), Q_out=self.Q)
+            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, knots=self.knots_fn(c), Q_out=self.Q, **self._prev)
         elif self.counter is not None:
             eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset_dev=self.counter,
-                     env_offset=self.env_offset, Q_out=self.Q)
+                     env_offset=self.env_offset, Q_out=self.Q, **self._prev)
         else:
             eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=c, env_offset=self.env_offset,
-                     Q_out=self.Q)
+                     Q_out=self.Q, **self._prev)
 
     def _period(self, c):
         if self.counter is None and self.knots_fn is None:
@@ -181,7 +192,7 @@ class ScheduleRun:
             # step + plant_step is ~30 us per period - more than the GPU needs for a few dozen envs)
             if self._prep is None:
                 self._prep = self.eng.prepare_step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=0,
-                                                   env_offset=self.env_offset, Q_out=self.Q)
+                                                   env_offset=self.env_offset, Q_out=self.Q, **self._prev)
                 self._prep_plant = self.eng.prepare_plant_step(self.s, self.Q, self.b.n_ctrl, period=0, **self.plant)
             self._prep.run(offset=c)
             self._prep_plant.run(period=c)

@@ -414,6 +414,9 @@ typedef struct {
                                            table = controlDisturbance * N(0,1) drawn on the host; Q_log keeps the CALCULATED control.
                                            NULL = none.  Needs ctrl_rows > 0 */
   float Q_bias;                         /* controlBias */
+  float* Q_applied_out;                 /* [E] the control the plant was driven by this period: what the simulator hands the NEXT controller
+                                           call as Q_ccrc / "Q_applied_-1" (CartPole/__init__.py:489, 517-518) - point
+                                           cpmppi_step_args.previous_input there for the costs that read it; NULL = not needed */
 } cpmppi_plant_args;
 int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* stream);
 

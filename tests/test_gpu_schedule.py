@@ -492,7 +492,7 @@ def test_reference_experiment_with_control_disturbance_on_the_device_loop(g, i):
 
 
 @pytest.mark.parametrize("E,N,H,cost,dt_save", [(5, 512, 20, "default", 0.004), (3, 256, 15, "quadratic_boundary_grad_minimal", 0.04),
-                                                 (1600, 1024, 20, "quadratic_boundary_grad_minimal", 0.02)])
+                                                 (1600, 1024, 20, "quadratic_boundary_grad_minimal", 0.02), (4, 512, 20, "quadratic_boundary", 0.01)])
 def test_graph_replayed_schedule_equals_the_launched_loop(E, N, H, cost, dt_save):
     """run_schedule captured as a HIP graph of control periods (device step counter: Philox offset = schedule row = recording row)
     and replayed gives the launched loop's recording bit for bit - moving targets, flips, partial last graph included."""
@@ -518,3 +518,47 @@ def test_graph_replayed_schedule_equals_the_launched_loop(E, N, H, cost, dt_save
     assert np.ptp(b.target_position, axis=0).min() > 0 and (b.target_equilibrium == -1).any()
     # the controller did follow the flips: with target_equilibrium = -1 the plugin costs reward the hanging pole
     assert outs[0]["states"].shape[0] == b.n_sim // b.n_save + 1
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_device_loop_hands_the_previous_control_to_the_costs_that_read_it(groups):
+    """The simulator hands every controller call the control applied before it (Q_ccrc / "Q_applied_-1", CartPole/__init__.py:489,
+    517-518); quadratic_boundary (and _nonconvex, _grad) charge the change from it (quadratic_boundary.py:83-85).  The device loop:
+    cpmppi_plant_step publishes the applied control (Q_applied_out), the next cpmppi_step reads it as previous_input - bit-equal to a
+    host-paced loop that passes it by hand, different from a loop that does not."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
+    from cartpolesimulation_amd.pipeline import EnvGroups, run_schedule_groups
+    E, N, H = 4, 512, 20
+    cfg = dict(seed=33, length_of_experiment=0.3, keep_target_equilibrium_x_seconds_up=0.1, turning_points=dict(track_relative_complexity=12),
+               random_initial_state=dict(init_limits=dict(angle=[0.0, 20.0], angleD=40.0, position=0.4, positionD=0.2)))
+    b = SC.RandomExperimentSetter(cfg).draw(E, 78)
+    mppi = MPPIConfig(num_rollouts=N, mpc_horizon=H, cost_function_specification="quadratic_boundary")
+    eng = MPPIEngine(E, mppi)
+    if groups == 1:
+        res = BatchedCartPoleExperiment(eng, seed=7).run_schedule(b)
+    else:
+        eg = EnvGroups(E, mppi, groups)
+        res = run_schedule_groups(eg, b, 7)
+        torch.cuda.synchronize()
+    Q_loop = res["Q"].cpu().numpy()
+
+    def by_hand(with_previous):
+        s, u, prev, out = eng.tensor(b.s0).clone(), eng.zeros(E, H), eng.zeros(E), []
+        for c in range(b.n_periods + 1):
+            row = int(b.rows_at(c * b.n_ctrl))
+            tp, te = b.target_position[row].astype(f32), b.target_equilibrium[row].astype(f32)
+            Q, _ = eng.step(s, u, tp, te, seed=7, offset=c, **({"previous_input": prev} if with_previous else {}))
+            out.append(Q.cpu().numpy().copy())
+            prev = Q.clone()
+            if c < b.n_periods:
+                eng.plant_step(s, Q, b.n_ctrl, dt_sim=b.dt_simulation, period=c)
+        return np.stack(out)
+
+    assert np.array_equal(Q_loop, by_hand(True))
+    assert np.abs(Q_loop - by_hand(False)).max() > 5e-5                                # (a small term at the shipped weight 1.0: 1.7e-4 here)
+    if groups > 1:
+        eg.close()
+    eng.close()
