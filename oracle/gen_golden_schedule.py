@@ -128,7 +128,7 @@ def gen_setter(out, tag, cfg, K, cartpole_seed0):
     s0, te, interp, tp = [], [], [], []
     for i in range(K):
         inst = APP.CartPole()
-        inst.rng_CartPole = Generator(SFC64(cartpole_seed0 + i))   # (the YAML's `seed:` is empty = clock-seeded)
+        inst.rng_CartPole = Generator(SFC64(cartpole_seed0 + i))
         inst = RES.set(inst)
         s0.append(np.array(inst.s, dtype=f32)); te.append(int(inst.target_equilibrium)); interp.append(inst.interpolation_type)
         tp.append(np.array([float(inst.random_track_f(x)) for x in t[t < cfg["length_of_experiment"]]]))
@@ -151,17 +151,17 @@ class CallLog:
         ctrl.step = self
 
     def __call__(self, s, time=None, updated_attributes={}):
-        s_in = np.array(s, dtype=f32)
+        s_in, s_64 = np.array(s, dtype=f32), np.array(s, dtype=np.float64)
         Q = self.inner(s, time, updated_attributes)
         a = updated_attributes
-        self.calls.append(dict(s=s_in, time=float(time), tp=float(a["target_position"]), te=float(a["target_equilibrium"]),
+        self.calls.append(dict(s=s_in, s64=s_64, time=float(time), tp=float(a["target_position"]), te=float(a["target_equilibrium"]),
                                L=float(a["L"]), m_pole=float(a.get("m_pole", np.nan)), Q=f32(Q), u=self.ctrl.u_prev.copy(),
                                minS=float(np.min(self.ctrl.S_tilde_k))))
         return Q
 
 
 def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=1234, p_Q=None, L_updater=None, m_pole_updater=None,
-                    informer=None, disturbance=None):
+                    informer=None, disturbance=None, sensor=None):
     DG.load_config = lambda name: copy.deepcopy(cfg)
     if p_Q is not None:                                            # (cartpole_physical_parameters.yml `actuator_noise`, read at :83)
         LEG.p_Q = p_Q
@@ -183,6 +183,19 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
         APP.controlDisturbance[...], APP.controlBias[...] = disturbance["controlDisturbance"], disturbance["controlBias"]
         APP.rng = Generator(SFC64(disturbance["seed"]))
         out[f"{tag}/disturbance"] = np.array(json.dumps(disturbance))
+    shipped_sensor = (APP.config["cartpole"]["latency"], copy.deepcopy(APP.config["cartpole"]["vertical_angle_offset"]))
+    if sensor is not None:
+        # the measurement chain between plant and controller (add_noise_and_latency, :336-340): `latency` and the vertical_angle_offset
+        # block are read by CartPole.__init__ (:136-143); the noise amplitudes and mode are module-level values of CartPole/noise_adder.py
+        # (read from the YAML at import, :42-49) and its generator an attribute of the instance's NoiseAdder (:56)
+        import CartPole.noise_adder as NA
+        APP.config["cartpole"]["latency"] = sensor["latency"]
+        APP.config["cartpole"]["vertical_angle_offset"] = dict(sensor["vertical_angle_offset"])
+        shipped_noise = (NA.NOISE_MODE, NA.sigma_angle, NA.sigma_position, NA.sigma_angleD, NA.sigma_positionD)
+        NA.NOISE_MODE = "ON"
+        NA.sigma_angle, NA.sigma_position = sensor["noise"]["sigma_angle"], sensor["noise"]["sigma_position"]
+        NA.sigma_angleD, NA.sigma_positionD = sensor["noise"]["sigma_angleD"], sensor["noise"]["sigma_positionD"]
+        out[f"{tag}/sensor"] = np.array(json.dumps(sensor))
     RES = DG.random_experiment_setter()
     out[f"{tag}/config"] = np.array(json.dumps(cfg))
     out[f"{tag}/N"], out[f"{tag}/H"], out[f"{tag}/ctrl_seed"] = np.int64(N), np.int64(H), np.int64(ctrl_seed)
@@ -192,6 +205,8 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
         set_legacy_size(N, H, ctrl_seed + i)
         inst = APP.CartPole()
         inst.rng_CartPole = Generator(SFC64(cartpole_seed0 + i))
+        if sensor is not None:
+            inst.NoiseAdderInstance.rng_noise_adder = Generator(SFC64(sensor["noise"]["seed"]))
         # the controller is created inside RES.set (set_controller, :759-779): hook the class's configure so that the log
         # sits in front of step from the very first call (set_cartpole_state_at_t0 steps the controller twice before the
         # experiment: once on the placeholder state when the controller is set, once on the initial state)
@@ -222,7 +237,7 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
         body = [r.rsplit(",", 1)[0] for r in rows[k0:] if r]         # without the last column (Q_update_time)
         out[f"{key}/csv_rows"] = np.array("\r\n".join(body))
         out[f"{key}/csv_preamble"] = np.array("\r\n".join(rows[3:k0]))   # header block below the title / revision lines
-        for name in ("s", "time", "tp", "te", "L", "m_pole", "Q", "u", "minS"):
+        for name in ("s", "time", "tp", "te", "L", "m_pole", "Q", "u", "minS") + (("s64",) if sensor is not None else ()):
             out[f"{key}/call/{name}"] = np.array([c[name] for c in calls])
         out[f"{key}/interpolation_type"] = np.array(inst_interp[-1])
         if L_updater is not None:
@@ -238,6 +253,9 @@ def gen_experiments(out, tag, cfg, K, cartpole_seed0, N=256, H=20, ctrl_seed=123
     APP.L[...], APP.m_pole[...] = shipped_L["init_value"], shipped_m["init_value"]      # (module-level arrays the updaters write into)
     if disturbance is not None:
         APP.controlDisturbance[...], APP.controlBias[...] = 0.0, 0.0
+    if sensor is not None:
+        APP.config["cartpole"]["latency"], APP.config["cartpole"]["vertical_angle_offset"] = shipped_sensor
+        NA.NOISE_MODE, NA.sigma_angle, NA.sigma_position, NA.sigma_angleD, NA.sigma_positionD = shipped_noise
 
 
 inst_interp, L_log, M_log = [], [], []
@@ -317,5 +335,15 @@ if __name__ == "__main__":
     # in a row drawing from ONE generator
     gen_experiments(out, "exp_dist", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=83, length_of_experiment=0.4)), 2, 980,
                     ctrl_seed=999, p_Q=0.0, disturbance=dict(controlDisturbance=0.3, controlBias=0.05, seed=4242))
+    # the MEASUREMENT CHAIN switched on: 5 ms of latency (2.5 simulation steps: interpolated), measurement noise, a vertical-angle
+    # offset that moves ('bounce', every 0.03 s), the informer switching (informed: the controller gets the offset taken out again)
+    gen_experiments(out, "exp_sensor", data_gen_config(dt=dict(saving=0.004), **dict(fast, seed=84, length_of_experiment=0.4)), 1, 990,
+                    ctrl_seed=1111, p_Q=0.0,
+                    informer=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.05, change_to_off_after_x_seconds_on=0.07),
+                    sensor=dict(latency=0.005,
+                                noise=dict(sigma_angle=0.001, sigma_position=0.0005, sigma_angleD=0.075, sigma_positionD=0.005, seed=777),
+                                vertical_angle_offset=dict(init_value=2.0, change_every_x_seconds=0.03, mode="bounce",
+                                                           range_random=[-3.141592, 3.141592], range_clip=[-0.05, 0.1], increment=0.01,
+                                                           reset_every_x_seconds="inf")))
     np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
     print("wrote", os.path.join(OUT, "schedule.npz"), len(out), "arrays")

@@ -251,8 +251,112 @@ def controller_informer(cfg, np_random=None):
     return get
 
 
+def parameter_updater(cfg, py_random=None, np_random=None):
+    """ParameterUpdater (CartPole/parameter_updater.py:6-76) -> update(current_value, time_now) -> new value.  The arithmetic is
+    whatever `current_value` brings (the simulator keeps L / m_pole in 0-d float32 arrays, the vertical angle offset in a float64)."""
+    inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                          # noqa: E731
+    st = dict(change=inf(cfg["change_every_x_seconds"]), reset=inf(cfg["reset_every_x_seconds"]), last_change=0.0, last_reset=0.0,
+              direction=1, increment=cfg["increment"])
+    mode, clip, init = cfg["mode"], cfg["range_clip"], cfg["init_value"]
+
+    def update(cur, t):
+        if st["change"] and t - st["last_change"] < st["change"]:                               # :32-33
+            return cur
+        if st["reset"] and mode != "constant" and t - st["last_reset"] >= st["reset"]:          # :34-36
+            st["last_reset"] = t
+            return init
+        st["last_change"] = t
+        if mode == "constant":
+            inc = 0.0
+        elif mode == "random walk":
+            inc = (1.0 if py_random.random() < 0.5 else -1.0) * st["increment"]
+        elif mode == "increase":
+            inc = st["increment"]
+        elif mode == "random":
+            return np_random.uniform(*cfg["range_random"])
+        elif mode == "random_gaussian":
+            return np_random.normal(init, cfg["increment"])
+        elif mode == "bounce":
+            inc = st["direction"] * st["increment"]
+            if cur + inc >= clip[1] or cur + inc <= clip[0]:
+                st["direction"] = -st["direction"]
+        else:
+            raise ValueError(mode)
+        new = cur + inc
+        if clip:
+            new = np.clip(new, *clip)
+        return new
+
+    return update
+
+
+class MeasurementChain:
+    """add_noise_and_latency (CartPole/__init__.py:336-356): what the simulator hands its controller instead of the true state.
+    Every simulation step: the state joins a latency buffer (float64, zero-initialised with cos = 1: CartPole/latency_adder.py:24-26);
+    the delayed state is interpolated between the entries latency / dt and one more steps back (:63-67); measurement noise
+    (CartPole/noise_adder.py:71-82: angle, then cos / sin, position, angleD, positionD - four float32 draws per step from the
+    instance's generator, each times its sigma in float32, added in float64); the vertical angle offset is updated with the time
+    after the step and added (:348-356).  `for_controller(informed)`: informed, the controller gets the offset taken out again
+    (:501-505)."""
+
+    def __init__(self, latency, dt_sampling, noise=None, offset_updater=None, offset_init_deg=0.0):
+        self.len = latency / dt_sampling                                                        # latency_adder.py:74-80
+        self.li, self.frac = int(self.len), self.len - int(self.len)
+        self.hist = []                                                                          # states appended so far (step 1, 2, ...)
+        self.noise = noise                                                                      # (generator, sigma_angle, sigma_position, sigma_angleD, sigma_positionD) or None
+        self.update_offset = offset_updater
+        self.offset = np.deg2rad(offset_init_deg)                                               # :142-143
+        self.s = None
+
+    def _past(self, k):
+        """The state k appends before the latest; before anything was appended: the buffer's initial content."""
+        i = len(self.hist) - 1 - k
+        if i < 0:
+            z = np.zeros(6)
+            z[O.ANGLE_COS_IDX] = 1.0
+            return z
+        return self.hist[i]
+
+    def step(self, s, time_now):
+        self.hist.append(np.array(s, dtype=np.float64))
+        s1, s2 = self._past(self.li), self._past(self.li + 1)
+        m = s1 + self.frac * (s2 - s1)
+        if self.noise is not None:
+            gen, sa, sp, sad, spd = self.noise
+            m[O.ANGLE_IDX] += sa * gen.standard_normal(dtype=f32)
+            m[O.ANGLE_IDX] = wrap_angle_rad(m[O.ANGLE_IDX])
+            m[O.ANGLE_COS_IDX], m[O.ANGLE_SIN_IDX] = np.cos(m[O.ANGLE_IDX]), np.sin(m[O.ANGLE_IDX])
+            m[O.POSITION_IDX] += sp * gen.standard_normal(dtype=f32)
+            m[O.ANGLED_IDX] += sad * gen.standard_normal(dtype=f32)
+            m[O.POSITIOND_IDX] += spd * gen.standard_normal(dtype=f32)
+        if self.update_offset is not None:
+            self.offset = self.update_offset(self.offset, time_now)
+        m[O.ANGLE_IDX] = wrap_angle_rad(m[O.ANGLE_IDX] + self.offset)
+        m[O.ANGLE_COS_IDX], m[O.ANGLE_SIN_IDX] = np.cos(m[O.ANGLE_IDX]), np.sin(m[O.ANGLE_IDX])
+        self.s = m
+
+    def for_controller(self, informed):
+        if not informed:
+            return self.s
+        c = self.s.copy()
+        c[O.ANGLE_IDX] = wrap_angle_rad(c[O.ANGLE_IDX] - self.offset)
+        c[O.ANGLE_COS_IDX], c[O.ANGLE_SIN_IDX] = np.cos(c[O.ANGLE_IDX]), np.sin(c[O.ANGLE_IDX])
+        return c
+
+
+def wrap_angle_rad(angle):
+    """CartPole/_CartPole_mathematical_helpers.py:13-21 (math.fmod on a float64)."""
+    import math
+    m = math.fmod(angle, 2 * np.pi)
+    if m < -np.pi:
+        return m + 2 * np.pi
+    if m > np.pi:
+        return m - 2 * np.pi
+    return m
+
+
 def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L_steps=None, m_pole_steps=None, informer=None,
-                   disturbance=None):
+                   disturbance=None, sensor=None):
     """One experiment as CartPole.run_cartpole_random_experiment runs it (noise, latency, disturbance OFF as shipped).
     controller_step(s, time, target_position, target_equilibrium, L) -> Q.  Returns dict(rows: column -> list, calls).
     ``L_steps`` [n + 1]: a pole length that changes in time - entry g is what the simulator holds DURING simulation step g
@@ -262,7 +366,9 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
     ``disturbance`` = (z, controlDisturbance, controlBias): the simulator's additive control disturbance (CartPole/
     noise_control_signal.py:14-16 at every controller update, CartPole/__init__.py:523-524, 881-882): Q_applied = Q_calculated +
     controlDisturbance * z[call] + controlBias in float32 (0-d float32 arrays and a float32 draw: the Python float Q_calculated is the
-    weak operand); the plant, `u` and the next call's Q_ccrc use Q_applied."""
+    weak operand); the plant, `u` and the next call's Q_ccrc use Q_applied.
+    ``sensor``: a MeasurementChain - the in-loop controller calls then see the measured state (the t = 0 call sees the true one,
+    :869-870); `calls` records what was handed over (float64), the rows gain `vertical_angle_offset`."""
     c = config
     dt_sim = c["dt"]["simulation"]
     n_ctrl = max(1, int(np.rint(c["dt"]["control"] / dt_sim)))                                  # :909-916
@@ -283,12 +389,13 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
     def control(g):
         informed[0] = True if informer is None else bool(informer(times[g]))                    # :495-500 (get_parameters, twice: idempotent)
         L_c, m_c = (Lf, mf) if informed[0] else (L_init, m_init)
-        Q = controller_step(s.copy(), times[g], tp_g[g], te_g[g], L_c)
-        calls.append(dict(s=s.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q), L=L_c, m_pole=m_c))
+        s_c = s.copy() if (sensor is None or g == 0) else np.array(sensor.for_controller(informed[0]))   # :501-507
+        Q = controller_step(s_c.copy(), times[g], tp_g[g], te_g[g], L_c)
+        calls.append(dict(s=s_c.copy(), time=times[g], tp=tp_g[g], te=te_g[g], Q=f32(Q), L=L_c, m_pole=m_c))
         return f32(Q)
 
     rows = {k: [] for k in ("time", "s", "angleDD", "positionDD", "Q", "Q_ccrc", "u", "target_position", "target_equilibrium", "L",
-                            "m_pole", "informed", "Q_calculated")}
+                            "m_pole", "informed", "Q_calculated", "vertical_angle_offset")}
     n_call = [0]
 
     def applied(Qc):
@@ -309,6 +416,7 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
         rows["Q"].append(Q); rows["Q_ccrc"].append(Q_ccrc); rows["u"].append(O.Q2u(Q, p))
         rows["target_position"].append(tp_g[g]); rows["target_equilibrium"].append(te_g[g]); rows["L"].append(Lf)
         rows["m_pole"].append(mf); rows["informed"].append(informed[0]); rows["Q_calculated"].append(Q_calc)
+        rows["vertical_angle_offset"].append(0.0 if sensor is None else float(sensor.offset))
 
     save(0)                                                                                     # :875 (the t = 0 row)
     ctrl_counter = save_counter = 0
@@ -319,6 +427,8 @@ def run_experiment(setup, config, controller_step, L=None, p=O.DEFAULT_PARAMS, L
             mf = float(m_pole_steps[g])
             p = replace(p, m_pole=f32(mf))
         s = O.plant_substep(s, aDD, xDD, dt_sim, Lf, p)                                         # integration, bounce, cos/sin, wrap
+        if sensor is not None:
+            sensor.step(s, times[g])                                                            # add_noise_and_latency :310
         ctrl_counter += 1
         if ctrl_counter == n_ctrl:                                                              # Update_Q :475-527
             Q_ccrc = Q

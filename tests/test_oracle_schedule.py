@@ -246,6 +246,55 @@ def test_experiment_with_the_control_disturbance_switched_on(g, i):
     assert np.abs(out2["rows"]["angleDD"][:r] - col("angleDD")[:r]).max() > 0.5
 
 
+def _sensor_chain(g, tag="exp_sensor"):
+    sen = json.loads(g[f"{tag}/sensor"].item())
+    n = sen["noise"]
+    return S.MeasurementChain(sen["latency"], 0.002,
+                              noise=(Generator(SFC64(n["seed"])), n["sigma_angle"], n["sigma_position"], n["sigma_angleD"], n["sigma_positionD"]),
+                              offset_updater=S.parameter_updater(sen["vertical_angle_offset"]),
+                              offset_init_deg=sen["vertical_angle_offset"]["init_value"])
+
+
+def test_experiment_with_the_measurement_chain_switched_on(g):
+    """exp_sensor: the reference's simulator with 5 ms of latency (2.5 simulation steps: the delayed state is interpolated),
+    measurement noise from its seeded generator, a vertical-angle offset in 'bounce' mode and a switching informer (informed, the
+    controller gets the offset taken out again).  The oracle's MeasurementChain reproduces the float64 state every controller call
+    was handed to 1e-6 over the first calls (float32 against float64 controller arithmetic in the loop: 9e-8 measured), the
+    recording's vertical_angle_offset columns exactly; without the chain the loop is somewhere else entirely."""
+    tag, key = "exp_sensor", "exp_sensor/0"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    inf = json.loads(g[f"{tag}/informer"].item())
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    cs = g[f"{key}/call/s"]
+
+    def run(**kw):
+        st = S.ExperimentSetter(cfg).set(Generator(SFC64(int(g[f"{tag}/cartpole_seed0"]))))
+        ctrl = O.LegacyMPPIController(int(g[f"{tag}/ctrl_seed"]), N, H, SQRTRHOINV=0.02, p_Q=float(g[f"{tag}/p_Q"]))
+        ctrl.step(cs[0], f32(g[f"{key}/call/tp"][0]), L=O.DEFAULT_PARAMS.L)
+        return S.run_experiment(st, cfg, lambda s, t, tp, te, L: ctrl.step(np.asarray(s, f32), f32(tp), L=O.DEFAULT_PARAMS.L),
+                                informer=S.controller_informer(inf), **kw)
+
+    out = run(sensor=_sensor_chain(g))
+    rows, calls = out["rows"], out["calls"]
+    col = lambda name: g[f"{key}/col/{name}"]                         # noqa: E731
+    off = col("vertical_angle_offset")
+    assert np.array_equal(rows["vertical_angle_offset"], off) and len(np.unique(off)) > 8 and off[0] == np.deg2rad(2.0)
+    assert np.array_equal(np.cos(off), col("vertical_angle_offset_cos")) and np.array_equal(np.sin(off), col("vertical_angle_offset_sin"))
+    assert np.array_equal(np.where(rows["informed"], "true", "default"), col("L_for_controller"))
+    K = 12
+    so, sf = np.array([c["s"] for c in calls]), g[f"{key}/call/s64"][1:]
+    assert so.dtype == np.float64 and np.abs(so[:K] - sf[:K]).max() < 1e-6
+    # the chain matters: the handed-over state is far from the true one (latency on a moving pole, noise on the velocities, 2-6 degrees
+    # of offset while the controller is not informed)
+    true_at_calls = np.stack([col(n)[::5] for n in ("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")], axis=-1)
+    assert np.abs(sf[1:K] - true_at_calls[1:K]).max() > 0.03
+    np.testing.assert_allclose(np.array([c["Q"] for c in calls])[:K], g[f"{key}/call/Q"][1:K + 1], atol=1e-5)
+    r = (K - 1) * out["n_ctrl"] // out["n_save"]
+    np.testing.assert_allclose(rows["s"][:r, 0], col("angle")[:r], atol=1e-5)
+    out0 = run()
+    assert np.abs(np.array([c["Q"] for c in out0["calls"]])[:K] - g[f"{key}/call/Q"][1:K + 1]).max() > 0.01
+
+
 def test_experiment_that_ends_inside_a_control_period(g):
     """exp_tail: 25 simulation steps = two control periods and five trailing steps, no turning points (length x complexity < 1: the
     target is 0 whatever the start, random_target_generator.py:31-33): controller calls at t = 0, 0.02, 0.04, three saved rows."""
