@@ -75,14 +75,17 @@ class cpmppi_plant_args(C.Structure):
                 ("target_position_out", C.c_void_p), ("target_equilibrium_out", C.c_void_p), ("L_out", C.c_void_p),
                 ("row_envs", C.c_uint32),
                 ("m_pole", C.c_void_p), ("m_pole_table", C.c_void_p), ("L_controller_table", C.c_void_p),
-                ("Q_disturbance_table", C.c_void_p), ("Q_bias", C.c_float), ("Q_applied_out", C.c_void_p)]
+                ("Q_disturbance_table", C.c_void_p), ("Q_bias", C.c_float), ("Q_applied_out", C.c_void_p),
+                ("s_measured", C.c_void_p), ("state_history", C.c_void_p), ("history_len", C.c_uint32), ("latency_steps", C.c_uint32),
+                ("latency_frac", C.c_double), ("measurement_noise_table", C.c_void_p), ("angle_offset_table", C.c_void_p),
+                ("informed_table", C.c_void_p)]
 
 
 class cpmppi_recording(C.Structure):
     _fields_ = [("E", C.c_uint32), ("rows", C.c_uint32), ("time", C.c_void_p), ("states", C.c_void_p), ("dd", C.c_void_p),
                 ("Q", C.c_void_p), ("Q_ccrc", C.c_void_p), ("target_position", C.c_void_p), ("target_equilibrium", C.c_void_p),
                 ("L", C.c_void_p), ("m_pole", C.c_double), ("u_max", C.c_float), ("first_update_row", C.c_uint32),
-                ("q_update_time", C.c_double), ("m_pole_rows", C.c_void_p), ("informed", C.c_void_p), ("Q_applied", C.c_void_p)]
+                ("q_update_time", C.c_double), ("m_pole_rows", C.c_void_p), ("informed", C.c_void_p), ("Q_applied", C.c_void_p), ("angle_offset", C.c_void_p)]
 
 
 class cpmppi_comm_info(C.Structure):

@@ -288,7 +288,21 @@ struct PlantDev {
   const float* Qd_table;
   float Q_bias;
   float* Qa_out;
+  // measurement chain
+  float *s_meas, *hist;
+  uint32_t hist_len, lat_steps;
+  double lat_frac;
+  const float* noise_table;
+  const double* off_table;
+  const uint8_t* informed_table;
 };
+
+// wrap_angle_rad on a float64 (CartPole/_CartPole_mathematical_helpers.py:13-21)
+__device__ __forceinline__ double wrap_angle_f64(double a) {
+  constexpr double PI = 3.141592653589793, TWO_PI = 6.283185307179586;
+  const double m = fmod(a, TWO_PI);
+  return m < -PI ? m + TWO_PI : (m > PI ? m - TWO_PI : m);
+}
 
 __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const PlantDev a) {
   const uint32_t env = blockIdx.x * BLOCK + threadIdx.x;
@@ -336,6 +350,10 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const Pla
       if (Ln != Lcur || mn != p.m_pole) { Lcur = Ln; p.m_pole = mn; ec = make_env_const(p, Lcur); }
     }
     plant_substep(st, aDD, xDD, a.dt_sim, p, ec);
+    if (a.hist && known) {                                             // the latency buffer (CartPole/latency_adder.py:36-47)
+      float* hs = a.hist + ((size_t)(g % a.hist_len) * E + env) * 6u;
+      hs[0] = st.th; hs[1] = st.w; hs[2] = st.c; hs[3] = st.s; hs[4] = st.x; hs[5] = st.v;
+    }
     ode_precise(st.c, st.s, st.w, st.v, u, p, ec, aDD, xDD);
     if (known && g % a.save_every == 0u) {
       const uint64_t r = g / a.save_every;
@@ -352,6 +370,35 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const Pla
     if (a.tp_table && a.tp_out) a.tp_out[env] = a.tp_table[r];
     if (a.te_table && a.te_out) a.te_out[env] = a.te_table[r];
     if (a.L_table && a.L_out) a.L_out[env] = (a.Lc_table ? a.Lc_table : a.L_table)[r];
+    if (a.s_meas && a.n_sub == a.period_steps) {                       // what the NEXT controller call sees (add_noise_and_latency, :336-356)
+      const uint64_t g1 = g0 + a.n_sub;
+      double m_th = st.th, m_w = st.w, m_c = st.c, m_s = st.s, m_x = st.x, m_v = st.v;
+      if (a.hist) {
+        // the state k steps back; before step 1: the buffer's initial content (zeros, cos = 1)
+        const bool h1 = g1 >= (uint64_t)a.lat_steps + 1u, h2 = g1 >= (uint64_t)a.lat_steps + 2u;
+        const float* p1 = a.hist + ((size_t)((g1 - (h1 ? a.lat_steps : 0u)) % a.hist_len) * E + env) * 6u;
+        const float* p2 = a.hist + ((size_t)((g1 - (h2 ? a.lat_steps + 1u : 0u)) % a.hist_len) * E + env) * 6u;
+        const double a_th = h1 ? (double)p1[0] : 0.0, a_w = h1 ? (double)p1[1] : 0.0, a_c = h1 ? (double)p1[2] : 1.0,
+                     a_s = h1 ? (double)p1[3] : 0.0, a_x = h1 ? (double)p1[4] : 0.0, a_v = h1 ? (double)p1[5] : 0.0;
+        const double b_th = h2 ? (double)p2[0] : 0.0, b_w = h2 ? (double)p2[1] : 0.0, b_c = h2 ? (double)p2[2] : 1.0,
+                     b_s = h2 ? (double)p2[3] : 0.0, b_x = h2 ? (double)p2[4] : 0.0, b_v = h2 ? (double)p2[5] : 0.0;
+        const double f = a.lat_frac;
+        m_th = a_th + f * (b_th - a_th); m_w = a_w + f * (b_w - a_w); m_c = a_c + f * (b_c - a_c);
+        m_s = a_s + f * (b_s - a_s); m_x = a_x + f * (b_x - a_x); m_v = a_v + f * (b_v - a_v);
+      }
+      if (a.noise_table && c + 1u < a.ctrl_rows) {                     // noise_adder.py:71-82
+        const float* nz = a.noise_table + ((size_t)(c + 1u) * E + env) * 4u;
+        m_th = wrap_angle_f64(m_th + (double)nz[0]);
+        m_c = cos(m_th); m_s = sin(m_th);
+        m_x += (double)nz[1]; m_w += (double)nz[2]; m_v += (double)nz[3];
+      }
+      const double off = a.off_table ? a.off_table[r] : 0.0;          // :348-356 (always re-forms cos / sin from the float64 angle)
+      m_th = wrap_angle_f64(m_th + off);
+      if (!a.informed_table || a.informed_table[r]) m_th = wrap_angle_f64(m_th - off);   // :501-505 (cos / sin formed again: only the last pair survives)
+      m_c = cos(m_th); m_s = sin(m_th);
+      float* sm = a.s_meas + (size_t)env * 6u;
+      sm[0] = (float)m_th; sm[1] = (float)m_w; sm[2] = (float)m_c; sm[3] = (float)m_s; sm[4] = (float)m_x; sm[5] = (float)m_v;
+    }
   }
 }
 
@@ -1927,6 +1974,20 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table || a->m_pole_table || a->L_controller_table;
   if (a->Q_disturbance_table && a->ctrl_rows == 0)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: Q_disturbance_table needs ctrl_rows > 0");
+  if (a->s_measured) {
+    const bool delayed = a->latency_steps != 0u || a->latency_frac != 0.0;
+    if (delayed && (!a->state_history || a->history_len < a->latency_steps + 2u))
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: a latency needs state_history with history_len >= latency_steps + 2");
+    if (!(a->latency_frac >= 0.0 && a->latency_frac < 1.0))
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: latency_frac must lie in [0, 1)");
+    if ((a->angle_offset_table || a->informed_table) && a->sched_rows == 0)
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: schedule tables need sched_rows > 0");
+    if (a->measurement_noise_table && a->ctrl_rows == 0)
+      return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: measurement_noise_table needs ctrl_rows > 0");
+    if (misaligned(a->s_measured) || misaligned(a->state_history) || misaligned(a->measurement_noise_table) ||
+        ((uintptr_t)a->angle_offset_table & 7u))
+      return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_step: misaligned");
+  }
   if (a->L_controller_table && !a->L_table)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: L_controller_table stands in for L_table in L_out: give both");
   if (tables && a->sched_rows == 0) return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: schedule tables need sched_rows > 0");
@@ -1957,6 +2018,9 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   d.tp_out = a->target_position_out; d.te_out = a->target_equilibrium_out; d.L_out = a->L_out;
   d.m_pole = a->m_pole; d.m_table = a->m_pole_table; d.Lc_table = a->L_controller_table;
   d.Qd_table = a->Q_disturbance_table; d.Q_bias = a->Q_bias; d.Qa_out = a->Q_applied_out;
+  d.s_meas = a->s_measured; d.hist = a->state_history; d.hist_len = a->history_len; d.lat_steps = a->latency_steps;
+  d.lat_frac = a->latency_frac; d.noise_table = a->measurement_noise_table; d.off_table = a->angle_offset_table;
+  d.informed_table = a->informed_table;
   hipLaunchKernelGGL(plant_kernel, dim3((a->E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, plant, d);
   CPMPPI_HIP(h, hipGetLastError());
   return CPMPPI_OK;

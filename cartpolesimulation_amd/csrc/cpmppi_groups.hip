@@ -192,6 +192,9 @@ int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmp
       b.L_out = at(b.L_out, e0);
       b.m_pole = at(b.m_pole, e0); b.m_pole_table = at(b.m_pole_table, e0); b.L_controller_table = at(b.L_controller_table, e0);
       b.Q_disturbance_table = at(b.Q_disturbance_table, e0); b.Q_applied_out = at(b.Q_applied_out, e0);
+      b.s_measured = at(b.s_measured, e0 * 6); b.state_history = at(b.state_history, e0 * 6);
+      b.measurement_noise_table = at(b.measurement_noise_table, e0 * 4); b.angle_offset_table = at(b.angle_offset_table, e0);
+      b.informed_table = at(b.informed_table, e0);
       pa[i] = b;
     }
   }

@@ -140,7 +140,14 @@ int write_one(const Job& j, uint32_t e, std::string& buf, std::string& tmp) {
     const size_t infl = told ? 5 : 8;
     buf.append(inf, infl);
     if (r.m_pole_rows) f64col((double)r.m_pole_rows[i]); else { buf.push_back(','); buf.append(mp, mpl); }
-    buf.append(inf, infl); buf.append(",0.0,1.0,0.0,", 13);
+    buf.append(inf, infl);
+    if (r.angle_offset) {
+      const double* ao = r.angle_offset + i * 3;
+      f64col(ao[0]); f64col(ao[1]); f64col(ao[2]);
+      buf.push_back(',');
+    } else {
+      buf.append(",0.0,1.0,0.0,", 13);
+    }
     if (t >= r.first_update_row) buf.append(qt, qtl);
     buf.append("\r\n", 2);
   }

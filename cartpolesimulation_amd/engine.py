@@ -270,7 +270,9 @@ class MPPIEngine:
     def plant_step(self, s, Q, n_substeps, dt_sim=0.002, period=0, period_dev=None, period_steps=None, L=None, states_log=None,
                    dd_log=None, save_every=None, Q_log=None, target_position_table=None, target_equilibrium_table=None,
                    L_table=None, sched_stride=1, target_position_out=None, target_equilibrium_out=None, L_out=None, m_pole=None,
-                   m_pole_table=None, L_controller_table=None, Q_disturbance_table=None, Q_bias=0.0, Q_applied_out=None, _prepare=False):
+                   m_pole_table=None, L_controller_table=None, Q_disturbance_table=None, Q_bias=0.0, Q_applied_out=None,
+                   s_measured=None, state_history=None, latency=0.0, measurement_noise_table=None, angle_offset_table=None,
+                   informed_table=None, _prepare=False):
         """cpmppi_plant_step: one control period of the simulated cartpoles with the experiment schedule and the recording in the
         same launch (include/cpmppi.h).  ``s`` [E,6] in place under held ``Q`` [E]; logs ``states_log`` [rows,E,6], ``dd_log``
         [rows,E,2], ``Q_log`` [periods,E]; schedule tables [sched_rows,E] sampled every ``sched_stride`` simulation steps; ``*_out``
@@ -278,7 +280,11 @@ class MPPIEngine:
         [sched_rows,E]: the PLANT's pole mass (default: the config's); ``L_controller_table``: what ``L_out`` publishes instead of
         ``L_table`` (the pole length the controller is told, CartPole/controller_informer.py).  ``Q_disturbance_table`` [periods,E]
         + ``Q_bias``: the plant is driven by (Q + table[period]) + Q_bias (the simulator's additive control disturbance);
-        ``Q_applied_out`` [E] receives that control (the next controller call's ``previous_input``)."""
+        ``Q_applied_out`` [E] receives that control (the next controller call's ``previous_input``).
+        The measurement chain (CartPole.add_noise_and_latency): ``s_measured`` [E,6] receives what the next controller call sees -
+        the state ``latency`` seconds back (``state_history`` [>= latency / dt_sim + 2, E, 6], zeros with cos = 1 before the run),
+        plus ``measurement_noise_table`` [calls,E,4], plus ``angle_offset_table`` [sched_rows,E] float64 on the angle (taken out again
+        where ``informed_table`` [sched_rows,E] uint8 says so; None = everywhere)."""
         if not (torch.is_tensor(s) and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()):
             raise ValueError("s must be a contiguous float32 ROCm tensor (it is updated in place)")
         E = s.shape[0]
@@ -323,6 +329,31 @@ class MPPIEngine:
             if Q_log is not None and qd.shape[0] != Q_log.shape[0]:
                 raise ValueError("Q_disturbance_table and Q_log must have the same number of rows (one per controller call)")
             a.Q_disturbance_table, a.ctrl_rows, a.Q_bias = qd.data_ptr(), qd.shape[0], float(Q_bias)
+        sm = dev("s_measured", s_measured, (6,))
+        if sm is not None and sm.shape[0] != E:
+            raise ValueError("s_measured must be [E,6]")
+        hist = dev("state_history", state_history, (E, 6))
+        nz = dev("measurement_noise_table", measurement_noise_table, (E, 4))
+        off = dev("angle_offset_table", angle_offset_table, (E,), torch.float64)
+        inf = dev("informed_table", informed_table, (E,), torch.uint8)
+        if sm is not None:
+            steps = float(latency) / float(dt_sim)
+            a.latency_steps = int(steps)
+            a.latency_frac = steps - int(steps)
+            a.s_measured = sm.data_ptr()
+            if hist is not None:
+                a.state_history, a.history_len = hist.data_ptr(), hist.shape[0]
+            if nz is not None:
+                if Q_log is not None and nz.shape[0] != Q_log.shape[0]:
+                    raise ValueError("measurement_noise_table and Q_log must have the same number of rows (one per controller call)")
+                a.measurement_noise_table, a.ctrl_rows = nz.data_ptr(), nz.shape[0]
+            for t in (off, inf):
+                if t is not None:
+                    if sched and t.shape[0] != sched[0]:
+                        raise ValueError("the schedule tables must have the same number of rows")
+                    sched.append(t.shape[0])
+            a.angle_offset_table = off.data_ptr() if off is not None else None
+            a.informed_table = inf.data_ptr() if inf is not None else None
         qa = dev("Q_applied_out", Q_applied_out.reshape(E, 1) if Q_applied_out is not None else None, (1,))
         a.Q_applied_out = qa.data_ptr() if qa is not None else None
         mt = self.tensor(m_pole).reshape(E) if m_pole is not None else None
@@ -331,7 +362,7 @@ class MPPIEngine:
         outs = [dev(n, t.reshape(E, 1) if t is not None else None, (1,)) for n, t in (
             ("target_position_out", target_position_out), ("target_equilibrium_out", target_equilibrium_out), ("L_out", L_out))]
         a.target_position_out, a.target_equilibrium_out, a.L_out = [t.data_ptr() if t is not None else None for t in outs]
-        keep = (s, Q, Lt, mt, qd, qa, period_dev, states_log, dd_log, Q_log, tabs, outs)
+        keep = (s, Q, Lt, mt, qd, qa, sm, hist, nz, off, inf, period_dev, states_log, dd_log, Q_log, tabs, outs)
         if _prepare:
             return PreparedPlantStep(self, a, keep)
         self._check(self.lib.cpmppi_plant_step(self._h, C.byref(a), self._stream()))

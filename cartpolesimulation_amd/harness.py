@@ -156,6 +156,30 @@ class ScheduleRun:
             if qd.shape != (T + 1, E):
                 raise ValueError(f"Q_disturbance is {qd.shape}, expected one row per controller call {(T + 1, E)}")
             self.plant.update(Q_disturbance_table=eng.tensor(qd), Q_bias=float(b.Q_bias))
+        # the measurement chain (CartPole.add_noise_and_latency): the controller reads s_meas, which every plant step refills; the
+        # t = 0 call sees the true state (:869-870)
+        self.s_ctrl = self.s
+        if b.latency or b.measurement_noise is not None or b.angle_offset is not None:
+            self.s_ctrl = self.s.clone()
+            self.plant.update(s_measured=self.s_ctrl, latency=float(b.latency))
+            n_back = float(b.latency) / b.dt_simulation
+            if n_back > 0:
+                hist = np.zeros((int(n_back) + 2, E, 6), np.float32)
+                hist[:, :, 2] = 1.0                                               # (CartPole/latency_adder.py:25-26)
+                self.plant.update(state_history=eng.tensor(hist))
+            if b.measurement_noise is not None:
+                nz = np.ascontiguousarray(b.measurement_noise, np.float32)
+                if nz.shape != (T + 1, E, 4):
+                    raise ValueError(f"measurement_noise is {nz.shape}, expected one row per controller call {(T + 1, E, 4)}")
+                self.plant.update(measurement_noise_table=eng.tensor(nz))
+            if b.angle_offset is not None:
+                if b.stride != 1 or b.angle_offset.shape[0] != b.n_sim + 1:
+                    raise ValueError("the angle-offset table is per simulation step: draw the batch with stride 1")
+                self.plant.update(angle_offset_table=torch.as_tensor(np.ascontiguousarray(b.angle_offset, np.float64), device=self.s.device))
+                if b.informed is not None:
+                    told = np.asarray(b.informed, bool)
+                    told = told if told.ndim == 2 else np.broadcast_to(told[:, None], (len(told), E))
+                    self.plant.update(informed_table=torch.as_tensor(np.ascontiguousarray(told, np.uint8), device=self.s.device))
         # the control applied in the last period = the next call's Q_ccrc / "Q_applied_-1" (CartPole/__init__.py:489, 517-518), for the
         # cost plugins that read a previous input (0 before the first update, :838)
         from .optimizer_mppi import PREVIOUS_INPUT_COSTS
@@ -178,12 +202,12 @@ class ScheduleRun:
     def _control(self, c):
         eng = self.eng
         if self.knots_fn is not None:
-            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, knots=self.knots_fn(c), Q_out=self.Q, **self._prev)
+            eng.step(self.s_ctrl, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, knots=self.knots_fn(c), Q_out=self.Q, **self._prev)
         elif self.counter is not None:
-            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset_dev=self.counter,
+            eng.step(self.s_ctrl, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset_dev=self.counter,
                      env_offset=self.env_offset, Q_out=self.Q, **self._prev)
         else:
-            eng.step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=c, env_offset=self.env_offset,
+            eng.step(self.s_ctrl, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=c, env_offset=self.env_offset,
                      Q_out=self.Q, **self._prev)
 
     def _period(self, c):
@@ -191,7 +215,7 @@ class ScheduleRun:
             # the launched loop: two library calls per period on argument blocks built once (the Python-side argument handling of
             # step + plant_step is ~30 us per period - more than the GPU needs for a few dozen envs)
             if self._prep is None:
-                self._prep = self.eng.prepare_step(self.s, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=0,
+                self._prep = self.eng.prepare_step(self.s_ctrl, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=0,
                                                    env_offset=self.env_offset, Q_out=self.Q, **self._prev)
                 self._prep_plant = self.eng.prepare_plant_step(self.s, self.Q, self.b.n_ctrl, period=0, **self.plant)
             self._prep.run(offset=c)

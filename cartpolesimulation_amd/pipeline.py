@@ -184,7 +184,7 @@ def run_schedule_groups(groups: EnvGroups, batch, seed):
     from .harness import ScheduleRun
     eng = groups.args_engine
     run = ScheduleRun(eng, batch, seed)                        # the batch's buffers and logs, set up on the caller's stream
-    step = groups.prepare(run.s, run.u_nom, run.cur_tp, run.cur_te, L=run.cur_L, seed=seed, Q_out=run.Q, **run._prev)
+    step = groups.prepare(run.s_ctrl, run.u_nom, run.cur_tp, run.cur_te, L=run.cur_L, seed=seed, Q_out=run.Q, **run._prev)
     plant = eng.prepare_plant_step(run.s, run.Q, batch.n_ctrl, period=0, **run.plant)
     groups.fork()
     groups.run(step, plant, periods=run.T, offset=0, period=0)

@@ -140,6 +140,9 @@ def recording_block(result, phys, L_default=None):
         out["Q_applied"] = np.ascontiguousarray(Qa[k])
     if b.m_pole_table is not None:                                   # the `m_pole:` updater's values, row by row
         out["m_pole"] = np.ascontiguousarray(np.asarray(b.m_pole_table, f32)[np.minimum(steps, b.m_pole_table.shape[0] - 1)])
+    if b.angle_offset is not None:                                   # vertical_angle_offset and its cos / sin (numpy's, as the reference logs them)
+        off = np.asarray(b.angle_offset, np.float64)[np.minimum(steps, b.angle_offset.shape[0] - 1)]
+        out["angle_offset"] = np.ascontiguousarray(np.stack([off, np.cos(off), np.sin(off)], axis=-1))
     if b.informed is not None:                                       # the controller informer's answer in force at the row
         told = np.asarray(b.informed, bool)[np.minimum(steps, len(b.informed) - 1)]
         out["informed"] = np.ascontiguousarray(np.broadcast_to(told if told.ndim == 2 else told[:, None], (R, E)), dtype=np.uint8)
@@ -155,13 +158,16 @@ def typed_columns(block, env, phys, q_update_time=0.0):
     u_max = f32(phys.u_max)
     m_pole = py(block["m_pole"][:, env]) if block.get("m_pole") is not None else [float(f32(phys.m_pole))] * R
     told = ["true" if x else "default" for x in block["informed"][:, env]] if block.get("informed") is not None else ["true"] * R
+    ao = block["angle_offset"][:, env] if block.get("angle_offset") is not None else None
     cols = {"time": py(block["time"]), "angle": list(s[:, 0]), "angleD": list(s[:, 1]), "angleDD": list(dd[:, 0]),
             "angle_cos": list(s[:, 2]), "angle_sin": list(s[:, 3]), "position": list(s[:, 4]), "positionD": list(s[:, 5]),
             "positionDD": list(dd[:, 1]), "Q_calculated": py(Q), "Q_applied": list(Qa), "Q_ccrc": list(block["Q_ccrc"][:, env]),
             "u": list(u_max * Qa), "target_position": py(block["target_position"][:, env]),
             "target_equilibrium": [int(x) for x in block["target_equilibrium"][:, env]], "L": py(block["L"][:, env]),
             "L_for_controller": told, "m_pole": m_pole, "m_pole_for_controller": told,
-            "vertical_angle_offset": [0.0] * R, "vertical_angle_offset_cos": [1.0] * R, "vertical_angle_offset_sin": [0.0] * R,
+            "vertical_angle_offset": [0.0] * R if ao is None else py(ao[:, 0]),
+            "vertical_angle_offset_cos": [1.0] * R if ao is None else py(ao[:, 1]),
+            "vertical_angle_offset_sin": [0.0] * R if ao is None else py(ao[:, 2]),
             "Q_update_time": [None if r < block["first_update_row"] else float(q_update_time) for r in range(R)]}
     assert list(cols) == COLUMNS
     return cols
@@ -187,11 +193,12 @@ def write_recordings_native(paths, block, phys, header, title=None, q_update_tim
     for k, a in arrs.items():
         setattr(rec, k, a.ctypes.data)
     rec.m_pole, rec.u_max = float(f32(phys.m_pole)), float(f32(phys.u_max))
-    for k, field, dt in (("m_pole", "m_pole_rows", f32), ("informed", "informed", np.uint8), ("Q_applied", "Q_applied", f32)):
+    for k, field, dt, tail in (("m_pole", "m_pole_rows", f32, ()), ("informed", "informed", np.uint8, ()), ("Q_applied", "Q_applied", f32, ()),
+                               ("angle_offset", "angle_offset", np.float64, (3,))):
         if block.get(k) is not None:
             arrs[k] = a = np.ascontiguousarray(block[k], dtype=dt)
-            if a.shape != (R, E):
-                raise ValueError(f"recording block: {k} is {a.shape}, expected {(R, E)}")
+            if a.shape != (R, E) + tail:
+                raise ValueError(f"recording block: {k} is {a.shape}, expected {(R, E) + tail}")
             setattr(rec, field, a.ctypes.data)
     rec.first_update_row, rec.q_update_time = int(block["first_update_row"]), float(q_update_time)
     pre = preamble_bytes(header, title=title)

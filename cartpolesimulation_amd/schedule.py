@@ -74,6 +74,12 @@ class ExperimentBatch:
                                         # mass (informer_table) or the initial ones; None = always (mode 'ON', as shipped)
     Q_disturbance: np.ndarray = None    # [n_periods + 1, E] float32 = controlDisturbance * N(0, 1) per controller call, or None:
     Q_bias: float = 0.0                 # the plant is driven by Q_applied = (Q_calculated + Q_disturbance) + Q_bias (float32)
+    # the measurement chain between plant and controller (CartPole.add_noise_and_latency): all off / None as shipped
+    latency: float = 0.0                # seconds; the controller is handed the state latency / dt_simulation steps back (interpolated)
+    measurement_noise: np.ndarray = None  # [n_periods + 1, E, 4] float32 = sigma * N(0, 1) for (angle, position, angleD, positionD) of the
+                                        # state handed to controller call k (row 0, the t = 0 call, is unused: it sees the true state)
+    angle_offset: np.ndarray = None     # [n_sim + 1, E] float64 per simulation step: the vertical angle offset added to the measured angle
+                                        # (taken out again for a controller that is informed)
 
     @property
     def E(self):
@@ -283,7 +289,7 @@ def equilibrium_table(times, steps, te0, keep_up, keep_down):
     return out
 
 
-def parameter_table(updater, times, py_random=None, np_random=None):
+def parameter_table(updater, times, py_random=None, np_random=None, dtype=f32, init=None, time_after_step=False):
     """A physical parameter that changes in time (cartpole_physical_parameters.yml `L:` / `m_pole:` blocks; CartPole/parameter_updater.py
     ParameterUpdater, called by CartPole.update_parameters at the START of every simulation step with the time BEFORE the step,
     CartPole/__init__.py:529-537) -> float32 [len(times)]: entry g is the value the simulator holds DURING step g (entry 0: the
@@ -291,7 +297,9 @@ def parameter_table(updater, times, py_random=None, np_random=None):
     `change_every_x_seconds` (empty = every step), `reset_every_x_seconds`, `range_clip`.  The value is carried in float32 (the
     reference keeps it in a 0-d float32 array: `current + increment` and the clip are float32 operations).  Random modes draw from
     `py_random` (random.Random: the reference uses the module-level random()) / `np_random` (numpy RandomState: np.random.uniform /
-    normal); seeded like the reference's globals they give the reference's own sequence."""
+    normal); seeded like the reference's globals they give the reference's own sequence.
+    The vertical angle offset is the same updater held in a float64 (``dtype``), started from ``init`` = deg2rad(init_value) and
+    called AFTER the step's time update (``time_after_step``; CartPole/__init__.py:142-143, 348-352)."""
     import random as _random
     u = dict(updater)
     inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                      # noqa: E731
@@ -299,25 +307,27 @@ def parameter_table(updater, times, py_random=None, np_random=None):
     mode, increment, clip = u["mode"], u["increment"], u["range_clip"]
     py_random = py_random or _random.Random(0)
     np_random = np_random or np.random.RandomState(0)
-    init = u["init_value"]
-    if init == "random":
-        init = np_random.uniform(*u["range_random"])
-    cur = f32(init)
+    f = dtype
+    reset_to = u["init_value"]
+    if reset_to == "random":
+        reset_to = np_random.uniform(*u["range_random"])
+    cur = f(reset_to if init is None else init)
     last_change = last_reset = 0.0
     direction = 1
-    out = np.empty(len(times), f32)
+    out = np.empty(len(times), f)
     out[0] = cur
+    init = reset_to
     for g in range(1, len(times)):
-        t = times[g - 1]
+        t = times[g] if time_after_step else times[g - 1]
         if change_every and t - last_change < change_every:
             pass
         elif reset_every and mode != "constant" and t - last_reset >= reset_every:
             last_reset = t
-            cur = f32(init)
+            cur = f(init)
         else:
             last_change = t
             if mode in ("random", "random_gaussian"):
-                cur = f32(np_random.uniform(*u["range_random"]) if mode == "random" else np_random.normal(init, increment))
+                cur = f(np_random.uniform(*u["range_random"]) if mode == "random" else np_random.normal(init, increment))
                 out[g] = cur
                 continue
             if mode == "constant":
@@ -328,14 +338,14 @@ def parameter_table(updater, times, py_random=None, np_random=None):
                 inc = increment
             elif mode == "bounce":
                 inc = direction * increment
-                nxt = cur + f32(inc)
+                nxt = cur + f(inc)
                 if nxt >= clip[1] or nxt <= clip[0]:
                     direction = -direction
             else:
                 raise ValueError("mode with value {} not valid".format(mode))
-            cur = cur + f32(inc)
+            cur = cur + f(inc)
             if clip:
-                cur = f32(np.clip(cur, f32(clip[0]), f32(clip[1])))
+                cur = f(np.clip(cur, f(clip[0]), f(clip[1])))
         out[g] = cur
     return out
 
@@ -395,6 +405,20 @@ def control_disturbance(E, n_calls, seed, first=0):
     return np.ascontiguousarray(z.reshape(-1, per)[:, 2:].T)
 
 
+def measurement_noise(E, n_sim, n_ctrl, seed, sigmas):
+    """The simulator's measurement noise (CartPole/noise_adder.py:71-82) as the controller calls see it: every simulation step draws
+    four float32 standard normals - angle, position, angleD, positionD, in this order - from the instance's generator
+    (SFC64(cartpole seed), one NoiseAdder per experiment: every experiment of a seeded run sees the SAME sequence) and scales each by
+    its sigma in float32; only the draws of the steps that end a control period reach a controller.
+    -> float32 [n_sim // n_ctrl + 1, E, 4]; row k belongs to controller call k (row 0: the t = 0 call sees the true state)."""
+    z = np.random.Generator(np.random.SFC64(int(seed))).standard_normal(size=(int(n_sim), 4), dtype=f32)
+    calls = n_sim // n_ctrl
+    rows = np.zeros((calls + 1, 4), f32)
+    rows[1:] = z[np.arange(1, calls + 1) * n_ctrl - 1]                           # simulation step g draws row g - 1
+    rows *= np.array([f32(x) for x in sigmas], f32)                              # (python float * np.float32 -> float32 product)
+    return np.array(np.broadcast_to(rows[:, None, :], (calls + 1, int(E), 4)))
+
+
 def apply_parameter_schedule(batch, parameters, seed=0, first=0):
     """The simulator's time-varying physical parameters for a batch drawn with stride 1: `parameters` holds any of the blocks `L`,
     `m_pole` (ParameterUpdater configs) and `inform_controller_about_parameters_change` of cartpole_physical_parameters.yml's
@@ -405,7 +429,7 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
     with seed + first + e (the reference draws from the process-global, clock-seeded generators: nothing to reproduce there)."""
     import dataclasses
     import random as _random
-    per_step = [k for k in ("L", "m_pole", "inform_controller_about_parameters_change") if parameters.get(k) is not None]
+    per_step = [k for k in ("L", "m_pole", "inform_controller_about_parameters_change", "vertical_angle_offset") if parameters.get(k) is not None]
     if per_step and batch.stride != 1:
         raise ValueError("parameter tables are per simulation step: draw the batch with stride=1")
     E, out = batch.E, {}
@@ -424,7 +448,7 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
             continue
         if blk.get("mode") in ("constant", "increase", "bounce") and blk.get("init_value") != "random":
             col = parameter_table(blk, batch.times)               # the same for every experiment: tabulated once
-            out[field_] = np.ascontiguousarray(np.broadcast_to(col[:, None], (len(col), E)))
+            out[field_] = np.array(np.broadcast_to(col[:, None], (len(col), E)))
         else:
             out[field_] = np.stack([parameter_table(blk, batch.times, _random.Random(int(seed) + first + e),
                                                     np.random.RandomState(int(seed) + first + e)) for e in range(E)], axis=1)
@@ -432,10 +456,37 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
     if inf is not None:
         if inf.get("mode") != "switching_random":
             col = informer_table(inf, batch.times, batch.n_ctrl)
-            out["informed"] = np.ascontiguousarray(np.broadcast_to(col[:, None], (len(col), E)))
+            out["informed"] = np.array(np.broadcast_to(col[:, None], (len(col), E)))
         else:
             out["informed"] = np.stack([informer_table(inf, batch.times, batch.n_ctrl, np.random.RandomState(int(seed) + first + e + 1))
                                         for e in range(E)], axis=1)
+    # the measurement chain (add_noise_and_latency, CartPole/__init__.py:336-356)
+    if parameters.get("latency"):
+        lat = float(parameters["latency"])
+        if lat < 0 or lat / batch.dt_simulation > 200:                               # latency_adder.py:8, 77-78
+            raise ValueError("Not possible to add so much latency!")
+        out["latency"] = lat
+    noise = parameters.get("noise")
+    if isinstance(noise, dict) and noise.get("noise_mode", "OFF") != "OFF":
+        if parameters.get("seed") is None:
+            raise ValueError("parameters['seed'] is empty: the reference then seeds the measurement noise from the clock; give a seed")
+        out["measurement_noise"] = measurement_noise(E, batch.n_sim, batch.n_ctrl, parameters["seed"],
+                                                     [noise["sigma_angle"], noise["sigma_position"], noise["sigma_angleD"], noise["sigma_positionD"]])
+    vao = parameters.get("vertical_angle_offset")
+    if vao is not None:
+        init = np.deg2rad(vao["init_value"]) if vao["init_value"] != "random" else None
+        kw = dict(dtype=np.float64, time_after_step=True)
+        if vao.get("mode") in ("constant", "increase", "bounce") and init is not None:
+            col = parameter_table(vao, batch.times, init=init, **kw)
+            out["angle_offset"] = np.array(np.broadcast_to(col[:, None], (len(col), E)))
+        else:
+            cols = []
+            for e in range(E):
+                rs = np.random.RandomState(int(seed) + first + e + 2)
+                i0 = init if init is not None else np.deg2rad(rs.uniform(*vao["range_random"]))
+                cols.append(parameter_table(dict(vao, init_value=vao["init_value"] if init is not None else 0.0), batch.times,
+                                            _random.Random(int(seed) + first + e + 2), rs, init=i0, **kw))
+            out["angle_offset"] = np.stack(cols, axis=1)
     return dataclasses.replace(batch, **out)
 
 
@@ -451,6 +502,15 @@ def active_parameters(cartpole_section):
     inf = sec.get("inform_controller_about_parameters_change")
     if isinstance(inf, dict) and inf.get("mode", "ON") != "ON":
         out["inform_controller_about_parameters_change"] = dict(inf)
+    if float(sec.get("latency") or 0.0) != 0.0:
+        out["latency"] = float(sec["latency"])
+    noise = sec.get("noise")
+    if isinstance(noise, dict) and noise.get("noise_mode", "OFF") != "OFF":
+        out["noise"] = dict(noise)
+        out["seed"] = sec.get("seed")
+    vao = sec.get("vertical_angle_offset")
+    if isinstance(vao, dict) and (vao.get("mode", "constant") != "constant" or vao.get("init_value") not in (0, 0.0)):
+        out["vertical_angle_offset"] = dict(vao)
     mode = sec.get("controlDisturbance_mode", "OFF")
     if mode != "OFF" and (float(sec.get("controlDisturbance") or 0.0) != 0.0 or float(sec.get("controlBias") or 0.0) != 0.0):
         out.update(controlDisturbance_mode=mode, controlDisturbance=sec.get("controlDisturbance"), controlBias=sec.get("controlBias"),

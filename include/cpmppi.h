@@ -417,6 +417,24 @@ typedef struct {
   float* Q_applied_out;                 /* [E] the control the plant was driven by this period: what the simulator hands the NEXT controller
                                            call as Q_ccrc / "Q_applied_-1" (CartPole/__init__.py:489, 517-518) - point
                                            cpmppi_step_args.previous_input there for the costs that read it; NULL = not needed */
+  /* The measurement chain between plant and controller (CartPole.add_noise_and_latency, CartPole/__init__.py:336-356; latency 0,
+   * noise OFF, offset 0 as shipped): with s_measured given, a period that is followed by a controller call ends with
+   *   delayed  = state(g - latency_steps) + latency_frac * (state(g - latency_steps - 1) - state(g - latency_steps))   (float64;
+   *              before the first step: zeros with cos = 1, CartPole/latency_adder.py:24-26, 63-67)
+   *   noise      (measurement_noise_table row c + 1: angle += n0, wrap, cos / sin, position += n1, angleD += n2, positionD += n3)
+   *   offset     angle = wrap(angle + angle_offset), cos / sin (:348-356); informed (informed_table, NULL = yes): taken out again
+   *              with another wrap + cos / sin (:501-505)
+   * and s_measured[E][6] = that state in float32 - point cpmppi_step_args.s0 there (the caller puts the initial state in before
+   * the t = 0 call, which sees the true state, :869-870). */
+  float* s_measured;                    /* [E][6] out; NULL = no measurement chain */
+  float* state_history;                 /* [history_len][row_envs][6] ring: the state after simulation step g at slot g % history_len; the
+                                           caller fills it with zeros and cos = 1 before the run.  Needed when latency > 0 */
+  uint32_t history_len;                 /* >= latency_steps + 2 */
+  uint32_t latency_steps;               /* int(latency / dt_sim) */
+  double latency_frac;                  /* latency / dt_sim - latency_steps */
+  const float* measurement_noise_table; /* [ctrl_rows][row_envs][4] sigma * N(0,1) for angle, position, angleD, positionD, or NULL */
+  const double* angle_offset_table;     /* [sched_rows][row_envs] the vertical angle offset after the table row's step, or NULL = 0 */
+  const uint8_t* informed_table;        /* [sched_rows][row_envs] 1 = the controller is informed (the offset is taken out), NULL = 1 */
 } cpmppi_plant_args;
 int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* stream);
 
@@ -515,6 +533,8 @@ typedef struct {
                                            informer's state when the row was saved); NULL = 'true' in every row (mode ON, as shipped) */
   const float* Q_applied;               /* [rows][E] the control the plant was driven by when it differs from the calculated one (control
                                            disturbance): the Q_applied and u columns; NULL = Q */
+  const double* angle_offset;           /* [rows][E][3] the vertical angle offset, its cos and its sin when the row was saved, or NULL:
+                                           0.0, 1.0, 0.0 in every row */
 } cpmppi_recording;
 int cpmppi_write_recordings(const char* const* paths, const char* preamble, size_t preamble_len, const cpmppi_recording* rec,
                             int n_threads);

@@ -66,7 +66,7 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
                    'sizeof(cpmppi_plant_args), offsetof(cpmppi_plant_args, period), offsetof(cpmppi_plant_args, save_every), '
                    'offsetof(cpmppi_plant_args, sched_stride), offsetof(cpmppi_plant_args, row_envs), sizeof(cpmppi_recording), '
                    'offsetof(cpmppi_recording, q_update_time), sizeof(cpmppi_comm_info) + sizeof(cpmppi_launch_info), '
-                   'offsetof(cpmppi_plant_args, Q_applied_out), offsetof(cpmppi_recording, Q_applied)); return 0; }\n')
+                   'offsetof(cpmppi_plant_args, informed_table), offsetof(cpmppi_recording, angle_offset)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
@@ -74,7 +74,7 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
     assert got == [C.sizeof(_lib.cpmppi_config), C.sizeof(A), C.sizeof(_lib.cpmppi_gru_model), A.noise.offset, A.Q_out.offset,
                    A.offset_dev.offset, A.u_nom_out.offset, C.sizeof(P), P.period.offset, P.save_every.offset, P.sched_stride.offset,
                    P.row_envs.offset, C.sizeof(R), R.q_update_time.offset, C.sizeof(_lib.cpmppi_comm_info) + C.sizeof(_lib.cpmppi_launch_info),
-                   P.Q_applied_out.offset, R.Q_applied.offset]
+                   P.informed_table.offset, R.angle_offset.offset]
 
 
 def test_integration_doc_binding_matches_the_library():

@@ -562,3 +562,71 @@ def test_device_loop_hands_the_previous_control_to_the_costs_that_read_it(groups
     if groups > 1:
         eg.close()
     eng.close()
+
+
+def test_reference_experiment_with_the_measurement_chain_on_the_device_loop(g):
+    """exp_sensor: the reference's simulator with 5 ms latency (2.5 simulation steps), measurement noise, a moving vertical-angle
+    offset and a switching informer.  schedule.apply_parameter_schedule tabulates noise draws and offset, cpmppi_plant_step keeps the
+    latency ring buffer and ends every period with the measured state (float64 arithmetic on the device): what each controller call
+    is handed agrees with what the reference's controller was handed to 2e-6 over the first ten calls (the closed loops drift apart
+    at the float32 level), the plant follows to 1e-4, the recording carries the offset columns."""
+    from cartpolesimulation_amd import recording as R
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import legacy_mppi_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import ScheduleRun
+    tag, key = "exp_sensor", "exp_sensor/0"
+    cfg = json.loads(g[f"{tag}/config"].item())
+    cfg["dt"]["saving"] = cfg["dt"]["simulation"]
+    sen, inf = json.loads(g[f"{tag}/sensor"].item()), json.loads(g[f"{tag}/informer"].item())
+    N, H = int(g[f"{tag}/N"]), int(g[f"{tag}/H"])
+    b = SC.RandomExperimentSetter(cfg).draw(1, int(g[f"{tag}/cartpole_seed0"]))
+    prm = dict(latency=sen["latency"], noise=dict(sen["noise"], noise_mode="ON"), vertical_angle_offset=sen["vertical_angle_offset"],
+               inform_controller_about_parameters_change=inf, seed=sen["noise"]["seed"])
+    b = SC.apply_parameter_schedule(b, prm)
+    eng = MPPIEngine(1, legacy_mppi_config(num_rollouts=N, mpc_horizon=H))
+    stdev = np.float64(g[f"{tag}/stdev"])
+
+    def run_with(batch):
+        rng = Generator(SFC64(int(g[f"{tag}/ctrl_seed"])))
+        for _ in range(5):
+            rng.uniform(-1.0, 1.0)
+
+        def knots(_c):
+            kn = O.sample_knots(rng, N, H, stdev)
+            rng.uniform(-1.0, 1.0)
+            return kn[None]
+
+        un = eng.zeros(1, H)
+        eng.step(g[f"{key}/call/s"][0][None], un, float(g[f"{key}/call/tp"][0]), 1.0, knots=knots(0))
+        run = ScheduleRun(eng, batch, 0, knots_fn=knots, u_nom0=un)
+        seen = [run.s_ctrl.cpu().numpy()[0].copy()]
+        while run.periods_left:
+            run.enqueue_next()
+            seen.append(run.s_ctrl.cpu().numpy()[0].copy())
+        return run.finish(), np.array(seen)
+
+    res, seen = run_with(b)
+    K = 10
+    want = g[f"{key}/call/s64"][1:]
+    assert np.array_equal(seen[0], g[f"{key}/call/s"][1])               # the t = 0 call sees the true state
+    assert np.abs(seen[:K + 1] - want[:K + 1]).max() < 2e-6
+    blk = R.recording_block(res, eng.phys)
+    true_states = blk["states"][::b.n_ctrl, 0]
+    assert np.abs(seen[1:K + 1] - true_states[1:K + 1]).max() > 0.03       # ... which is NOT the true state once the chain is on
+    n_save_ref = 2
+    col = lambda n: g[f"{key}/col/{n}"]                                # noqa: E731
+    np.testing.assert_allclose(res["Q"].cpu().numpy()[:K + 1, 0], g[f"{key}/call/Q"][1:K + 2], atol=1e-4)
+    r = K * b.n_ctrl // n_save_ref + 1
+    st = blk["states"][::n_save_ref, 0]
+    for j, n in enumerate(("angle", "angleD", "angle_cos", "angle_sin", "position", "positionD")):
+        np.testing.assert_allclose(st[:r, j], col(n)[:r], atol=2e-4, rtol=1e-4, err_msg=n)
+    assert np.array_equal(blk["angle_offset"][::n_save_ref, 0, 0], col("vertical_angle_offset"))
+    assert np.array_equal(blk["angle_offset"][::n_save_ref, 0, 1], col("vertical_angle_offset_cos"))
+    assert np.array_equal(np.where(blk["informed"][::n_save_ref, 0], "true", "default"), col("L_for_controller"))
+    # each part of the chain on its own moves what the controller sees (and with it the loop)
+    import dataclasses
+    for drop in (dict(latency=0.0), dict(measurement_noise=None), dict(angle_offset=None)):
+        _, other = run_with(dataclasses.replace(b, **drop))
+        assert np.abs(other[1:4] - want[1:4]).max() > 1e-3, drop
+    eng.close()

@@ -136,7 +136,7 @@ def test_native_writer_never_appends_and_cleans_up_after_a_failure(tmp_path):
     assert sorted(os.listdir(tmp_path)) == sorted(os.path.basename(p) for p in good)
 
 
-@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0", "exp_varM/0", "exp_dist/1"])
+@pytest.mark.parametrize("key", ["exp_fine/0", "exp_fine/1", "exp_coarse/0", "exp_varM/0", "exp_dist/1", "exp_sensor/0"])
 def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, key):
     """The data rows of a recording written by the REFERENCE (its CartPole class + csv_logger, tests/golden/schedule.npz) from the
     values it logged: fed the same values, both writers here give the same bytes (all columns but the wall-clock Q_update_time)."""
@@ -154,6 +154,11 @@ def test_writer_reproduces_the_references_own_recording(golden_dir, tmp_path, ke
     if key.startswith("exp_dist"):                                   # the control disturbance: Q_applied differs from Q_calculated
         block["Q_applied"] = col("Q_applied").astype(f32)[:, None]
         assert np.abs(block["Q_applied"] - block["Q"]).max() > 0.3
+    if key.startswith("exp_sensor"):                                 # a vertical angle offset that moves: three columns of Python floats
+        off = col("vertical_angle_offset")
+        block["angle_offset"] = np.stack([off, np.cos(off), np.sin(off)], axis=-1)[:, None]
+        block["informed"] = (col("L_for_controller") == "true").astype(np.uint8)[:, None]
+        assert len(np.unique(off)) > 8
     if key.startswith("exp_varM"):                                   # a pole mass that changes, a controller informer that switches
         block["m_pole"] = col("m_pole").astype(f32)[:, None]
         block["informed"] = (col("L_for_controller") == "true").astype(np.uint8)[:, None]

@@ -239,3 +239,33 @@ def test_active_parameters_of_a_physical_parameters_file():
     assert set(got) == {"L", "m_pole", "inform_controller_about_parameters_change", "controlDisturbance_mode", "controlDisturbance",
                         "controlBias", "seed"} and got["seed"] == 7 and got["controlDisturbance"] == 0.3
     assert SC.active_parameters(dict(sec, controlDisturbance=0.3, controlDisturbance_mode="OFF")) is None
+
+
+def test_measurement_chain_tables_follow_the_references(g):
+    """exp_sensor: the vertical-angle-offset updater (a float64, updated with the time AFTER the step, started from deg2rad(init)) and
+    the measurement-noise draws (four float32 normals per simulation step from SFC64(seed), scaled in float32; the rows of the steps
+    that end a control period) as apply_parameter_schedule tabulates them."""
+    sen = json.loads(g["exp_sensor/sensor"].item())
+    cfg = json.loads(g["exp_sensor/config"].item())
+    inf = json.loads(g["exp_sensor/informer"].item())
+    b = SC.RandomExperimentSetter(cfg).draw(2, int(g["exp_sensor/cartpole_seed0"]), stride=1)
+    prm = dict(latency=sen["latency"], noise=dict(sen["noise"], noise_mode="ON"), vertical_angle_offset=sen["vertical_angle_offset"],
+               inform_controller_about_parameters_change=inf, seed=sen["noise"]["seed"])
+    full = SC.apply_parameter_schedule(b, prm)
+    assert full.latency == 0.005 and full.angle_offset.dtype == np.float64 and full.angle_offset.shape == (b.n_sim + 1, 2)
+    assert np.array_equal(full.angle_offset[::2, 0], g["exp_sensor/0/col/vertical_angle_offset"])
+    assert np.array_equal(full.angle_offset[:, 0], full.angle_offset[:, 1])
+    nz = full.measurement_noise
+    assert nz.shape == (b.n_periods + 1, 2, 4) and nz.dtype == np.float32 and not nz[0].any() and np.array_equal(nz[:, 0], nz[:, 1])
+    z = np.random.Generator(np.random.SFC64(sen["noise"]["seed"])).standard_normal(size=(b.n_sim, 4), dtype=np.float32)
+    n = sen["noise"]
+    want = z[9::10] * np.array([n["sigma_angle"], n["sigma_position"], n["sigma_angleD"], n["sigma_positionD"]], np.float32)
+    assert np.array_equal(nz[1:, 0], want)
+    # what the file's section would switch on
+    sec = dict(seed=5, latency=0.005, noise=dict(noise_mode="ON", sigma_angle=0.0, sigma_position=0.0005, sigma_angleD=0.075, sigma_positionD=0.005),
+               vertical_angle_offset=dict(init_value=2.0, mode="constant"), controlDisturbance_mode="additive", controlDisturbance=0.0, controlBias=0.0)
+    assert set(SC.active_parameters(sec)) == {"latency", "noise", "seed", "vertical_angle_offset"}
+    with pytest.raises(ValueError):
+        SC.apply_parameter_schedule(b, dict(latency=0.5))                               # more than the reference's buffer holds
+    with pytest.raises(ValueError):
+        SC.apply_parameter_schedule(b, dict(noise=dict(sen["noise"], noise_mode="ON")))  # no seed
