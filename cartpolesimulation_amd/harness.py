@@ -4,9 +4,9 @@ This is the build's counterpart of the reference's experiment loop (run_data_gen
 CartPole/data_generator.py:259-367 -> CartPole.run_cartpole_random_experiment, CartPole/__init__.py:659-735, whose
 inner update_state loop is :283-324): every control period the controller sees the state and holds Q for
 dt_control / dt_simulation plant steps.  Plant (cpmppi_plant_advance) and controller (cpmppi_step) both run on the
-GPU and no value crosses PCIe inside the loop; measurement noise and latency are OFF as in the shipped YAML
-(cartpole_physical_parameters.yml:18,20); the additive control disturbance (:13-15, amplitude 0 as shipped) and the parameter
-updaters / controller informer (:29-52) come as tables of the batch (schedule.apply_parameter_schedule).
+GPU and no value crosses PCIe inside the loop; the simulator's measurement chain (latency, measurement noise, vertical angle offset:
+cartpole_physical_parameters.yml:18-28, all off as shipped), its additive control disturbance (:13-15, amplitude 0 as shipped) and its
+parameter updaters / controller informer (:29-52) come as tables of the batch (schedule.apply_parameter_schedule).
 
 `run` holds target position, target equilibrium and pole length constant per env; `run_schedule` runs a batch of the data
 generator's random experiments (schedule.ExperimentBatch): the target position follows each experiment's random trace and the

@@ -253,8 +253,9 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     ParallelDataGeneration.sh:17), so no two ranks ever ask for the same file name; no collective is involved.
     ``parameters``: the `L` / `m_pole` / `inform_controller_about_parameters_change` blocks of cartpole_physical_parameters.yml's
     `cartpole:` section - a pole length and a pole mass that change DURING the experiments (CartPole/parameter_updater.py) and a
-    controller that is told the true length only part of the time - and its `controlDisturbance` / `controlBias` / `seed`: the additive
-    control disturbance the reference's author collects training data with (schedule.apply_parameter_schedule)."""
+    controller that is told the true length only part of the time - its `controlDisturbance` / `controlBias` / `seed`: the additive
+    control disturbance the reference's author collects training data with - and its measurement chain: `latency`, `noise`
+    (noise_mode + the four sigmas), `vertical_angle_offset` (schedule.apply_parameter_schedule)."""
     import time
     from .harness import BatchedCartPoleExperiment
     from .schedule import RandomExperimentSetter, merged_config
@@ -264,7 +265,8 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     n_total = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
     cseed = cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1
     _first = 0                                                     # global index of this process's first experiment (Philox keys)
-    _stride = 1 if parameters and any(parameters.get(k) is not None for k in ("L", "m_pole", "inform_controller_about_parameters_change")) else None
+    _stride = 1 if parameters and any(parameters.get(k) is not None for k in ("L", "m_pole", "inform_controller_about_parameters_change",
+                                                                                "vertical_angle_offset")) else None
     if int(world) > 1:
         from .schedule import draw_shard
         batch, _first = draw_shard(cfg, n_total, cseed, rank, world, L=L, stride=_stride)

@@ -376,7 +376,7 @@ int cpmppi_plant_advance_record(cpmppi_handle* h, uint32_t E, float* s, const fl
  * n_substeps = 0 records only (1. and 2.: the run's last controller call is followed by no plant step, :690-716).
  * period_dev: c = *period_dev - 1, the device step counter of cpmppi_step_args.offset_dev (already advanced by the step); a
  * counter that is still 0 advances the plant from table row 0 WITHOUT recording or publishing.  Any log / table / out pointer may
- * be NULL.  Measurement noise and latency: OFF, as in the shipped YAML.  The pole MASS the controller computes with is
+ * be NULL.  The pole MASS the controller computes with is
  * the handle's (config.m_pole / cpmppi_set_pole_mass), whatever the plant's: a per-env controller-side mass does not exist. */
 typedef struct {
   uint32_t E;

@@ -266,7 +266,10 @@ def test_generate_dataset_on_device(tmp_path):
                            range_clip=[0.05, 0.12], increment=0.004, reset_every_x_seconds="inf"),
                inform_controller_about_parameters_change=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.05,
                                                               change_to_off_after_x_seconds_on=0.07),
-               controlDisturbance=0.2, controlBias=-0.02, seed=11)
+               controlDisturbance=0.2, controlBias=-0.02, seed=11, latency=0.007,
+               noise=dict(noise_mode="ON", sigma_angle=0.0, sigma_position=0.0005, sigma_angleD=0.075, sigma_positionD=0.005),
+               vertical_angle_offset=dict(init_value=1.0, change_every_x_seconds=0.05, mode="increase", range_random=[-3.14, 3.14],
+                                          range_clip=None, increment=0.004, reset_every_x_seconds="inf"))
     pp = R.generate_dataset(eng, E, str(tmp_path / "prm"), config=cfg, seed=7, parameters=prm)
     times = SC.accumulated_times(200, 0.002)
     Ltab = SC.parameter_table(prm["L"], times)
@@ -282,6 +285,9 @@ def test_generate_dataset_on_device(tmp_path):
         qc_, qa_ = d["Q_calculated"].to_numpy().astype(np.float32), d["Q_applied"].to_numpy().astype(np.float32)
         assert np.array_equal(qa_[::2], ((qc_[::2] + np.float32(0.2) * zq).astype(np.float32) + np.float32(-0.02)).astype(np.float32))
         assert np.array_equal(d["u"].to_numpy().astype(np.float32), np.float32(1.77) * qa_) and np.abs(qa_ - qc_).max() > 0.2
+        vo = d["vertical_angle_offset"].to_numpy()
+        assert vo[0] == np.deg2rad(1.0) and (np.diff(vo) >= 0).all() and 5 <= len(np.unique(vo)) <= 9
+        assert np.array_equal(d["vertical_angle_offset_cos"].to_numpy(), np.cos(vo)) and np.array_equal(d["vertical_angle_offset_sin"].to_numpy(), np.sin(vo))
         assert len(np.unique(m)) > 3 and m.min() >= np.float32(0.05) and m.max() <= np.float32(0.12) and m[0] == np.float32(0.087)
         for i in (0, 7, 23, 40):
             r = d.iloc[i]
