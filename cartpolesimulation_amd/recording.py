@@ -350,8 +350,8 @@ def main(argv=None):
             else mppi_config_from_yaml(cfgs, **over)
         with open(os.path.join(args.config_root, "cartpole_physical_parameters.yml")) as fh:
             parameters = active_parameters(yaml.safe_load(fh)["cartpole"])
-        if parameters and parameters.get("seed") is None and "controlDisturbance" in parameters:
-            parameters["seed"] = args.seed
+        if parameters and parameters.get("seed") is None and ("controlDisturbance" in parameters or "noise" in parameters):
+            parameters["seed"] = args.seed                             # (the file's own `seed:` is empty = clock)
     else:
         n, h, cost = args.rollouts or 3500, args.horizon or 35, args.cost or "legacy_mppi_cartpole"
         cfg = legacy_mppi_config(num_rollouts=n, mpc_horizon=h) if cost == "legacy_mppi_cartpole" \
