@@ -630,3 +630,47 @@ def test_reference_experiment_with_the_measurement_chain_on_the_device_loop(g):
         _, other = run_with(dataclasses.replace(b, **drop))
         assert np.abs(other[1:4] - want[1:4]).max() > 1e-3, drop
     eng.close()
+
+
+def test_everything_on_launched_graph_and_groups_agree():
+    """Every table of the schedule at once - pole length and mass updaters, a switching informer, control disturbance, latency,
+    measurement noise, a moving angle offset, a cost that reads the previous control - run launched, as a replayed HIP graph (device
+    step counter) and as two env groups enqueued from C: the same recording bit for bit."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
+    from cartpolesimulation_amd.pipeline import EnvGroups, run_schedule_groups
+    E, N, H = 6, 512, 20
+    cfg = dict(seed=41, length_of_experiment=0.5, dt=dict(saving=0.004), keep_target_equilibrium_x_seconds_up=0.1,
+               turning_points=dict(track_relative_complexity=12),
+               random_initial_state=dict(init_limits=dict(angle=[0.0, 20.0], angleD=40.0, position=0.4, positionD=0.2)))
+    upd = lambda init, every, inc, lo, hi, mode="bounce": dict(init_value=init, change_every_x_seconds=every, mode=mode,   # noqa: E731
+                                                                range_random=[lo, hi], range_clip=[lo, hi], increment=inc, reset_every_x_seconds="inf")
+    prm = dict(L=upd(0.395, 0.014, 0.01, 0.3, 0.45), m_pole=upd(0.087, 0.03, 0.004, 0.05, 0.12, "random walk"),
+               inform_controller_about_parameters_change=dict(mode="switching_random", change_to_on_after_x_seconds_off=0.08,
+                                                              change_to_off_after_x_seconds_on=0.1),
+               controlDisturbance=0.2, controlBias=0.01, seed=13, latency=0.0085,
+               noise=dict(noise_mode="ON", sigma_angle=0.002, sigma_position=0.0005, sigma_angleD=0.075, sigma_positionD=0.005),
+               vertical_angle_offset=upd(1.5, 0.02, 0.005, -0.03, 0.06))
+    b = SC.apply_parameter_schedule(SC.RandomExperimentSetter(cfg).draw(E, 91, stride=1), prm, seed=92)
+    assert all(x is not None for x in (b.L_table, b.m_pole_table, b.informed, b.Q_disturbance, b.measurement_noise, b.angle_offset))
+    assert 0 < b.informed.mean() < 1 and b.latency == 0.0085
+    mppi = MPPIConfig(num_rollouts=N, mpc_horizon=H, cost_function_specification="quadratic_boundary")
+    outs = []
+    for form in ("launched", "graph", "groups"):
+        eng = MPPIEngine(E, mppi)
+        if form == "groups":
+            eg = EnvGroups(E, mppi, 2)
+            res = run_schedule_groups(eg, b, 7)
+            torch.cuda.synchronize()
+        else:
+            res = BatchedCartPoleExperiment(eng, seed=7).run_schedule(b, graph=form == "graph", steps_per_graph=6)
+        outs.append({k: res[k].cpu().numpy() for k in ("states", "dd", "Q", "final_state", "u_nom")})
+        if form == "groups":
+            eg.close()
+        eng.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), ("graph", k)
+        assert np.array_equal(outs[0][k], outs[2][k]), ("groups", k)
+    assert np.isfinite(outs[0]["states"]).all() and np.abs(outs[0]["Q"]).max() > 0.05
