@@ -674,3 +674,60 @@ def test_everything_on_launched_graph_and_groups_agree():
         assert np.array_equal(outs[0][k], outs[1][k]), ("graph", k)
         assert np.array_equal(outs[0][k], outs[2][k]), ("groups", k)
     assert np.isfinite(outs[0]["states"]).all() and np.abs(outs[0]["Q"]).max() > 0.05
+
+
+@pytest.mark.parametrize("latency", [0.0, 0.001, 0.004, 0.0332])
+def test_measured_state_follows_the_oracle_chain_at_any_latency(latency):
+    """cpmppi_plant_step's measurement chain alone, under given controls: the state handed to the next controller call against the
+    oracle's MeasurementChain fed with the DEVICE's own states of every simulation step (so that only the chain is compared) - no
+    latency, half a step, exactly two steps, more than a control period (the ring buffer spans periods; before the first step it
+    holds zeros with cos = 1), with noise rows, a per-step angle offset and a random informer."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, T, n_ctrl, dt = 5, 6, 10, 0.002
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=64, mpc_horizon=10))
+    rng = Generator(SFC64(31))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-6, 6), rng.uniform(-0.15, 0.15), rng.uniform(-0.5, 0.5)) for _ in range(E)])
+    Qs = rng.uniform(-1, 1, (T, E)).astype(f32)
+    n_sim = T * n_ctrl
+    nz = rng.normal(0, 0.05, (T + 1, E, 4)).astype(f32)
+    off = np.cumsum(rng.normal(0, 0.02, (n_sim + 1, E)), axis=0)              # float64, moves every step
+    told = rng.uniform(size=(n_sim + 1, E)) < 0.5
+    tp = np.zeros((n_sim + 1, E), f32)
+    s = eng.tensor(s0.copy())
+    states = eng.zeros(n_sim + 1, E, 6)
+    states[0] = s
+    n_back = latency / dt
+    hist = np.zeros((int(n_back) + 2, E, 6), f32)
+    hist[:, :, 2] = 1.0
+    s_meas = eng.zeros(E, 6)
+    kw = dict(dt_sim=dt, period_steps=n_ctrl, states_log=states, save_every=1, target_position_table=eng.tensor(tp), s_measured=s_meas,
+              latency=latency, state_history=eng.tensor(hist) if n_back > 0 else None, measurement_noise_table=eng.tensor(nz),
+              angle_offset_table=torch.as_tensor(off, device=s.device), informed_table=torch.as_tensor(told.astype(np.uint8), device=s.device),
+              Q_log=eng.zeros(T + 1, E))
+    seen = []
+    for c in range(T):
+        eng.plant_step(s, Qs[c], n_ctrl, period=c, **kw)
+        seen.append(s_meas.cpu().numpy().copy())
+    st = states.cpu().numpy()
+    for e in range(E):
+        chain = S.MeasurementChain(latency, dt)
+        for gstep in range(1, n_sim + 1):
+            chain.hist.append(st[gstep, e].astype(np.float64))
+            if gstep % n_ctrl:
+                continue
+            k = gstep // n_ctrl
+            s1, s2 = chain._past(chain.li), chain._past(chain.li + 1)
+            m = s1 + chain.frac * (s2 - s1)
+            m[0] = S.wrap_angle_rad(m[0] + float(nz[k, e, 0]))
+            m[2], m[3] = np.cos(m[0]), np.sin(m[0])
+            m[4] += nz[k, e, 1]; m[1] += nz[k, e, 2]; m[5] += nz[k, e, 3]
+            m[0] = S.wrap_angle_rad(m[0] + off[gstep, e])
+            if told[gstep, e]:
+                m[0] = S.wrap_angle_rad(m[0] - off[gstep, e])
+            m[2], m[3] = np.cos(m[0]), np.sin(m[0])
+            got = seen[k - 1][e]
+            assert np.all(np.abs(got - m) <= 2e-7 + 2e-7 * np.abs(m)), (latency, e, k, got, m)
+    if latency > 0.02:                                               # the first call reaches back before the first step: the buffer's zeros
+        assert abs(seen[0][0][4]) < 1e-2 + abs(float(nz[1, 0, 1])) and not np.allclose(seen[0][0][4], st[n_ctrl, 0, 4], atol=1e-4)
+    eng.close()
