@@ -187,6 +187,23 @@ class ScheduleRun:
         if eng.mppi.cost_function_specification in PREVIOUS_INPUT_COSTS:
             self.prev_Q = eng.zeros(E)
             self.plant.update(Q_applied_out=self.prev_Q)
+        # the pole MASS the controller computes with (predictor_ODE takes it from the simulator's 'm_pole' attribute at every call,
+        # predictors_customization.py:55-58; predictor_ODE_v0 does not): one value per handle, so it can follow the plant's mass only
+        # when every experiment of the batch has the same schedule (the deterministic updater modes) - told or not as the informer says
+        self.m_ctrl = None
+        if b.m_pole_table is not None and getattr(eng.mppi, "predictor_type", "ODE_v0") == "ODE":
+            mt = np.asarray(b.m_pole_table, np.float32)
+            if (mt == mt[:, :1]).all():
+                calls = np.minimum(np.arange(T + 1) * b.n_ctrl, mt.shape[0] - 1)
+                told = np.ones(T + 1, bool)
+                if b.informed is not None:
+                    inf = np.asarray(b.informed, bool)
+                    if inf.ndim == 2:
+                        if not (inf == inf[:, :1]).all():
+                            raise ValueError("a per-experiment informer cannot steer the controller's one pole mass: use a deterministic informer mode")
+                        inf = inf[:, 0]
+                    told = inf[np.minimum(calls, len(inf) - 1)]
+                self.m_ctrl = np.where(told, mt[calls, 0], mt[0, 0]).astype(np.float32)
         self.counter = self.graph = None
         self.per = 0
         self._prep = self._prep_plant = None                       # argument blocks built once (the launched Philox loop)
@@ -199,8 +216,16 @@ class ScheduleRun:
     def periods_left(self):
         return self.c < self.T
 
+    def set_controller_mass(self, c, engines=None):
+        """Before controller call c: the pole mass the simulator would hand it (the launch reads it from the handle when enqueued)."""
+        if self.m_ctrl is not None:
+            for e in (engines or [self.eng]):
+                e.set_pole_mass(float(self.m_ctrl[c]))
+
     def _control(self, c):
         eng = self.eng
+        if c is not None:
+            self.set_controller_mass(c)
         if self.knots_fn is not None:
             eng.step(self.s_ctrl, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, knots=self.knots_fn(c), Q_out=self.Q, **self._prev)
         elif self.counter is not None:
@@ -214,6 +239,7 @@ class ScheduleRun:
         if self.counter is None and self.knots_fn is None:
             # the launched loop: two library calls per period on argument blocks built once (the Python-side argument handling of
             # step + plant_step is ~30 us per period - more than the GPU needs for a few dozen envs)
+            self.set_controller_mass(c)
             if self._prep is None:
                 self._prep = self.eng.prepare_step(self.s_ctrl, self.u_nom, self.cur_tp, self.cur_te, L=self.cur_L, seed=self.seed, offset=0,
                                                    env_offset=self.env_offset, Q_out=self.Q, **self._prev)
@@ -230,6 +256,8 @@ class ScheduleRun:
     def capture(self, steps_per_graph=10):
         """Capture `steps_per_graph` control periods as ONE HIP graph (device step counter: Philox offset = schedule row =
         recording row, no launch argument changes between periods); enqueue_next then replays it."""
+        if self.m_ctrl is not None and len(np.unique(self.m_ctrl)) > 1:
+            raise ValueError("a captured graph replays ONE pole mass for the controller: run this batch launched (graph=False)")
         dev = self.s.device
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)              # controller calls made
         fixed = getattr(self.eng, "_fixed_stream_obj", None)

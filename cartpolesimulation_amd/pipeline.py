@@ -187,7 +187,16 @@ def run_schedule_groups(groups: EnvGroups, batch, seed):
     step = groups.prepare(run.s_ctrl, run.u_nom, run.cur_tp, run.cur_te, L=run.cur_L, seed=seed, Q_out=run.Q, **run._prev)
     plant = eng.prepare_plant_step(run.s, run.Q, batch.n_ctrl, period=0, **run.plant)
     groups.fork()
-    groups.run(step, plant, periods=run.T, offset=0, period=0)
+    if run.m_ctrl is not None and len(np.unique(run.m_ctrl)) > 1:
+        # the controller's pole mass follows the plant's (predictor_ODE): a handle parameter read when a launch is enqueued - one
+        # library call per period instead of one for the whole run
+        for c in range(run.T):
+            run.set_controller_mass(c, groups.engines)
+            groups.run(step, plant, periods=1, offset=c, period=c)
+        run.set_controller_mass(run.T, groups.engines)
+    else:
+        run.set_controller_mass(0, groups.engines)
+        groups.run(step, plant, periods=run.T, offset=0, period=0)
     groups.run(step, plant, periods=1, offset=run.T, period=run.T, n_substeps=run.tail)   # the run's last controller call (+ trailing steps)
     groups.join()
     return dict(states=run.states, dd=run.dd, Q=run.Qs, final_state=run.s, u_nom=run.u_nom, batch=batch)

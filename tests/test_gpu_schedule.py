@@ -731,3 +731,61 @@ def test_measured_state_follows_the_oracle_chain_at_any_latency(latency):
     if latency > 0.02:                                               # the first call reaches back before the first step: the buffer's zeros
         assert abs(seen[0][0][4]) < 1e-2 + abs(float(nz[1, 0, 1])) and not np.allclose(seen[0][0][4], st[n_ctrl, 0, 4], atol=1e-4)
     eng.close()
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_controller_pole_mass_follows_a_uniform_schedule_with_predictor_ODE(groups):
+    """predictor_ODE takes the pole mass from the simulator's 'm_pole' attribute at every call (predictors_customization.py:55-58): with
+    a deterministic `m_pole:` updater every experiment has the same schedule, and the device loop sets the handle's mass before each
+    controller call - the true mass while the informer says so, the initial one otherwise.  Equal to a loop paced by hand; different
+    from a controller that keeps the initial mass; predictor_ODE_v0 ignores the attribute (as the reference's does)."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment, ScheduleRun
+    from cartpolesimulation_amd.pipeline import EnvGroups, run_schedule_groups
+    E, N, H = 4, 512, 20
+    cfg = dict(seed=35, length_of_experiment=0.3, keep_target_equilibrium_x_seconds_up=0.1, turning_points=dict(track_relative_complexity=12),
+               random_initial_state=dict(init_limits=dict(angle=[0.0, 20.0], angleD=40.0, position=0.4, positionD=0.2)))
+    prm = dict(m_pole=dict(init_value=0.087, change_every_x_seconds=0.02, mode="increase", range_random=[0.015, 0.3], range_clip=[0.015, 0.3],
+                           increment=0.02, reset_every_x_seconds="inf"),
+               inform_controller_about_parameters_change=dict(mode="switching_regular", change_to_on_after_x_seconds_off=0.04,
+                                                              change_to_off_after_x_seconds_on=0.1))
+    b = SC.apply_parameter_schedule(SC.RandomExperimentSetter(cfg).draw(E, 79, stride=1), prm)
+    mppi = MPPIConfig(num_rollouts=N, mpc_horizon=H, predictor_type="ODE")
+    eng = MPPIEngine(E, mppi)
+    run = ScheduleRun(eng, b, 7)
+    calls = np.arange(b.n_periods + 1) * b.n_ctrl
+    want = np.where(b.informed[calls, 0], b.m_pole_table[calls, 0], np.float32(0.087)).astype(f32)
+    assert np.array_equal(run.m_ctrl, want) and len(np.unique(want)) > 4 and (want == np.float32(0.087)).sum() >= 3
+    if groups == 1:
+        res = BatchedCartPoleExperiment(eng, seed=7).run_schedule(b)
+    else:
+        eg = EnvGroups(E, mppi, groups)
+        res = run_schedule_groups(eg, b, 7)
+        torch.cuda.synchronize()
+    Q_loop = res["Q"].cpu().numpy()
+
+    def by_hand(masses):
+        s, u, out = eng.tensor(b.s0).clone(), eng.zeros(E, H), []
+        m_tab = eng.tensor(b.m_pole_table)
+        for c in range(b.n_periods + 1):
+            row = int(b.rows_at(c * b.n_ctrl))
+            eng.set_pole_mass(float(masses[c]))
+            Q, _ = eng.step(s, u, b.target_position[row].astype(f32), b.target_equilibrium[row].astype(f32), seed=7, offset=c)
+            out.append(Q.cpu().numpy().copy())
+            if c < b.n_periods:
+                eng.plant_step(s, Q, b.n_ctrl, dt_sim=b.dt_simulation, period=c, period_steps=b.n_ctrl, m_pole_table=m_tab)
+        return np.stack(out)
+
+    assert np.array_equal(Q_loop, by_hand(want))
+    assert np.abs(Q_loop - by_hand(np.full(len(want), 0.087, f32))).max() > 1e-3
+    with pytest.raises(ValueError):
+        BatchedCartPoleExperiment(eng, seed=7).run_schedule(b, graph=True)              # a graph replays one mass
+    eng.set_pole_mass(0.087)
+    v0 = MPPIEngine(E, MPPIConfig(num_rollouts=N, mpc_horizon=H))
+    assert ScheduleRun(v0, b, 7).m_ctrl is None                                          # predictor_ODE_v0 never reads the attribute
+    v0.close()
+    if groups > 1:
+        eg.close()
+    eng.close()
