@@ -196,14 +196,19 @@ class ScheduleRun:
             if (mt == mt[:, :1]).all():
                 calls = np.minimum(np.arange(T + 1) * b.n_ctrl, mt.shape[0] - 1)
                 told = np.ones(T + 1, bool)
+                shared = True
                 if b.informed is not None:
                     inf = np.asarray(b.informed, bool)
                     if inf.ndim == 2:
-                        if not (inf == inf[:, :1]).all():
-                            raise ValueError("a per-experiment informer cannot steer the controller's one pole mass: use a deterministic informer mode")
+                        shared = bool((inf == inf[:, :1]).all())
                         inf = inf[:, 0]
                     told = inf[np.minimum(calls, len(inf) - 1)]
-                self.m_ctrl = np.where(told, mt[calls, 0], mt[0, 0]).astype(np.float32)
+                if shared:
+                    self.m_ctrl = np.where(told, mt[calls, 0], mt[0, 0]).astype(np.float32)
+                else:
+                    import warnings
+                    warnings.warn("the informer differs between experiments ('switching_random'): the controller's one pole mass cannot follow "
+                                  "it and stays the handle's; the plants follow their own tables")
         self.counter = self.graph = None
         self.per = 0
         self._prep = self._prep_plant = None                       # argument blocks built once (the launched Philox loop)
