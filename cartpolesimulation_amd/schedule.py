@@ -350,6 +350,81 @@ def parameter_table(updater, times, py_random=None, np_random=None, dtype=f32, i
     return out
 
 
+def parameter_tables(updater, times, seeds, dtype=f32, init=None, time_after_step=False):
+    """parameter_table for MANY experiments at once -> [len(times), len(seeds)]: column e is parameter_table(updater, times,
+    random.Random(seeds[e]), numpy.random.RandomState(seeds[e]), ...).  WHEN the value changes is the same for every experiment (a
+    function of time only); only what it changes to differs, so the per-step state machine runs once and every change is applied to
+    all columns together, each column drawing from its own generators in its own order."""
+    import random as _random
+    u = dict(updater)
+    inf = lambda v: np.inf if isinstance(v, str) and v == "inf" else v                      # noqa: E731
+    change_every, reset_every = inf(u["change_every_x_seconds"]), inf(u["reset_every_x_seconds"])
+    mode, increment, clip = u["mode"], u["increment"], u["range_clip"]
+    if mode not in ("constant", "random walk", "increase", "random", "random_gaussian", "bounce"):
+        raise ValueError("mode with value {} not valid".format(mode))
+    f, E, n = dtype, len(seeds), len(times)
+    rs = [np.random.RandomState(int(sd)) for sd in seeds]
+    # the schedule of events: 0 = keep, 1 = reset, 2 = change
+    events = np.zeros(n, np.int8)
+    last_change = last_reset = 0.0
+    for g in range(1, n):
+        t = times[g] if time_after_step else times[g - 1]
+        if change_every and t - last_change < change_every:
+            continue
+        if reset_every and mode != "constant" and t - last_reset >= reset_every:
+            last_reset = t
+            events[g] = 1
+        else:
+            last_change = t
+            events[g] = 2
+    n_changes = int((events == 2).sum())
+    reset_to = np.empty(E, np.float64)
+    if u["init_value"] == "random":                               # the first draw of every experiment's numpy generator
+        for e in range(E):
+            reset_to[e] = rs[e].uniform(*u["range_random"])
+    else:
+        reset_to[:] = u["init_value"]
+    cur = reset_to.astype(f) if init is None else np.broadcast_to(np.asarray(init, np.float64), (E,)).astype(f)
+    draws = None
+    if mode == "random":
+        draws = np.stack([r.uniform(*u["range_random"], size=n_changes) for r in rs], axis=1) if n_changes else np.empty((0, E))
+    elif mode == "random_gaussian":
+        draws = np.stack([r.normal(reset_to[e], increment, size=n_changes) for e, r in enumerate(rs)], axis=1) if n_changes else np.empty((0, E))
+    elif mode == "random walk":
+        draws = np.empty((n_changes, E))
+        for e, sd in enumerate(seeds):
+            pr = _random.Random(int(sd))
+            draws[:, e] = [1.0 if pr.random() < 0.5 else -1.0 for _ in range(n_changes)]
+    direction = np.ones(E)
+    out = np.empty((n, E), f)
+    out[0] = cur
+    k = 0
+    for g in range(1, n):
+        ev = events[g]
+        if ev == 1:
+            cur = reset_to.astype(f)
+        elif ev == 2:
+            if mode in ("random", "random_gaussian"):
+                cur = draws[k].astype(f)
+            else:
+                if mode == "constant":
+                    inc = np.zeros(E)
+                elif mode == "random walk":
+                    inc = draws[k] * increment
+                elif mode == "increase":
+                    inc = np.full(E, increment)
+                else:                                              # bounce
+                    inc = direction * increment
+                    nxt = cur + inc.astype(f)
+                    direction = np.where((nxt >= clip[1]) | (nxt <= clip[0]), -direction, direction)
+                cur = cur + inc.astype(f)
+                if clip:
+                    cur = np.clip(cur, f(clip[0]), f(clip[1])).astype(f)
+            k += 1
+        out[g] = cur
+    return out
+
+
 def informer_table(informer, times, n_ctrl, np_random=None):
     """`inform_controller_about_parameters_change` (cartpole_physical_parameters.yml; CartPole/controller_informer.py:5-50): the
     simulator asks its ControllerInformer at every controller update - simulation steps 0, n_ctrl, 2 n_ctrl, ... with the time AFTER
@@ -372,18 +447,17 @@ def informer_table(informer, times, n_ctrl, np_random=None):
     else:
         on_after_now, off_after_now = on_after, off_after
     told, since_on, since_off = False, 0.0, 0.0
-    for g in range(len(times)):
-        if g % n_ctrl == 0:
-            t = times[g]
-            if not told and t - since_off >= on_after_now:
-                told, since_on = True, t
-                if rnd:
-                    on_after_now = np_random.uniform(0, on_after)
-            elif told and t - since_on >= off_after_now:
-                told, since_off = False, t
-                if rnd:
-                    off_after_now = np_random.uniform(0, off_after)
-        out[g] = told
+    for g in range(0, len(times), n_ctrl):                       # asked at the controller updates only; the answer holds in between
+        t = times[g]
+        if not told and t - since_off >= on_after_now:
+            told, since_on = True, t
+            if rnd:
+                on_after_now = np_random.uniform(0, on_after)
+        elif told and t - since_on >= off_after_now:
+            told, since_off = False, t
+            if rnd:
+                off_after_now = np_random.uniform(0, off_after)
+        out[g:g + n_ctrl] = told
     return out
 
 
@@ -450,8 +524,7 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
             col = parameter_table(blk, batch.times)               # the same for every experiment: tabulated once
             out[field_] = np.array(np.broadcast_to(col[:, None], (len(col), E)))
         else:
-            out[field_] = np.stack([parameter_table(blk, batch.times, _random.Random(int(seed) + first + e),
-                                                    np.random.RandomState(int(seed) + first + e)) for e in range(E)], axis=1)
+            out[field_] = parameter_tables(blk, batch.times, [int(seed) + first + e for e in range(E)])
     inf = parameters.get("inform_controller_about_parameters_change")
     if inf is not None:
         if inf.get("mode") != "switching_random":
@@ -480,13 +553,12 @@ def apply_parameter_schedule(batch, parameters, seed=0, first=0):
             col = parameter_table(vao, batch.times, init=init, **kw)
             out["angle_offset"] = np.array(np.broadcast_to(col[:, None], (len(col), E)))
         else:
-            cols = []
-            for e in range(E):
-                rs = np.random.RandomState(int(seed) + first + e + 2)
-                i0 = init if init is not None else np.deg2rad(rs.uniform(*vao["range_random"]))
-                cols.append(parameter_table(dict(vao, init_value=vao["init_value"] if init is not None else 0.0), batch.times,
-                                            _random.Random(int(seed) + first + e + 2), rs, init=i0, **kw))
-            out["angle_offset"] = np.stack(cols, axis=1)
+            seeds = [int(seed) + first + e + 2 for e in range(E)]
+            if init is None:                                       # 'random' start: drawn in DEGREES like the YAML's number, per experiment
+                i0 = np.deg2rad([np.random.RandomState(sd + 7).uniform(*np.rad2deg(vao["range_random"])) for sd in seeds])
+                out["angle_offset"] = parameter_tables(dict(vao, init_value=0.0), batch.times, seeds, init=i0, **kw)
+            else:
+                out["angle_offset"] = parameter_tables(vao, batch.times, seeds, init=init, **kw)
     return dataclasses.replace(batch, **out)
 
 

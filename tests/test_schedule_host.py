@@ -269,3 +269,26 @@ def test_measurement_chain_tables_follow_the_references(g):
         SC.apply_parameter_schedule(b, dict(latency=0.5))                               # more than the reference's buffer holds
     with pytest.raises(ValueError):
         SC.apply_parameter_schedule(b, dict(noise=dict(sen["noise"], noise_mode="ON")))  # no seed
+
+
+def test_parameter_tables_for_many_experiments_equal_the_single_experiment_form():
+    """schedule.parameter_tables (every experiment's column at once: the change schedule is a function of time only) against
+    parameter_table column by column - all six modes, 'random' and given initial values, a change at every step and every few steps,
+    resets, the float32 form (L, m_pole) and the float64 form updated after the step (the vertical angle offset)."""
+    import random
+    times = SC.accumulated_times(900, 0.002)
+    base = dict(init_value=0.1, change_every_x_seconds=0.014, range_random=[0.05, 0.3], range_clip=[0.06, 0.25], increment=0.01,
+                reset_every_x_seconds=0.5)
+    seeds = [5, 6, 9]
+    for mode in ("constant", "increase", "bounce", "random walk", "random", "random_gaussian"):
+        for init in (0.1, "random"):
+            for every in (0.014, None):
+                for kw in (dict(dtype=np.float32), dict(dtype=np.float64, init=0.02, time_after_step=True)):
+                    u = dict(base, mode=mode, init_value=init, change_every_x_seconds=every)
+                    tabs = SC.parameter_tables(u, times, seeds, **kw)
+                    assert tabs.shape == (len(times), 3) and tabs.dtype == kw["dtype"]
+                    for e, sd in enumerate(seeds):
+                        col = SC.parameter_table(u, times, random.Random(sd), np.random.RandomState(sd), **kw)
+                        assert np.array_equal(col, tabs[:, e]), (mode, init, every, kw, e)
+    with pytest.raises(ValueError):
+        SC.parameter_tables(dict(base, mode="sideways"), times, seeds)
