@@ -47,7 +47,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; --config C3: 100, C4: 200)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; C3: 10, C4: 20)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 5; C3: 110, C4: 220 - a full pass: the first one after idle runs slow)")
     ap.add_argument("--envs", type=int, default=8192, help="independent MPPI problem instances per GPU")
     ap.add_argument("--rollouts", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=50)
@@ -85,7 +85,7 @@ def parse_args(argv=None):
         args.envs, args.rollouts, args.horizon = PRESETS[args.config]
     # the small configurations take ~0.1-0.3 ms per step and start from u_nom = 0 (the first steps meet more rare events
     # than the settled loop): their default run is as long as the side measurements of the default line
-    d_steps, d_warm = {"C3": (100, 10), "C4": (200, 20)}.get(args.config, (20, 3))
+    d_steps, d_warm = {"C3": (100, 110), "C4": (200, 220)}.get(args.config, (20, 5))           # (default line: the driver's --steps 20 --warmup 5)
     args.steps = d_steps if args.steps is None else args.steps
     args.warmup = d_warm if args.warmup is None else args.warmup
     return args
