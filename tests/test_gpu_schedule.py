@@ -789,3 +789,67 @@ def test_controller_pole_mass_follows_a_uniform_schedule_with_predictor_ODE(grou
     if groups > 1:
         eg.close()
     eng.close()
+
+
+def test_plant_step_and_groups_refuse_what_they_cannot_run():
+    """Argument validation of the round's C entry points straight through ctypes: a refused call returns its error code with a text in
+    cpmppi_last_error and launches nothing (the state is untouched)."""
+    import ctypes as C
+    from cartpolesimulation_amd import _lib as L
+    from cartpolesimulation_amd.configs import MPPIConfig, build_c_config
+    from cartpolesimulation_amd.engine import MPPIEngine
+    E = 4
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=64, mpc_horizon=10))
+    lib = eng.lib
+    s, Q = eng.tensor(np.tile(O.create_cartpole_state(0.1, 0.0, 0.0, 0.0), (E, 1))), eng.zeros(E)
+    before = s.clone()
+    tab, tab64 = eng.zeros(11, E), torch.zeros(11, E, dtype=torch.float64, device=s.device)
+    meas, hist = eng.zeros(E, 6), eng.zeros(3, E, 6)
+
+    def call(**kw):
+        a = L.cpmppi_plant_args()
+        a.E, a.s, a.Q, a.n_substeps, a.period_steps, a.dt_sim = E, s.data_ptr(), Q.data_ptr(), 10, 10, 0.002
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if torch.is_tensor(v) else v)
+        rc = lib.cpmppi_plant_step(eng._h, C.byref(a), None)
+        return rc, lib.cpmppi_last_error(eng._h).decode()
+
+    bad = [
+        (dict(n_substeps=11), -1, "n_substeps"),
+        (dict(dt_sim=0.0), -1, "bad argument"),
+        (dict(L_table=tab), -1, "sched_rows"),                                             # a table without its row count
+        (dict(L_controller_table=tab, sched_rows=11), -1, "L_controller_table"),           # ... stands in for L_table: give both
+        (dict(Q_disturbance_table=tab), -1, "ctrl_rows"),
+        (dict(row_envs=2), -1, "row_envs"),
+        (dict(s_measured=meas, latency_steps=2, state_history=hist, history_len=3), -1, "history_len"),
+        (dict(s_measured=meas, latency_steps=1), -1, "state_history"),
+        (dict(s_measured=meas, latency_frac=1.5, state_history=hist, history_len=3), -1, "latency_frac"),
+        (dict(s_measured=meas, measurement_noise_table=eng.zeros(3, E, 4)), -1, "ctrl_rows"),
+        (dict(s_measured=meas, angle_offset_table=tab64), -1, "sched_rows"),
+        (dict(s_measured=meas, angle_offset_table=tab64.data_ptr() + 4, sched_rows=11), -5, "misaligned"),
+        (dict(Q_log=tab, ctrl_rows=11, period=11), -1, "period"),
+    ]
+    for kw, code, text in bad:
+        rc, msg = call(**kw)
+        assert rc == code and text in msg, (kw.keys(), rc, msg)
+    torch.cuda.synchronize()
+    assert torch.equal(s, before)                                      # nothing was launched
+    assert call()[0] == 0                                              # ... and the plain call still runs
+    torch.cuda.synchronize()
+    assert not torch.equal(s, before)
+    # env groups
+    cfg = build_c_config(E, eng.mppi, eng.phys)
+    g = C.c_void_p()
+    assert lib.cpmppi_groups_create(C.byref(cfg), 0, 0, 0, C.byref(g)) == -1 and b"groups" in lib.cpmppi_groups_last_error(None)
+    assert lib.cpmppi_groups_create(C.byref(cfg), 0, 9, 0, C.byref(g)) == 0 and lib.cpmppi_groups_count(g) == E    # (more groups than envs: one env each)
+    assert lib.cpmppi_groups_run(g, None, None, 1) == -1 and b"neither" in lib.cpmppi_groups_last_error(g)
+    a = L.cpmppi_plant_args()
+    a.E, a.s, a.Q, a.n_substeps, a.period_steps, a.dt_sim = E - 1, s.data_ptr(), Q.data_ptr(), 10, 10, 0.002
+    assert lib.cpmppi_groups_run(g, None, C.byref(a), 1) == -1 and b"total env count" in lib.cpmppi_groups_last_error(g)
+    a.E = E
+    counter = torch.zeros(1, dtype=torch.int64, device=s.device)
+    a.period_dev = counter.data_ptr()
+    assert lib.cpmppi_groups_run(g, None, C.byref(a), 1) == -1 and b"period_dev" in lib.cpmppi_groups_last_error(g)
+    assert lib.cpmppi_groups_slice(g, E, None, None) == -1 and lib.cpmppi_groups_handle(g, E) is None
+    lib.cpmppi_groups_destroy(g)
+    eng.close()
