@@ -93,7 +93,7 @@ class BatchedCartPoleExperiment:
         return dict(states=states, Q=Qs, final_state=s, u_nom=u_nom)
 
     # ------------------------------------------------------------------ the data generator's experiments (moving targets)
-    def run_schedule(self, batch, env_offset=0, graph=False, steps_per_graph=10, knots_fn=None, u_nom0=None):
+    def run_schedule(self, batch, env_offset=0, graph=False, steps_per_graph=10, knots_fn=None, u_nom0=None, optimizer=None):
         """Run the E experiments of a schedule.ExperimentBatch to their end: CartPole.run_cartpole_random_experiment
         (CartPole/__init__.py:659-735) for all of them at once.  Per control period two launches - the fused MPPI step, reading
         the period's target position / equilibrium (/ pole length) from three [E] vectors, and cpmppi_plant_step, which advances
@@ -102,10 +102,15 @@ class BatchedCartPoleExperiment:
         the last row).  -> dict of device tensors: states [R,E,6], dd [R,E,2] (angleDD, positionDD), Q [periods + 1, E], final
         state and nominal sequences; rows are the simulation steps 0, n_save, 2 n_save, ...
         ``u_nom0`` [E,H]: nominal sequences to start from (a controller that has been stepped before; default zeros).
-        ``knots_fn(c)`` (tests): perturbation knots [E,N,P] for controller call c instead of the in-kernel Philox draw."""
-        run = ScheduleRun(self.engine, batch, self.seed, env_offset=env_offset, knots_fn=knots_fn, u_nom0=u_nom0)
+        ``knots_fn(c)`` (tests): perturbation knots [E,N,P] for controller call c instead of the in-kernel Philox draw.
+        ``optimizer``: any of the package's optimizers configured for the batch's E envs (`controller_mpc(..., num_envs=E)
+        .configure(...).optimizer`: cem, rpgd, gradient, ...) computes the controls instead of the fused MPPI step - host-paced, one
+        `optimizer.step` per control period on device tensors, the plant / schedule / recording launch unchanged."""
+        run = ScheduleRun(self.engine, batch, self.seed, env_offset=env_offset, knots_fn=knots_fn, u_nom0=u_nom0, optimizer=optimizer)
         if batch.dt_simulation != self.dt_simulation or batch.n_ctrl != self.n_sub:
             raise ValueError("the batch was drawn for other time scales than this experiment runner's")
+        if graph and optimizer is not None:
+            raise ValueError("an optimizer object is paced by the host: run this batch launched (graph=False)")
         if graph and knots_fn is None and run.T > 0:
             run.capture(steps_per_graph)
             while run.periods_left:
@@ -120,8 +125,15 @@ class ScheduleRun:
     """The device loop of BatchedCartPoleExperiment.run_schedule as an object that enqueues one piece at a time, so that several
     runs - env groups on their own streams, pipeline.run_schedule_groups - can be interleaved by one host thread."""
 
-    def __init__(self, engine, batch, seed, env_offset=0, knots_fn=None, u_nom0=None):
+    def __init__(self, engine, batch, seed, env_offset=0, knots_fn=None, u_nom0=None, optimizer=None):
         self.eng, self.b, self.seed, self.env_offset, self.knots_fn = engine, batch, int(seed), int(env_offset), knots_fn
+        self.optimizer = optimizer
+        if optimizer is not None:
+            if getattr(optimizer, "num_envs", batch.E) != batch.E:
+                raise ValueError(f"the optimizer is configured for {optimizer.num_envs} envs, the batch has {batch.E}")
+            if getattr(optimizer, "variable_parameters", None) is None:
+                from types import SimpleNamespace
+                optimizer.variable_parameters = SimpleNamespace()
         eng, b = engine, batch
         E, T = b.E, b.n_periods
         self.T, self.c = T, 0
@@ -229,6 +241,22 @@ class ScheduleRun:
 
     def _control(self, c):
         eng = self.eng
+        if self.optimizer is not None:
+            # what the simulator hands controller.step (CartPole/__init__.py:509-520), as attributes of the optimizer's
+            # variable_parameters; the optimizer returns the controls as a device tensor
+            vp = self.optimizer.variable_parameters
+            vp.target_position, vp.target_equilibrium = self.cur_tp, self.cur_te
+            if self.cur_L is not None:
+                vp.L = self.cur_L
+            if self.m_ctrl is not None:
+                vp.m_pole = float(self.m_ctrl[c])
+            if self.prev_Q is not None:
+                vp.Q_ccrc = self.prev_Q
+                setattr(vp, "Q_applied_-1", self.prev_Q)
+            t = float(self.b.times[min(c * self.b.n_ctrl, len(self.b.times) - 1)])
+            q = self.optimizer.step(self.s_ctrl, t, as_tensor=True)
+            self.Q.copy_(q.reshape(-1))
+            return
         if c is not None:
             self.set_controller_mass(c)
         if self.knots_fn is not None:
@@ -241,7 +269,7 @@ class ScheduleRun:
                      Q_out=self.Q, **self._prev)
 
     def _period(self, c):
-        if self.counter is None and self.knots_fn is None:
+        if self.counter is None and self.knots_fn is None and self.optimizer is None:
             # the launched loop: two library calls per period on argument blocks built once (the Python-side argument handling of
             # step + plant_step is ~30 us per period - more than the GPU needs for a few dozen envs)
             self.set_controller_mass(c)
@@ -261,6 +289,8 @@ class ScheduleRun:
     def capture(self, steps_per_graph=10):
         """Capture `steps_per_graph` control periods as ONE HIP graph (device step counter: Philox offset = schedule row =
         recording row, no launch argument changes between periods); enqueue_next then replays it."""
+        if self.optimizer is not None:
+            raise ValueError("an optimizer object is paced by the host: run this batch launched (graph=False)")
         if self.m_ctrl is not None and len(np.unique(self.m_ctrl)) > 1:
             raise ValueError("a captured graph replays ONE pole mass for the controller: run this batch launched (graph=False)")
         dev = self.s.device

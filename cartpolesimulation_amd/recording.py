@@ -239,7 +239,7 @@ def experiment_folder(root, secondary_experiment_index=None, digits=3):
 
 def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, seed=None, cartpole_seed=None, L=None, native=True,
                      graph=False, secondary_experiment_index=None, controller_name="mpc", optimizer_name="mppi", title=None, groups=1,
-                     rank=0, world=1, parameters=None):
+                     rank=0, world=1, parameters=None, optimizer=None):
     """Batched run_data_generator: ``config`` = config_data_gen.yml as a dict (or overrides of the shipped file, see
     schedule.merged_config) - length_of_experiment, the three dt, the random initial state, the target trace's turning points
     and interpolation types, the target-equilibrium dwell times, number_of_experiments, ML_Pipeline_mode / split.  All
@@ -255,7 +255,10 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     `cartpole:` section - a pole length and a pole mass that change DURING the experiments (CartPole/parameter_updater.py) and a
     controller that is told the true length only part of the time - its `controlDisturbance` / `controlBias` / `seed`: the additive
     control disturbance the reference's author collects training data with - and its measurement chain: `latency`, `noise`
-    (noise_mode + the four sigmas), `vertical_angle_offset` (schedule.apply_parameter_schedule)."""
+    (noise_mode + the four sigmas), `vertical_angle_offset` (schedule.apply_parameter_schedule).
+    ``optimizer``: one of the package's optimizer objects configured for the run's experiments (`controller_mpc(config_root=...,
+    num_envs=n).configure().optimizer` - the shipped config_controllers.yml names rpgd) controls the plants instead of the fused MPPI
+    step; `engine` may then be None (the optimizer's own engine runs the plant)."""
     import time
     from .harness import BatchedCartPoleExperiment
     from .schedule import RandomExperimentSetter, merged_config
@@ -264,6 +267,14 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
         cfg["seed"] = int(seed)
     n_total = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
     cseed = cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1
+    if optimizer is not None:
+        if int(groups) > 1 or graph:
+            raise ValueError("an optimizer object is paced by the host: groups=1, graph=False")
+        if getattr(optimizer, "engine", None) is None:
+            from .shard import env_shard
+            optimizer.configure(num_envs=env_shard(n_total, int(world), int(rank))[1])
+        engine = optimizer.engine
+        optimizer_name = getattr(optimizer, "optimizer_name", optimizer_name)
     _first = 0                                                     # global index of this process's first experiment (Philox keys)
     _stride = 1 if parameters and any(parameters.get(k) is not None for k in ("L", "m_pole", "inform_controller_about_parameters_change",
                                                                                 "vertical_angle_offset")) else None
@@ -292,7 +303,7 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
             eg.close()
     else:
         exp = BatchedCartPoleExperiment(engine, batch.dt_simulation, batch.dt_control, seed=cfg["seed"])
-        res = exp.run_schedule(batch, graph=graph, env_offset=_first)
+        res = exp.run_schedule(batch, graph=graph, env_offset=_first, optimizer=optimizer)
         torch.cuda.synchronize()
     per_call = (time.perf_counter() - t0) / (batch.n_periods + 1)   # what Q_update_time can honestly say: wall time per controller update of the batch
     phys = engine.phys
@@ -333,10 +344,20 @@ def main(argv=None):
                     help="Train / Validate / Test folders (config_data_gen.yml: ML_Pipeline_mode)")
     ap.add_argument("-i", "--secondary_experiment_index", type=int, default=-1)
     ap.add_argument("--groups", type=int, default=1, help="independent env groups, each on its own stream (pipeline.py)")
+    ap.add_argument("--optimizer", default=None,
+                    help="mppi (the fused hot path; default without --config-root) or any other optimizer of the package - cem, cem-gmm, "
+                         "rpgd, gradient, ... - paced by the host; with --config-root the default is the checkout's own "
+                         "config_controllers.yml `mpc: optimizer` (shipped: rpgd)")
     ap.add_argument("--cost", default=None,
                     choices=["legacy_mppi_cartpole", "default", "quadratic_boundary_grad_minimal", "quadratic_boundary_grad"])
     args = ap.parse_args(argv)
-    phys, parameters, dg = None, None, {}
+    phys, parameters, dg, optimizer = None, None, {}, None
+    opt_name = args.optimizer
+    if args.config_root and opt_name is None:
+        import yaml as _yaml
+        with open(os.path.join(args.config_root, "Control_Toolkit_ASF", "config_controllers.yml")) as fh:
+            opt_name = _yaml.safe_load(fh)["mpc"].get("optimizer") or "mppi"
+    opt_name = opt_name or "mppi"
     if args.config_root:
         from .schedule import active_parameters
         import yaml
@@ -368,8 +389,21 @@ def main(argv=None):
     out = args.out if args.out is not None else dg.get("PATH_TO_EXPERIMENT_RECORDINGS_DEFAULT", "./Experiment_Recordings/")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))     # one process per GPU under torchrun
     from .shard import env_shard
-    eng = MPPIEngine(env_shard(n_exp, world, rank)[1], cfg, phys=phys, device=int(os.environ.get("LOCAL_RANK", "0")))
+    n_local, device = env_shard(n_exp, world, rank)[1], int(os.environ.get("LOCAL_RANK", "0"))
+    eng = None
+    if opt_name == "mppi":
+        eng = MPPIEngine(n_local, cfg, phys=phys, device=device)
+    else:                                                          # another optimizer of the package, built as controller_mpc builds it
+        from .controller_mpc import controller_mpc
+        over = {k: v for k, v in (("num_rollouts", args.rollouts), ("mpc_horizon", args.horizon), ("seed", seed)) if v is not None}
+        if args.cost not in (None, "legacy_mppi_cartpole"):
+            over["cost_function_specification"] = args.cost
+        ctrl = controller_mpc("CartPole", {}, control_limits=([-1.0], [1.0]), config=over, phys=phys, device=device, num_envs=n_local,
+                              config_root=args.config_root)
+        ctrl.configure(opt_name)
+        optimizer = ctrl.optimizer
     paths = generate_dataset(eng, n_exp, out, seed=seed, rank=rank, world=world, config=dg, groups=args.groups, parameters=parameters,
+                             optimizer=optimizer,
                              secondary_experiment_index=None if args.secondary_experiment_index < 0 else args.secondary_experiment_index)
     print(f"wrote {len(paths)} recordings under {os.path.dirname(paths[0])}")
 

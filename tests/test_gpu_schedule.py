@@ -853,3 +853,49 @@ def test_plant_step_and_groups_refuse_what_they_cannot_run():
     assert lib.cpmppi_groups_slice(g, E, None, None) == -1 and lib.cpmppi_groups_handle(g, E) is None
     lib.cpmppi_groups_destroy(g)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["rpgd", "cem"])
+def test_device_loop_with_another_optimizer_of_the_package(name):
+    """The shipped config_controllers.yml names `optimizer: rpgd`: run_schedule(optimizer=...) lets any of the package's optimizers
+    (built by controller_mpc for the batch's E envs) compute the controls - one optimizer.step per control period on device tensors,
+    fed the schedule's target position / equilibrium like the simulator feeds controller.step - while plant, schedule and recording
+    stay the one plant launch.  Equal to a loop paced by hand with an identically seeded optimizer; the plants are steered
+    (the targets are followed better than with no control at all)."""
+    from cartpolesimulation_amd import schedule as SC
+    from cartpolesimulation_amd.controller_mpc import controller_mpc
+    from cartpolesimulation_amd.harness import BatchedCartPoleExperiment
+    E = 3
+    cfg = dict(seed=37, length_of_experiment=0.24, keep_target_equilibrium_x_seconds_up=0.1, turning_points=dict(track_relative_complexity=12),
+               random_initial_state=dict(init_limits=dict(angle=[0.0, 10.0], angleD=20.0, position=0.3, positionD=0.1)))
+    b = SC.RandomExperimentSetter(cfg).draw(E, 81)
+    over = dict(seed=9, mpc_horizon=15, num_rollouts=32) if name == "rpgd" else dict(seed=9, mpc_horizon=15, num_rollouts=128)
+
+    def build():
+        c = controller_mpc("CartPole", {}, control_limits=([-1.0], [1.0]), config=over, num_envs=E)
+        c.configure(name)
+        return c.optimizer
+
+    opt = build()
+    assert opt.optimizer_name == name
+    res = BatchedCartPoleExperiment(opt.engine, seed=0).run_schedule(b, optimizer=opt)
+    Q_loop, states = res["Q"].cpu().numpy(), res["states"].cpu().numpy()
+    assert Q_loop.shape == (b.n_periods + 1, E) and np.isfinite(states).all() and np.abs(Q_loop).max() > 0.05
+    with pytest.raises(ValueError):
+        BatchedCartPoleExperiment(opt.engine, seed=0).run_schedule(b, optimizer=opt, graph=True)
+    # by hand, a fresh optimizer with the same seed
+    opt2 = build()
+    eng = opt2.engine
+    s, out = eng.tensor(b.s0).clone(), []
+    for c in range(b.n_periods + 1):
+        row = int(b.rows_at(c * b.n_ctrl))
+        vp = opt2.variable_parameters
+        vp.target_position, vp.target_equilibrium = b.target_position[row].astype(f32), b.target_equilibrium[row].astype(f32)
+        Q = opt2.step(s, float(b.times[c * b.n_ctrl]), as_tensor=True).reshape(-1).clone()
+        out.append(Q.cpu().numpy().copy())
+        if c < b.n_periods:
+            eng.plant_step(s, Q, b.n_ctrl, dt_sim=b.dt_simulation, period=c)
+    assert np.array_equal(Q_loop, np.stack(out))
+    assert np.allclose(states[-1], s.cpu().numpy(), atol=0, rtol=0)
+    opt.engine.close()
+    eng.close()

@@ -338,7 +338,7 @@ def test_generator_cli_reads_a_checkouts_yaml_files(tmp_path, capsys):
     dump("Control_Toolkit_ASF/config_cost_function.yml", dict(cost_function_name_default="quadratic_boundary_grad_minimal",
                                                               CartPole=dict(quadratic_boundary_grad_minimal={})))
     dump("SI_Toolkit_ASF/config_predictors.yml", dict(predictors=dict(ODE_v0_default=dict(predictor_type="ODE_v0", intermediate_steps=10))))
-    R.main(["--config-root", str(root)])
+    R.main(["--config-root", str(root)])                               # (this checkout's config_controllers.yml names mppi)
     assert "wrote 3 recordings" in capsys.readouterr().out
     files = sorted(os.listdir(tmp_path / "rec"))
     assert files == ["Experiment-1.csv", "Experiment-2.csv", "Experiment.csv"]
@@ -347,6 +347,21 @@ def test_generator_cli_reads_a_checkouts_yaml_files(tmp_path, capsys):
     qc, qa = d["Q_calculated"].to_numpy().astype(f32), d["Q_applied"].to_numpy().astype(f32)
     z = SC.control_disturbance(3, 11, 3)[:, 1]                                          # experiment 1 of the run, seed of the YAML
     assert np.array_equal(qa[::2], ((qc[::2] + f32(0.1) * z).astype(f32) + f32(0.0)).astype(f32))
+    # another optimizer of the package: the checkout's own section of config_optimizers.yml, the same plant, schedule and recording
+    import yaml as _y
+    opts = _y.safe_load((root / "Control_Toolkit_ASF" / "config_optimizers.yml").read_text())
+    opts["rpgd"] = dict(seed=None, mpc_horizon=12, mpc_timestep=0.02, SAMPLING_DISTRIBUTION="uniform", period_interpolation_inducing_points=4,
+                        learning_rate=0.05, adam_beta_1=0.9, adam_beta_2=0.999, adam_epsilon=1.0e-8, gradmax_clip=5, rtol=1.0e-3,
+                        num_rollouts=16, opt_keep_k_ratio=0.75, outer_its=2, resamp_per=10, sample_stdev=0.5, sample_mean=0.0,
+                        sample_whole_control_space=True, uniform_dist_max=0.8, uniform_dist_min=-0.8, shift_previous=1, warmup=False,
+                        warmup_iterations=250)
+    dump("Control_Toolkit_ASF/config_optimizers.yml", opts)
+    R.main(["--config-root", str(root), "--optimizer", "rpgd", "--experiments", "2", "--out", str(tmp_path / "rec_rpgd")])
+    d2 = pd.read_csv(tmp_path / "rec_rpgd" / "Experiment-1.csv", comment="#", float_precision="round_trip")
+    assert len(d2) == 21 and np.isfinite(d2["angle"]).all() and np.abs(d2["Q_calculated"]).max() > 0.01
+    assert np.array_equal(d2["L"].to_numpy(), d["L"].to_numpy()) and list(d2["L_for_controller"]) == list(d["L_for_controller"])
+    head = open(tmp_path / "rec_rpgd" / "Experiment-1.csv").read(2000)
+    assert "rpgd" in head
     # flags override the files
     R.main(["--config-root", str(root), "--experiments", "2", "--length", "0.1", "--out", str(tmp_path / "rec2")])
     assert sorted(os.listdir(tmp_path / "rec2")) == ["Experiment-1.csv", "Experiment.csv"]
@@ -371,7 +386,7 @@ def test_generator_cli_on_the_reference_checkout(monkeypatch):
 
     monkeypatch.setattr(ENG, "MPPIEngine", Engine)
     monkeypatch.setattr(R, "generate_dataset", gen)
-    R.main(["--config-root", "/root/reference", "--seed", "4", "--experiments", "8"])
+    R.main(["--config-root", "/root/reference", "--seed", "4", "--experiments", "8", "--optimizer", "mppi"])
     import yaml
     dg = yaml.safe_load(open("/root/reference/config_data_gen.yml"))
     opt = yaml.safe_load(open("/root/reference/Control_Toolkit_ASF/config_optimizers.yml"))["mppi"]
