@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPMPPI_LIB") or os.path.join(_HERE, "libcpmppi.so")   # CPMPPI_LIB: development builds (tools/)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 COST_QBGM, COST_DEFAULT, COST_LEGACY, COST_QBG, COST_QB, COST_QB_NONCONVEX = 0, 1, 2, 3, 4, 5
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 CONTROL_CLIP, CONTROL_PENALISE = 0, 1
@@ -25,8 +25,9 @@ EXPORTS = ("cpmppi_create", "cpmppi_destroy", "cpmppi_last_error", "cpmppi_get_c
            "cpmppi_step_gather", "cpmppi_last_launch", "cpmppi_comm_set_timeout", "cpmppi_write_recordings", "cpmppi_plant_step",
            "cpmppi_abi_version", "cpmppi_stream_create", "cpmppi_stream_destroy", "cpmppi_comm_get_info",
            "cpmppi_groups_create", "cpmppi_groups_destroy", "cpmppi_groups_count", "cpmppi_groups_slice", "cpmppi_groups_handle",
-           "cpmppi_groups_stream", "cpmppi_groups_fork", "cpmppi_groups_join", "cpmppi_groups_run", "cpmppi_groups_last_error")
-COMM_ID_BYTES, COMM_SLOTS = 128, 4
+           "cpmppi_groups_stream", "cpmppi_groups_fork", "cpmppi_groups_join", "cpmppi_groups_run", "cpmppi_groups_last_error",
+           "cpmppi_comm_set_stamped", "cpmppi_groups_comm_init", "cpmppi_groups_run_gather")
+COMM_ID_BYTES, COMM_SLOTS, GATHER_STAMP_FLOATS = 128, 4, 4
 
 
 class cpmppi_config(C.Structure):
@@ -90,7 +91,8 @@ class cpmppi_recording(C.Structure):
 
 class cpmppi_comm_info(C.Structure):
     _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32),
-                ("rccl_version", C.c_int32), ("stream_memory_ops", C.c_uint32), ("gathers_enqueued", C.c_uint32)]
+                ("rccl_version", C.c_int32), ("stream_memory_ops", C.c_uint32), ("gathers_enqueued", C.c_uint32),
+                ("stamped", C.c_uint32)]
 
 
 PREDICTOR_ODE_V0, PREDICTOR_GRU = 0, 1
@@ -179,6 +181,9 @@ def load():
     lib.cpmppi_groups_fork.argtypes = [vp, vp]
     lib.cpmppi_groups_join.argtypes = [vp, vp]
     lib.cpmppi_groups_run.argtypes = [vp, C.POINTER(cpmppi_step_args), C.POINTER(cpmppi_plant_args), u32]
+    lib.cpmppi_groups_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_char_p]
+    lib.cpmppi_groups_run_gather.argtypes = [vp, C.POINTER(cpmppi_step_args), C.POINTER(cpmppi_plant_args), u32, vp]
+    lib.cpmppi_comm_set_stamped.argtypes = [vp, C.c_int]
     lib.cpmppi_groups_last_error.argtypes = [vp]
     lib.cpmppi_groups_last_error.restype = C.c_char_p
     lib.cpmppi_last_launch.argtypes = [vp, C.POINTER(cpmppi_launch_info)]

@@ -361,7 +361,10 @@ __global__ __launch_bounds__(BLOCK) void plant_kernel(const Params p0, const Pla
         float* lg = a.states_log + ((size_t)r * E + env) * 6u;
         lg[0] = st.th; lg[1] = st.w; lg[2] = st.c; lg[3] = st.s; lg[4] = st.x; lg[5] = st.v;
       }
-      if (i + 1u < a.n_sub) log_dd(g);                                 // (the period's last step gets its control from the next call)
+      // a FULL period's last step gets its control (hence its derivatives) from the next controller call; the steps of a
+      // trailing partial period (n_sub < period_steps: the run ends inside a period) are followed by no call - their rows are
+      // completed here under the held control, as the reference's save does (advisor, round 5)
+      if (i + 1u < a.period_steps) log_dd(g);
     }
   }
   se[0] = st.th; se[1] = st.w; se[2] = st.c; se[3] = st.s; se[4] = st.x; se[5] = st.v;
@@ -1037,11 +1040,23 @@ __global__ __launch_bounds__(BLOCK) void fold_env_kernel(const Params p, const f
   out[env] = f;
 }
 
-// development aid (tools/variant_sweep.py): the two size limits below which the straight-line builds are launched, overridable
-// from the environment so that one library can be swept over them
-static uint64_t env_u64(const char* name, uint64_t dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
+// development aid (tools/variant_sweep.py, tools/dev/placement.py): the two size limits below which the straight-line builds are
+// launched and an LDS pad, overridable from the environment - in a -DCPMPPI_DEV_KNOBS build ONLY (build_variant "devknobs"), and
+// read when a handle is created, not per launch.  The shipped library has the constants: no getenv on the launch path, and no stray
+// environment variable can change which kernel production launches (advisor, round 5).
+struct DevKnobs { uint64_t lone_form_max_waves = 1024ull, latency_max_rollouts = 131071ull, lds_pad = 0; };
+static DevKnobs g_knobs;
+static void refresh_dev_knobs() {
+#ifdef CPMPPI_DEV_KNOBS
+  auto env_u64 = [](const char* name, uint64_t dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? (uint64_t)strtoull(v, nullptr, 10) : dflt;
+  };
+  const DevKnobs d;
+  g_knobs.lone_form_max_waves = env_u64("CPMPPI_LONE_FORM_MAX_WAVES", d.lone_form_max_waves);
+  g_knobs.latency_max_rollouts = env_u64("CPMPPI_LATENCY_MAX_ROLLOUTS", d.latency_max_rollouts);
+  g_knobs.lds_pad = env_u64("CPMPPI_LDS_PAD", 0);
+#endif
 }
 template <int COST, bool FAST, int R, int V, int INTEG = PREDICTOR_ODE_V0>
 hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream_t s, const Params& p,
@@ -1056,7 +1071,7 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
     default: {
       // development aid (tools/dev/placement.py): CPMPPI_LDS_PAD=<bytes> of extra dynamic LDS per workgroup caps how many
       // workgroups the dispatcher can put on one CU (160 KB each)
-      static const size_t pad = (size_t)env_u64("CPMPPI_LDS_PAD", 0);
+      const size_t pad = (size_t)g_knobs.lds_pad;
       if (pad) {
         static bool raised = false;
         if (!raised) {
@@ -1083,10 +1098,10 @@ hipError_t launch_rollout_noise(uint32_t noise, dim3 grid, size_t lds, hipStream
 #endif
 constexpr uint64_t MID_SIZE_MAX_ROLLOUTS = CPMPPI_MID_SIZE_MAX;   // (a -D override exists for A/B builds only)
 constexpr uint64_t PACKED_MIN_ROLLOUTS = 131072ull;
-static uint64_t lone_form_max_waves() { return env_u64("CPMPPI_LONE_FORM_MAX_WAVES", 1024ull); }
+static uint64_t lone_form_max_waves() { return g_knobs.lone_form_max_waves; }
 // (round 5, tools/variant_sweep.py: between 65536 and 131072 rollouts - where the size rule still picks one rollout per lane - the
 // straight-line latency build beats the throughput build's loop: 48 x 2048 x 50 71.3 vs 79.8 us, 96 x 1024 x 50 74.9 vs 83.3)
-static uint64_t latency_max_rollouts() { return env_u64("CPMPPI_LATENCY_MAX_ROLLOUTS", 131071ull); }
+static uint64_t latency_max_rollouts() { return g_knobs.latency_max_rollouts; }
 template <int COST>
 hipError_t launch_rollout_math(uint32_t math, uint32_t ode, uint32_t rpl, uint32_t noise, dim3 grid, size_t lds, hipStream_t s,
                                const Params& p, const StepPtrs& a, uint32_t* variant_out) {
@@ -1190,6 +1205,7 @@ int cpmppi_create(const cpmppi_config* cfg, int device, cpmppi_handle** out) try
   fill_params(*cfg, h->prm);
   h->plant_m_pole = cfg->m_pole;
   h->nb = (cfg->N + GRU_ROLLOUTS_PER_BLOCK - 1) / GRU_ROLLOUTS_PER_BLOCK;     // the finest block split in use
+  refresh_dev_knobs();
   if (const char* ev = getenv("CPMPPI_FUSE_FINALIZE")) h->fuse_finalize = ev[0] != '0';
   if (const char* ev = getenv("CPMPPI_HOST_ZERO_COPY_MAX")) h->host_zero_copy_max = (uint32_t)strtoul(ev, nullptr, 10);
   DeviceGuard guard(device);                     // the caller's current device is restored on every exit path
@@ -1480,7 +1496,7 @@ static int step_impl(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, 
   p.S_out = a->S_out; p.partial = h->workspace;
   p.counter = nullptr; p.u_nom_out = a->u_nom_out ? a->u_nom_out : a->u_nom; p.Q_out = a->Q_out;
   p.host_ticket = host_ticket;
-  p.gs = gather ? GatherSync{gather->flags, gather->publish, gather->need, a->E} : GatherSync{nullptr, 0u, 0u, 0u};
+  p.gs = gather ? GatherSync{gather->flags, gather->publish, gather->need, gather->envs ? gather->envs : a->E} : GatherSync{nullptr, 0u, 0u, 0u};
   hipEvent_t* ev = nullptr;
   const uint32_t group_pos = h->profile_every ? h->profile_count++ % h->profile_every : 0;
   const bool grouped = h->profile_every > 1;
@@ -1974,6 +1990,10 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* a, void* stream
   const bool tables = a->target_position_table || a->target_equilibrium_table || a->L_table || a->m_pole_table || a->L_controller_table;
   if (a->Q_disturbance_table && a->ctrl_rows == 0)
     return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: Q_disturbance_table needs ctrl_rows > 0");
+  // (the kernel writes the ring whenever it is given, measurement chain or not: advisor, round 5)
+  if (a->state_history && a->history_len == 0u)
+    return fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_plant_step: state_history needs history_len > 0");
+  if (misaligned(a->state_history)) return fail(h, CPMPPI_ERR_ALIGN, "cpmppi_plant_step: misaligned");
   if (a->s_measured) {
     const bool delayed = a->latency_steps != 0u || a->latency_frac != 0.0;
     if (delayed && (!a->state_history || a->history_len < a->latency_steps + 2u))
@@ -2085,3 +2105,7 @@ int cpmppi_stream_destroy(void* stream) {
 }
 
 }  // extern "C"
+
+int cpmppi_internal_step_ticket(cpmppi_handle* h, const cpmppi_step_args* a, void* stream, const cpmppi_comm::GatherTicket* ticket) {
+  return step_impl(h, a, stream, nullptr, ticket);
+}

@@ -65,12 +65,21 @@ Rccl g_rccl;
 bool load_rccl(const char* path) {
   Rccl& r = g_rccl;
   if (r.dl) return true;
-  // a caller-given path first; then whatever the process has already loaded under the names PyTorch-ROCm and ROCm use;
-  // then a fresh load by those names (libcpmppi.so's RUNPATH covers /opt/rocm/lib)
-  const char* names[] = {path, "librccl.so", "librccl.so.1"};
+  // a caller-given path wins and is loaded as given (round 6: it used to lose against an RCCL the process had already loaded -
+  // PyTorch's - because the already-loaded names were tried first); RTLD_LOCAL: its nccl* symbols are looked up here with dlsym
+  // and must not interpose anybody else's.  Without a path: whatever the process has already loaded under the names PyTorch-ROCm
+  // and ROCm use, then a fresh load by those names (libcpmppi.so's RUNPATH covers /opt/rocm/lib)
+  if (path && path[0]) {
+    r.dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!r.dl) {
+      const char* e = dlerror();
+      r.err = std::string("cannot load the collective library given as rccl_path: ") + (e ? e : path);
+      return false;
+    }
+  }
+  const char* names[] = {"librccl.so", "librccl.so.1"};
   for (int pass = 0; pass < 2 && !r.dl; ++pass) {
     for (const char* n : names) {
-      if (!n || !n[0]) continue;
       r.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (r.dl) break;
     }
@@ -108,6 +117,9 @@ struct CommState {
   bool pending[SLOTS] = {};
   // cpmppi_step_gather: ordering through device memory instead of events (no packet on the launch stream)
   unsigned* flags = nullptr;            // [0] envs finalized, [1] steps published (fallback waiter), [2] gathers completed, [3] error
+                                        // TWO blocks of FLAG_WORDS: flags (every step of a single handle; the odd step numbers of env
+                                        // groups) and flags + FLAG_WORDS (the even step numbers of env groups - `two_blocks`)
+  bool two_blocks = false;              // env groups share the communicator (cpmppi_groups_comm_init): see begin_step_gather
   unsigned* published = nullptr;        // 8 bytes of signal memory: steps published, watched by hipStreamWaitValue32 (NULL = fallback)
   unsigned* err_host = nullptr;         // pinned, device-mapped host word: the error flag as the host reads it
   unsigned gather_index = 0;            // step_gathers enqueued so far
@@ -115,25 +127,45 @@ struct CommState {
   unsigned long long timeout_ticks = 1000000000ull;   // 10 s of the 100 MHz device clock (cpmppi_comm_set_timeout)
   unsigned debug_delay_us = 0;          // tests: a spin of this length on the side stream in front of every all-gather
   const float* last_send = nullptr;     // the buffer the previous step_gather's all-gather reads
+  bool stamped = false;                 // cpmppi_comm_set_stamped: CPMPPI_GATHER_STAMP_FLOATS words behind every gathered block
 };
 
 // Fallback waiter (no stream memory operations), side stream, one lane: posts "gathers completed = post" (the all-gather in
 // front of it on the stream has finished) and then holds the stream until the rollout kernel's last finalizing block has
 // published step `need` (finalize_env, cpmppi_rollout.hpp).  A wait that gives up raises the error for device and host; the
 // all-gather behind it then sends whatever the buffer holds - the error tells every consumer not to use it.
-__global__ void post_wait_kernel(unsigned* flags, unsigned post, unsigned need, unsigned* err_host, unsigned long long timeout_ticks) {
-  if (post != 0u) __hip_atomic_store(flags + 2, post, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// (`other`: the second flag block of a communicator shared by env groups, or NULL - completions go to both, the step `need` is
+// published in the block of its parity, an error is raised in both)
+__global__ void post_wait_kernel(unsigned* flags, unsigned* other, unsigned post, unsigned need, unsigned* err_host, unsigned long long timeout_ticks) {
+  if (post != 0u) {
+    __hip_atomic_store(flags + 2, post, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (other) __hip_atomic_store(other + 2, post, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (need == 0u) return;
+  unsigned* mine = (other && (need & 1u) == 0u) ? other : flags;
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-  while ((int)(__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+  while ((int)(__hip_atomic_load(mine + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
     __builtin_amdgcn_s_sleep(64);      // (~4096 cycles between polls: the wave shares a SIMD with a rollout wave)
-    if (__hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    if (__hip_atomic_load(mine + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
       __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (other) __hip_atomic_store(other + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
+}
+
+// cpmppi_comm_set_stamped, side stream, one lane, between the wait for the published step and the all-gather: the step number goes
+// into the word behind the sequences - the peers' proof that the block is this step's and complete - UNLESS a device-side wait of
+// this communicator has given up: a dropped step left its buffer as it was, and the stamp stays what it was too (an older number).
+// While the error is up no block is stamped, including blocks of steps finished just before the drop whose gather ran after it:
+// the peers discard a little too much, never too little.  (It lives on the side stream on purpose: the rollout kernels are exactly
+// the round-5 binaries - a stamp store inside their finalize cost one instantiation a scratch slot.)
+__global__ void stamp_kernel(const unsigned* flags, const unsigned* other, unsigned* stamp, unsigned number) {
+  unsigned err = __hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (other) err |= __hip_atomic_load(other + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (err == 0u) __hip_atomic_store(stamp, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // tests only (cpmppi_debug_comm_delay): keeps the side stream busy for `ticks` of the 100 MHz clock - a slow peer
@@ -147,7 +179,9 @@ __global__ void delay_kernel(unsigned long long ticks) {
 constexpr int FLAG_WORDS = 16;
 hipError_t upload_slow_path_words(CommState* c) {
   unsigned long long w[3] = {(unsigned long long)(uintptr_t)c->published, (unsigned long long)(uintptr_t)c->err_host, c->timeout_ticks};
-  return hipMemcpy(c->flags + 4, w, sizeof(w), hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpy(c->flags + 4, w, sizeof(w), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->flags + FLAG_WORDS + 4, w, sizeof(w), hipMemcpyHostToDevice);
+  return e;
 }
 
 // Host wait for the side stream with a way out.  In stream-memory-operation mode the side stream's wait for a published step
@@ -175,6 +209,7 @@ bool drain_side_stream(CommState* c) {
   __atomic_store_n(c->err_host, 1u, __ATOMIC_RELEASE);
   const unsigned one = 1u;
   (void)hipMemcpy(c->flags + 3, &one, sizeof(one), hipMemcpyHostToDevice);      // (the side stream is non-blocking: this copy does not queue behind it)
+  (void)hipMemcpy(c->flags + FLAG_WORDS + 3, &one, sizeof(one), hipMemcpyHostToDevice);
   __atomic_store_n(reinterpret_cast<volatile unsigned*>(c->published), c->gather_index, __ATOMIC_RELEASE);
   (void)hipStreamSynchronize(c->side);
   return true;
@@ -197,11 +232,16 @@ void destroy(CommState* c) {
 // Gather number g (0-based) publishes steps = g + 1.  The buffer this step writes was last read by the all-gather two
 // steps back when the caller alternates two buffers (completed once gathers >= g - 1); when the step writes the very
 // buffer the previous gather reads (in place, or the same output twice in a row) that one must be complete (>= g).
+// Env groups under one communicator (two_blocks) do not march in step: a group may be finalizing step g + 1 while another still
+// finalizes step g (never further apart: the `need` wait sees to that), and the finalizing blocks count their arrivals in word [0]
+// of the flag block they are handed.  So the steps alternate between TWO flag blocks by the parity of their number - the kernels,
+// which know one block, are untouched; completions and errors are mirrored into both.
 void begin_step_gather(CommState* c, const float* out_buffer, GatherTicket* out) {
   const unsigned g = c->gather_index;
-  out->flags = c->flags;
   out->publish = g + 1u;
+  out->flags = (c->two_blocks && (out->publish & 1u) == 0u) ? c->flags + FLAG_WORDS : c->flags;
   out->need = (out_buffer == c->last_send) ? g : (g >= 1u ? g - 1u : 0u);
+  out->envs = 0u;
 }
 void abort_step_gather(CommState*) {}
 
@@ -269,8 +309,8 @@ int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, cons
   if (const char* ev = getenv("CPMPPI_COMM_READY_FENCE")) if (ev[0] == '1') ready_flags = hipEventDisableTiming;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, ready_flags);
   for (int i = 0; i < SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->flags, FLAG_WORDS * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMemset(c->flags, 0, FLAG_WORDS * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->flags, 2 * FLAG_WORDS * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(c->flags, 0, 2 * FLAG_WORDS * sizeof(unsigned));
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) memset(c->err_host, 0, 64);
   if (e == hipSuccess) {
@@ -329,7 +369,8 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
   if (!c) return CPMPPI_OK;
   OnDevice guard(cpmppi_internal_device(h));
   if (c->pending_post != 0u) {          // fallback waiter: the last gather's completion has not been posted yet
-    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, c->pending_post, 0u, c->err_host, c->timeout_ticks);
+    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, c->two_blocks ? c->flags + FLAG_WORDS : nullptr,
+                       c->pending_post, 0u, c->err_host, c->timeout_ticks);
     COMM_HIP(h, hipGetLastError());
     c->pending_post = 0u;
   }
@@ -339,6 +380,7 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
     // reported once; cleared for device and host so that the handle can go on (the steps since the error left their
     // nominal sequences unwritten)
     (void)hipMemset(c->flags + 3, 0, sizeof(unsigned));
+    (void)hipMemset(c->flags + FLAG_WORDS + 3, 0, sizeof(unsigned));
     (void)hipDeviceSynchronize();
     __atomic_store_n(c->err_host, 0u, __ATOMIC_RELEASE);
     return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, "cpmppi_comm_sync: a device-side wait between a step and an all-gather timed out "
@@ -355,6 +397,16 @@ int cpmppi_comm_set_timeout(cpmppi_handle* h, double seconds) {
   c->timeout_ticks = (seconds <= 0.0 || seconds > 1.0e9) ? ~0ull : (unsigned long long)(seconds * 1.0e8 + 0.5);
   OnDevice guard(cpmppi_internal_device(h));
   COMM_HIP(h, upload_slow_path_words(c));          // (a synchronous copy: launches already enqueued keep the old value)
+  return CPMPPI_OK;
+}
+
+int cpmppi_comm_set_stamped(cpmppi_handle* h, int on) {
+  if (!h) return CPMPPI_ERR_BAD_ARG;
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c) return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_set_stamped: no communicator (cpmppi_comm_init)");
+  if (c->gather_index != 0u && (on != 0) != c->stamped)
+    return cpmppi_internal_fail(h, CPMPPI_ERR_BAD_ARG, "cpmppi_comm_set_stamped: the block layout cannot change once a step has been gathered");
+  c->stamped = on != 0;
   return CPMPPI_OK;
 }
 
@@ -397,6 +449,7 @@ int cpmppi_comm_get_info(cpmppi_handle* h, cpmppi_comm_info* out) {
   if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == ncclSuccess) out->rccl_version = v;
   out->stream_memory_ops = c->published ? 1u : 0u;
   out->gathers_enqueued = c->gather_index;
+  out->stamped = c->stamped ? 1u : 0u;
   return CPMPPI_OK;
 }
 
@@ -424,10 +477,11 @@ int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t 
   CommState* c = cpmppi_internal_comm(h);
   OnDevice guard(cpmppi_internal_device(h));
   const unsigned g = c->gather_index;
+  unsigned* other = c->two_blocks ? c->flags + FLAG_WORDS : nullptr;
   if (c->published) {
     COMM_HIP(h, hipStreamWaitValue32(c->side, c->published, g + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
   } else {
-    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, c->pending_post, g + 1u, c->err_host, c->timeout_ticks);
+    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, other, c->pending_post, g + 1u, c->err_host, c->timeout_ticks);
     COMM_HIP(h, hipGetLastError());
     c->pending_post = 0u;
   }
@@ -435,12 +489,23 @@ int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t 
     hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, c->side, (unsigned long long)c->debug_delay_us * 100ull);
     COMM_HIP(h, hipGetLastError());
   }
-  COMM_NCCL(h, g_rccl.AllGather(send, recv_all, count, ncclFloat, c->comm, c->side));
-  if (c->published) COMM_HIP(h, hipStreamWriteValue32(c->side, c->flags + 2, g + 1u, 0));
-  else c->pending_post = g + 1u;          // posted by the next step's post_wait_kernel, or by cpmppi_comm_sync
+  if (c->stamped) {
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, c->side, c->flags, other,
+                       reinterpret_cast<unsigned*>(const_cast<float*>(send) + count), g + 1u);
+    COMM_HIP(h, hipGetLastError());
+  }
+  COMM_NCCL(h, g_rccl.AllGather(send, recv_all, count + (c->stamped ? CPMPPI_GATHER_STAMP_FLOATS : 0), ncclFloat, c->comm, c->side));
+  if (c->published) {
+    COMM_HIP(h, hipStreamWriteValue32(c->side, c->flags + 2, g + 1u, 0));
+    if (other) COMM_HIP(h, hipStreamWriteValue32(c->side, other + 2, g + 1u, 0));
+  } else {
+    c->pending_post = g + 1u;          // posted by the next step's post_wait_kernel, or by cpmppi_comm_sync
+  }
   c->gather_index = g + 1u;
   c->last_send = send;
   return CPMPPI_OK;
 }
+
+void share_between_groups(CommState* c) { c->two_blocks = true; }
 
 }  // namespace cpmppi_comm

@@ -151,8 +151,21 @@ int cpmppi_groups_join(cpmppi_groups* g, void* stream) {
   return e == hipSuccess ? CPMPPI_OK : gfail(g, CPMPPI_ERR_HIP, std::string("cpmppi_groups_join: ") + hipGetErrorString(e));
 }
 
-int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods) {
+}  // extern "C"
+
+namespace {
+
+// cpmppi_groups_run (recv_all == NULL) / cpmppi_groups_run_gather
+int run_impl(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods, float* recv_all) {
   if (!g) return CPMPPI_ERR_BAD_ARG;
+  cpmppi_comm::CommState* comm = nullptr;
+  if (recv_all) {
+    if (!step) return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run_gather: a step argument block is required");
+    comm = cpmppi_internal_comm(g->g[0].h);
+    if (!comm) return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run_gather: no communicator (cpmppi_groups_comm_init)");
+    if (step->predictor == CPMPPI_PREDICTOR_GRU && step->u_nom_out && step->u_nom_out != step->u_nom)
+      return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run_gather: the GRU predictor steps in place");
+  }
   if (!step && !plant) return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run: neither a step nor a plant argument block");
   if (step && step->E != g->E) return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run: step->E must be the groups' total env count");
   if (plant && plant->E != g->E) return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run: plant->E must be the groups' total env count");
@@ -198,12 +211,32 @@ int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmp
       pa[i] = b;
     }
   }
+  const bool alternate = comm && step->u_nom_out && step->u_nom_out != step->u_nom;
   for (uint32_t k = 0; k < periods; ++k) {
+    cpmppi_comm::GatherTicket ticket{};
+    float* out_all = nullptr;
+    if (comm) {
+      // a device-side wait gave up (a peer stalled beyond the timeout): say so now (as cpmppi_step_gather does)
+      if (cpmppi_comm::comm_error_pending(g->g[0].h))
+        return gfail(g, CPMPPI_ERR_COMM, "cpmppi_groups_run_gather: an earlier step's device-side wait for an all-gather timed out; "
+                                         "cpmppi_comm_sync(cpmppi_groups_handle(g, 0)) reports and clears the condition");
+      // ONE ticket per period, shared by the launches of every group: the step number all envs of the device publish together
+      const bool swapped = alternate && (k & 1u);
+      out_all = alternate ? (swapped ? step->u_nom : step->u_nom_out) : step->u_nom;
+      cpmppi_comm::begin_step_gather(comm, out_all, &ticket);
+      ticket.envs = g->E;
+      if (alternate)
+        for (size_t i = 0; i < g->g.size(); ++i) {
+          const size_t off = (size_t)g->g[i].first * H;
+          sa[i].u_nom = (swapped ? step->u_nom_out : step->u_nom) + off;
+          sa[i].u_nom_out = out_all + off;
+        }
+    }
     for (size_t i = 0; i < g->g.size(); ++i) {
       cpmppi_handle* h = g->g[i].h;
       if (step) {
         sa[i].offset = step->offset + k;
-        const int rc = cpmppi_step(h, &sa[i], g->g[i].stream);
+        const int rc = comm ? cpmppi_internal_step_ticket(h, &sa[i], g->g[i].stream, &ticket) : cpmppi_step(h, &sa[i], g->g[i].stream);
         if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_run: group ") + std::to_string(i) + ": " + cpmppi_last_error(h));
       }
       if (plant) {
@@ -212,11 +245,43 @@ int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmp
         if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_run: group ") + std::to_string(i) + ": " + cpmppi_last_error(h));
       }
     }
+    if (comm) {
+      // side stream: wait until the LAST env of the LAST group has published this step -> all-gather of the device's whole
+      // u_nom[E, H] -> post its completion.  (A launch of this period that failed above has returned already: the side stream
+      // is then left without this period's wait; cpmppi_comm_sync's escape covers a step that never publishes.)
+      const int rc = cpmppi_comm::enqueue_gather(g->g[0].h, out_all, recv_all, (size_t)g->E * H);
+      if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_run_gather: ") + cpmppi_last_error(g->g[0].h));
+    }
   }
   return CPMPPI_OK;
   } catch (const std::exception&) {
     return CPMPPI_ERR_NOMEM;
   }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods) {
+  return run_impl(g, step, plant, periods, nullptr);
+}
+
+int cpmppi_groups_run_gather(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods,
+                             float* recv_all) {
+  if (!g) return CPMPPI_ERR_BAD_ARG;
+  if (!recv_all) return gfail(g, CPMPPI_ERR_BAD_ARG, "cpmppi_groups_run_gather: recv_all is required");
+  return run_impl(g, step, plant, periods, recv_all);
+}
+
+// ONE communicator and ONE side stream for all env groups of the device; it lives in group 0's handle (cpmppi_comm_* calls take
+// cpmppi_groups_handle(g, 0)) and goes with it in cpmppi_groups_destroy.
+int cpmppi_groups_comm_init(cpmppi_groups* g, const void* id, int world, int rank, const char* rccl_path) {
+  if (!g || g->g.empty()) return CPMPPI_ERR_BAD_ARG;
+  const int rc = cpmppi_comm_init(g->g[0].h, id, world, rank, rccl_path);
+  if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_comm_init: ") + cpmppi_last_error(g->g[0].h));
+  cpmppi_comm::share_between_groups(cpmppi_internal_comm(g->g[0].h));
+  return CPMPPI_OK;
 }
 
 }  // extern "C"

@@ -294,6 +294,9 @@ class ScheduleRun:
         if self.m_ctrl is not None and len(np.unique(self.m_ctrl)) > 1:
             raise ValueError("a captured graph replays ONE pole mass for the controller: run this batch launched (graph=False)")
         dev = self.s.device
+        # the graph replays the handle's controller mass as it is when CAPTURED: the run's (constant) one, which may differ from
+        # the mass the handle was created with (an uninformed controller; advisor, round 5)
+        self.set_controller_mass(0)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)              # controller calls made
         fixed = getattr(self.eng, "_fixed_stream_obj", None)
         cap = torch.cuda.Stream(device=dev)

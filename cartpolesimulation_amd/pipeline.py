@@ -92,9 +92,32 @@ class EnvGroups:
         return self.args_engine.prepare_step(s0, u_nom, target_position, target_equilibrium, L=L, seed=seed, offset=0, env_offset=0,
                                              Q_out=Q_out, S_out=S_out, **kw)
 
-    def run(self, step=None, plant=None, periods=1, offset=0, period=0, n_substeps=None):
+    def comm_init(self, unique_id, world, rank, rccl_path=None, stamped=False, timeout_s=None):
+        """cpmppi_groups_comm_init: ONE communicator and side stream for all groups of this device (collective over all ranks);
+        `run(..., gather_into=recv_all)` then all-gathers the device's whole u_nom[E, H] once per period."""
+        if isinstance(rccl_path, str):
+            rccl_path = rccl_path.encode()
+        self._check(self.lib.cpmppi_groups_comm_init(self._g, unique_id, int(world), int(rank), rccl_path))
+        self.world, self.rank, self.stamped = int(world), int(rank), bool(stamped)
+        h0 = self.lib.cpmppi_groups_handle(self._g, 0)
+        if stamped:
+            self.engines[0]._check(self.lib.cpmppi_comm_set_stamped(h0, 1))
+        if timeout_s is not None:
+            self.engines[0]._check(self.lib.cpmppi_comm_set_timeout(h0, float(timeout_s)))
+
+    def comm_sync(self):
+        """Host wait for every all-gather enqueued so far (after `join` + a stream sync of the caller's); raises on a timeout."""
+        self.engines[0]._check(self.lib.cpmppi_comm_sync(self.lib.cpmppi_groups_handle(self._g, 0)))
+
+    def comm_info(self):
+        out = _L.cpmppi_comm_info()
+        self.engines[0]._check(self.lib.cpmppi_comm_get_info(self.lib.cpmppi_groups_handle(self._g, 0), C.byref(out)))
+        return {n: int(getattr(out, n)) for n, _ in out._fields_}
+
+    def run(self, step=None, plant=None, periods=1, offset=0, period=0, n_substeps=None, gather_into=None):
         """cpmppi_groups_run: `periods` control periods of every group enqueued from C, round robin - step (Philox step counter
-        offset + k) and, if given, plant step (period + k).  `step` / `plant`: PreparedStep / PreparedPlantStep over the full arrays."""
+        offset + k) and, if given, plant step (period + k).  `step` / `plant`: PreparedStep / PreparedPlantStep over the full arrays.
+        `gather_into` [world, E*H (+ stamp words)]: cpmppi_groups_run_gather - one all-gather of u_nom[E, H] per period too."""
         sa = pa = None
         if step is not None:
             step.args.offset = int(offset)
@@ -104,6 +127,9 @@ class EnvGroups:
             if n_substeps is not None:
                 plant.args.n_substeps = int(n_substeps)
             pa = C.byref(plant.args)
+        if gather_into is not None:
+            self._check(self.lib.cpmppi_groups_run_gather(self._g, sa, pa, int(periods), gather_into.data_ptr()))
+            return
         self._check(self.lib.cpmppi_groups_run(self._g, sa, pa, int(periods)))
 
     def prepare_step(self, s0, u_nom, target_position, target_equilibrium, L=None, seed=0, Q_out=None, S_out=None, **kw):

@@ -266,6 +266,8 @@ def generate_dataset(engine, num_experiments=None, out_dir=None, config=None, se
     if seed is not None:
         cfg["seed"] = int(seed)
     n_total = int(num_experiments if num_experiments is not None else cfg["number_of_experiments"])
+    if cfg.get("seed") is None:
+        raise ValueError("config['seed'] is empty: the reference then seeds from the clock; give a seed for a reproducible batch")
     cseed = cartpole_seed if cartpole_seed is not None else cfg["seed"] + 1
     if optimizer is not None:
         if int(groups) > 1 or graph:

@@ -119,13 +119,39 @@ class NativeGather:
     ``before_step(i)`` (device-side wait for the gather that still reads the buffer this step overwrites), the step,
     ``after_step(i)`` (enqueue the gather of the buffer just written).  Nothing here blocks the host."""
 
-    def __init__(self, engine, unique_id, world, rank, rccl_path=None):
-        self.engine, self.world, self.rank = engine, int(world), int(rank)
+    def __init__(self, engine, unique_id, world, rank, rccl_path=None, stamped=False):
+        """``stamped``: every gathered block carries its step number behind the sequences (cpmppi_comm_set_stamped, cpmppi.h): a
+        receiver can tell a block its sender DROPPED (a device-side wait that timed out leaves the old stamp) from a fresh one -
+        :meth:`accepted`.  ``rccl_path``: a collective library to bind instead of the process's RCCL (bytes or str)."""
+        from . import _lib as _L
+        self.engine, self.world, self.rank, self.stamped = engine, int(world), int(rank), bool(stamped)
         e = engine
+        if isinstance(rccl_path, str):
+            rccl_path = rccl_path.encode()
         e._check(e.lib.cpmppi_comm_init(e._h, unique_id, self.world, self.rank, rccl_path))
         n = e.E * e.H
-        self.u = [e.zeros(e.E, e.H), e.zeros(e.E, e.H)]
-        self.gathered = [torch.empty(self.world, n, dtype=torch.float32, device=e.device) for _ in range(2)]
+        pad = _L.GATHER_STAMP_FLOATS if self.stamped else 0
+        if self.stamped:
+            e._check(e.lib.cpmppi_comm_set_stamped(e._h, 1))
+        self.count = n
+        self._flat = [torch.zeros(n + pad, dtype=torch.float32, device=e.device) for _ in range(2)]     # (stamp words zeroed once)
+        self.u = [f[:n].view(e.E, e.H) for f in self._flat]
+        self.gathered = [torch.zeros(self.world, n + pad, dtype=torch.float32, device=e.device) for _ in range(2)]
+
+    def blocks(self, i):
+        """[world, E_local*H]: the sequences of every rank as gathered after step i (without the stamp words)."""
+        return self.recv(i)[:, :self.count]
+
+    def stamps(self, i):
+        """[world] int64: the stamp every rank's block of step i's gather carries (stamped communicators)."""
+        if not self.stamped:
+            raise ValueError("this communicator is not stamped")
+        return self.recv(i)[:, self.count:self.count + 1].contiguous().view(torch.int32).to(torch.int64).view(-1)
+
+    def accepted(self, i, gather_number=None):
+        """[world] bool: block r of step i's gather was written by its sender's step number ``gather_number`` (default i + 1: one
+        cpmppi_step_gather per step since the communicator was made) and is complete; a False entry = a stale block to be ignored."""
+        return self.stamps(i) == int(i + 1 if gather_number is None else gather_number)
 
     def before_step(self, i):
         e = self.engine

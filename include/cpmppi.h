@@ -41,11 +41,13 @@
 extern "C" {
 #endif
 
-#define CPMPPI_ABI_VERSION 4u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_*;
+#define CPMPPI_ABI_VERSION 5u   /* 2: cpmppi_step_args.u_nom_out, cpmppi_plant_advance_record(log_rows), cpmppi_comm_*;
                                    3: cpmppi_config.ode_predictor (+ cost ids 4 / 5, cpmppi_last_launch, cpmppi_comm_set_timeout);
                                    4: cpmppi_plant_step / cpmppi_plant_args (the experiment schedule), cpmppi_write_recordings takes
                                       per-row columns (cpmppi_recording), cpmppi_launch_info.cost_plugin, CPMPPI_ERR_IO,
-                                      cpmppi_comm_info, cpmppi_groups_*.  cpmppi_abi_version() reports what a loaded library was built as. */
+                                      cpmppi_comm_info, cpmppi_groups_*.  cpmppi_abi_version() reports what a loaded library was built as;
+                                   5: cpmppi_comm_set_stamped (+ cpmppi_comm_info.stamped), cpmppi_groups_comm_init / cpmppi_groups_run_gather;
+                                      a caller-given rccl_path now wins over an RCCL the process has already loaded. */
 #define CPMPPI_STATE_DIM 6u
 #define CPMPPI_MAX_HORIZON 1024u
 
@@ -463,18 +465,32 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* str
  * release the wait from the host, raise the error and return CPMPPI_ERR_COMM (a rollout launch that never published - failed,
  * aborted - cannot wedge them).  cpmppi_step_gather refuses a stream that is being captured.
  * PEERS: a rank whose device-side wait timed out keeps its buffers intact and its already-enqueued all-gathers still run, so the
- * other ranks receive a well-formed but STALE block from it and no error of their own.  Treat gathered blocks as unverified until
- * cpmppi_comm_sync has returned CPMPPI_OK on EVERY rank (exchange the return codes with the collective of your choice).
- * Errors: CPMPPI_ERR_COMM.  RCCL is bound at run time: the library loads without it. */
+ * other ranks receive a well-formed but STALE block from it and no error of their own.  Two ways to know:
+ *   - cpmppi_comm_set_stamped(h, 1) (before the first cpmppi_step_gather, the same on every rank): every gathered block carries
+ *     CPMPPI_GATHER_STAMP_FLOATS trailing words - the u_nom / u_nom_out buffers handed to cpmppi_step_gather are then
+ *     [E*H + CPMPPI_GATHER_STAMP_FLOATS] floats (the caller zeroes the trailing words once), recv_all is
+ *     [world][E*H + CPMPPI_GATHER_STAMP_FLOATS].  Word 0 of the trailer (read as uint32_t) is the STAMP: the number of the
+ *     cpmppi_step_gather call (1, 2, ... per communicator; the same on every rank, collectives being called in the same order) that
+ *     produced the block, written on the side stream between the step's publication and its all-gather - unless a device-side
+ *     wait of the communicator has given up: a rank that dropped a step (timeout) leaves buffer AND stamp as they were, and stamps
+ *     nothing until cpmppi_comm_sync has cleared the condition.  A receiver accepts block r of the n-th gather iff its stamp == n
+ *     and otherwise keeps what it had for rank r (it may so discard a good block that was gathered while the error was up - never
+ *     accept a stale one).  No extra collective, nothing on the launch stream; words 1.. of the trailer are reserved (0).
+ *   - or treat gathered blocks as unverified until cpmppi_comm_sync has returned CPMPPI_OK on EVERY rank (exchange the return
+ *     codes with the collective of your choice).
+ * Errors: CPMPPI_ERR_COMM.  RCCL is bound at run time: the library loads without it.  rccl_path, when given, is loaded as given
+ * and wins over an RCCL the process already holds (a site-specific build; the two-process test double of tests/fake_rccl). */
 typedef struct {
   uint32_t world, rank;            /* as given to cpmppi_comm_init */
   int32_t rccl_ranks, rccl_rank;   /* ncclCommCount / ncclCommUserRank of the communicator; -1 = this RCCL does not export them */
   int32_t rccl_version;            /* ncclGetVersion (e.g. 22606), 0 = unknown */
   uint32_t stream_memory_ops;      /* 1 = hipStreamWaitValue32 / WriteValue32 order the side stream, 0 = the one-lane waiter kernel */
-  uint32_t gathers_enqueued;       /* cpmppi_step_gather calls so far */
+  uint32_t gathers_enqueued;       /* cpmppi_step_gather calls so far (= the stamp of the most recent one) */
+  uint32_t stamped;                /* cpmppi_comm_set_stamped */
 } cpmppi_comm_info;
 #define CPMPPI_COMM_ID_BYTES 128
 #define CPMPPI_COMM_SLOTS 4
+#define CPMPPI_GATHER_STAMP_FLOATS 4   /* 16 bytes: every rank's block in recv_all stays 16-byte aligned */
 int cpmppi_comm_unique_id(void* id_out, const char* rccl_path);
 int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, const char* rccl_path);
 int cpmppi_comm_gather(cpmppi_handle* h, uint32_t slot, const float* send, float* recv_all, size_t count, void* stream);
@@ -483,6 +499,7 @@ int cpmppi_comm_sync(cpmppi_handle* h);
 int cpmppi_comm_set_timeout(cpmppi_handle* h, double seconds);
 int cpmppi_comm_destroy(cpmppi_handle* h);
 int cpmppi_comm_get_info(cpmppi_handle* h, cpmppi_comm_info* out);
+int cpmppi_comm_set_stamped(cpmppi_handle* h, int on);
 
 /* cpmppi_step + the all-gather of its result in ONE call - the production form of the per-step collective:
  * recv_all[world][E*H] <- all-gather of the nominal sequences this step writes (args->u_nom_out, or args->u_nom when the
@@ -563,6 +580,18 @@ int cpmppi_stream_destroy(void* stream);
  *                          plant->period + k).  `step` and `plant` describe the FULL [E, ...] arrays exactly as for one handle over
  *                          all envs; every group works on its slice of them in place (plant->row_envs is filled in).  No group waits
  *                          for another.  step->offset_dev / plant->period_dev (one shared device counter) are refused.
+ *   cpmppi_groups_comm_init   the env groups of a device under ONE communicator and ONE side stream (collective over all ranks, as
+ *                          cpmppi_comm_init).  The communicator lives in group 0's handle: cpmppi_comm_set_timeout / _set_stamped /
+ *                          _sync / _get_info / _destroy take cpmppi_groups_handle(g, 0)
+ *   cpmppi_groups_run_gather  cpmppi_groups_run + the per-step all-gather of cpmppi_step_gather: per period ONE all-gather of the
+ *                          device's whole u_nom[E, H] (recv_all[world][E*H], + the stamp words when stamped) on the side stream.  The
+ *                          finalizing blocks of ALL groups count themselves on the communicator's shared arrival counter
+ *                          (alternating with the step's parity: the groups drift by at most one step), the last env of the last
+ *                          group publishes the step, and a group's finalize that is about to overwrite sequences a gather still
+ *                          reads waits for it - exactly the single-handle protocol, with `envs` = all envs of the device.  With
+ *                          step->u_nom_out given, the two buffers alternate per period of the call (period 0 reads u_nom and writes
+ *                          u_nom_out, period 1 the other way round, ...); NULL = in place.  recv_all holds the LAST period's gather
+ *                          once cpmppi_comm_sync(cpmppi_groups_handle(g, 0)) has returned.
  * Errors as for the single-handle calls; text in cpmppi_groups_last_error. */
 typedef struct cpmppi_groups cpmppi_groups;
 int cpmppi_groups_create(const cpmppi_config* cfg, int device, uint32_t groups, uint32_t env_offset, cpmppi_groups** out);
@@ -574,6 +603,9 @@ void* cpmppi_groups_stream(cpmppi_groups* g, uint32_t group);
 int cpmppi_groups_fork(cpmppi_groups* g, void* stream);
 int cpmppi_groups_join(cpmppi_groups* g, void* stream);
 int cpmppi_groups_run(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods);
+int cpmppi_groups_comm_init(cpmppi_groups* g, const void* id, int world, int rank, const char* rccl_path);
+int cpmppi_groups_run_gather(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_args* plant, uint32_t periods,
+                             float* recv_all);
 const char* cpmppi_groups_last_error(const cpmppi_groups* g);
 
 /* The ABI version this library was BUILT as (CPMPPI_ABI_VERSION of its header): lets a client that was compiled against another

@@ -233,3 +233,24 @@ def test_rollout_kernels_have_no_scratch_and_no_vgpr_spills():
     for k in hot:
         if "kernelILi0ELb1ELi2ELi2ELi1ELi" in k["name"]:      # (both ODE predictors)
             assert k["vgpr_count"] + k["agpr_count"] <= 128, (k["name"], k["vgpr_count"])
+
+
+def test_the_stand_in_collective_library_exports_what_the_communicator_binds():
+    """tests/fake_rccl/libfake_rccl.so (test infrastructure for the two-process GPU tests) exports exactly the symbols
+    csrc/cpmppi_comm.hip looks up with dlsym, and draws ids only it accepts - no GPU call here."""
+    import ctypes as C
+    import re
+    path = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build_fake_rccl()
+    src = open(os.path.join(ROOT, "cartpolesimulation_amd", "csrc", "cpmppi_comm.hip")).read()
+    bound = set(re.findall(r'dlsym\(r\.dl, "(nccl\w+)"\)', src))
+    assert len(bound) == 8
+    lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    for name in bound:
+        getattr(lib, name)
+    ident = C.create_string_buffer(128)
+    assert lib.ncclGetUniqueId(ident) == 0 and ident.raw[:4] == b"EKAF" and any(ident.raw[4:20])
+    v = C.c_int()
+    assert lib.ncclGetVersion(C.byref(v)) == 0 and v.value == 99
