@@ -513,44 +513,118 @@ class GroupedWorkload:
     steps (cartpolesimulation_amd/pipeline.py): the `*_pipelined` side configurations.  Same synthetic inputs and Philox keys as
     the unsplit configuration (global env indices); no group ever waits for another inside the timed region."""
 
+    _serial = 0
+
     def __init__(self, ctx, E, N, H, groups, math="fast"):
         import torch
+        from cartpolesimulation_amd import _lib as _L
         from cartpolesimulation_amd.configs import MPPIConfig
         from cartpolesimulation_amd.pipeline import EnvGroups
         self.ctx, self.E, self.N, self.H = ctx, E, N, H
         base = ctx["rank"] * E
         self.groups = EnvGroups(E, MPPIConfig(num_rollouts=N, mpc_horizon=H, math_mode=math), groups, device=ctx["local_rank"], env_offset=base)
         full = synthetic_inputs(E, H, seed=2 + ctx["rank"], device=ctx["device"])
-        self.parts = [Workload(ctx, e1 - e0, N, H, math=math, engine=eng, inputs=tuple(t[e0:e1].contiguous() for t in full), env_base=base + e0)
+        sub = dict(ctx, collective=False)                   # (the parts only verify: the collective belongs to the groups as a whole)
+        self.parts = [Workload(sub, e1 - e0, N, H, math=math, engine=eng, inputs=tuple(t[e0:e1].contiguous() for t in full), env_base=base + e0)
                       for eng, (e0, e1) in zip(self.groups.engines, self.groups.slices)]
-        # one argument block over all envs; cpmppi_groups_run enqueues every group's launch of a step from C
-        self.u_all = torch.zeros(E, H, device=ctx["device"])
-        self.Q_all = torch.empty(E, device=ctx["device"])
         self.full_inputs = full
-        self.step_all = self.groups.prepare(full[0], self.u_all, full[1], full[2], L=full[3], seed=self.parts[0].seed, Q_out=self.Q_all)
+        self.Q_all = torch.empty(E, device=ctx["device"])
+        self.collective_impl, self.collective_report, self.recv, self.done = None, None, None, 0
+        n, dev = E * H, ctx["device"]
+        if ctx["collective"]:
+            # env groups + the per-step all-gather (VERDICT r5 #2): ONE communicator and side stream for the device, one all-gather
+            # of the whole u_nom[E, H] per step, two alternating buffers, stamped blocks (cpmppi_groups_run_gather)
+            if ctx["backend"] != "nccl":
+                raise RuntimeError("the grouped configurations gather through the library's own RCCL communicator (backend nccl)")
+            from cartpolesimulation_amd.shard import exchange_unique_id
+            GroupedWorkload._serial += 1
+            uid = exchange_unique_id(self.groups.lib, ctx["rank"], key=f"cpmppi_groups_comm_id_{GroupedWorkload._serial}")
+            self.groups.comm_init(uid, ctx["world"], ctx["rank"], stamped=True)
+            pad = _L.GATHER_STAMP_FLOATS
+            self._flat = [torch.zeros(n + pad, device=dev) for _ in range(2)]
+            self.u = [f[:n].view(E, H) for f in self._flat]
+            self.recv = torch.zeros(ctx["world"], n + pad, device=dev)
+            self.step_ab = [self.groups.prepare(full[0], self.u[b], full[1], full[2], L=full[3], seed=self.parts[0].seed, Q_out=self.Q_all,
+                                                u_nom_out=self.u[1 - b]) for b in range(2)]
+            self.collective_impl = ("cpmppi_groups_run_gather: the env groups of the device under ONE communicator and side stream, one "
+                                    "ncclAllGather of u_nom[E, H] per step (stamped blocks), ordered with the groups' rollout kernels "
+                                    "through device memory")
+        else:
+            # one argument block over all envs; cpmppi_groups_run enqueues every group's launch of a step from C
+            self.u = [torch.zeros(E, H, device=dev)]
+            self.step_ab = [self.groups.prepare(full[0], self.u[0], full[1], full[2], L=full[3], seed=self.parts[0].seed, Q_out=self.Q_all)]
         torch.cuda.synchronize()
+
+    @property
+    def u_all(self):
+        """The nominal sequences as the steps run so far left them."""
+        return self.u[self.done & 1] if self.recv is not None else self.u[0]
+
+    def _run(self, periods, offset):
+        if self.recv is not None:
+            self.groups.run(self.step_ab[self.done & 1], None, periods=periods, offset=offset, gather_into=self.recv)
+        else:
+            self.groups.run(self.step_ab[0], None, periods=periods, offset=offset)
+        self.done += periods
+
+    def _settle(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.recv is not None:
+            import torch.distributed as dist
+            self.groups.comm_sync()
+            dist.barrier()
+            torch.cuda.synchronize()
 
     def run(self, steps, warmup, overlap=True):
         import numpy as np
         import torch
         self.groups.fork()
         # (outside the timed region) 1.0 = the groups were serialised
-        self.stream_overlap = self.groups.overlap(self.step_all) if overlap else None
-        self.u_all.zero_()
+        self.stream_overlap = self.groups.overlap(self.step_ab[0]) if overlap else None
+        for u in self.u:
+            u.zero_()
         torch.cuda.synchronize()
         self.groups.fork()
-        self.groups.run(self.step_all, None, periods=warmup, offset=0)
-        torch.cuda.synchronize()
+        self._run(warmup, 0)
+        self._settle()
         t0 = time.perf_counter()
-        self.groups.run(self.step_all, None, periods=steps, offset=warmup)   # K steps of every group: ONE library call, nothing else
-        torch.cuda.synchronize()
+        self._run(steps, warmup)                 # K steps of every group (+ K all-gathers): ONE library call, nothing else
+        self._settle()
         elapsed = time.perf_counter() - t0
+        W, rank = self.ctx["world"], self.ctx["rank"]
+        if self.recv is not None:
+            import torch.distributed as dist
+            from cartpolesimulation_amd.shard import block_stamps
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.ctx["device"])
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            # the last gather: this rank's block = what it computed, every rank's block = that rank's own checksum, every stamp = the
+            # number of step-gathers made (see Workload.run for the form of the check)
+            n = self.E * self.H
+            bits = lambda t: t.contiguous().view(torch.int32).to(torch.int64)            # noqa: E731
+            mine = bits(self.u_all.reshape(-1)).sum().reshape(1)
+            sums = torch.empty(W, dtype=torch.int64, device=mine.device)
+            dist.all_gather_into_tensor(sums, mine)
+            got = bits(self.recv[:, :n]).sum(dim=1)
+            info = self.groups.comm_info()
+            stamps = block_stamps(self.recv, n)
+            self.collective_report = {"impl": self.collective_impl, "ranks_requested": W, "rccl_ranks": info.get("rccl_ranks"),
+                                      "rccl_version": info.get("rccl_version"), "stream_memory_ops": info.get("stream_memory_ops"),
+                                      "stamped": info.get("stamped"), "gathers": info.get("gathers_enqueued"),
+                                      "rank_blocks_match_every_ranks_own_checksum": bool(torch.equal(got, sums)),
+                                      "rank_blocks_distinct": bool(W == 1 or len({int(x) for x in got.tolist()}) == W),
+                                      "every_block_stamped_with_the_last_step": bool((stamps == self.done).all())}
+            rep = self.collective_report
+            assert torch.equal(self.recv[rank, :n], self.u_all.reshape(-1)), "all-gather of the controls is wrong"
+            assert (rep["rank_blocks_match_every_ranks_own_checksum"] and rep["rank_blocks_distinct"] and rep["rccl_ranks"] == W
+                    and rep["every_block_stamped_with_the_last_step"] and rep["gathers"] == self.done), f"the collective is wrong: {rep}"
         # the groups' own kernel durations (they overlap: informative only) from a pass of their own - the library's HIP events cost
         # these small launches 0.9 us per step (profiles/r5/prof_overhead.txt) and the timed pass above is wall time only
         for w in self.parts:
             w.eng.set_profiling(True, group=8 if steps >= 16 else 1)
-        self.groups.run(self.step_all, None, periods=steps, offset=warmup + steps)
-        torch.cuda.synchronize()
+        self._run(steps, warmup + steps)
+        self._settle()
         for w, (e0, e1) in zip(self.parts, self.groups.slices):         # (the parts verify from the nominal sequences these steps left)
             w.u_nom.copy_(self.u_all[e0:e1])
         k = []
@@ -561,7 +635,7 @@ class GroupedWorkload:
             w.timed_kernel, w.next_step = w.eng.last_launch()["kernel"], warmup + 2 * steps
             assert torch.isfinite(w.u_nom).all()
         E, N = self.E, self.N
-        return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": self.ctx["world"] * E * N * steps / elapsed,
+        return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
                 "group_kernel_ms": k, "kernels": sorted({w.timed_kernel for w in self.parts}), "stream_overlap": self.stream_overlap}
 
     def verify(self):
@@ -648,9 +722,28 @@ def main():
             assert torch.equal(out.view(world, 4)[:, 0], torch.arange(world, dtype=torch.float32))
             dist.barrier()
             blocks = out.view(world, 4)
+            # the receiver's side of the STAMPED blocks (cpmppi_comm_set_stamped; what C4_pipelined's gather carries under --gpus N):
+            # three gathers of [n + stamp words] per rank; the last rank re-sends its block of gather 1 as gather 2 - a rank that
+            # dropped a step - and every rank must reject exactly that block and keep what it had
+            from cartpolesimulation_amd._lib import GATHER_STAMP_FLOATS
+            from cartpolesimulation_amd.shard import merge_accepted
+            n, seqs, rejected = 20, torch.zeros(world, 20), []
+            for number in (1, 2, 3):
+                sent = number - 1 if (number == 2 and rank == world - 1 and world > 1) else number
+                blk = torch.zeros(n + GATHER_STAMP_FLOATS)
+                blk[:n] = float(rank) + sent / 100.0
+                blk[n:n + 1] = torch.tensor([sent], dtype=torch.int32).view(torch.float32)
+                got = torch.empty(world, n + GATHER_STAMP_FLOATS)
+                dist.all_gather_into_tensor(got.view(-1), blk)
+                seqs, ok = merge_accepted(seqs, got, n, number)
+                rejected += [[number, r] for r in range(world) if not bool(ok[r])]
+            want = torch.arange(world, dtype=torch.float32) + 0.03
             coll = {"impl": "torch.distributed all_gather_into_tensor over gloo (dry run: CPU tensors, no RCCL)", "ranks_requested": world,
                     "rccl_ranks": None, "backend_ranks": dist.get_world_size(),
-                    "rank_blocks_distinct": bool(world == 1 or len({float(x) for x in blocks[:, 0].tolist()}) == world)}
+                    "rank_blocks_distinct": bool(world == 1 or len({float(x) for x in blocks[:, 0].tolist()}) == world),
+                    "stamped_blocks": {"gathers": 3, "rejected": rejected, "final_rows_are_gather_3": bool(torch.allclose(seqs[:, 0], want))},
+                    "pipelined_under_collective": "C4_pipelined: env groups under one communicator, cpmppi_groups_run_gather "
+                                                  "(a real run reports it in configs.C4_pipelined.collective)"}
         else:
             coll = None
         if rank == 0:
@@ -742,31 +835,51 @@ def main():
                                    "frac": gru_flops / (rr["kernel_ms"] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                    "note": "useful GRU flops against the dense f16 MFMA peak (split-f16 products issue 3.6x these)"}
             extras[name] = obj
-        if world == 1 and not collective:
+        if world == 1 or backend == "nccl":
             # the same small configurations with their envs in independent groups, each on its own stream (pipeline.py): what the
-            # share-nothing structure of the problem allows and one launch per step cannot use
-            for name, base, groups, steps_, warm_ in (("C4_pipelined", "C4", 2, 200, 220), ("C3_pipelined", "C3", 2, 100, 110)):
+            # share-nothing structure of the problem allows and one launch per step cannot use.  Under --gpus N (or
+            # CPMPPI_BENCH_FORCE_COLLECTIVE=1) the groups run under ONE communicator with the per-step all-gather
+            # (cpmppi_groups_run_gather): the 8-GPU shape of BASELINE configs[3] is this form
+            pipelined = (("C4_pipelined", "C4", 2, 200, 220), ("C3_pipelined", "C3", 2, 100, 110)) if world == 1 else (("C4_pipelined", "C4", 2, 200, 220),)
+            for name, base, groups, steps_, warm_ in pipelined:
                 e_, n_, h_ = PRESETS[base]
                 try:
                     # the yardstick first: the SAME code path with ONE group = one launch per step, enqueued from C, wall time only
                     one = GroupedWorkload(ctx, e_, n_, h_, 1)
                     one_ms = one.run(steps_, warm_, overlap=False)["ms_per_step"]
                     one.close()
+                    plain_ms = None
+                    if collective:
+                        # ... and the grouped form WITHOUT the collective, same process, same box: what the gather costs
+                        plain = GroupedWorkload(dict(ctx, collective=False), e_, n_, h_, groups)
+                        plain_ms = plain.run(steps_, warm_, overlap=False)["ms_per_step"]
+                        plain.close()
                     gw = GroupedWorkload(ctx, e_, n_, h_, groups)
                     rr = gw.run(steps_, warm_)
                 except Exception as ex:  # noqa: BLE001
+                    if world > 1:
+                        raise                              # (the other ranks are inside the same collective sequence)
                     extras[name] = {"error": f"{type(ex).__name__}: {ex}"}
                     side_failed.append(name)
                     continue
-                if not args.no_verify:
+                if not args.no_verify and rank == 0 and world == 1:
                     to_verify.append((name, gw))
                 else:
-                    gw.close()
+                    try:
+                        if rank == 0 and not args.no_verify:
+                            verified[name] = gw.verify()
+                    except Exception as ex:  # noqa: BLE001
+                        verified[name] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+                    finally:
+                        gw.close()
                 extras[name] = {"workload": f"{e_} envs per GPU x {n_} samples x {h_}-step horizon as {groups} independent env groups of "
                                             f"{e_ // groups}, each its own handle, stream and chain of steps; {steps_} steps after {warm_}",
                                 "value": rr["value"], "unit": "rollouts/s", "n_gpus": world, "ms_per_step": rr["ms_per_step"],
                                 "groups": groups, "group_kernel_ms": rr["group_kernel_ms"], "kernels": rr["kernels"],
                                 "stream_overlap": rr["stream_overlap"],
+                                **({"collective": gw.collective_report or {"impl": gw.collective_impl},
+                                    "without_collective_ms_per_step": plain_ms, "collective_cost": rr["ms_per_step"] / plain_ms}
+                                   if gw.collective_impl else {}),
                                 "one_group_ms_per_step": one_ms, "vs_one_launch_per_step": one_ms / rr["ms_per_step"],
                                 "roofline_valu": {"bound": "fp32-valu", "unit": "TFLOP/s", "peak": FP32_VALU_PEAK_TFLOPS,
                                                   "achieved": algorithmic_flops_per_rollout(h_) * e_ * n_ / (rr["ms_per_step"] * 1e-3) / 1e12,

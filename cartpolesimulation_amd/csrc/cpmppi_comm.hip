@@ -57,14 +57,21 @@ struct Rccl {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  std::string err;
+  std::string err, path;                // path: the caller-given library this process is bound to ("" = RCCL by name)
 };
 
 Rccl g_rccl;
 
 bool load_rccl(const char* path) {
   Rccl& r = g_rccl;
-  if (r.dl) return true;
+  if (r.dl) {
+    // one collective library per process: a later call that names ANOTHER one must not get the first silently
+    if (path && path[0] && r.path != path) {
+      r.err = "a collective library is already bound in this process (" + (r.path.empty() ? std::string("RCCL by name") : r.path) + "): rccl_path " + path + " refused";
+      return false;
+    }
+    return true;
+  }
   // a caller-given path wins and is loaded as given (round 6: it used to lose against an RCCL the process had already loaded -
   // PyTorch's - because the already-loaded names were tried first); RTLD_LOCAL: its nccl* symbols are looked up here with dlsym
   // and must not interpose anybody else's.  Without a path: whatever the process has already loaded under the names PyTorch-ROCm
@@ -76,6 +83,7 @@ bool load_rccl(const char* path) {
       r.err = std::string("cannot load the collective library given as rccl_path: ") + (e ? e : path);
       return false;
     }
+    r.path = path;
   }
   const char* names[] = {"librccl.so", "librccl.so.1"};
   for (int pass = 0; pass < 2 && !r.dl; ++pass) {
@@ -101,6 +109,7 @@ bool load_rccl(const char* path) {
     r.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
     dlclose(r.dl);
     r.dl = nullptr;
+    r.path.clear();
     return false;
   }
   return true;
@@ -135,8 +144,10 @@ struct CommState {
 // published step `need` (finalize_env, cpmppi_rollout.hpp).  A wait that gives up raises the error for device and host; the
 // all-gather behind it then sends whatever the buffer holds - the error tells every consumer not to use it.
 // (`other`: the second flag block of a communicator shared by env groups, or NULL - completions go to both, the step `need` is
-// published in the block of its parity, an error is raised in both)
-__global__ void post_wait_kernel(unsigned* flags, unsigned* other, unsigned post, unsigned need, unsigned* err_host, unsigned long long timeout_ticks) {
+// published in the block of its parity, an error is raised in both.  `stamp`: cpmppi_comm_set_stamped - what stamp_kernel does,
+// folded in: every dispatch on the side stream costs the env groups' kernels ~1.5 us, see share_between_groups)
+__global__ void post_wait_kernel(unsigned* flags, unsigned* other, unsigned post, unsigned need, unsigned* err_host, unsigned long long timeout_ticks,
+                                 unsigned* stamp) {
   if (post != 0u) {
     __hip_atomic_store(flags + 2, post, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (other) __hip_atomic_store(other + 2, post, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -153,6 +164,11 @@ __global__ void post_wait_kernel(unsigned* flags, unsigned* other, unsigned post
       __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
+  }
+  if (stamp) {
+    unsigned err = __hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (other) err |= __hip_atomic_load(other + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err == 0u) __hip_atomic_store(stamp, need, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -302,6 +318,7 @@ int cpmppi_comm_init(cpmppi_handle* h, const void* id, int world, int rank, cons
   }
   int lo = 0, hi = 0;
   hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = the numerically lowest = greatest priority
+  if (const char* pr = getenv("CPMPPI_COMM_SIDE_PRIORITY")) if (strcmp(pr, "normal") == 0) hi = 0;      // (development aid: A/B)
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);
   // launch -> side: both streams are on this device and the RCCL kernel reads the send buffer through the same L2, so the
   // event needs no system-scope fence (the default fence is a cache write-back on the launch stream's critical path)
@@ -370,7 +387,7 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
   OnDevice guard(cpmppi_internal_device(h));
   if (c->pending_post != 0u) {          // fallback waiter: the last gather's completion has not been posted yet
     hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, c->two_blocks ? c->flags + FLAG_WORDS : nullptr,
-                       c->pending_post, 0u, c->err_host, c->timeout_ticks);
+                       c->pending_post, 0u, c->err_host, c->timeout_ticks, (unsigned*)nullptr);
     COMM_HIP(h, hipGetLastError());
     c->pending_post = 0u;
   }
@@ -478,20 +495,20 @@ int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t 
   OnDevice guard(cpmppi_internal_device(h));
   const unsigned g = c->gather_index;
   unsigned* other = c->two_blocks ? c->flags + FLAG_WORDS : nullptr;
+  unsigned* stamp = c->stamped ? reinterpret_cast<unsigned*>(const_cast<float*>(send) + count) : nullptr;
   if (c->published) {
     COMM_HIP(h, hipStreamWaitValue32(c->side, c->published, g + 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    if (stamp) {                        // (right behind the wait: the step has just been published)
+      hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, c->side, c->flags, other, stamp, g + 1u);
+      COMM_HIP(h, hipGetLastError());
+    }
   } else {
-    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, other, c->pending_post, g + 1u, c->err_host, c->timeout_ticks);
+    hipLaunchKernelGGL(post_wait_kernel, dim3(1), dim3(1), 0, c->side, c->flags, other, c->pending_post, g + 1u, c->err_host, c->timeout_ticks, stamp);
     COMM_HIP(h, hipGetLastError());
     c->pending_post = 0u;
   }
   if (c->debug_delay_us) {
     hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, c->side, (unsigned long long)c->debug_delay_us * 100ull);
-    COMM_HIP(h, hipGetLastError());
-  }
-  if (c->stamped) {
-    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, c->side, c->flags, other,
-                       reinterpret_cast<unsigned*>(const_cast<float*>(send) + count), g + 1u);
     COMM_HIP(h, hipGetLastError());
   }
   COMM_NCCL(h, g_rccl.AllGather(send, recv_all, count + (c->stamped ? CPMPPI_GATHER_STAMP_FLOATS : 0), ncclFloat, c->comm, c->side));
@@ -506,6 +523,22 @@ int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t 
   return CPMPPI_OK;
 }
 
-void share_between_groups(CommState* c) { c->two_blocks = true; }
+// Env groups: two flag blocks, and the ONE-KERNEL form of the side stream's ordering (post the previous gather, wait for this step,
+// stamp - post_wait_kernel) even where stream memory operations exist.  Measured on MI355X, 64 envs x 2048 x 50 as two groups, one
+// rank on RCCL (profiles/r6/groups_gather_cost_*.txt): the runtime performs hipStreamWaitValue32 / hipStreamWriteValue32 as blit
+// kernels of its own (__amd_rocclr_streamOpsWait / Write in the kernel trace), so the stream-operation form is FIVE dispatches per
+// step on the side stream (wait, stamp, all-gather, two completion writes) against TWO here - and with both groups' kernels in
+// flight every side-stream dispatch costs the step ~1.5 us: 69.1-70.9 us per step against 66.1-66.8 (63.5 without any collective).
+// (One handle, one kernel in flight at a time: the stream-operation form stays, 76.3 vs 74.3 us.)
+int share_between_groups(CommState* c) {
+  c->two_blocks = true;
+  const char* w = getenv("CPMPPI_COMM_WAITER");
+  if (c->published && !(w && strcmp(w, "stream-ops") == 0)) {
+    (void)hipFree(c->published);
+    c->published = nullptr;
+    if (upload_slow_path_words(c) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return CPMPPI_ERR_HIP;
+  }
+  return CPMPPI_OK;
+}
 
 }  // namespace cpmppi_comm

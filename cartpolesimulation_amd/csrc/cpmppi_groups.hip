@@ -280,7 +280,10 @@ int cpmppi_groups_comm_init(cpmppi_groups* g, const void* id, int world, int ran
   if (!g || g->g.empty()) return CPMPPI_ERR_BAD_ARG;
   const int rc = cpmppi_comm_init(g->g[0].h, id, world, rank, rccl_path);
   if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_comm_init: ") + cpmppi_last_error(g->g[0].h));
-  cpmppi_comm::share_between_groups(cpmppi_internal_comm(g->g[0].h));
+  if (cpmppi_comm::share_between_groups(cpmppi_internal_comm(g->g[0].h)) != CPMPPI_OK) {
+    (void)cpmppi_comm_destroy(g->g[0].h);
+    return gfail(g, CPMPPI_ERR_HIP, "cpmppi_groups_comm_init: could not switch the communicator to the env-group form");
+  }
   return CPMPPI_OK;
 }
 

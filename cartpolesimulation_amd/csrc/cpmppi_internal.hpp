@@ -17,7 +17,7 @@ struct GatherTicket {
   unsigned envs;          // envs that publish the step together: 0 = the launch's own (one handle); env groups: all groups' envs
 };
 void begin_step_gather(CommState* c, const float* out_buffer, GatherTicket* out);
-void share_between_groups(CommState* c);     // the communicator serves env groups: steps alternate between two flag blocks
+int share_between_groups(CommState* c);      // the communicator serves env groups: steps alternate between two flag blocks
 void abort_step_gather(CommState* c);
 int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t count);
 int comm_error_pending(cpmppi_handle* h);    // a device-side wait of this handle has timed out (sticky until cpmppi_comm_sync)

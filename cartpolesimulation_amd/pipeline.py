@@ -163,6 +163,7 @@ class EnvGroups:
             f = 4                                                      # bytes per float
             b.E = n
             b.s0 = a.s0 + e0 * 6 * f; b.u_nom = a.u_nom + e0 * self.H * f
+            b.u_nom_out = (a.u_nom_out + e0 * self.H * f) if a.u_nom_out else None
             b.target_position = a.target_position + e0 * f; b.target_equilibrium = a.target_equilibrium + e0 * f
             b.L = (a.L + e0 * f) if a.L else None
             b.Q_out = a.Q_out + e0 * f

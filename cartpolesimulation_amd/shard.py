@@ -111,6 +111,25 @@ def exchange_unique_id(lib, rank, key="cpmppi_comm_id", rccl_path=None):
     return got[1:]
 
 
+def block_stamps(gathered, count):
+    """[world] int64: the stamp behind every rank's block of a stamped gather ``gathered[world, count + GATHER_STAMP_FLOATS]``
+    (cpmppi_comm_set_stamped, include/cpmppi.h): the number of the step-gather that produced the block."""
+    return gathered[:, count:count + 1].contiguous().view(torch.int32).to(torch.int64).view(-1)
+
+
+def accepted_blocks(gathered, count, number):
+    """[world] bool: which blocks of the ``number``-th step-gather (1, 2, ...) a receiver may use - those stamped with exactly that
+    number.  A rank that dropped the step (its device-side wait for an earlier all-gather timed out) sent its buffer as it was,
+    old stamp included: that block is stale and the receiver keeps what it had for that rank."""
+    return block_stamps(gathered, count) == int(number)
+
+
+def merge_accepted(previous, gathered, count, number):
+    """The receiver's rule in one place: -> (sequences[world, count], accepted[world]) where rejected ranks keep ``previous``'s rows."""
+    ok = accepted_blocks(gathered, count, number)
+    return torch.where(ok[:, None], gathered[:, :count], previous), ok
+
+
 class NativeGather:
     """The per-step all-gather of u_nom[E_local,H] through libcpmppi's own RCCL communicator.
 
@@ -146,7 +165,7 @@ class NativeGather:
         """[world] int64: the stamp every rank's block of step i's gather carries (stamped communicators)."""
         if not self.stamped:
             raise ValueError("this communicator is not stamped")
-        return self.recv(i)[:, self.count:self.count + 1].contiguous().view(torch.int32).to(torch.int64).view(-1)
+        return block_stamps(self.recv(i), self.count)
 
     def accepted(self, i, gather_number=None):
         """[world] bool: block r of step i's gather was written by its sender's step number ``gather_number`` (default i + 1: one

@@ -41,6 +41,11 @@ def test_gpus_flag_starts_that_many_ranks(n):
     else:
         assert coll["ranks_requested"] == n and coll["backend_ranks"] == n and coll["rank_blocks_distinct"] is True
         assert coll["rccl_ranks"] is None and "gloo" in coll["impl"]
+        # the stamped blocks of the per-step gather (the grouped C4 form runs under the collective with --gpus N): the one stale
+        # block - the last rank re-sending gather 1 as gather 2 - is rejected by the receiver's rule, everything else accepted
+        st = coll["stamped_blocks"]
+        assert st["gathers"] == 3 and st["rejected"] == [[2, n - 1]] and st["final_rows_are_gather_3"] is True
+        assert "cpmppi_groups_run_gather" in coll["pipelined_under_collective"]
 
 
 def test_rank_count_must_match_gpus_flag():

@@ -142,6 +142,53 @@ def test_plant_step_tables_at_any_stride_and_time_scale(n_ctrl, n_save, stride):
     eng.close()
 
 
+@pytest.mark.parametrize("n_ctrl,n_save,tail", [(10, 5, 5), (10, 2, 4), (8, 4, 7), (10, 5, 3)])
+def test_a_trailing_partial_period_completes_its_saved_rows(n_ctrl, n_save, tail):
+    """A run that ends INSIDE a control period (cpmppi_plant_step with n_substeps < period_steps) with dt_save < dt_control: no
+    controller call follows the trailing steps, so a row saved on the run's LAST step gets its second derivatives from that very
+    launch, under the held control - as the reference's save does (CartPole/__init__.py:403-433).  (Advisor, round 5: the kernel
+    deferred the derivatives of a launch's last step to a next call that never comes; 25 steps at 10 / 5 left zeros in the
+    recording's final row.)  Cases: the tail ends on a saved step; it ends between two saved steps."""
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    E, T = 3, 2
+    eng = MPPIEngine(E, MPPIConfig(num_rollouts=64, mpc_horizon=10))
+    rng = Generator(SFC64(1000 * n_ctrl + 10 * n_save + tail))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-3, 3), rng.uniform(-4, 4), rng.uniform(-0.15, 0.15), rng.uniform(-0.5, 0.5))
+                   for _ in range(E)])
+    Qs = rng.uniform(-1, 1, (T + 1, E)).astype(f32)
+    Lv = rng.uniform(0.25, 0.45, E).astype(f32)
+    n_sim = T * n_ctrl + tail
+    R = n_sim // n_save + 1
+    s = eng.tensor(s0.copy())
+    guard = 7.0
+    states, dd, Qlog = eng.zeros(R, E, 6) + guard, eng.zeros(R, E, 2) + guard, eng.zeros(T + 1, E)
+    states[0] = s
+    kw = dict(dt_sim=0.002, period_steps=n_ctrl, L=Lv, states_log=states, dd_log=dd, save_every=n_save, Q_log=Qlog)
+    for c in range(T):
+        eng.plant_step(s, Qs[c], n_ctrl, period=c, **kw)
+    eng.plant_step(s, Qs[T], tail, period=T, **kw)                           # the run's last controller call + the trailing steps
+    st_h, dd_h = states.cpu().numpy(), dd.cpu().numpy()
+    assert (st_h != guard).all() and (dd_h != guard).all()                   # every row of both logs was written
+    for e in range(E):
+        r, Q = s0[e].copy(), Qs[0, e]
+        add, pdd = O.plant_ode(r, Q, Lv[e])
+        rows = [(r.copy(), add, pdd)]
+        for gstep in range(1, n_sim + 1):
+            r = O.plant_substep(r, add, pdd, 0.002, Lv[e])
+            if gstep % n_ctrl == 0:
+                Q = Qs[gstep // n_ctrl, e]
+            add, pdd = O.plant_ode(r, Q, Lv[e])
+            if gstep % n_save == 0:
+                rows.append((r.copy(), add, pdd))
+        assert len(rows) == R
+        for i, (rs, a_, p_) in enumerate(rows):
+            assert np.all(np.abs(st_h[i, e] - rs) <= 3e-5 + 3e-5 * np.abs(rs)), (e, i)
+            assert abs(dd_h[i, e, 0] - a_) <= 2e-3 + 1e-4 * abs(a_) and abs(dd_h[i, e, 1] - p_) <= 5e-4 + 1e-4 * abs(p_), (e, i)
+    assert np.array_equal(Qlog.cpu().numpy(), Qs)
+    eng.close()
+
+
 def _replay(g, tag, i, math_mode, graph=False):
     """One fixture experiment on the device loop with the reference's own perturbations (SFC64 knots from the host)."""
     from cartpolesimulation_amd import schedule as SC
