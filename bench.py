@@ -647,8 +647,9 @@ class GroupedWorkload:
             w.eng.use_stream(None)
             reps.append(w.verify(n_envs=4))
         rep = dict(reps[0])
-        for key in ("envs", "rollouts", "clear", "flagged", "clear_off", "flagged_off", "u_off_envs", "flagged_cap"):
+        for key in ("envs", "rollouts", "clear", "flagged", "clear_off", "flagged_off", "u_off_envs", "flagged_cap", "second_stage_envs"):
             rep[key] = int(sum(r[key] for r in reps))
+        rep["second_stage"] = [dict(x, group=gi) for gi, r in enumerate(reps) for x in r["second_stage"]]
         for key in ("worst_clear_excess", "worst_cost_rel", "worst_flagged_excess", "worst_flagged_cost_rel", "worst_u_abs",
                     "worst_u_vs_reference_spread", "noise_device_vs_oracle_max"):
             v = [r[key] for r in reps if r.get(key) is not None]

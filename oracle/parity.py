@@ -303,7 +303,7 @@ def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0,
     # (worst_* over a bucket that stayed EMPTY are None, not 0.0: "nothing was compared" must not read as a perfect match)
     rep = dict(envs=int(E), rollouts=int(E * N), clear=0, flagged=0, clear_off=0, flagged_off=0, worst_clear_excess=None,
                worst_cost_rel=None, worst_flagged_excess=None, worst_flagged_cost_rel=None, worst_u_abs=0.0,
-               worst_u_vs_reference_spread=0.0, u_off_envs=0, rule=rule.name)
+               worst_u_vs_reference_spread=0.0, u_off_envs=0, rule=rule.name, second_stage_envs=0, second_stage=[])
     up = lambda key, v: rep.__setitem__(key, v if rep[key] is None else max(rep[key], v))       # noqa: E731
     for e0 in range(0, E, chunk):
         sl = slice(e0, min(E, e0 + chunk))
@@ -331,18 +331,20 @@ def verify_envs(ocfg, s0, u_before, knots, tp, te, L, S_gpu, u_gpu, rule=ODE_V0,
                                                      reference_spread_ratio(u_gpu[e], ref["u_a"][i], ref["u_b"][i], u_alt=u_alt))
             allow = softmin_allowance(ref["S_a"][i], ref["S_b"][i], du[i])
             gap = float(envelope(ref["u_a"][i], ref["u_b"][i], *u_alt).max())
-            off = bool((d > 1e-4 + np.maximum(gap, allow)).any())
-            if off and gap > 1e-4:
+            if gap > 1e-4:
                 # an env on which the reference's own realisations already disagree by more than the band (a chaotic start: their
-                # scatter is a heavy-tailed quantity seven samples estimate poorly): six more realisations, each with another
-                # float32 sin / cos, join the envelope before the env is called off.  Counted and reported.
+                # scatter is a heavy-tailed quantity seven samples estimate poorly) gets six more, each with another float32
+                # sin / cos, in its envelope.  Decided from the ORACLE's quantities alone, before the device's result is looked
+                # at, for every such env whether it would pass or fail without them (round 5 widened the envelope only after a
+                # failure - an allowance that grows on failure is a biased rule: VERDICT r5 weak 1(ii), advisor).  Counted.
                 j = slice(e, e + 1)
                 more = trig_jitter_realisations(ocfg, s0[j], u_before[j], du[i:i + 1], tp[j], te[j], L=L[j], params=params)
                 gap2 = float(envelope(ref["u_a"][i], ref["u_b"][i], *u_alt, *[m[0][0] for m in more]).max())
-                rep["second_stage_envs"] = rep.get("second_stage_envs", 0) + 1
-                rep["second_stage"] = dict(realisations=len(more), envelope_before=gap, envelope_after=gap2, deviation=float(d.max()))
-                off = bool((d > 1e-4 + np.maximum(gap2, allow)).any())
-            rep["u_off_envs"] += int(off)
+                rep["second_stage_envs"] += 1
+                rep["second_stage"].append(dict(env=int(e), realisations=len(more), envelope_before=gap, envelope_after=gap2,
+                                                deviation=float(d.max())))
+                gap = gap2
+            rep["u_off_envs"] += int(bool((d > 1e-4 + np.maximum(gap, allow)).any()))
     cap = min(int(np.ceil(rule.flagged_cap * rep["flagged"])), int(np.ceil(rule.total_cap * rep["rollouts"])))
     rep["flagged_cap"] = cap
     rep["ok"] = bool(rep["clear_off"] == 0 and rep["flagged_off"] <= cap and rep["u_off_envs"] == 0)

@@ -119,8 +119,10 @@ def test_config_full_size(name, E, N, H, seed):
         assert total == E * N
         # the rule is not vacuous: the bulk of the launch is compared at band + envelope, and the flagged bucket - capped per
         # env at 2 % above - holds next to nothing outside over the whole launch
-        # (input seed 21: the oracle itself flags a third of the launch - 66.9 % clear - against a quarter on seed 2)
-        assert T["clear"] >= (0.70 if seed in (2, 3) else 0.60) * total, f"{name} {mode}: only {T['clear']} of {total} rollouts are clear of every flag"
+        # (ONE floor for every input seed, fixed by what it is to mean - the MAJORITY of the launch is compared at full strength - and
+        # not by the numbers seen: measured clear fractions over five seeds in profiles/r6/c3_spread.txt, 66.9 % on the most
+        # adverse one (seed 21: the oracle itself flags a third of that launch) to 76 %)
+        assert T["clear"] >= 0.50 * total, f"{name} {mode}: only {T['clear']} of {total} rollouts are clear of every flag"
         assert T["flagged_off"] <= 0.005 * T["flagged"], f"{name} {mode}: {T['flagged_off']} of {T['flagged']} flagged rollouts outside"
         assert T["worst_spread_ratio"] <= 3.0, (f"{name} {mode}: env {T['worst_spread_env']}: |u - u_A| is {T['worst_spread_ratio']:.2f} x "
                                                 f"max(1e-4, the spread of the oracle's realisations)")
@@ -141,8 +143,20 @@ def test_config_full_size(name, E, N, H, seed):
             small.step(s0[e:e + 1], u1, tp[e:e + 1], te[e:e + 1], L=Lv[e:e + 1], knots=kn[e:e + 1].contiguous())
             if exact:
                 assert np.array_equal(u1.cpu().numpy()[0], un_h[e])
-            elif seed in (2, 3):       # (seed 21's envs are chaotic enough for the two lane mappings' roundings to differ by more
-                np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=1e-4)     # than the band; each is checked against the oracle above)
+                continue
+            # the OTHER lane mapping is another realisation of the same arithmetic (its intermediate substeps carry the rotation
+            # differently): held to the same rule as the launch itself - band + the envelope of the oracle's realisations on this
+            # env - for EVERY input seed (round 5 skipped this check on seed 21); where the env is benign, additionally to the
+            # launch's own result within the band
+            j = slice(e, e + 1)
+            du1 = O.interpolate_knots(kn_h[e], H)[None]
+            r1 = PU.c_oracle_step_with_flags(ocfg, s0[j], u0[j], du1, tp[j], te[j], L=Lv[j], probes=True)
+            alt = [a[0] for a in r1["u_alt"]]
+            PU.assert_controls(u1.cpu().numpy()[0], r1["u_a"][0], r1["u_b"][0], f"{name} env {e}, lane mapping {rpl}", u_alt=alt,
+                               allowance=PU.softmin_allowance(r1["S_a"][0], r1["S_b"][0], du1[0]))
+            if float(PU.envelope(r1["u_a"][0], r1["u_b"][0], *alt).max()) <= 1e-4:
+                np.testing.assert_allclose(u1.cpu().numpy()[0], un_h[e], atol=2e-4)
+        small.close()
 
     # ---- the same perturbations through the reference-layout buffer and through its re-tiled form: identical costs
     du_full = eng.interpolate(kn)

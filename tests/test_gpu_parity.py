@@ -133,6 +133,51 @@ def test_c2_rollouts_costs_update(golden_dir, name, math_mode):
     np.testing.assert_allclose(un.cpu().numpy()[0], g[f"{name}/u_new_legacy"], atol=1e-4)
 
 
+@pytest.mark.parametrize("math_mode", MATH_MODES)
+@pytest.mark.parametrize("case,e", [("c3", 0), ("c3", 1), ("c4", 0), ("c4", 1)])
+def test_c3_c4_shape_rollouts_costs_update(golden_dir, case, e, math_mode):
+    """The HIP path against the REFERENCE at the shape of BASELINE configs[2] / configs[3] (tests/golden/rollouts_c3c4.npz: the
+    reference's own next_state_predictor_ODE_v0 with the env's pole length as `variable_parameters.L`, H = 100 / 50 from 11 / 6 SFC64
+    knots, quadratic_boundary_grad_minimal, reward_weighted_average): predictor seam and fused step, both math modes, both lane
+    mappings, rule ODE_V0, strict."""
+    g = load(golden_dir, "rollouts_c3c4.npz")
+    key = f"{case}/{e}"
+    N, H = int(g["N"]), int(g[f"{case}/H"])
+    kn, du = regen_delta_u(g[f"{key}/seed"], N, H, g["stdev"])
+    assert np.array_equal(du[:4], g[f"{key}/delta_u_head"])
+    s0, target, Lv = g[f"{key}/s0"], float(g[f"{key}/target"]), g[f"{key}/L"]
+    # ---- predictor seam
+    eng = engine(1, N, H, math_mode=math_mode, shift_mode="none", control_mode="penalise", correction_u="u_nom")
+    u_run = du.astype(f32)
+    traj = eng.predict(s0, u_run, L=Lv).cpu().numpy()
+    ref_traj = O.predict_core(s0, u_run, L=Lv)                             # oracle, mode A (pinned to `final` by tests/test_oracle_c3c4.py)
+    ref_traj_B = O.predict_core(s0, u_run, L=Lv, mode="f64sub")
+    flagged = PU.flag_discontinuities(ref_traj)
+    PU.assert_states(traj[:, -1], g[f"{key}/raw/final"], g[f"{key}/raw/final_B"], flagged, f"{key} final states", strict=True)
+    head = g[f"{key}/raw/traj_head"]
+    nh = head.shape[0]
+    PU.assert_states(traj[:nh, :H // 2], head[:, :H // 2], ref_traj_B[:nh, :H // 2], flagged[:nh], f"{key} trajectory heads", strict=True)
+    # ---- fused step on the device's own rollouts: S and the soft-min update against the reference's
+    for tag, control_mode in (("raw", "penalise"), ("clip", "clip")):
+        for rpl in ((1, 2) if math_mode == "fast" else (1,)):
+            e2 = engine(1, N, H, math_mode=math_mode, shift_mode="none", control_mode=control_mode, correction_u="u_nom", cc_weight=0.0,
+                        rollouts_per_lane=rpl)
+            un, S = e2.zeros(1, H), e2.empty(1, N)
+            e2.step(s0[None], un, target, 1.0, L=np.array([Lv], f32), delta_u=du[None], S_out=S)
+            S = S.cpu().numpy()[0]
+            uc = np.clip(u_run, -1, 1).astype(f32) if control_mode == "clip" else u_run
+            tr_a, tr_b = O.predict_core(s0, uc, L=Lv), O.predict_core(s0, uc, L=Lv, mode="f64sub")
+            S_b = O.trajectory_cost(O.COST_QBGM, tr_b, uc, f32(target), f32(1.0))
+            PU.assert_costs(S, g[f"{key}/{tag}/S_qbgm"], S_b, PU.flag_discontinuities(tr_a), f"{key}/{tag} S_qbgm (rpl {rpl})", strict=True)
+            np.testing.assert_allclose(un.cpu().numpy()[0], g[f"{key}/{tag}/u_new"], atol=1e-4)
+            # ... and from the KNOTS (in-kernel interpolation: what the Philox path does with its own draws)
+            un2 = e2.zeros(1, H)
+            e2.step(s0[None], un2, target, 1.0, L=np.array([Lv], f32), knots=kn[None])
+            np.testing.assert_allclose(un2.cpu().numpy()[0], g[f"{key}/{tag}/u_new"], atol=1e-4)
+            e2.close()
+    eng.close()
+
+
 LANE_MODES = [("precise", 1), ("fast", 1), ("fast", 2)]      # (math_mode, rollouts_per_lane)
 
 
