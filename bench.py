@@ -69,6 +69,9 @@ def parse_args(argv=None):
                          "C3 = 64 envs x 4096 x 100 in one launch; C4 = 64 envs per GPU x 2048 x 50 (512 envs over 8 GPUs)")
     ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane: 0 auto, 1, 2 (tuning knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
+                    help="quick (default): one ~1 s all-core pass + one ~0.3 s one-core pass per build of the C oracle; full: the longer "
+                         "samples of rounds 1-5 (~2.7 s / ~1 s per build).  Same fields")
     ap.add_argument("--no-single-env", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the timed configurations (the `verified` objects; it runs after the timed "
@@ -135,11 +138,14 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(N, H, budget_s=8.0, integrator="ODE_v0"):
+def cpu_baseline(N, H, budget_s=8.0, integrator="ODE_v0", full=False):
     """The plain-C oracle (validated against the golden vectors) timed on this host's cores: same step, same shape.
     Three builds of the same source (oracle/Makefile): the checker itself (-O2, strict float32, sin/cos through double)
     and two timing-only builds compiled here for this host (-O3 -march=native with libm float trig, without and with
-    -ffast-math: the reference's numba kernels are fastmath=True), each on all cores and on one."""
+    -ffast-math: the reference's numba kernels are fastmath=True), each on all cores and on one.
+    Default: ONE timed all-core pass per build of ~1 s (after a one-env-per-core calibration pass) and a one-core pass of ~0.3 s -
+    about 130 + CPU-seconds on a 128-thread host, the whole leg a few seconds of wall time; `full` (--cpu-baseline full): the
+    round-5 sample (a third of `budget_s` per all-core pass, ~1 s per one-core pass).  Same fields either way."""
     import numpy as np
     from oracle import oracle_np as O
     from oracle import oracle_c as OC
@@ -166,11 +172,13 @@ def cpu_baseline(N, H, budget_s=8.0, integrator="ODE_v0"):
         if name.startswith("_"):
             table[name] = flags
             continue
-        t1 = run(threads, threads, lib)                     # one env per core: calibrates the sample size
-        reps = int(max(1, min(64, budget_s / 3.0 / max(t1, 1e-3))))
+        t1 = run(threads, threads, lib)                     # one env per core: calibrates the sample size ...
+        if not full:                                        # ... and four per core: a sample that no longer fits the caches runs slower per env
+            t1 = max(t1, run(4 * threads, threads, lib) / 4.0)
+        reps = int(max(1, min(64, (budget_s / 3.0 if full else 1.0) / max(t1, 1e-3))))
         E = threads * reps
         t = run(E, threads, lib)
-        k1 = int(max(2, min(64, 2 * 1.0 / max(run(2, 1, lib), 1e-3))))      # ~1 s of one core
+        k1 = int(max(2, min(64, 2 * (1.0 if full else 0.3) / max(run(2, 1, lib), 1e-3))))      # ~1 s (0.3 s) of one core
         ts = run(k1, 1, lib)
         table[name] = {"flags": flags, "all_cores": {"value": E * N / t, "cores": threads,
                                                      "sample": f"{E} envs x {N} x {H} x 10 substeps in {t:.2f} s"},
@@ -689,6 +697,12 @@ def profiled_traffic(noise, E, N, H):
 
 
 def main():
+    t_main = time.perf_counter()
+    phases = {}
+
+    def mark(name):                                        # wall seconds since the process entered main(): where a run's time goes
+        phases[name] = round(time.perf_counter() - t_main, 2)
+
     args = parse_args()
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # started by torch.distributed.run
     if args.gpus > 1 and not in_rank:
@@ -697,6 +711,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    mark("imports_done")
     world = int(os.environ.get("WORLD_SIZE", "1")) if in_rank else 1
     rank = int(os.environ.get("RANK", "0")) if in_rank else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_rank else 0
@@ -777,6 +792,7 @@ def main():
     main_wl = Workload(ctx, E, N, H, noise=args.noise, math=args.math, predictor=args.predictor, rpl=args.rpl,
                        predictor_type=args.predictor_type)
     r = main_wl.run(args.steps, args.warmup)
+    mark("headline_timed")
     cfg = main_wl.cfg
     # Verification against the oracle happens AFTER every timed region of the run (rank 0 only): the workloads are kept until
     # then.  (Not only a matter of principle: the C oracle's OpenMP pool, once started in this process, slows the host-paced
@@ -888,6 +904,7 @@ def main():
                                                   "note": "from the WALL time per step of all groups (their kernels overlap: a kernel's own "
                                                           "duration, `group_kernel_ms`, says nothing about throughput here)"}}
 
+    mark("side_configurations_timed")
     if rank == 0:
         k_ms = r["kernel_ms"]
         traffic, traffic_src, traffic_date = profiled_traffic(args.noise, E, N, H)
@@ -998,6 +1015,7 @@ def main():
             else:
                 w1.close()
         # ---- every timed region is over: the checker's turn
+        mark("single_env_timed")
         if not args.no_verify:
             for name, w in to_verify:
                 # a checker that cannot run (no C compiler for the oracle, an exception on its side) must not cost the bench line:
@@ -1009,14 +1027,18 @@ def main():
                 finally:
                     if w is not main_wl:
                         w.close()
+                mark("verified_" + name)
             out["verified"] = verified["main"]
             for name, v in verified.items():
                 if name == "single_env":
                     out["single_env"]["verified"] = v
                 elif name != "main" and name in out.get("configs", {}):
                     out["configs"][name]["verified"] = v
+        mark("verified")
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
-            out["cpu_baseline"] = cpu_baseline(N, H, integrator=args.predictor_type)
+            out["cpu_baseline"] = cpu_baseline(N, H, integrator=args.predictor_type, full=args.cpu_baseline == "full")
+        mark("cpu_baseline_done")
+        out["wall_s"] = phases                               # cumulative wall seconds at the end of each phase of this process
         print(json.dumps(out), flush=True)
     if in_rank:
         dist.barrier()

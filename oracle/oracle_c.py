@@ -103,10 +103,33 @@ def predict(cfg_c, s0, Q, L=None, L_default=0.395, n_threads=0, use_lib=None):
     return traj
 
 
+def _bench_key():
+    """What the timing builds depend on: the source, the Makefile (flags), the compiler and - they are -march=native - the host's CPU."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("cpmppi_oracle.c", "Makefile"):
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(fh.read())
+    try:
+        h.update(subprocess.check_output([os.environ.get("CC", "gcc"), "--version"]))
+        with open("/proc/cpuinfo") as fh:
+            h.update("".join(l for l in fh if l.startswith(("model name", "flags"))).encode())
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    return h.hexdigest()
+
+
 def build_bench_variants():
-    """cpu_baseline timing builds (oracle/Makefile `bench`), always recompiled for the host this runs on (-march=native).
-    Returns {name: (ctypes lib, compiler flags)}.  Timing only — never used as a checker."""
-    subprocess.check_call(["make", "-s", "-B", "-C", HERE, "bench"])
+    """cpu_baseline timing builds (oracle/Makefile `bench`), compiled for the host this runs on (-march=native) - once per (source,
+    flags, compiler, CPU): oracle/_bench/KEY remembers what the cached libraries were built from (the directory is git- and
+    gpurun-ignored, so a fresh box always compiles).  Returns {name: (ctypes lib, compiler flags)}.  Timing only - never a checker."""
+    key, stamp = _bench_key(), os.path.join(HERE, "_bench", "KEY")
+    libs = [os.path.join(HERE, "_bench", f"liboracle_{n}.so") for n in ("native", "native_fastmath")]
+    fresh = os.path.exists(stamp) and open(stamp).read().strip() == key and all(os.path.exists(x) for x in libs)
+    if not fresh:
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "bench"])
+        with open(stamp, "w") as f:
+            f.write(key + "\n")
     out = {}
     for name, flags in (("native", "-O3 -march=native -ffp-contract=off, libm float trig"),
                         ("native_fastmath", "-O3 -march=native -ffast-math, libm float trig")):

@@ -27,6 +27,7 @@ ap.add_argument("--config", default="C4")
 ap.add_argument("--groups", type=int, default=2)
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--overlap", action="store_true", help="also print EnvGroups.overlap (sum of the groups' times alone / time together), as bench.py's stream_overlap")
 ap.add_argument("--only", default=None, choices=[None, "none", "gather", "gather-stamped", "inplace", "inplace-stamped"], help="one case only (for a kernel trace)")
 args = ap.parse_args()
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
@@ -76,6 +77,9 @@ def case(name, collective, stamped=False, alternate=True):
         kw = dict(u_nom_out=u[1]) if (collective and alternate) else {}
         prep = [g.prepare(s0, u[0], tp, te, L=Lt, seed=1234, **kw)]
         ts.append(timed(g, prep, recv, args.steps))
+        if args.overlap and not collective:
+            g.fork()
+            print(f"stream_overlap {g.overlap(prep[0], steps=50):.3f}  (kernel {g.engines[0].last_launch()['kernel']})", flush=True)
         g.close()
     print(f"{name:48s} {np.median(ts):7.2f} us/step  (min {np.min(ts):.2f}, max {np.max(ts):.2f}); the host's enqueueing alone "
           f"{np.median(ENQ[-args.reps:]):6.2f} us/step", flush=True)
