@@ -14,9 +14,10 @@
 //   * cpmppi_step_gather (the production path): through DEVICE MEMORY.  The env-finalizing blocks of the rollout kernel
 //     count themselves; the last one publishes the step number (system-scope release) into 8 bytes of SIGNAL MEMORY.  The
 //     side stream carries, per step, hipStreamWaitValue32(published >= step) -> ncclAllGather -> hipStreamWriteValue32(
-//     gathers completed = step): the two stream-memory operations are packets of the command processor, which polls and
-//     writes memory itself - no guest wave on the rollout kernel's SIMDs, no kernel launch beside RCCL's own (round 3: two
-//     one-lane kernels per step).  The finalize of the step that overwrites a gathered buffer (two steps later) checks the
+//     gathers completed = step).  (Rounds 4-5 described the two stream memory operations as packets the command processor
+//     executes itself; the round-6 kernel trace shows this runtime performs them as one-lane blit kernels of its own,
+//     __amd_rocclr_streamOpsWait / __amd_rocclr_streamOpsWrite.  For one handle the form was measured better than the folded
+//     waiter kernel below and stays; env groups use the kernel form - share_between_groups.)  The finalize of the step that overwrites a gathered buffer (two steps later) checks the
 //     completed count before its stores.  The launch stream carries the rollout kernels and NOTHING else: an event record
 //     or a cross-stream wait is a barrier packet the next dispatch has to queue behind - measured 4-5 us each next to a
 //     91 us kernel at BASELINE configs[3] (torch.distributed's snapshot copy + Work object + two waits per step: 33 us).

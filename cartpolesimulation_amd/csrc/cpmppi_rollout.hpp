@@ -266,8 +266,8 @@ __device__ __forceinline__ void finalize_env(const Params& p, const float* parti
       const uint32_t arrived = __hip_atomic_fetch_add(gs.flags, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (arrived == gs.envs - 1u) {
         __hip_atomic_store(gs.flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the side stream waits for this number: hipStreamWaitValue32 on signal memory (the command processor polls it: no
-        // wave of another kernel on our SIMDs), or - where that is unavailable - a one-lane kernel polling flags[1]
+        // the side stream waits for this number: hipStreamWaitValue32 on signal memory (a one-lane blit kernel of the runtime's,
+        // as the round-6 kernel trace shows), or - env groups; devices without stream memory operations - our one-lane kernel polling flags[1]
         uint32_t* published = reinterpret_cast<uint32_t*>(gs_word64(gs.flags, GS_PUBLISHED));
         if (published) __hip_atomic_store(published, gs.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         else __hip_atomic_store(gs.flags + 1, gs.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -119,17 +119,23 @@ def _bench_key():
     return h.hexdigest()
 
 
-def build_bench_variants():
-    """cpu_baseline timing builds (oracle/Makefile `bench`), compiled for the host this runs on (-march=native) - once per (source,
-    flags, compiler, CPU): oracle/_bench/KEY remembers what the cached libraries were built from (the directory is git- and
-    gpurun-ignored, so a fresh box always compiles).  Returns {name: (ctypes lib, compiler flags)}.  Timing only - never a checker."""
+def compile_bench_variants():
+    """The compile step of build_bench_variants alone (bench.py starts it in a thread behind its timed regions, so that it runs
+    under the verification leg instead of in front of the baseline)."""
     key, stamp = _bench_key(), os.path.join(HERE, "_bench", "KEY")
     libs = [os.path.join(HERE, "_bench", f"liboracle_{n}.so") for n in ("native", "native_fastmath")]
     fresh = os.path.exists(stamp) and open(stamp).read().strip() == key and all(os.path.exists(x) for x in libs)
     if not fresh:
-        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "bench"])
+        subprocess.check_call(["make", "-s", "-B", "-j2", "-C", HERE, "bench"])
         with open(stamp, "w") as f:
             f.write(key + "\n")
+
+
+def build_bench_variants():
+    """cpu_baseline timing builds (oracle/Makefile `bench`), compiled for the host this runs on (-march=native) - once per (source,
+    flags, compiler, CPU): oracle/_bench/KEY remembers what the cached libraries were built from (the directory is git- and
+    gpurun-ignored, so a fresh box always compiles).  Returns {name: (ctypes lib, compiler flags)}.  Timing only - never a checker."""
+    compile_bench_variants()
     out = {}
     for name, flags in (("native", "-O3 -march=native -ffp-contract=off, libm float trig"),
                         ("native_fastmath", "-O3 -march=native -ffast-math, libm float trig")):
