@@ -257,8 +257,11 @@ class Workload:
             ok, why = 0, "torch.distributed requested (CPMPPI_BENCH_COLLECTIVE / non-RCCL backend)"
         else:
             try:
-                uid = exchange_unique_id(self.eng.lib, rank, key=f"cpmppi_comm_id_{Workload._serial}")
-                self.native = NativeGather(self.eng, uid, W, rank)
+                # (development aid: CPMPPI_BENCH_RCCL_PATH names the collective library the communicator binds - with
+                # tests/fake_rccl/libfake_rccl.so two ranks can share ONE device, which RCCL refuses)
+                lib_path = os.environ.get("CPMPPI_BENCH_RCCL_PATH") or None
+                uid = exchange_unique_id(self.eng.lib, rank, key=f"cpmppi_comm_id_{Workload._serial}", rccl_path=lib_path and lib_path.encode())
+                self.native = NativeGather(self.eng, uid, W, rank, rccl_path=lib_path)
             except Exception as e:                       # RCCL missing / init failed on this rank
                 ok, why = 0, repr(e)
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if self.ctx["backend"] == "nccl" else "cpu")
@@ -551,12 +554,14 @@ class GroupedWorkload:
         if ctx["collective"]:
             # env groups + the per-step all-gather: ONE communicator and side stream for the device, one all-gather
             # of the whole u_nom[E, H] per step, two alternating buffers, stamped blocks (cpmppi_groups_run_gather)
-            if ctx["backend"] != "nccl":
+            lib_path = os.environ.get("CPMPPI_BENCH_RCCL_PATH") or None
+            if ctx["backend"] != "nccl" and not lib_path:
                 raise RuntimeError("the grouped configurations gather through the library's own RCCL communicator (backend nccl)")
             from cartpolesimulation_amd.shard import exchange_unique_id
             GroupedWorkload._serial += 1
-            uid = exchange_unique_id(self.groups.lib, ctx["rank"], key=f"cpmppi_groups_comm_id_{GroupedWorkload._serial}")
-            self.groups.comm_init(uid, ctx["world"], ctx["rank"], stamped=True)
+            uid = exchange_unique_id(self.groups.lib, ctx["rank"], key=f"cpmppi_groups_comm_id_{GroupedWorkload._serial}",
+                                     rccl_path=lib_path and lib_path.encode())
+            self.groups.comm_init(uid, ctx["world"], ctx["rank"], rccl_path=lib_path, stamped=True)
             pad = _L.GATHER_STAMP_FLOATS
             self._flat = [torch.zeros(n + pad, device=dev) for _ in range(2)]
             self.u = [f[:n].view(E, H) for f in self._flat]
@@ -861,7 +866,7 @@ def main():
                                    "frac": gru_flops / (rr["kernel_ms"] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                    "note": "useful GRU flops against the dense f16 MFMA peak (split-f16 products issue 3.6x these)"}
             extras[name] = obj
-        if world == 1 or backend == "nccl":
+        if world == 1 or backend == "nccl" or os.environ.get("CPMPPI_BENCH_RCCL_PATH"):
             # the same small configurations with their envs in independent groups, each on its own stream (pipeline.py): what the
             # share-nothing structure of the problem allows and one launch per step cannot use.  Under --gpus N (or
             # CPMPPI_BENCH_FORCE_COLLECTIVE=1) the groups run under ONE communicator with the per-step all-gather

@@ -1444,7 +1444,8 @@ int cpmppi_step_gather(cpmppi_handle* h, const cpmppi_step_args* a, float* recv_
   const bool in_place = !a->u_nom_out || a->u_nom_out == a->u_nom;
   cpmppi_comm::GatherTicket t;
   cpmppi_comm::begin_step_gather(h->comm, in_place ? a->u_nom : a->u_nom_out, &t);
-  const int rc = step_impl(h, a, stream, nullptr, &t);
+  int rc = cpmppi_comm::enqueue_guard(h, t, a->E, stream);
+  if (rc == CPMPPI_OK) rc = step_impl(h, a, stream, nullptr, &t);
   if (rc != CPMPPI_OK) {
     cpmppi_comm::abort_step_gather(h->comm);
     return rc;

@@ -138,6 +138,7 @@ struct CommState {
   unsigned debug_delay_us = 0;          // tests: a spin of this length on the side stream in front of every all-gather
   const float* last_send = nullptr;     // the buffer the previous step_gather's all-gather reads
   bool stamped = false;                 // cpmppi_comm_set_stamped: CPMPPI_GATHER_STAMP_FLOATS words behind every gathered block
+  unsigned guard_min_envs = 128;        // launches with more envs than this wait for the late gather in front of the kernel (gather_guard_kernel)
 };
 
 // Fallback waiter (no stream memory operations), side stream, one lane: posts "gathers completed = post" (the all-gather in
@@ -185,6 +186,34 @@ __global__ void stamp_kernel(const unsigned* flags, const unsigned* other, unsig
   if (err == 0u) __hip_atomic_store(stamp, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// LAUNCH stream, one lane, in front of a rollout kernel with MANY envs (enqueue_guard): the wait the finalizing blocks would do - "the
+// all-gather that still reads the buffer this step overwrites has completed" - done once, by one lane, BEFORE the kernel occupies the
+// device.  Why: every env's finalizing block spins inside the rollout kernel until that gather is complete, holding its workgroup
+// slot; with more envs than the device has slots (8192 envs per launch against ~2000 resident workgroups) a gather that is late by
+// more than a step finds every slot taken by spinning blocks, and whatever it still needs ON THIS DEVICE at normal priority cannot be
+// dispatched.  OBSERVED (round 6, the first bench run with two ranks sharing one device): the other rank's rollout blocks - which
+// have to finish before that rank can join the gather - starved behind this rank's spinning blocks, both ranks ran into the 10 s
+// timeout and dropped the step.  NOT observed with one process per device: the side stream's dispatches are high-priority and got
+// through 4096 spinning blocks within the 30 ms the gather was late (tests/test_gpu_boundary.py) - there the guard is insurance
+// (normal-priority RCCL builds, a runtime that does not preempt), not a fix.  With it a late gather costs one spinning lane; the
+// finalizing blocks then find the count reached (or the error up) at once.  Same timeout, same error words as the wait in the kernel.
+// Launches of a few dozen envs keep the in-kernel wait alone: their finalizing blocks cannot fill the device, and a 5 us dispatch in
+// front of a 64 us kernel is what the design avoids on the launch stream.  (In place - u_nom_out == NULL - the guard waits for the
+// PREVIOUS step's gather and so serialises step and gather for many-env launches: alternate two buffers, as the header says.)
+__global__ void gather_guard_kernel(unsigned* flags, unsigned* other, unsigned need, unsigned* err_host, unsigned long long timeout_ticks) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while ((int)(__hip_atomic_load(flags + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+    __builtin_amdgcn_s_sleep(16);
+    if (__hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+      __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (other) __hip_atomic_store(other + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+
 // tests only (cpmppi_debug_comm_delay): keeps the side stream busy for `ticks` of the 100 MHz clock - a slow peer
 __global__ void delay_kernel(unsigned long long ticks) {
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
@@ -218,8 +247,10 @@ bool drain_side_stream(CommState* c) {
     const hipError_t q = hipStreamQuery(c->side);
     if (q != hipErrorNotReady) { (void)hipGetLastError(); return false; }
     clock_gettime(CLOCK_MONOTONIC, &t);
-    if ((double)(t.tv_sec - t0.tv_sec) + 1.0e-9 * (double)(t.tv_nsec - t0.tv_nsec) > limit_s) break;
-    timespec nap{0, 200000};
+    const double waited = (double)(t.tv_sec - t0.tv_sec) + 1.0e-9 * (double)(t.tv_nsec - t0.tv_nsec);
+    if (waited > limit_s) break;
+    if (waited < 200.0e-6) continue;                       // (the usual case - the last gather is a few us away: poll, do not sleep)
+    timespec nap{0, waited < 5.0e-3 ? 20000 : 200000};
     nanosleep(&nap, nullptr);
   }
   (void)hipGetLastError();
@@ -448,6 +479,12 @@ int cpmppi_debug_comm_orphan_wait(cpmppi_handle* h) {
   c->gather_index = g + 1u;
   return CPMPPI_OK;
 }
+// tests only: launches with more than `envs` envs get the guard kernel (~0u = never: the round-5 behaviour)
+int cpmppi_debug_comm_guard_min_envs(cpmppi_handle* h, unsigned envs) {
+  if (!h || !cpmppi_internal_comm(h)) return CPMPPI_ERR_BAD_ARG;
+  cpmppi_internal_comm(h)->guard_min_envs = envs;
+  return CPMPPI_OK;
+}
 // tests only: 1 = stream memory operations order the side stream, 0 = the fallback waiter kernel
 int cpmppi_debug_comm_mode(cpmppi_handle* h) {
   if (!h || !cpmppi_internal_comm(h)) return CPMPPI_ERR_BAD_ARG;
@@ -531,6 +568,17 @@ int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t 
 // step on the side stream (wait, stamp, all-gather, two completion writes) against TWO here - and with both groups' kernels in
 // flight every side-stream dispatch costs the step ~1.5 us: 69.1-70.9 us per step against 66.1-66.8 (63.5 without any collective).
 // (One handle, one kernel in flight at a time: the stream-operation form stays, 76.3 vs 74.3 us.)
+// see gather_guard_kernel.  `envs`: the envs whose finalizing blocks would wait (of the launch; of all groups' launches together)
+int enqueue_guard(cpmppi_handle* h, const GatherTicket& t, unsigned envs, void* stream) {
+  CommState* c = cpmppi_internal_comm(h);
+  if (!c || t.need == 0u || envs <= c->guard_min_envs) return CPMPPI_OK;
+  OnDevice guard(cpmppi_internal_device(h));
+  unsigned* other = c->two_blocks ? (t.flags == c->flags ? c->flags + FLAG_WORDS : c->flags) : nullptr;
+  hipLaunchKernelGGL(gather_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t.flags, other, t.need, c->err_host, c->timeout_ticks);
+  COMM_HIP(h, hipGetLastError());
+  return CPMPPI_OK;
+}
+
 int share_between_groups(CommState* c) {
   c->two_blocks = true;
   const char* w = getenv("CPMPPI_COMM_WAITER");

@@ -236,6 +236,10 @@ int run_impl(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_
       cpmppi_handle* h = g->g[i].h;
       if (step) {
         sa[i].offset = step->offset + k;
+        if (comm) {
+          const int rg = cpmppi_comm::enqueue_guard(g->g[0].h, ticket, g->E, g->g[i].stream);
+          if (rg != CPMPPI_OK) return gfail(g, rg, std::string("cpmppi_groups_run_gather: ") + cpmppi_last_error(g->g[0].h));
+        }
         const int rc = comm ? cpmppi_internal_step_ticket(h, &sa[i], g->g[i].stream, &ticket) : cpmppi_step(h, &sa[i], g->g[i].stream);
         if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_run: group ") + std::to_string(i) + ": " + cpmppi_last_error(h));
       }

@@ -20,6 +20,7 @@ void begin_step_gather(CommState* c, const float* out_buffer, GatherTicket* out)
 int share_between_groups(CommState* c);      // the communicator serves env groups: steps alternate between two flag blocks
 void abort_step_gather(CommState* c);
 int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t count);
+int enqueue_guard(cpmppi_handle* h, const GatherTicket& t, unsigned envs, void* stream);   // launch stream: gather_guard_kernel (many envs only)
 int comm_error_pending(cpmppi_handle* h);    // a device-side wait of this handle has timed out (sticky until cpmppi_comm_sync)
 }  // namespace cpmppi_comm
 

@@ -764,3 +764,66 @@ def test_failed_step_leaves_the_event_recorder_intact():
         r, _ = eng.get_profile()
         assert len(r) == 4 // group and (r > 0).all(), (group, r)
     eng.close()
+
+
+def test_a_late_gather_does_not_starve_a_launch_of_many_envs():
+    """Round 6: every env's finalizing block waits INSIDE the rollout kernel for the all-gather that still reads the buffer the step
+    overwrites.  With more envs than the device has workgroup slots, a gather that is late by more than a step finds every slot held
+    by a spinning block.  Two ranks sharing ONE device deadlocked on that until the timeout (the other rank's rollout blocks could
+    not be dispatched: bench.py --gpus 2 on one device, first run); launches of many envs therefore wait in front of the kernel, with
+    one lane (gather_guard_kernel).  Here, one process: 4096 envs of one block each, gather 0 joins 30 ms late, 1 s timeout.  WITH
+    the guard (the default) nothing is dropped, the run takes the 30 ms, every gathered block equals the loop without a collective
+    and carries its stamp.  WITHOUT it the outcome is printed, not asserted beyond "either it gets through or the timeout is
+    reported": measured on MI355X it gets through too (the side stream's high-priority dispatches pass the spinning blocks)."""
+    import ctypes as C
+    import time
+    from cartpolesimulation_amd import _lib as L
+    from cartpolesimulation_amd.engine import MPPIEngine
+    from cartpolesimulation_amd.configs import MPPIConfig
+    from cartpolesimulation_amd.shard import NativeGather
+    E, N, H, K = 4096, 256, 10, 6
+    rng = Generator(SFC64(71))
+    s0 = np.stack([O.create_cartpole_state(rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.1) for _ in range(E)])
+    tp, te = rng.uniform(-0.05, 0.05, E).astype(f32), np.ones(E, f32)
+    cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H)
+    ref = MPPIEngine(E, cfg)
+    u_ref, want = ref.zeros(E, H), []
+    for i in range(K):
+        ref.step(s0, u_ref, tp, te, seed=6, offset=i)
+        want.append(u_ref.clone())
+    for guard in (False, True):
+        eng = MPPIEngine(E, cfg)
+        uid = C.create_string_buffer(L.COMM_ID_BYTES)
+        assert eng.lib.cpmppi_comm_unique_id(uid, None) == 0
+        g = NativeGather(eng, uid.raw, 1, 0, stamped=True)
+        assert eng.lib.cpmppi_comm_set_timeout(eng._h, 1.0) == 0
+        if not guard:
+            assert eng.lib.cpmppi_debug_comm_guard_min_envs(eng._h, 0xFFFFFFFF) == 0       # the round-5 behaviour
+        recv = [torch.zeros(1, E * H + L.GATHER_STAMP_FLOATS, device=u_ref.device) for _ in range(K)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        err = None
+        try:
+            for i in range(K):
+                eng.lib.cpmppi_debug_comm_delay(eng._h, 30000 if i == 0 else 0)          # gather 0 joins 30 ms late
+                eng.step(s0, g.u_in(i), tp, te, seed=6, offset=i, u_nom_out=g.u_out(i), gather_into=recv[i])
+            torch.cuda.synchronize()
+            g.sync()
+        except L.CpmppiError as e:
+            err = e
+            try:
+                g.sync()
+            except L.CpmppiError:
+                pass
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if guard:
+            assert err is None and dt < 0.5, (err, dt)
+            for i in range(K):
+                assert torch.equal(recv[i][0, :E * H].view(E, H), want[i]), f"gather {i}"
+                assert int(recv[i][0, E * H:E * H + 1].view(torch.int32)) == i + 1
+        else:
+            print(f"[without the guard] {dt:.2f} s, error: {err}")
+            assert err is None or (err.code == -6 and dt >= 0.9)
+        g.close(); eng.close()
+    ref.close()
