@@ -528,6 +528,10 @@ class Workload:
         self.eng.close()
 
 
+class CollectiveUnavailable(RuntimeError):
+    """Raised by EVERY rank together (agreed by an all-reduce): a side configuration's communicator could not be made."""
+
+
 class GroupedWorkload:
     """A small configuration with its envs split into G groups, each on its own handle + stream and running its own chain of
     steps (cartpolesimulation_amd/pipeline.py): the `*_pipelined` side configurations.  Same synthetic inputs and Philox keys as
@@ -557,11 +561,23 @@ class GroupedWorkload:
             lib_path = os.environ.get("CPMPPI_BENCH_RCCL_PATH") or None
             if ctx["backend"] != "nccl" and not lib_path:
                 raise RuntimeError("the grouped configurations gather through the library's own RCCL communicator (backend nccl)")
+            import torch.distributed as dist
             from cartpolesimulation_amd.shard import exchange_unique_id
             GroupedWorkload._serial += 1
-            uid = exchange_unique_id(self.groups.lib, ctx["rank"], key=f"cpmppi_groups_comm_id_{GroupedWorkload._serial}",
-                                     rccl_path=lib_path and lib_path.encode())
-            self.groups.comm_init(uid, ctx["world"], ctx["rank"], rccl_path=lib_path, stamped=True)
+            ok, why = 1, ""
+            try:
+                uid = exchange_unique_id(self.groups.lib, ctx["rank"], key=f"cpmppi_groups_comm_id_{GroupedWorkload._serial}",
+                                         rccl_path=lib_path and lib_path.encode())
+                self.groups.comm_init(uid, ctx["world"], ctx["rank"], rccl_path=lib_path, stamped=True)
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, repr(e)
+            # every rank takes the same way out: a communicator that could not be made on ANY rank makes this configuration
+            # unavailable on ALL of them, before anybody has entered a collective the others would wait in
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if ctx["backend"] == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                self.groups.close()
+                raise CollectiveUnavailable(f"the env groups' communicator could not be created on every rank" + (f" (this rank: {why})" if why else ""))
             pad = _L.GATHER_STAMP_FLOATS
             self._flat = [torch.zeros(n + pad, device=dev) for _ in range(2)]
             self.u = [f[:n].view(E, H) for f in self._flat]
@@ -888,7 +904,7 @@ def main():
                     gw = GroupedWorkload(ctx, e_, n_, h_, groups)
                     rr = gw.run(steps_, warm_)
                 except Exception as ex:  # noqa: BLE001
-                    if world > 1:
+                    if world > 1 and not isinstance(ex, CollectiveUnavailable):
                         raise                              # (the other ranks are inside the same collective sequence)
                     extras[name] = {"error": f"{type(ex).__name__}: {ex}"}
                     side_failed.append(name)

@@ -3,7 +3,7 @@
 entry / exit time stamps of the diagnostic build -> waves per SIMD and per CU, and the lifetime of a wave against the number of waves
 it shares its SIMD with.
 
-  python __graft_entry__.py --variant dbg -DCPMPPI_DEBUG_COUNTERS=1
+  python __graft_entry__.py --variant dbg -DCPMPPI_DEBUG_COUNTERS=1 [-DCPMPPI_DEV_KNOBS   for --lds-pad]
   CPMPPI_LIB=build_variants/dbg.so python tools/dev/placement.py --config C4 [--rpl 0|1|2] [--lds-pad BYTES]
 """
 import argparse

@@ -3,7 +3,9 @@
 (wall clock over K back-to-back steps, one stream) for every (rollouts per lane, build variant) the library can be steered to through
 CPMPPI_LONE_FORM_MAX_WAVES / CPMPPI_LATENCY_MAX_ROLLOUTS, over a range of launch sizes.
 
-Usage: python tools/variant_sweep.py [--shapes 2048x50 4096x100 1024x50] [--envs 16 32 64 ...] [--json out.json]
+Since round 6 the two overrides exist in a -DCPMPPI_DEV_KNOBS build only (the shipped library has the constants):
+  python __graft_entry__.py --variant devknobs -DCPMPPI_DEV_KNOBS
+Usage: CPMPPI_LIB=build_variants/devknobs.so python tools/variant_sweep.py [--shapes 2048x50 4096x100 1024x50] [--envs 16 32 64 ...] [--json out.json]
 """
 import argparse
 import json
