@@ -83,10 +83,14 @@ int main(int argc, char** argv) {
     float *ub[2], *recv[2];
     if (cpmppi_comm_unique_id(id, NULL) != CPMPPI_OK) { fprintf(stderr, "comm id: %s\n", cpmppi_last_error(NULL)); return 6; }
     if (cpmppi_comm_init(h, id, 1, 0, NULL) != CPMPPI_OK) { fprintf(stderr, "comm init: %s\n", cpmppi_last_error(h)); return 6; }
+    /* stamped blocks: CPMPPI_GATHER_STAMP_FLOATS words behind the sequences of every buffer and of every rank's block */
+    if (cpmppi_comm_set_stamped(h, 1) != CPMPPI_OK) { fprintf(stderr, "stamped: %s\n", cpmppi_last_error(h)); return 6; }
+    const size_t nblk = (size_t)E * H + CPMPPI_GATHER_STAMP_FLOATS;
     for (int b = 0; b < 2; ++b) {
-      HIPCHECK(hipMalloc((void**)&ub[b], (size_t)E * H * sizeof(float)));
-      HIPCHECK(hipMalloc((void**)&recv[b], (size_t)E * H * sizeof(float)));
-      HIPCHECK(hipMemset(ub[b], 0, (size_t)E * H * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&ub[b], nblk * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&recv[b], nblk * sizeof(float)));
+      HIPCHECK(hipMemset(ub[b], 0, nblk * sizeof(float)));
+      HIPCHECK(hipMemset(recv[b], 0, nblk * sizeof(float)));
     }
     for (int it = 0; it < steps; ++it) {
       cpmppi_step_args a;
@@ -106,6 +110,9 @@ int main(int argc, char** argv) {
     printf("g");
     for (uint32_t k = 0; k < H; ++k) printf(" %.9g", hu[k]);
     printf("\n");
+    uint32_t stamp = 0;                                     /* the number of the step-gather that produced the block */
+    HIPCHECK(hipMemcpy(&stamp, recv[steps & 1] + (size_t)E * H, sizeof stamp, hipMemcpyDeviceToHost));
+    printf("st %u\n", stamp);
     cpmppi_comm_destroy(h);
   }
   cpmppi_destroy(h);
@@ -150,10 +157,27 @@ int main(int argc, char** argv) {
     b.states_log = slog; b.dd_log = ddlog; b.save_rows = rows; b.save_every = n_save; b.Q_log = Qlog; b.ctrl_rows = T + 1;
     b.target_position_table = tab; b.target_equilibrium_table = tab + (size_t)srows * E; b.sched_rows = srows; b.sched_stride = stride;
     b.target_position_out = cur; b.target_equilibrium_out = cur + E;
-    if (cpmppi_groups_fork(gr, NULL) != CPMPPI_OK || cpmppi_groups_run(gr, &a, &b, T) != CPMPPI_OK) { fprintf(stderr, "groups run: %s\n", cpmppi_groups_last_error(gr)); return 9; }
+    /* ... with the groups under ONE communicator (one rank here) and one all-gather of the device's u_nom[E, H] per period:
+     * cpmppi_groups_comm_init + cpmppi_groups_run_gather instead of cpmppi_groups_run - the recording must not change by a bit */
+    unsigned char gid[CPMPPI_COMM_ID_BYTES];
+    float* grecv;
+    HIPCHECK(hipMalloc((void**)&grecv, ((size_t)E * H + CPMPPI_GATHER_STAMP_FLOATS) * sizeof(float)));
+    if (cpmppi_comm_unique_id(gid, NULL) != CPMPPI_OK || cpmppi_groups_comm_init(gr, gid, 1, 0, NULL) != CPMPPI_OK) { fprintf(stderr, "groups comm: %s\n", cpmppi_groups_last_error(gr)); return 9; }
+    if (cpmppi_groups_fork(gr, NULL) != CPMPPI_OK || cpmppi_groups_run_gather(gr, &a, &b, T, grecv) != CPMPPI_OK) { fprintf(stderr, "groups run: %s\n", cpmppi_groups_last_error(gr)); return 9; }
     a.offset = T; b.period = T; b.n_substeps = 0;                                                         /* the last controller call: record only */
-    if (cpmppi_groups_run(gr, &a, &b, 1) != CPMPPI_OK || cpmppi_groups_join(gr, NULL) != CPMPPI_OK) { fprintf(stderr, "groups run: %s\n", cpmppi_groups_last_error(gr)); return 9; }
+    if (cpmppi_groups_run_gather(gr, &a, &b, 1, grecv) != CPMPPI_OK || cpmppi_groups_join(gr, NULL) != CPMPPI_OK) { fprintf(stderr, "groups run: %s\n", cpmppi_groups_last_error(gr)); return 9; }
     HIPCHECK(hipDeviceSynchronize());
+    if (cpmppi_comm_sync(cpmppi_groups_handle(gr, 0)) != CPMPPI_OK) { fprintf(stderr, "groups comm sync: %s\n", cpmppi_last_error(cpmppi_groups_handle(gr, 0))); return 9; }
+    {
+      cpmppi_comm_info info;
+      float* hg = (float*)malloc((size_t)E * H * sizeof(float));
+      float* hn = (float*)malloc((size_t)E * H * sizeof(float));
+      if (cpmppi_comm_get_info(cpmppi_groups_handle(gr, 0), &info) != CPMPPI_OK) return 9;
+      HIPCHECK(hipMemcpy(hg, grecv, (size_t)E * H * sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHECK(hipMemcpy(hn, un, (size_t)E * H * sizeof(float), hipMemcpyDeviceToHost));
+      printf("gg %d %u %d\n", memcmp(hg, hn, (size_t)E * H * sizeof(float)) == 0, info.gathers_enqueued, info.rccl_ranks);   /* the last gather = u_nom */
+      free(hg); free(hn);
+    }
     float* hr = (float*)malloc((size_t)E * 6 * sizeof(float));
     HIPCHECK(hipMemcpy(hr, slog + (size_t)(rows - 1) * E * 6, (size_t)E * 6 * sizeof(float), hipMemcpyDeviceToHost));
     printf("R");

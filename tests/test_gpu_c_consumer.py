@@ -43,6 +43,9 @@ def test_c_consumer_matches_the_python_binding(tmp_path):
     (u_c,), (g_c,) = rows("u"), rows("g")
     # the multi-GPU entry points from plain C, one rank: the same controls again, and the gathered copy of the result
     assert np.array_equal(Qg_c, Q_c) and np.array_equal(g_c, u_c)
+    # ... with stamped blocks: the last gathered block carries the number of the last step-gather
+    (st,) = [l.split() for l in lines if l.startswith("st ")]
+    assert int(st[1]) == steps
     # the same through the Python binding
     eng = MPPIEngine(E, mppi)
     f32 = np.float32
@@ -58,7 +61,11 @@ def test_c_consumer_matches_the_python_binding(tmp_path):
     assert np.array_equal(np.stack(Q_py), Q_c), (np.stack(Q_py), Q_c)
     assert np.array_equal(un.cpu().numpy()[0], u_c)
     assert np.abs(Q_c).max() > 1e-3
-    # ---- the data generator's loop from C through the env-group entry points == the Python harness as ONE chain
+    # ---- the data generator's loop from C through the env-group entry points == the Python harness as ONE chain; the groups run
+    # under ONE communicator with an all-gather of u_nom per period (cpmppi_groups_comm_init / cpmppi_groups_run_gather, one rank):
+    # "gg <last gathered block == u_nom> <gathers enqueued> <ranks as RCCL reports them>"
+    (gg,) = [l.split() for l in lines if l.startswith("gg ")]
+    assert gg[1:] == ["1", str(steps + 3 + 1), "1"], gg
     (R_c,), (Qc_c,), (D_c,) = rows("R"), rows("Qc"), rows("D")
     T, n_ctrl, n_save, stride = steps + 3, 10, 5, 5
     srows = T * n_ctrl // stride + 1

@@ -109,3 +109,25 @@ def test_unique_id_reaches_every_rank_through_the_store():
     ret = mgr.dict()
     mp.spawn(_id_worker, args=(3, port, ret), nprocs=3, join=True)
     assert len(ret[0]) == _lib.COMM_ID_BYTES and ret[0] == ret[1] == ret[2] and ret[0] != probe.raw
+
+
+def test_stamped_blocks_receivers_rule():
+    """shard.block_stamps / accepted_blocks / merge_accepted on CPU tensors: a block is used iff the word behind its sequences is
+    the number of the gather it arrived with (cpmppi_comm_set_stamped, include/cpmppi.h); a rejected rank keeps its previous rows."""
+    import torch
+    from cartpolesimulation_amd import _lib as L
+    from cartpolesimulation_amd.shard import accepted_blocks, block_stamps, merge_accepted
+    W, n, pad = 3, 10, L.GATHER_STAMP_FLOATS
+    prev = torch.arange(W * n, dtype=torch.float32).view(W, n)
+    got = torch.zeros(W, n + pad)
+    got[:, :n] = 100.0 + prev
+    stamps = torch.tensor([7, 5, 7], dtype=torch.int32)                       # rank 1 dropped steps 6 and 7: its block is stale
+    got[:, n] = stamps.view(torch.float32)
+    assert block_stamps(got, n).tolist() == [7, 5, 7]
+    assert accepted_blocks(got, n, 7).tolist() == [True, False, True]
+    merged, ok = merge_accepted(prev, got, n, 7)
+    assert ok.tolist() == [True, False, True]
+    assert torch.equal(merged[0], got[0, :n]) and torch.equal(merged[2], got[2, :n]) and torch.equal(merged[1], prev[1])
+    # a stamp is an integer bit pattern: 2**31 - 1 survives the float32 container, NaN patterns included
+    got[0, n] = torch.tensor([0x7FC00001], dtype=torch.int32).view(torch.float32)
+    assert int(block_stamps(got, n)[0]) == 0x7FC00001
