@@ -72,6 +72,23 @@ def _stamps(log, n):
     return log[:, :, n].view(np.uint32).astype(np.int64)
 
 
+def test_three_ranks_block_order_and_contents(tmp_path):
+    """Three processes on one device: block r of every gather is rank r's (the all-gather's block order), every block bit-equal to
+    the single-process run of all 3 * E_local envs, on every rank."""
+    E, N, H, K, seed, W = 3, 512, 20, 24, 81, 3
+    outs, data = _ranks(tmp_path, "steps", world=W, envs=E, rollouts=N, horizon=H, steps=K, seed=seed)
+    ref = _single_process(W * E, N, H, K, seed)
+    n = E * H
+    for r in range(W):
+        assert outs[r]["info"]["rccl_ranks"] == W and outs[r]["info"]["rccl_rank"] == r and outs[r]["refused"] == []
+        log = data[r]["log"]
+        assert log.shape == (K, W, n + 4)
+        for p in range(W):
+            assert np.array_equal(log[:, p, :n].reshape(K, E, H), ref[:, p * E:(p + 1) * E]), (r, p)
+        assert np.array_equal(_stamps(log, n), np.repeat(np.arange(1, K + 1)[:, None], W, axis=1))
+    assert np.array_equal(data[0]["log"], data[1]["log"]) and np.array_equal(data[0]["log"], data[2]["log"])
+
+
 @pytest.mark.parametrize("slow_us", [0, 400])
 def test_two_ranks_gather_every_step_equal_to_the_single_process_run(tmp_path, slow_us):
     """50 cpmppi_step_gather steps per rank, no host sync in between, alternating buffers: every block of every gather, on both
