@@ -27,6 +27,7 @@ ap.add_argument("--config", default="C4")
 ap.add_argument("--groups", type=int, default=2)
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--rpl", type=int, default=0, help="rollouts per lane (0 = the library's size rule)")
 ap.add_argument("--overlap", action="store_true", help="also print EnvGroups.overlap (sum of the groups' times alone / time together), as bench.py's stream_overlap")
 ap.add_argument("--only", default=None, choices=[None, "none", "gather", "gather-stamped", "inplace", "inplace-stamped"], help="one case only (for a kernel trace)")
 args = ap.parse_args()
@@ -37,7 +38,7 @@ dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", device_id=dev)
 E, N, H = PRESETS[args.config]
 s0, tp, te, Lt = synthetic_inputs(E, H, 2, dev)
-cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H)
+cfg = MPPIConfig(num_rollouts=N, mpc_horizon=H, rollouts_per_lane=args.rpl)
 n, pad = E * H, L.GATHER_STAMP_FLOATS
 
 
