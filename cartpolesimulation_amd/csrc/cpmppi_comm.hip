@@ -428,8 +428,14 @@ int cpmppi_comm_sync(cpmppi_handle* h) {
   if (__atomic_load_n(c->err_host, __ATOMIC_ACQUIRE) != 0u) {
     // reported once; cleared for device and host so that the handle can go on (the steps since the error left their
     // nominal sequences unwritten)
-    (void)hipMemset(c->flags + 3, 0, sizeof(unsigned));
-    (void)hipMemset(c->flags + FLAG_WORDS + 3, 0, sizeof(unsigned));
+    // (first everything enqueued so far runs out - with the error still up, i.e. dropping its stores; then the error words AND the
+    // arrival counters are reset: a period of env groups whose launches were only partly enqueued - cpmppi_groups_run_gather
+    // returning from a failed launch - leaves a count that would never reach its total)
+    (void)hipDeviceSynchronize();
+    for (unsigned* blk : {c->flags, c->flags + FLAG_WORDS}) {
+      (void)hipMemset(blk + 3, 0, sizeof(unsigned));
+      (void)hipMemset(blk, 0, sizeof(unsigned));
+    }
     (void)hipDeviceSynchronize();
     __atomic_store_n(c->err_host, 0u, __ATOMIC_RELEASE);
     return cpmppi_internal_fail(h, CPMPPI_ERR_COMM, "cpmppi_comm_sync: a device-side wait between a step and an all-gather timed out "
@@ -577,6 +583,17 @@ int enqueue_guard(cpmppi_handle* h, const GatherTicket& t, unsigned envs, void* 
   hipLaunchKernelGGL(gather_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t.flags, other, t.need, c->err_host, c->timeout_ticks);
   COMM_HIP(h, hipGetLastError());
   return CPMPPI_OK;
+}
+
+// a step-gather that could not be enqueued completely (a launch of one env group failed after others had been enqueued): the
+// communicator is put into the error state - later waits and stores are skipped, the next call is refused, cpmppi_comm_sync drains,
+// resets the arrival counters and clears
+void poison(CommState* c) {
+  if (!c) return;
+  __atomic_store_n(c->err_host, 1u, __ATOMIC_RELEASE);
+  const unsigned one = 1u;
+  (void)hipMemcpy(c->flags + 3, &one, sizeof(one), hipMemcpyHostToDevice);
+  (void)hipMemcpy(c->flags + FLAG_WORDS + 3, &one, sizeof(one), hipMemcpyHostToDevice);
 }
 
 int share_between_groups(CommState* c) {

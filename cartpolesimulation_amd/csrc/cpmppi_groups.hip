@@ -241,7 +241,10 @@ int run_impl(cpmppi_groups* g, const cpmppi_step_args* step, const cpmppi_plant_
           if (rg != CPMPPI_OK) return gfail(g, rg, std::string("cpmppi_groups_run_gather: ") + cpmppi_last_error(g->g[0].h));
         }
         const int rc = comm ? cpmppi_internal_step_ticket(h, &sa[i], g->g[i].stream, &ticket) : cpmppi_step(h, &sa[i], g->g[i].stream);
-        if (rc != CPMPPI_OK) return gfail(g, rc, std::string("cpmppi_groups_run: group ") + std::to_string(i) + ": " + cpmppi_last_error(h));
+        if (rc != CPMPPI_OK) {
+          if (comm && i > 0) cpmppi_comm::poison(comm);      // other groups' launches of this period are out: their arrivals will never be complete
+          return gfail(g, rc, std::string("cpmppi_groups_run: group ") + std::to_string(i) + ": " + cpmppi_last_error(h));
+        }
       }
       if (plant) {
         pa[i].period = plant->period + k;

@@ -21,6 +21,7 @@ int share_between_groups(CommState* c);      // the communicator serves env grou
 void abort_step_gather(CommState* c);
 int enqueue_gather(cpmppi_handle* h, const float* send, float* recv_all, size_t count);
 int enqueue_guard(cpmppi_handle* h, const GatherTicket& t, unsigned envs, void* stream);   // launch stream: gather_guard_kernel (many envs only)
+void poison(CommState* c);                   // a partly enqueued step-gather: error state until cpmppi_comm_sync
 int comm_error_pending(cpmppi_handle* h);    // a device-side wait of this handle has timed out (sticky until cpmppi_comm_sync)
 }  // namespace cpmppi_comm
 
