@@ -21,6 +21,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("trace")
 ap.add_argument("--last", type=int, default=150)
 ap.add_argument("--json", default=None)
+ap.add_argument("--alone-phases", action="store_true",
+                help="the traced program also ran EnvGroups.overlap() (every group's steps alone, then all together): derive "
+                     "bench.py's `stream_overlap` = time alone / time together from the trace's own time stamps")
 args = ap.parse_args()
 
 rows = list(csv.DictReader(open(args.trace)))
@@ -67,6 +70,58 @@ out = {"trace": args.trace, "window_us": window / 1e3, "streams_with_rollout_ker
        "concurrency": sum(r["e"] - r["s"] for r in ks) / busy1,
        "other_kernels_in_window": [{"kernel": k[0], "stream": k[1], "count": len(v), "duration_us_median": st.median(v)} for k, v in
                                    sorted(others.items(), key=lambda kv: -len(kv[1]))]}
+if args.alone_phases:
+    # EnvGroups.overlap(): `steps` launches of every group ALONE, one group after the other, then the same launches of all groups
+    # together.  A kernel is "solo" if no rollout kernel of another stream is in flight at any time of its life; a run of >= 20
+    # consecutive solo kernels of one stream is that group's alone phase, the interleaved kernels right behind the LAST alone phase
+    # are the together phase (as many launches per stream as an alone phase had).
+    allk = sorted(roll, key=lambda r: r["s"])
+    by_stream = {}
+    for r in allk:
+        by_stream.setdefault(r["Stream_Id"], []).append(r)
+    import bisect
+    starts = {sid: [r["s"] for r in v] for sid, v in by_stream.items()}
+
+    def solo(r):
+        for sid, v in by_stream.items():
+            if sid == r["Stream_Id"]:
+                continue
+            i = bisect.bisect_left(starts[sid], r["e"])          # kernels of the other stream starting before this one ends ...
+            j = i - 1
+            while j >= 0 and v[j]["s"] > r["s"] - 10_000_000:    # ... that end after it starts (look back 10 ms at most)
+                if v[j]["e"] > r["s"]:
+                    return False
+                j -= 1
+        return True
+    flags = [(r, solo(r)) for r in allk]
+    runs, cur = [], []
+    for r, so in flags:
+        if so and (not cur or cur[-1]["Stream_Id"] == r["Stream_Id"]):
+            cur.append(r)
+        else:
+            if len(cur) >= 20:
+                runs.append(cur)
+            cur = [r] if so else []
+    if len(cur) >= 20:
+        runs.append(cur)
+    # the LAST alone phase of every stream (overlap() is the last thing the tool runs per repetition; the final repetition counts)
+    last = {}
+    for run in runs:
+        last[run[0]["Stream_Id"]] = run
+    if len(last) >= 2:
+        n = min(len(v) for v in last.values())
+        alone_us = {sid: (v[-1]["e"] - v[0]["s"]) / 1e3 / len(v) for sid, v in last.items()}
+        t_end = max(v[-1]["e"] for v in last.values())
+        tog = [r for r in allk if r["s"] >= t_end]
+        per = {}
+        for r in tog:
+            per.setdefault(r["Stream_Id"], []).append(r)
+        per = {sid: v[:n] for sid, v in per.items() if sid in last}
+        if per and all(len(v) == n for v in per.values()):
+            t0_, t1_ = min(v[0]["s"] for v in per.values()), max(v[-1]["e"] for v in per.values())
+            together_us = (t1_ - t0_) / 1e3 / n
+            out["alone_phases"] = {"launches_per_phase": n, "alone_us_per_step": alone_us, "together_us_per_step": together_us,
+                                   "alone_over_together": sum(alone_us.values()) / together_us}
 print(json.dumps(out, indent=1))
 if args.json:
     json.dump(out, open(args.json, "w"), indent=1)
