@@ -345,8 +345,15 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   const uint32_t n = ++c->seq;
   unsigned long long delay = 0;
   if (const char* d = getenv("FAKE_RCCL_DELAY_US")) {            // "<gather number>:<microseconds>": that gather joins late on this rank
-    unsigned g = 0, us = 0;
-    if (sscanf(d, "%u:%u", &g, &us) == 2 && g == n) delay = (unsigned long long)us * 100ull;
+    unsigned g = 0, us = 0, permille = 0, seed = 0;
+    if (sscanf(d, "rand:%u:%u:%u", &permille, &us, &seed) == 3) {
+      // "rand:<per mille>:<max microseconds>:<seed>": a random subset of the gathers joins late by a random time (stress runs)
+      uint32_t x = (seed * 2654435761u) ^ (n * 40503u) ^ ((uint32_t)c->rank * 0x9E3779B9u);
+      x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+      if (x % 1000u < permille) delay = (unsigned long long)((x >> 10) % (us + 1u)) * 100ull;
+    } else if (sscanf(d, "%u:%u", &g, &us) == 2 && g == n) {
+      delay = (unsigned long long)us * 100ull;
+    }
   }
   hipLaunchKernelGGL(allgather_kernel, dim3(1), dim3(256), 0, stream, c->peers, c->world, c->rank, n, (const float*)send, (float*)recv,
                      count, c->timeout_ticks, c->err, delay);

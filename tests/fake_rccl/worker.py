@@ -85,10 +85,17 @@ def main():
     ap.add_argument("--stall-gather", type=int, default=20)
     ap.add_argument("--timeout-ms", type=float, default=2.0)
     ap.add_argument("--slow-collective-us", type=int, default=0, help="cpmppi_debug_comm_delay in front of every all-gather")
+    ap.add_argument("--jitter", default="", help="stress: '<per mille>:<max us>' - a random subset of this rank's gathers joins late by a random time "
+                                                 "(inside the stand-in collective), and the host naps at random between calls")
     ap.add_argument("--base", required=True, help="path prefix for the id file, the barrier files and the result")
     a = ap.parse_args()
     if a.mode == "stall" and a.rank == a.stall_rank:
         os.environ["FAKE_RCCL_DELAY_US"] = f"{a.stall_gather}:60000"
+    naps = None
+    if a.jitter:
+        pm, us = (int(x) for x in a.jitter.split(":"))
+        os.environ["FAKE_RCCL_DELAY_US"] = f"rand:{pm}:{us}:{a.seed + 17 * a.rank}"
+        naps = np.random.Generator(np.random.SFC64(a.seed + 1000 * a.rank))
 
     import torch
     from cartpolesimulation_amd import _lib as _L
@@ -141,6 +148,8 @@ def main():
                 continue
             if a.mode == "stall":
                 torch.cuda.current_stream(dev).synchronize()                    # the launch stream only: the host keeps pace with the steps
+            if naps is not None and naps.uniform() < 0.05:
+                time.sleep(float(naps.uniform(0.0, 2e-3)))                      # the ranks drift apart and catch up again
             i += 1
         torch.cuda.synchronize()
         try:
@@ -179,6 +188,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(K1):
             grp.run(prep[i & 1], periods=1, offset=i, gather_into=log[i])
+            if naps is not None and naps.uniform() < 0.05:
+                time.sleep(float(naps.uniform(0.0, 2e-3)))
         grp.run(prep[K1 & 1], periods=K2, offset=K1, gather_into=log[K1])
         grp.join()
         torch.cuda.synchronize()

@@ -179,3 +179,32 @@ def test_env_groups_under_one_communicator_two_ranks(tmp_path, slow_us):
         assert np.array_equal(st[:K1], np.repeat(np.arange(1, K1 + 1)[:, None], 2, axis=1)) and np.all(st[K1] == K1 + K2)
         assert np.array_equal(data[r]["u_final"], ref[-1, r * E:(r + 1) * E])
     assert np.array_equal(data[0]["log"], data[1]["log"])
+
+
+@pytest.mark.parametrize("mode", ["steps", "groups"])
+def test_two_ranks_with_random_stalls_on_both_sides(tmp_path, mode):
+    """Stress: 400 steps per rank with a fifth of the all-gathers joining late by up to 300 us on EITHER rank (inside the stand-in
+    collective) and host naps of up to 2 ms now and then, default timeout (nothing may be dropped): the ranks drift apart by several
+    steps and catch up again, the finalizes wait for real - and still every gathered block on both ranks is bit for bit the
+    single-process run, every block carries its step's stamp, nobody errs.  One handle per rank, and env groups under one communicator."""
+    E, N, H = 4, 256, 16
+    # (a soak run: CPMPPI_TWO_RANK_STRESS="<steps>:<per mille>:<max us>:<seed>", e.g. 6000:300:1500:7 - tools/dev/r6_soak_two_rank.sh)
+    steps, pm, us, seed = (int(x) for x in os.environ.get("CPMPPI_TWO_RANK_STRESS", "400:200:300:83").split(":"))
+    K, KB = (steps, 0) if mode == "steps" else (steps - steps // 4, steps // 4)
+    kw = dict(envs=E, rollouts=N, horizon=H, steps=K, seed=seed, jitter=f"{pm}:{us}")
+    if mode == "groups":
+        kw.update(batch=KB, groups=2)
+    outs, data = _ranks(tmp_path, mode, **kw)
+    ref = _single_process(2 * E, N, H, K + KB, seed)
+    n = E * H
+    for r in range(2):
+        assert outs[r]["errors"] == [] and outs[r].get("refused", []) == [] and outs[r].get("final_sync", "ok") == "ok"
+        log = data[r]["log"]
+        for p in range(2):
+            assert np.array_equal(log[:K, p, :n].reshape(K, E, H), ref[:K, p * E:(p + 1) * E]), (r, p)
+        st = _stamps(log, n)
+        assert np.array_equal(st[:K], np.repeat(np.arange(1, K + 1)[:, None], 2, axis=1))
+        if mode == "groups":
+            assert np.all(st[K] == K + KB) and np.array_equal(log[K, :, :n].reshape(2 * E, H), ref[-1])
+        assert np.array_equal(data[r]["u_final"], ref[-1, r * E:(r + 1) * E])
+    assert np.array_equal(data[0]["log"], data[1]["log"])
