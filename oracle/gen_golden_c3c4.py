@@ -9,7 +9,8 @@ Per case (c3: H = 100, envs 0, 1 of the bench's synthetic inputs for seed 2; c4:
     pole length handed over the way the simulator does it - `variable_parameters.L` (:47-54) - -> trajectories [N, H + 1, 6] (mode A:
     the float32 arithmetic of the shipped code under numpy >= 2); mode B = the reference's own substep function fed float64
     (SURVEY.md H1), float32 store per control step
-  * Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad_minimal.py::get_trajectory_cost on those trajectories
+  * Control_Toolkit_ASF/Cost_Functions/CartPole/quadratic_boundary_grad_minimal.py::get_trajectory_cost on those trajectories, and
+    the `default` plugin's stage sum + terminal cost (default.py:23-88)
   * Control_Toolkit_ASF/Controllers/controller_mppi_cartpole.py::initialize_perturbations ("interpolated", SFC64 knots: P = 11 at
     H = 100) and ::reward_weighted_average -> the soft-min update
 for the perturbed inputs as sampled ("raw") and clipped to [-1, 1] ("clip", what the product's default control_mode does).
@@ -65,6 +66,7 @@ def main():
             pred = G.next_state_predictor_ODE_v0(G.DT, G.S_SUB, N, variable_parameters=vp_pred)
             vp_cost = SimpleNamespace(target_position=f32(target), target_equilibrium=f32(1.0))
             qbgm = G.quadratic_boundary_grad_minimal(vp_cost, lib)
+            dflt = G.default_cost(vp_cost, lib)
             P = pred.cpe.params
             for tag, u_run in (("raw", (u_nom + delta_u).astype(f32)), ("clip", np.clip(u_nom + delta_u, f32(-1), f32(1)).astype(f32))):
                 traj = np.zeros((N, H + 1, 6), dtype=f32)                   # predict_core: out[:, k + 1] = step(out[:, k], Q[:, k])
@@ -72,6 +74,8 @@ def main():
                 for k in range(H):
                     traj[:, k + 1] = pred.step(traj[:, k], u_run[:, k, None])
                 S = np.asarray(qbgm.get_trajectory_cost(traj, u_run[..., None], None), dtype=f32)
+                stage_d = dflt._get_stage_cost(traj[:, :-1], u_run[..., None], None)          # (as gen_golden.gen_rollouts: stage sum + terminal)
+                S_d = np.asarray(np.sum(stage_d, 1) + dflt.get_terminal_cost(traj[:, -1])[:, 0], dtype=f32)
                 sB = np.tile(s0, (N, 1))
                 u_phys = pred.cpe.Q2u(u_run)
                 for k in range(H):
@@ -83,6 +87,7 @@ def main():
                 out[f"{key}/{tag}/final"], out[f"{key}/{tag}/final_B"] = traj[:, -1], sB
                 out[f"{key}/{tag}/traj_head"] = traj[:8]
                 out[f"{key}/{tag}/S_qbgm"], out[f"{key}/{tag}/u_new"] = S, u_new
+                out[f"{key}/{tag}/S_default"] = S_d
                 print(f"{key}/{tag}: L={float(Lv):.4f} S[min,max]=({S.min():.3f},{S.max():.3f}) max|final A-B|={np.abs(traj[:, -1] - sB).max():.2e} "
                       f"|u_new|max={np.abs(u_new).max():.4f}")
             out[f"{key}/s0"], out[f"{key}/target"], out[f"{key}/L"], out[f"{key}/seed"] = s0, f32(target), f32(Lv), np.int64(seed)

@@ -157,6 +157,20 @@ def test_c3_c4_shape_rollouts_costs_update(golden_dir, case, e, math_mode):
     head = g[f"{key}/raw/traj_head"]
     nh = head.shape[0]
     PU.assert_states(traj[:nh, :H // 2], head[:, :H // 2], ref_traj_B[:nh, :H // 2], flagged[:nh], f"{key} trajectory heads", strict=True)
+    # ---- cost seam on the ORACLE's trajectories, both plugins (isolates the cost arithmetic from integration differences)
+    for cost_name, ckey in (("quadratic_boundary_grad_minimal", "S_qbgm"), ("default", "S_default")):
+        eng.set_cost(cost_name)
+        _, _, total = eng.trajectory_cost(ref_traj, u_run, target, 1.0)
+        np.testing.assert_allclose(total.cpu().numpy(), g[f"{key}/raw/{ckey}"], rtol=1e-4)
+    # ---- fused step with the `default` plugin on the device's own rollouts (its indicator terms flag the rollouts that graze a threshold)
+    e_d = engine(1, N, H, math_mode=math_mode, shift_mode="none", control_mode="penalise", correction_u="u_nom", cc_weight=0.0,
+                 cost_function_specification="default", rollouts_per_lane=1)
+    un_d, S_dv = e_d.zeros(1, H), e_d.empty(1, N)
+    e_d.step(s0[None], un_d, target, 1.0, L=np.array([Lv], f32), delta_u=du[None], S_out=S_dv)
+    S_db = O.trajectory_cost(O.COST_DEFAULT, ref_traj_B, u_run, f32(target), f32(1.0))
+    fl_d = flagged | PU.flag_indicators(ref_traj, "default", target)
+    PU.assert_costs(S_dv.cpu().numpy()[0], g[f"{key}/raw/S_default"], S_db, fl_d, f"{key} S_default", strict=True)
+    e_d.close()
     # ---- fused step on the device's own rollouts: S and the soft-min update against the reference's
     for tag, control_mode in (("raw", "penalise"), ("clip", "clip")):
         for rpl in ((1, 2) if math_mode == "fast" else (1,)):

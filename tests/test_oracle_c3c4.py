@@ -62,6 +62,8 @@ def test_numpy_oracle_at_c3_c4_shape(g, case, e):
         assert np.all(np.abs(traj[:, -1] - g[f"{key}/{tag}/final"]) <= 0.2 * state_tol(g[f"{key}/{tag}/final"]))
         S = O.trajectory_cost(O.COST_QBGM, traj, u_run, target, f32(1.0))
         np.testing.assert_allclose(S, g[f"{key}/{tag}/S_qbgm"], rtol=2e-5)
+        S_d = O.trajectory_cost(O.COST_DEFAULT, traj, u_run, target, f32(1.0))          # the `default` plugin: stage sum + terminal indicator
+        np.testing.assert_allclose(S_d, g[f"{key}/{tag}/S_default"], rtol=2e-5)
         u_new = O.reward_weighted_average(g[f"{key}/{tag}/S_qbgm"], du)
         if tag == "clip":
             u_new = np.clip(u_new, -1, 1)
@@ -97,3 +99,9 @@ def test_c_oracle_at_c3_c4_shape(g, case, e):
         assert np.median(rel) < 2e-5 and (rel < 2e-3).mean() >= 0.97, (tag, np.median(rel), (rel < 2e-3).mean())
         np.testing.assert_allclose(u_new[0], g[f"{key}/{tag}/u_new"], atol=1e-4)
         assert abs(float(Q[0]) - float(g[f"{key}/{tag}/u_new"][0])) <= 1e-4
+        cfg_d = O.MPPIConfig(cost_id=O.COST_DEFAULT, control_mode=cm, **base)
+        _, _, S_d = OC.step(OC.make_config(cfg_d), s0[None], np.zeros((1, H), f32), du[None], target, 1.0, L=Ls)
+        ref_d = g[f"{key}/{tag}/S_default"]
+        rel_d = np.abs(S_d[0] - ref_d) / np.abs(ref_d)
+        # (the default plugin's 1e7 / 1e4 indicator terms flip on rollouts that graze a threshold: those are the tail)
+        assert np.median(rel_d) < 2e-5 and (rel_d < 2e-3).mean() >= 0.95, (tag, np.median(rel_d), (rel_d < 2e-3).mean())
