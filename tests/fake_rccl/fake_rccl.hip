@@ -20,7 +20,6 @@
 //                          Stream-ordered, no host involvement, device-side flags only - what a collective kernel does.
 //   Every device-side spin is bounded (FAKE_RCCL_TIMEOUT_S, default 20 s): a peer that never arrives raises a sticky error word the
 //   next call returns as ncclInternalError; the kernel never hangs the GPU.
-#include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
@@ -73,7 +72,6 @@ struct FakeComm {
   uint32_t seq = 0;                 // gathers enqueued
   unsigned long long timeout_ticks = 2000000000ull;
   std::string dir, shm_name;
-  unsigned delay_first_us = 0;
 };
 
 std::string hex_of(const char* p, int n) {
