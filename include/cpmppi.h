@@ -460,10 +460,11 @@ int cpmppi_plant_step(cpmppi_handle* h, const cpmppi_plant_args* args, void* str
  *                          waits for that gather, which completes only when EVERY rank has joined it
  *   cpmppi_comm_get_info   what the communicator IS, as RCCL itself reports it (ncclCommCount / ncclCommUserRank), next to what
  *                          cpmppi_comm_init was told: a bench line can then state how many ranks the collective really spanned
- * The wait for a published step on the side stream (hipStreamWaitValue32) has no timeout of its own and cpmppi_comm_set_timeout
- * does not cover it; cpmppi_comm_sync and cpmppi_comm_destroy therefore poll the side stream for at most the timeout and then
- * release the wait from the host, raise the error and return CPMPPI_ERR_COMM (a rollout launch that never published - failed,
- * aborted - cannot wedge them).  cpmppi_step_gather refuses a stream that is being captured.
+ * The side stream's wait for a published step is a one-lane kernel of the library's with the same timeout (the default form); the
+ * stream-memory-operation form of rounds 4-5 (environment: CPMPPI_COMM_WAITER=stream-ops; hipStreamWaitValue32 has no timeout of its
+ * own) is covered by cpmppi_comm_sync and cpmppi_comm_destroy, which poll the side stream for at most the timeout and then release
+ * the wait from the host, raise the error and return CPMPPI_ERR_COMM.  Either way a rollout launch that never published - failed,
+ * aborted - cannot wedge them.  cpmppi_step_gather refuses a stream that is being captured.
  * PEERS: a rank whose device-side wait timed out keeps its buffers intact and its already-enqueued all-gathers still run, so the
  * other ranks receive a well-formed but STALE block from it and no error of their own.  Two ways to know:
  *   - cpmppi_comm_set_stamped(h, 1) (before the first cpmppi_step_gather, the same on every rank): every gathered block carries
@@ -484,7 +485,7 @@ typedef struct {
   uint32_t world, rank;            /* as given to cpmppi_comm_init */
   int32_t rccl_ranks, rccl_rank;   /* ncclCommCount / ncclCommUserRank of the communicator; -1 = this RCCL does not export them */
   int32_t rccl_version;            /* ncclGetVersion (e.g. 22606), 0 = unknown */
-  uint32_t stream_memory_ops;      /* 1 = hipStreamWaitValue32 / WriteValue32 order the side stream, 0 = the one-lane waiter kernel */
+  uint32_t stream_memory_ops;      /* 0 = the one-lane waiter kernel orders the side stream (default), 1 = hipStreamWaitValue32 / WriteValue32 */
   uint32_t gathers_enqueued;       /* cpmppi_step_gather calls so far (= the stamp of the most recent one) */
   uint32_t stamped;                /* cpmppi_comm_set_stamped */
 } cpmppi_comm_info;
@@ -504,8 +505,8 @@ int cpmppi_comm_set_stamped(cpmppi_handle* h, int on);
 /* cpmppi_step + the all-gather of its result in ONE call - the production form of the per-step collective:
  * recv_all[world][E*H] <- all-gather of the nominal sequences this step writes (args->u_nom_out, or args->u_nom when the
  * step runs in place).  The launch stream receives the rollout kernel and nothing else; step and gather are ordered
- * through device memory (the kernel's finalizing blocks publish the step into signal memory, the side stream waits for
- * it with hipStreamWaitValue32 - a one-lane kernel where the device has no stream memory operations; the finalize of a
+ * through device memory (the kernel's finalizing blocks publish the step number, a one-lane kernel on the side stream waits
+ * for it - hipStreamWaitValue32 on signal memory with CPMPPI_COMM_WAITER=stream-ops; the finalize of a
  * later step that overwrites a buffer still being gathered waits for that gather).  Use two
  * u_nom buffers alternately (step i: u_nom = B[i & 1], u_nom_out = B[(i + 1) & 1]) so that the gather of step i runs
  * under step i + 1; in place is correct too, but then step i + 1's finalize waits for gather i.  recv_all must stay
