@@ -12,18 +12,20 @@
 //
 // Two ways to order the two streams:
 //   * cpmppi_step_gather (the production path): through DEVICE MEMORY.  The env-finalizing blocks of the rollout kernel
-//     count themselves; the last one publishes the step number (system-scope release) into 8 bytes of SIGNAL MEMORY.  The
-//     side stream carries, per step, hipStreamWaitValue32(published >= step) -> ncclAllGather -> hipStreamWriteValue32(
-//     gathers completed = step).  (Rounds 4-5 described the two stream memory operations as packets the command processor
-//     executes itself; the round-6 kernel trace shows this runtime performs them as one-lane blit kernels of its own,
-//     __amd_rocclr_streamOpsWait / __amd_rocclr_streamOpsWrite.  For one handle the form was measured better than the folded
-//     waiter kernel below and stays; env groups use the kernel form - share_between_groups.)  The finalize of the step that overwrites a gathered buffer (two steps later) checks the
-//     completed count before its stores.  The launch stream carries the rollout kernels and NOTHING else: an event record
-//     or a cross-stream wait is a barrier packet the next dispatch has to queue behind - measured 4-5 us each next to a
-//     91 us kernel at BASELINE configs[3] (torch.distributed's snapshot copy + Work object + two waits per step: 33 us).
-//     Where stream memory operations are unavailable (hipDeviceAttributeCanUseStreamWaitValue = 0; CPMPPI_COMM_WAITER=kernel
-//     forces it) ONE one-lane kernel per step does both jobs: it posts the previous gather's completion and waits for this
-//     step (post_wait_kernel).
+//     count themselves; the last one publishes the step number (a release into a flag word).  The side stream carries, per
+//     step, ONE one-lane kernel of ours - post_wait_kernel: post "gathers completed" for the previous all-gather, wait (with
+//     the handle's timeout) until this step is published, write the stamp - and the all-gather.  The finalize of the step
+//     that overwrites a gathered buffer (two steps later) checks the completed count before its stores; launches of many
+//     envs do that once, in front of the kernel (gather_guard_kernel).  The launch stream carries the rollout kernels and
+//     otherwise NOTHING for launches of a few dozen envs: an event record or a cross-stream wait is a barrier packet the
+//     next dispatch has to queue behind - measured 4-5 us each next to a 91 us kernel at BASELINE configs[3]
+//     (torch.distributed's snapshot copy + Work object + two waits per step: 33 us).
+//     CPMPPI_COMM_WAITER=stream-ops (where hipDeviceAttributeCanUseStreamWaitValue = 1) selects rounds 4-5's form instead:
+//     hipStreamWaitValue32(published >= step) on 8 bytes of signal memory -> ncclAllGather -> hipStreamWriteValue32(gathers
+//     completed = step).  Those rounds took the two stream memory operations for packets the command processor executes
+//     itself; the round-6 kernel trace shows this runtime performs them as one-lane blit kernels of its own
+//     (__amd_rocclr_streamOpsWait / __amd_rocclr_streamOpsWrite): one dispatch more per step than the folded kernel, and a
+//     wait without a timeout of its own (drain_side_stream's host-side escape covers it).
 //     The only device-side wait left that depends on OTHER ranks is the finalize's: it gives up after
 //     cpmppi_comm_set_timeout seconds (default 10; a peer may legitimately stall in a first-launch module load or a
 //     checkpoint), and a wait that gives up does NOT proceed - the stores it guards are skipped (the buffer a gather is
