@@ -140,7 +140,8 @@ struct CommState {
   unsigned debug_delay_us = 0;          // tests: a spin of this length on the side stream in front of every all-gather
   const float* last_send = nullptr;     // the buffer the previous step_gather's all-gather reads
   bool stamped = false;                 // cpmppi_comm_set_stamped: CPMPPI_GATHER_STAMP_FLOATS words behind every gathered block
-  unsigned guard_min_envs = 128;        // launches with more envs than this wait for the late gather in front of the kernel (gather_guard_kernel)
+  unsigned guard_min_envs = 512;        // launches with more envs than this wait for the late gather in front of the kernel (gather_guard_kernel):
+                                        // half of the ~1024 workgroups the device holds of the widest rollout kernel (256 CUs x 4)
 };
 
 // Fallback waiter (no stream memory operations), side stream, one lane: posts "gathers completed = post" (the all-gather in
@@ -199,8 +200,9 @@ __global__ void stamp_kernel(const unsigned* flags, const unsigned* other, unsig
 // through 4096 spinning blocks within the 30 ms the gather was late (tests/test_gpu_boundary.py) - there the guard is insurance
 // (normal-priority RCCL builds, a runtime that does not preempt), not a fix.  With it a late gather costs one spinning lane; the
 // finalizing blocks then find the count reached (or the error up) at once.  Same timeout, same error words as the wait in the kernel.
-// Launches of a few dozen envs keep the in-kernel wait alone: their finalizing blocks cannot fill the device, and a 5 us dispatch in
-// front of a 64 us kernel is what the design avoids on the launch stream.  (In place - u_nom_out == NULL - the guard waits for the
+// Launches of up to 512 envs keep the in-kernel wait alone: their finalizing blocks cannot fill the device (~1024 resident workgroups
+// of the widest rollout kernel; only the rank that is AHEAD spins), and a 5 us dispatch in front of a 64-200 us kernel is what the
+// design avoids on the launch stream.  (In place - u_nom_out == NULL - the guard waits for the
 // PREVIOUS step's gather and so serialises step and gather for many-env launches: alternate two buffers, as the header says.)
 __global__ void gather_guard_kernel(unsigned* flags, unsigned* other, unsigned need, unsigned* err_host, unsigned long long timeout_ticks) {
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();

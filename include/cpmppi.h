@@ -511,7 +511,7 @@ int cpmppi_comm_set_stamped(cpmppi_handle* h, int on);
  * u_nom buffers alternately (step i: u_nom = B[i & 1], u_nom_out = B[(i + 1) & 1]) so that the gather of step i runs
  * under step i + 1; in place is correct too, but then step i + 1's finalize waits for gather i.  recv_all must stay
  * untouched until cpmppi_comm_sync (host) returns or a later cpmppi_comm_gather/wait pair orders the reader.
- * A launch of more than 128 envs performs that wait once, with one lane, in FRONT of the kernel too (a one-lane kernel on `stream`,
+ * A launch of more than 512 envs performs that wait once, with one lane, in FRONT of the kernel too (a one-lane kernel on `stream`,
  * ~5 us): thousands of finalizing blocks spinning for a late gather would hold every workgroup slot of the device (two ranks sharing
  * one device deadlocked on that until the timeout) - so with many envs and in place the step no longer overlaps the previous gather:
  * alternate two buffers.
