@@ -261,7 +261,7 @@ class Workload:
                 # tests/fake_rccl/libfake_rccl.so two ranks can share ONE device, which RCCL refuses)
                 lib_path = os.environ.get("CPMPPI_BENCH_RCCL_PATH") or None
                 uid = exchange_unique_id(self.eng.lib, rank, key=f"cpmppi_comm_id_{Workload._serial}", rccl_path=lib_path and lib_path.encode())
-                self.native = NativeGather(self.eng, uid, W, rank, rccl_path=lib_path)
+                self.native = NativeGather(self.eng, uid, W, rank, rccl_path=lib_path, stamped=not self.collective_events)
             except Exception as e:                       # RCCL missing / init failed on this rank
                 ok, why = 0, repr(e)
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if self.ctx["backend"] == "nccl" else "cpu")
@@ -374,7 +374,7 @@ class Workload:
         assert torch.isfinite(u_final).all(), "non-finite nominal controls"
         self.collective_report = None
         if self.ctx["collective"]:        # the last gather delivered this rank's block (and finite blocks from every other rank)
-            last = (self.native.gathered[(i_last + 1) & 1] if self.native else self.gathered[i_last & 1]).view(W, self.E * self.H)
+            last = (self.native.gathered[(i_last + 1) & 1][:, :self.E * self.H] if self.native else self.gathered[i_last & 1].view(W, self.E * self.H))
             assert torch.equal(last[rank], u_final.view(-1)) and torch.isfinite(last).all(), "all-gather of the controls is wrong"
             # did the collective really span W ranks?  Every rank contributes the checksum of what IT computed (one all-gather of a
             # double through torch.distributed, outside the timed region); the W blocks this rank received through the library's
@@ -392,13 +392,18 @@ class Workload:
             # (cpmppi_comm_get_info); null on the torch.distributed form, whose communicator is not ours to query - there
             # backend_ranks is the process group's size
             info = self.native.info() if self.native else {}
+            stamps_ok = None
+            if self.native and not self.collective_events:
+                # stamped blocks (cpmppi_comm_set_stamped): every rank's block of the last gather carries the number of the last step-gather
+                stamps_ok = bool((self.native.stamps(i_last) == info["gathers_enqueued"]).all())
             self.collective_report = {"impl": self.collective_impl, "ranks_requested": W, "rccl_ranks": info.get("rccl_ranks"),
                                       "rccl_rank_of_rank0": info.get("rccl_rank"), "rccl_version": info.get("rccl_version"),
-                                      "stream_memory_ops": info.get("stream_memory_ops"),
+                                      "stream_memory_ops": info.get("stream_memory_ops"), "stamped": info.get("stamped"),
+                                      "every_block_stamped_with_the_last_step": stamps_ok,
                                       "backend": dist.get_backend(), "backend_ranks": dist.get_world_size(),
                                       "rank_blocks_match_every_ranks_own_checksum": blocks_match, "rank_blocks_distinct": distinct}
             spans = info["rccl_ranks"] == W if self.native else dist.get_world_size() == W
-            assert blocks_match and distinct and spans, f"the collective did not span {W} ranks: {self.collective_report}"
+            assert blocks_match and distinct and spans and stamps_ok is not False, f"the collective did not span {W} ranks: {self.collective_report}"
         k_ms = float(np.mean(rollout_ms))
         E, N, H = self.E, self.N, self.H
         return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "value": W * E * N * steps / elapsed,
